@@ -1,0 +1,171 @@
+/*
+ * snmf.h -- C ABI of libsnmf_hip.so, the MI355X (gfx950) sparse-NMF multiplicative-update engine.
+ *
+ * Drop-in boundary for the hot path of lordet01/SE_SNMF_NAT:
+ *     [w, h, objective] = sparse_nmf(v, p)            (reference: src/sparse_nmf.m:1)
+ *     [w, h, objective] = sparse_nmf_GPU(v, p)        (reference: src/sparse_nmf_GPU.m:1)
+ * and the 3-solve loop of run_basis_DNMF.m:36-55 built on it.  The reference is MATLAB; the
+ * binding a maintainer adds is a MEX shim (integration/sparse_nmf_mex.cpp) or, from Python,
+ * ctypes (se_snmf_nat_amd/_lib.py).  Every entry point below names the reference lines it replaces.
+ *
+ * Conventions: all matrices are column-major (MATLAB layout) with explicit leading dimensions
+ * where given; plain pointers and sizes only; every function returns an snmf_status and never
+ * throws; snmf_last_error() returns a thread-local message for the last failure.
+ * There is NO CPU fallback: without a usable HIP device every compute entry point fails with
+ * SNMF_ERR_NO_DEVICE.
+ */
+#ifndef SNMF_H_
+#define SNMF_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNMF_ABI_VERSION 1
+
+typedef enum snmf_status {
+    SNMF_OK = 0,
+    SNMF_ERR_INVALID = 1,   /* bad argument (NULL, non-positive size, ...) */
+    SNMF_ERR_NO_INIT = 2,   /* neither init_w nor r given: src/sparse_nmf.m:117-119 */
+    SNMF_ERR_DIM = 3,       /* MATLAB dimension error on the path (e.g. partial h_update_ind, :192) */
+    SNMF_ERR_NO_FIELD = 4,  /* p.cost_check missing: src/sparse_nmf.m:260 */
+    SNMF_ERR_NO_DEVICE = 5, /* no HIP device / HIP runtime failure */
+    SNMF_ERR_NOMEM = 6,
+    SNMF_ERR_STATE = 7,     /* call order violated (e.g. run before set_v) */
+    SNMF_ERR_UNSUPPORTED = 8
+} snmf_status;
+
+/* sparsity argument forms of src/sparse_nmf.m:150-155 */
+typedef enum snmf_sparsity_kind {
+    SNMF_SPARSITY_SCALAR = 0, /* length(p.sparsity)==1 -> ones(r,n)*s   (:151-152) */
+    SNMF_SPARSITY_RVEC = 1,   /* r x 1 column -> repmat(.,1,n)         (:153-154) */
+    SNMF_SPARSITY_FULL = 2    /* r x n given in full                    (:155)     */
+} snmf_sparsity_kind;
+
+/* Solver parameters = the fields of `p` the reference reads (src/sparse_nmf.m:79-164). */
+typedef struct snmf_params {
+    int32_t F;          /* rows of v       (m, :71) */
+    int32_t T;          /* columns of v    (n, :72) */
+    int32_t r;          /* rank            (:116-131) */
+    double beta;        /* divergence order after the cf switch (:99-110): is=0, kl=1, ed=2 */
+    int32_t max_iter;   /* :79-81, default 100 */
+    double conv_eps;    /* :91-93, default 0 */
+    int32_t cost_check; /* :260 (no default in the reference; the wrappers enforce presence) */
+    int32_t floor_v;    /* 1: v = max(v,1e-9) as sparse_nmf.m:169; 0: sparse_nmf_GPU.m (absent) */
+    int32_t sparsity_kind;     /* snmf_sparsity_kind */
+    double sparsity_scalar;    /* used when kind == SCALAR */
+    const uint8_t* w_update_ind; /* r flags or NULL = all true (:142-144) */
+    const uint8_t* h_update_ind; /* r flags or NULL = all true (:146-148) */
+} snmf_params;
+
+typedef struct snmf_ctx snmf_ctx;   /* device + stream + kernel configuration */
+typedef struct snmf_plan snmf_plan; /* one problem resident in HBM: V, W, H, workspaces */
+
+/* ---- library ---------------------------------------------------------------------------- */
+int snmf_abi_version(void);
+const char* snmf_last_error(void);
+int snmf_device_count(void); /* number of HIP devices visible, 0 if none (never fails) */
+
+/* ---- context ---------------------------------------------------------------------------- */
+/* Replaces the implicit gpuArray device state of src/sparse_nmf_GPU.m:161-166. */
+int snmf_ctx_create(snmf_ctx** out, int device);
+/* Use a caller-owned hipStream_t (e.g. torch's current stream); NULL = context's own stream. */
+int snmf_ctx_set_stream(snmf_ctx* ctx, void* hip_stream);
+int snmf_ctx_sync(snmf_ctx* ctx);
+void snmf_ctx_destroy(snmf_ctx* ctx);
+
+/* ---- one-shot drop-in ------------------------------------------------------------------- */
+/* [w,h,objective] = sparse_nmf(v,p) with explicit initial factors (the MATLAB wrapper draws
+ * them with MATLAB's own RNG, src/sparse_nmf.m:112-140, so RNG parity is by construction).
+ *   V      F x T  (ldV >= F), never modified                       (:71-72, :169)
+ *   W      F x r  in: init_w (:116-131)   out: w, unit-L2 columns  (:242)
+ *   H      r x T  in: init_h (:133-140)   out: h
+ *   sparsity: NULL for SCALAR, r doubles for RVEC, r x T doubles for FULL (:150-155)
+ *   div_out, cost_out: max_iter doubles each, zero-filled then objective.div/.cost (:171-173,
+ *                      :263-264); may be NULL
+ *   n_iter_out: number of iterations executed = length of the truncated vectors (:279-280)
+ */
+int snmf_sparse_nmf_f64(snmf_ctx* ctx, const snmf_params* p, const double* V, int64_t ldV,
+                        double* W, double* H, const double* sparsity, double* div_out,
+                        double* cost_out, int32_t* n_iter_out);
+int snmf_sparse_nmf_f32(snmf_ctx* ctx, const snmf_params* p, const float* V, int64_t ldV,
+                        float* W, float* H, const float* sparsity, double* div_out,
+                        double* cost_out, int32_t* n_iter_out);
+
+/* ---- resident-plan API (benchmarks, on-device pipelines, multi-GPU sharding) -------------- */
+/* A plan owns fp32 device copies of V (F x T), W (F x r), H (r x T) in the engine's padded
+ * layouts plus all workspaces.  Call order: create -> set_v/set_w/set_h[/set_sparsity] ->
+ * init -> run (or the step functions) -> get_*.  `p->T` is the LOCAL column count of this
+ * shard when the frame axis is sharded across ranks. */
+int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan** out);
+void snmf_plan_destroy(snmf_plan* plan);
+
+/* is_device != 0: pointer is device memory on the context's device (fp32/fp64 as named). */
+int snmf_plan_set_v_f64(snmf_plan* plan, const double* V, int64_t ld, int is_device);
+int snmf_plan_set_v_f32(snmf_plan* plan, const float* V, int64_t ld, int is_device);
+int snmf_plan_set_w_f64(snmf_plan* plan, const double* W, int64_t ld, int is_device);
+int snmf_plan_set_w_f32(snmf_plan* plan, const float* W, int64_t ld, int is_device);
+int snmf_plan_set_h_f64(snmf_plan* plan, const double* H, int64_t ld, int is_device);
+int snmf_plan_set_h_f32(snmf_plan* plan, const float* H, int64_t ld, int is_device);
+/* RVEC: r values; FULL: r x T (ld = r).  SCALAR needs no call. */
+int snmf_plan_set_sparsity_f64(snmf_plan* plan, const double* S, int is_device);
+int snmf_plan_set_sparsity_f32(snmf_plan* plan, const float* S, int is_device);
+
+/* src/sparse_nmf.m:157-169: normalise W columns, rescale H rows, floor V; resets the iteration
+ * counter and the objective history.  `wnorm_dev` (optional, r doubles, DEVICE) overrides the
+ * locally computed column norms -- unused for frame sharding (W is replicated) and kept for
+ * symmetry. */
+int snmf_plan_init(snmf_plan* plan);
+
+/* The hot loop src/sparse_nmf.m:186-286: up to `n_iters` more iterations (bounded by
+ * max_iter), early stop per :273-282 evaluated on the device.  Asynchronous on the context's
+ * stream unless conv_eps > 0 (then it synchronises every few iterations to read the stop flag).
+ * iters_done (optional) receives the total iterations executed so far (after a sync). */
+int snmf_plan_run(snmf_plan* plan, int32_t n_iters, int32_t* iters_done);
+
+/* Step functions for frame-sharded multi-GPU training; one iteration is
+ *     hstep -> wstats(stats) -> [all-reduce(sum) of stats across ranks] -> wapply(stats)
+ * stats is a DEVICE buffer of snmf_plan_stats_len() doubles:
+ *     [ G or Q (F*r) | P (F*r, beta != 1 only) | s (r) | div | sum(S.*H) ]
+ * hstep  : src/sparse_nmf.m:189-208 on the local columns (no-op when no row of h is updated)
+ * wstats : the T-reductions of :215-239 (+ the objective sums of :248-261 for the PREVIOUS
+ *          iterate) over the local columns
+ * wapply : the F x r epilogue of :215-244 on the reduced statistics, the convergence test of
+ *          :272-284 on the reduced cost, identical on every rank.
+ * finalize: objective of the last iterate (needs one more local pass + all-reduce of the two
+ *          scalars): objstats -> [all-reduce] -> objapply. */
+int64_t snmf_plan_stats_len(const snmf_plan* plan);
+int snmf_plan_hstep(snmf_plan* plan);
+int snmf_plan_wstats(snmf_plan* plan, double* stats_dev);
+int snmf_plan_wapply(snmf_plan* plan, const double* stats_dev);
+int snmf_plan_objstats(snmf_plan* plan, double* stats_dev);
+int snmf_plan_objapply(snmf_plan* plan, const double* stats_dev);
+/* 1 when the device-side convergence test has fired (synchronises the stream). */
+int snmf_plan_stopped(snmf_plan* plan, int32_t* stopped);
+
+/* Results.  W: F x r, H: r x T(local).  Host or device destinations. */
+int snmf_plan_get_w_f64(snmf_plan* plan, double* W, int64_t ld, int is_device);
+int snmf_plan_get_w_f32(snmf_plan* plan, float* W, int64_t ld, int is_device);
+int snmf_plan_get_h_f64(snmf_plan* plan, double* H, int64_t ld, int is_device);
+int snmf_plan_get_h_f32(snmf_plan* plan, float* H, int64_t ld, int is_device);
+/* objective.div / objective.cost (src/sparse_nmf.m:263-264,:279-280): writes n_iter entries
+ * of each (arrays must hold max_iter doubles; the tail is zero-filled). */
+int snmf_plan_get_objective(snmf_plan* plan, double* div_out, double* cost_out,
+                            int32_t* n_iter_out);
+
+/* ---- instrumentation (bench.py: HIP-event timing on the engine's own stream) ------------ */
+/* Average device time in milliseconds per launch of the named kernel family over the launches
+ * recorded since snmf_ctx_timing(ctx, 1) was switched on.  Families: "hstep", "wstats",
+ * "wapply", "reduce".  Timing inserts hipEvents around each launch (off by default). */
+int snmf_ctx_timing(snmf_ctx* ctx, int enable);
+int snmf_ctx_timing_get(snmf_ctx* ctx, const char* family, double* avg_ms, int64_t* launches);
+/* Kernel geometry chosen for a plan, for DESIGN.md / profiles bookkeeping. */
+int snmf_plan_describe(const snmf_plan* plan, char* buf, size_t buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNMF_H_ */

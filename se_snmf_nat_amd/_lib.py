@@ -1,0 +1,136 @@
+"""ctypes binding of libsnmf_hip.so (the C ABI in include/snmf.h).
+
+This is the Python analogue of the MEX shim in integration/sparse_nmf_mex.cpp: plain pointers
+and sizes across the boundary, no torch types.  There is no CPU fallback: if the shared library
+is missing the import of the compute entry points fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libsnmf_hip.so")
+SRC = [os.path.join(_HERE, "csrc", "snmf_api.hip")]
+HDRS = [os.path.join(_HERE, "csrc", "snmf_kernels.h"), os.path.join(_ROOT, "include", "snmf.h")]
+
+# every symbol include/snmf.h declares
+SYMBOLS = [
+    "snmf_abi_version", "snmf_last_error", "snmf_device_count",
+    "snmf_ctx_create", "snmf_ctx_set_stream", "snmf_ctx_sync", "snmf_ctx_destroy",
+    "snmf_sparse_nmf_f64", "snmf_sparse_nmf_f32",
+    "snmf_plan_create", "snmf_plan_destroy",
+    "snmf_plan_set_v_f64", "snmf_plan_set_v_f32", "snmf_plan_set_w_f64", "snmf_plan_set_w_f32",
+    "snmf_plan_set_h_f64", "snmf_plan_set_h_f32", "snmf_plan_set_sparsity_f64", "snmf_plan_set_sparsity_f32",
+    "snmf_plan_init", "snmf_plan_run", "snmf_plan_stats_len",
+    "snmf_plan_hstep", "snmf_plan_wstats", "snmf_plan_wapply", "snmf_plan_objstats", "snmf_plan_objapply",
+    "snmf_plan_stopped",
+    "snmf_plan_get_w_f64", "snmf_plan_get_w_f32", "snmf_plan_get_h_f64", "snmf_plan_get_h_f32",
+    "snmf_plan_get_objective",
+    "snmf_ctx_timing", "snmf_ctx_timing_get", "snmf_plan_describe",
+]
+
+SNMF_OK = 0
+STATUS_NAMES = {
+    0: "SNMF_OK", 1: "SNMF_ERR_INVALID", 2: "SNMF_ERR_NO_INIT", 3: "SNMF_ERR_DIM", 4: "SNMF_ERR_NO_FIELD",
+    5: "SNMF_ERR_NO_DEVICE", 6: "SNMF_ERR_NOMEM", 7: "SNMF_ERR_STATE", 8: "SNMF_ERR_UNSUPPORTED",
+}
+
+
+class SnmfParams(C.Structure):
+    _fields_ = [
+        ("F", C.c_int32), ("T", C.c_int32), ("r", C.c_int32),
+        ("beta", C.c_double), ("max_iter", C.c_int32), ("conv_eps", C.c_double),
+        ("cost_check", C.c_int32), ("floor_v", C.c_int32),
+        ("sparsity_kind", C.c_int32), ("sparsity_scalar", C.c_double),
+        ("w_update_ind", C.c_void_p), ("h_update_ind", C.c_void_p),
+    ]
+
+
+class SnmfError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+        self.message = message
+
+
+def build(force=False, verbose=False):
+    """Compile libsnmf_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if not force and os.path.exists(LIB_PATH):
+        newest = max(os.path.getmtime(p) for p in SRC + HDRS)
+        if os.path.getmtime(LIB_PATH) >= newest:
+            return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           "-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_HERE, "csrc"),
+           "-o", LIB_PATH] + SRC
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (building nothing).  Raises if it is missing: no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  The engine has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    PP = C.POINTER(SnmfParams)
+    sig = {
+        "snmf_abi_version": (C.c_int, []),
+        "snmf_last_error": (C.c_char_p, []),
+        "snmf_device_count": (C.c_int, []),
+        "snmf_ctx_create": (C.c_int, [C.POINTER(vp), C.c_int]),
+        "snmf_ctx_set_stream": (C.c_int, [vp, vp]),
+        "snmf_ctx_sync": (C.c_int, [vp]),
+        "snmf_ctx_destroy": (None, [vp]),
+        "snmf_sparse_nmf_f64": (C.c_int, [vp, PP, vp, i64, vp, vp, vp, vp, vp, C.POINTER(i32)]),
+        "snmf_sparse_nmf_f32": (C.c_int, [vp, PP, vp, i64, vp, vp, vp, vp, vp, C.POINTER(i32)]),
+        "snmf_plan_create": (C.c_int, [vp, PP, C.POINTER(vp)]),
+        "snmf_plan_destroy": (None, [vp]),
+        "snmf_plan_init": (C.c_int, [vp]),
+        "snmf_plan_run": (C.c_int, [vp, i32, C.POINTER(i32)]),
+        "snmf_plan_stats_len": (i64, [vp]),
+        "snmf_plan_hstep": (C.c_int, [vp]),
+        "snmf_plan_wstats": (C.c_int, [vp, vp]),
+        "snmf_plan_wapply": (C.c_int, [vp, vp]),
+        "snmf_plan_objstats": (C.c_int, [vp, vp]),
+        "snmf_plan_objapply": (C.c_int, [vp, vp]),
+        "snmf_plan_stopped": (C.c_int, [vp, C.POINTER(i32)]),
+        "snmf_plan_get_objective": (C.c_int, [vp, vp, vp, C.POINTER(i32)]),
+        "snmf_ctx_timing": (C.c_int, [vp, C.c_int]),
+        "snmf_ctx_timing_get": (C.c_int, [vp, C.c_char_p, C.POINTER(dbl), C.POINTER(i64)]),
+        "snmf_plan_describe": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
+    }
+    for nm in ("v", "w", "h"):
+        for ty in ("f64", "f32"):
+            sig[f"snmf_plan_set_{nm}_{ty}"] = (C.c_int, [vp, vp, i64, C.c_int])
+    for nm in ("w", "h"):
+        for ty in ("f64", "f32"):
+            sig[f"snmf_plan_get_{nm}_{ty}"] = (C.c_int, [vp, vp, i64, C.c_int])
+    for ty in ("f64", "f32"):
+        sig[f"snmf_plan_set_sparsity_{ty}"] = (C.c_int, [vp, vp, C.c_int])
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != SNMF_OK:
+        msg = load().snmf_last_error()
+        raise SnmfError(status, msg.decode() if msg else "")

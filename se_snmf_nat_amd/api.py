@@ -1,0 +1,372 @@
+"""Host-side mirror of the reference solver interface, on top of the C ABI (include/snmf.h).
+
+    w, h, objective = sparse_nmf(v, p)          <->  src/sparse_nmf.m:1
+    w, h, objective = sparse_nmf_GPU(v, p)      <->  src/sparse_nmf_GPU.m:1
+    B_hat, A_hat    = run_basis_dnmf(Y, X, D, B, R_x, R_d, p)   <->  run_basis_DNMF.m:36-55
+
+Same field names, argument meaning, defaults and error behaviour as the MATLAB functions.  All
+arithmetic of the solve happens in libsnmf_hip.so on the GPU; this module only does what the
+MATLAB wrapper (integration/sparse_nmf.m) does: defaulting (src/sparse_nmf.m:75-164), the random
+initial factors (:112-140) and marshalling.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import SnmfError, SnmfParams
+
+__all__ = ["Context", "Plan", "sparse_nmf", "sparse_nmf_GPU", "run_basis_dnmf", "SnmfError", "default_context"]
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class Context:
+    """snmf_ctx: one HIP device + stream (replaces the gpuArray state of sparse_nmf_GPU.m:161-166)."""
+
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._lib.snmf_ctx_create(C.byref(h), int(device)))
+        self._h = h
+        self.device = int(device)
+
+    def set_stream(self, hip_stream_ptr):
+        _lib.check(self._lib.snmf_ctx_set_stream(self._h, C.c_void_p(hip_stream_ptr or 0)))
+
+    def sync(self):
+        _lib.check(self._lib.snmf_ctx_sync(self._h))
+
+    def timing(self, enable):
+        _lib.check(self._lib.snmf_ctx_timing(self._h, 1 if enable else 0))
+
+    def timing_get(self, family):
+        ms, n = C.c_double(), C.c_int64()
+        _lib.check(self._lib.snmf_ctx_timing_get(self._h, family.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.snmf_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+def _cf_to_beta(p):
+    # src/sparse_nmf.m:95-110
+    cf = p.get("cf", "kl")
+    if cf == "is":
+        return 0.0
+    if cf == "kl":
+        return 1.0
+    if cf == "ed":
+        return 2.0
+    return float(p.get("beta", 1.0))
+
+
+def _mask(p, key, r):
+    m = p.get(key, None)
+    if m is None:
+        return np.ones(r, np.uint8)  # :142-148
+    m = np.ascontiguousarray(np.asarray(m).reshape(-1) != 0, dtype=np.uint8)
+    if m.size != r:
+        raise SnmfError(3, f"{key} must have r = {r} entries (got {m.size})")
+    return m
+
+
+def _make_params(F, T, r, beta, max_iter, conv_eps, cost_check, floor_v, kind, scalar, w_ind, h_ind):
+    sp = SnmfParams()
+    sp.F, sp.T, sp.r = int(F), int(T), int(r)
+    sp.beta = float(beta)
+    sp.max_iter = int(max_iter)
+    sp.conv_eps = float(conv_eps)
+    sp.cost_check = int(bool(cost_check))
+    sp.floor_v = int(bool(floor_v))
+    sp.sparsity_kind = int(kind)
+    sp.sparsity_scalar = float(scalar)
+    sp.w_update_ind = C.c_void_p(w_ind.ctypes.data) if w_ind is not None else None
+    sp.h_update_ind = C.c_void_p(h_ind.ctypes.data) if h_ind is not None else None
+    return sp
+
+
+def _sparsity_form(sparsity, r, n, dtype):
+    """src/sparse_nmf.m:150-155 -> (kind, scalar, array-or-None)."""
+    sp = np.asarray(sparsity, dtype=dtype)
+    if sp.size == 1:
+        return 0, float(sp.reshape(-1)[0]), None
+    if sp.ndim == 1 or (sp.ndim == 2 and sp.shape[1] == 1):
+        if sp.size != r:
+            raise SnmfError(3, f"sparsity column has {sp.size} rows, h has {r}")
+        return 1, 0.0, np.ascontiguousarray(sp.reshape(-1))
+    if sp.shape != (r, n):
+        raise SnmfError(3, f"sparsity matrix is {sp.shape}, h is ({r}, {n})")
+    return 2, 0.0, np.asfortranarray(sp)
+
+
+def _solve(v, p, *, gpu_variant, ctx, dtype, rng):
+    p = dict(p or {})
+    dt = np.dtype(dtype)
+    if dt not in (np.dtype(np.float64), np.dtype(np.float32)):
+        raise SnmfError(1, "dtype must be float64 or float32")
+    v = np.asarray(v)
+    if v.ndim != 2:
+        raise SnmfError(1, "v must be a 2-D matrix")
+    m, n = v.shape  # :71-72
+    max_iter = int(p.get("max_iter", 100))  # :79-81
+    random_seed = p.get("random_seed", 1)  # :83-85
+    sparsity = p.get("sparsity", 0)  # :87-89
+    conv_eps = float(p.get("conv_eps", 0))  # :91-93
+    beta = _cf_to_beta(p)
+    if rng is None:  # :112-114 (numpy stand-in for MATLAB's legacy generator)
+        rng = np.random.RandomState(int(random_seed) if random_seed and random_seed > 0 else None)
+
+    # :116-131
+    if p.get("init_w", None) is None:
+        if p.get("r", None) is None:
+            raise SnmfError(2, "Number of components or initialization must be given")
+        r = int(p["r"])
+        w0 = rng.random_sample((m, r))
+    else:
+        iw = np.asarray(p["init_w"], dtype=np.float64)
+        if iw.ndim != 2 or iw.shape[0] != m:
+            raise SnmfError(3, f"init_w is {iw.shape}, v has {m} rows")
+        ri = iw.shape[1]
+        if p.get("r", None) is not None and ri < int(p["r"]):
+            r = int(p["r"])
+            w0 = np.concatenate([iw, rng.random_sample((m, r - ri))], axis=1)
+        else:
+            r = ri
+            w0 = iw
+    # :133-140
+    ih = p.get("init_h", None)
+    if ih is None:
+        h0 = rng.random_sample((r, n))
+    elif isinstance(ih, str) and ih == "ones":
+        h0 = np.ones((r, n))
+    else:
+        h0 = np.asarray(ih, dtype=np.float64)
+        if h0.shape != (r, n):
+            raise SnmfError(3, f"init_h is {h0.shape}, expected ({r}, {n})")
+
+    w_ind = _mask(p, "w_update_ind", r)
+    h_ind = _mask(p, "h_update_ind", r)
+    kind, scalar, sarr = _sparsity_form(sparsity, r, n, dt)
+
+    if gpu_variant:
+        cost_check = 1  # sparse_nmf_GPU.m:261-277: cost and convergence test unconditional
+    else:
+        if "cost_check" not in p:  # src/sparse_nmf.m:260
+            raise SnmfError(4, "Reference to non-existent field 'cost_check'.")
+        cost_check = 1 if p["cost_check"] else 0
+
+    sp = _make_params(m, n, r, beta, max_iter, conv_eps, cost_check, not gpu_variant, kind, scalar, w_ind, h_ind)
+    vv = np.asfortranarray(v, dtype=dt)
+    W = np.asfortranarray(w0, dtype=dt).copy(order="F")
+    H = np.asfortranarray(h0, dtype=dt).copy(order="F")
+    div = np.zeros(max(max_iter, 1))
+    cost = np.zeros(max(max_iter, 1))
+    n_iter = C.c_int32(0)
+    lib = _lib.load()
+    ctx = ctx or default_context()
+    fn = lib.snmf_sparse_nmf_f64 if dt == np.float64 else lib.snmf_sparse_nmf_f32
+    _lib.check(fn(ctx._h, C.byref(sp), _ptr(vv), vv.strides[1] // dt.itemsize if n > 1 else m, _ptr(W), _ptr(H),
+                  _ptr(sarr) if sarr is not None else None, _ptr(div), _ptr(cost), C.byref(n_iter)))
+    ni = n_iter.value
+    if gpu_variant:
+        # sparse_nmf_GPU.m:263-264 never fills the vectors: zeros(1, max_iter) are returned
+        objective = {"div": np.zeros(max_iter), "cost": np.zeros(max_iter), "n_iter": ni}
+    elif cost_check:
+        # :279-280 truncate to 1:it on convergence; otherwise full length
+        stopped = ni < max_iter
+        objective = {"div": div[:ni].copy() if stopped else div[:max_iter].copy(),
+                     "cost": cost[:ni].copy() if stopped else cost[:max_iter].copy(), "n_iter": ni}
+    else:
+        objective = {"div": np.zeros(max_iter), "cost": np.zeros(max_iter), "n_iter": ni}
+    return W, H, objective
+
+
+def sparse_nmf(v, p=None, *, ctx=None, dtype=np.float64, rng=None):
+    """[w, h, objective] = sparse_nmf(v, p) -- drop-in for src/sparse_nmf.m on the MI355X.
+
+    `dtype` selects the host-buffer type handed over the C ABI (the device arithmetic is fp32
+    MFMA + fp64 objective either way)."""
+    return _solve(v, p, gpu_variant=False, ctx=ctx, dtype=dtype, rng=rng)
+
+
+def sparse_nmf_GPU(v, p=None, *, ctx=None, dtype=np.float64, rng=None):
+    """Drop-in for src/sparse_nmf_GPU.m (its deltas: no V floor, objective vectors left zero,
+    cost_check ignored)."""
+    return _solve(v, p, gpu_variant=True, ctx=ctx, dtype=dtype, rng=rng)
+
+
+def run_basis_dnmf(Y, X, D, B, R_x, R_d, p, *, ctx=None, dtype=np.float64):
+    """The 3-solve discriminative re-training loop of run_basis_DNMF.m:36-55 on formed features.
+
+    Y, X, D are the F x T features of mixture / clean / noise (run_basis_DNMF.m:13-34); B is the
+    F x (R_x+R_d) exemplar basis.  Returns (B_hat, A_hat)."""
+    p = dict(p)
+    B = np.asarray(B, dtype=np.float64)
+    p["w_update_ind"] = np.zeros(R_x + R_d, bool)  # :37
+    p["h_update_ind"] = np.ones(R_x + R_d, bool)  # :38
+    p["init_w"] = B  # :39
+    p.pop("init_h", None)
+    _, A_hat, _ = sparse_nmf(Y, p, ctx=ctx, dtype=dtype)  # :40
+    p["w_update_ind"] = np.ones(R_x, bool)  # :43
+    p["h_update_ind"] = np.zeros(R_x, bool)  # :44
+    p["init_w"] = B[:, :R_x]  # :45
+    p["init_h"] = A_hat[:R_x, :]  # :46
+    B_hat_x, _, _ = sparse_nmf(X, p, ctx=ctx, dtype=dtype)  # :47
+    p["w_update_ind"] = np.ones(R_d, bool)  # :49
+    p["h_update_ind"] = np.zeros(R_d, bool)  # :50
+    p["init_w"] = B[:, R_x:R_x + R_d]  # :51
+    p["init_h"] = A_hat[R_x:R_x + R_d, :]  # :52
+    B_hat_d, _, _ = sparse_nmf(D, p, ctx=ctx, dtype=dtype)  # :53
+    return np.concatenate([B_hat_x, B_hat_d], axis=1), A_hat  # :55
+
+
+class Plan:
+    """snmf_plan: a problem resident in HBM (V, W, H + workspaces).  Arrays may be numpy (host)
+    or anything exposing ``data_ptr()``/``dtype`` on the context's device (torch tensors)."""
+
+    def __init__(self, ctx, F, T, r, *, beta=1.0, max_iter=100, conv_eps=0.0, cost_check=True, floor_v=True,
+                 sparsity=0.0, w_update_ind=None, h_update_ind=None):
+        self.ctx = ctx
+        self._lib = _lib.load()
+        self.F, self.T, self.r, self.max_iter = int(F), int(T), int(r), int(max_iter)
+        self._w_ind = None if w_update_ind is None else np.ascontiguousarray(np.asarray(w_update_ind) != 0, np.uint8)
+        self._h_ind = None if h_update_ind is None else np.ascontiguousarray(np.asarray(h_update_ind) != 0, np.uint8)
+        self._sarr = None
+        if np.ndim(sparsity) == 0:
+            kind, scalar = 0, float(sparsity)
+        else:
+            kind, scalar, self._sarr = _sparsity_form(sparsity, r, T, np.float64)
+        sp = _make_params(F, T, r, beta, max_iter, conv_eps, cost_check, floor_v, kind, scalar, self._w_ind,
+                          self._h_ind)
+        h = C.c_void_p()
+        _lib.check(self._lib.snmf_plan_create(ctx._h, C.byref(sp), C.byref(h)))
+        self._h = h
+        if self._sarr is not None:
+            _lib.check(self._lib.snmf_plan_set_sparsity_f64(self._h, _ptr(self._sarr), 0))
+
+    # -- data ---------------------------------------------------------------------------------
+    def _set(self, name, a, rows):
+        if hasattr(a, "data_ptr"):  # device tensor, column-major expected: shape (cols, rows) contiguous
+            import torch
+            if a.dtype == torch.float32:
+                ty = "f32"
+            elif a.dtype == torch.float64:
+                ty = "f64"
+            else:
+                raise SnmfError(1, "device tensors must be float32 or float64")
+            if a.dim() != 2 or not a.is_contiguous() or a.shape[1] != rows:
+                raise SnmfError(1, f"device tensor for {name} must be contiguous with shape (cols, {rows}) "
+                                   "(= column-major rows x cols)")
+            fn = getattr(self._lib, f"snmf_plan_set_{name}_{ty}")
+            _lib.check(fn(self._h, C.c_void_p(a.data_ptr()), rows, 1))
+            return
+        a = np.asarray(a)
+        if a.dtype != np.float32:
+            a = a.astype(np.float64, copy=False)
+        a = np.asfortranarray(a)
+        ty = "f32" if a.dtype == np.float32 else "f64"
+        fn = getattr(self._lib, f"snmf_plan_set_{name}_{ty}")
+        _lib.check(fn(self._h, _ptr(a), a.shape[0], 0))
+
+    def set_v(self, v):
+        self._set("v", v, self.F)
+
+    def set_w(self, w):
+        self._set("w", w, self.F)
+
+    def set_h(self, h):
+        self._set("h", h, self.r)
+
+    def init(self):
+        _lib.check(self._lib.snmf_plan_init(self._h))
+
+    def run(self, n_iters=None):
+        done = C.c_int32()
+        _lib.check(self._lib.snmf_plan_run(self._h, self.max_iter if n_iters is None else int(n_iters),
+                                           C.byref(done)))
+        return done.value
+
+    def run_async(self, n_iters):
+        _lib.check(self._lib.snmf_plan_run(self._h, int(n_iters), None))
+
+    # -- step API (frame-sharded multi-GPU) ---------------------------------------------------
+    def stats_len(self):
+        return int(self._lib.snmf_plan_stats_len(self._h))
+
+    def hstep(self):
+        _lib.check(self._lib.snmf_plan_hstep(self._h))
+
+    def wstats(self, stats_ptr):
+        _lib.check(self._lib.snmf_plan_wstats(self._h, C.c_void_p(stats_ptr)))
+
+    def wapply(self, stats_ptr):
+        _lib.check(self._lib.snmf_plan_wapply(self._h, C.c_void_p(stats_ptr)))
+
+    def objstats(self, stats_ptr):
+        _lib.check(self._lib.snmf_plan_objstats(self._h, C.c_void_p(stats_ptr)))
+
+    def objapply(self, stats_ptr):
+        _lib.check(self._lib.snmf_plan_objapply(self._h, C.c_void_p(stats_ptr)))
+
+    def stopped(self):
+        s = C.c_int32()
+        _lib.check(self._lib.snmf_plan_stopped(self._h, C.byref(s)))
+        return bool(s.value)
+
+    # -- results ------------------------------------------------------------------------------
+    def get_w(self, dtype=np.float64):
+        out = np.empty((self.F, self.r), dtype=dtype, order="F")
+        fn = self._lib.snmf_plan_get_w_f64 if out.dtype == np.float64 else self._lib.snmf_plan_get_w_f32
+        _lib.check(fn(self._h, _ptr(out), self.F, 0))
+        return out
+
+    def get_h(self, dtype=np.float64):
+        out = np.empty((self.r, self.T), dtype=dtype, order="F")
+        fn = self._lib.snmf_plan_get_h_f64 if out.dtype == np.float64 else self._lib.snmf_plan_get_h_f32
+        _lib.check(fn(self._h, _ptr(out), self.r, 0))
+        return out
+
+    def get_objective(self):
+        div = np.zeros(max(self.max_iter, 1))
+        cost = np.zeros(max(self.max_iter, 1))
+        n = C.c_int32()
+        _lib.check(self._lib.snmf_plan_get_objective(self._h, _ptr(div), _ptr(cost), C.byref(n)))
+        return div[:self.max_iter], cost[:self.max_iter], n.value
+
+    def describe(self):
+        buf = C.create_string_buffer(1024)
+        _lib.check(self._lib.snmf_plan_describe(self._h, buf, 1024))
+        return buf.value.decode()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.snmf_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

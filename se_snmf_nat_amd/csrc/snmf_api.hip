@@ -1,0 +1,968 @@
+// snmf_api.hip -- host side of libsnmf_hip.so: the C ABI declared in include/snmf.h.
+//
+// Orchestrates the kernels of snmf_kernels.h into the loop of the reference solver
+// (lordet01/SE_SNMF_NAT src/sparse_nmf.m:157-292).  No CPU compute fallback exists here: every
+// numeric step is a HIP kernel launch; without a device the entry points fail.
+#include "snmf_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "snmf.h"
+
+using namespace snmf;
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? SNMF_ERR_NOMEM : SNMF_ERR_NO_DEVICE, "%s: %s", \
+                        #expr, hipGetErrorString(e_));                                             \
+    } while (0)
+#define SN_TRY(expr)              \
+    do {                          \
+        int s_ = (expr);          \
+        if (s_ != SNMF_OK) return s_; \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------
+struct TimerPair {
+    hipEvent_t a, b;
+    int fam;
+};
+enum { FAM_HSTEP = 0, FAM_WSTATS, FAM_WAPPLY, FAM_REDUCE, FAM_N };
+static const char* kFamNames[FAM_N] = {"hstep", "wstats", "wapply", "reduce"};
+
+struct snmf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int n_cu = 256;
+    size_t lds_max = 160 * 1024;
+    bool timing = false;
+    std::vector<TimerPair> pending;
+    double fam_ms[FAM_N] = {0, 0, 0, 0};
+    int64_t fam_n[FAM_N] = {0, 0, 0, 0};
+};
+
+struct ScopedTimer {
+    snmf_ctx* c;
+    TimerPair tp;
+    bool on;
+    ScopedTimer(snmf_ctx* c_, int fam) : c(c_), on(c_->timing) {
+        if (on) {
+            tp.fam = fam;
+            hipEventCreate(&tp.a);
+            hipEventCreate(&tp.b);
+            hipEventRecord(tp.a, c->stream);
+        }
+    }
+    ~ScopedTimer() {
+        if (on) {
+            hipEventRecord(tp.b, c->stream);
+            c->pending.push_back(tp);
+        }
+    }
+};
+
+static void drain_timers(snmf_ctx* c) {
+    if (c->pending.empty()) return;
+    hipStreamSynchronize(c->stream);
+    for (auto& tp : c->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, tp.a, tp.b) == hipSuccess) {
+            c->fam_ms[tp.fam] += ms;
+            c->fam_n[tp.fam] += 1;
+        }
+        hipEventDestroy(tp.a);
+        hipEventDestroy(tp.b);
+    }
+    c->pending.clear();
+}
+
+extern "C" int snmf_abi_version(void) { return SNMF_ABI_VERSION; }
+extern "C" const char* snmf_last_error(void) { return g_err.c_str(); }
+extern "C" int snmf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int snmf_ctx_create(snmf_ctx** out, int device) {
+    if (!out) return fail(SNMF_ERR_INVALID, "snmf_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(SNMF_ERR_NO_DEVICE, "no HIP device available (the engine has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(SNMF_ERR_INVALID, "device %d out of range [0,%d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    snmf_ctx* c = new snmf_ctx();
+    c->device = device;
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->lds_max = prop.sharedMemPerBlock > 0 ? (size_t)prop.sharedMemPerBlock : 64 * 1024;
+    {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && v > 0)
+            c->lds_max = std::max(c->lds_max, (size_t)v);
+    }
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(SNMF_ERR_NO_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    c->own_stream = true;
+    *out = c;
+    return SNMF_OK;
+}
+
+extern "C" int snmf_ctx_set_stream(snmf_ctx* c, void* s) {
+    if (!c) return fail(SNMF_ERR_INVALID, "ctx is NULL");
+    drain_timers(c);
+    if (c->own_stream && c->stream) {
+        hipStreamSynchronize(c->stream);
+        hipStreamDestroy(c->stream);
+    }
+    if (s) {
+        c->stream = (hipStream_t)s;
+        c->own_stream = false;
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    return SNMF_OK;
+}
+
+extern "C" int snmf_ctx_sync(snmf_ctx* c) {
+    if (!c) return fail(SNMF_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SNMF_OK;
+}
+
+extern "C" void snmf_ctx_destroy(snmf_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    drain_timers(c);
+    if (c->own_stream && c->stream) {
+        hipStreamSynchronize(c->stream);
+        hipStreamDestroy(c->stream);
+    }
+    delete c;
+}
+
+extern "C" int snmf_ctx_timing(snmf_ctx* c, int enable) {
+    if (!c) return fail(SNMF_ERR_INVALID, "ctx is NULL");
+    drain_timers(c);
+    c->timing = enable != 0;
+    if (enable) {
+        for (int i = 0; i < FAM_N; ++i) {
+            c->fam_ms[i] = 0;
+            c->fam_n[i] = 0;
+        }
+    }
+    return SNMF_OK;
+}
+
+extern "C" int snmf_ctx_timing_get(snmf_ctx* c, const char* family, double* avg_ms, int64_t* launches) {
+    if (!c || !family) return fail(SNMF_ERR_INVALID, "NULL argument");
+    drain_timers(c);
+    for (int i = 0; i < FAM_N; ++i) {
+        if (!strcmp(family, kFamNames[i])) {
+            if (avg_ms) *avg_ms = c->fam_n[i] ? c->fam_ms[i] / (double)c->fam_n[i] : 0.0;
+            if (launches) *launches = c->fam_n[i];
+            return SNMF_OK;
+        }
+    }
+    return fail(SNMF_ERR_INVALID, "unknown kernel family '%s'", family);
+}
+
+// ------------------------------------------------------------------------------------------
+// plan
+// ------------------------------------------------------------------------------------------
+struct snmf_plan {
+    snmf_ctx* ctx = nullptr;
+    snmf_params p{};
+    // geometry
+    int Fp = 0, rp = 0, Tp = 0, nf = 0, nk = 0;
+    int NT = 1;            // k_hstep frame tile = 32*NT
+    int NKT = 8, NWB = 8;  // k_wstats template geometry
+    int n_fg = 1, n_kg = 1, n_chunks = 1;
+    int grid_h = 1;
+    int ldh = 0, ldr = 0;
+    size_t lds_h = 0, lds_w = 0;
+    int bm = BM_KL;
+    int n_mat = 1;
+    bool upd_h = true, upd_w = true;
+    // device buffers
+    float *V = nullptr, *H[2] = {nullptr, nullptr}, *Wc = nullptr, *Wt4 = nullptr, *Wk4 = nullptr;
+    float *dphv = nullptr, *colsum = nullptr, *lamk = nullptr, *S = nullptr;
+    float *slabs = nullptr, *spart = nullptr;
+    double *part = nullptr, *stats = nullptr, *divh = nullptr, *costh = nullptr, *wn = nullptr;
+    DevState* st = nullptr;
+    uint8_t* w_ind = nullptr;
+    void* staging = nullptr;
+    size_t staging_bytes = 0;
+    int n_part = 0;
+    // state
+    bool have_v = false, have_w = false, have_h = false, have_s = false, inited = false;
+    int cur = 0;          // H[cur] holds the current iterate
+    int it_done = 0;      // update iterations launched
+    bool final_done = false;
+    double sh_const = 0.0;
+    std::vector<uint8_t> h_w_ind;
+};
+
+static size_t roundup(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+template <typename T>
+static int dalloc(T** p, size_t n) {
+    *p = nullptr;
+    hipError_t e = hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T));
+    if (e != hipSuccess) return fail(SNMF_ERR_NOMEM, "hipMalloc(%zu bytes): %s", n * sizeof(T), hipGetErrorString(e));
+    return SNMF_OK;
+}
+
+static int validate_params(const snmf_params* p) {
+    if (!p) return fail(SNMF_ERR_INVALID, "params is NULL");
+    if (p->F <= 0 || p->T <= 0) return fail(SNMF_ERR_INVALID, "F and T must be positive (F=%d, T=%d)", p->F, p->T);
+    if (p->r <= 0) return fail(SNMF_ERR_NO_INIT, "Number of components or initialization must be given");
+    if (p->max_iter < 0) return fail(SNMF_ERR_INVALID, "max_iter must be >= 0");
+    if (!(p->beta == p->beta)) return fail(SNMF_ERR_INVALID, "beta is NaN");
+    if (p->sparsity_kind < 0 || p->sparsity_kind > 2) return fail(SNMF_ERR_INVALID, "bad sparsity_kind");
+    if (p->cost_check != 0 && p->cost_check != 1)
+        return fail(SNMF_ERR_NO_FIELD, "cost_check must be given as 0 or 1 (src/sparse_nmf.m:260 has no default)");
+    return SNMF_OK;
+}
+
+extern "C" void snmf_plan_destroy(snmf_plan* pl) {
+    if (!pl) return;
+    hipSetDevice(pl->ctx->device);
+    hipStreamSynchronize(pl->ctx->stream);
+    void* ptrs[] = {pl->V,     pl->H[0],  pl->H[1], pl->Wc,   pl->Wt4,   pl->Wk4,  pl->dphv, pl->colsum, pl->lamk,
+                    pl->S,     pl->slabs, pl->spart, pl->part, pl->stats, pl->divh, pl->costh, pl->wn,    pl->st,
+                    pl->w_ind, pl->staging};
+    for (void* q : ptrs)
+        if (q) hipFree(q);
+    delete pl;
+}
+
+extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan** out) {
+    if (!ctx || !out) return fail(SNMF_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    SN_TRY(validate_params(p));
+    HIP_TRY(hipSetDevice(ctx->device));
+    snmf_plan* pl = new snmf_plan();
+    pl->ctx = ctx;
+    pl->p = *p;
+    pl->p.w_update_ind = nullptr;
+    pl->p.h_update_ind = nullptr;
+    const int F = p->F, T = p->T, r = p->r;
+    // masks (src/sparse_nmf.m:142-148, :176-179)
+    int n_h = 0, n_w = 0;
+    pl->h_w_ind.assign(r, 1);
+    for (int k = 0; k < r; ++k) {
+        const bool hk = p->h_update_ind ? p->h_update_ind[k] != 0 : true;
+        const bool wk = p->w_update_ind ? p->w_update_ind[k] != 0 : true;
+        n_h += hk;
+        n_w += wk;
+        pl->h_w_ind[k] = wk;
+    }
+    if (n_h != 0 && n_h != r) {
+        delete pl;
+        // bsxfun(@plus, sum(w(:,h_ind))', p.sparsity) with sum(h_ind) ~= r rows: MATLAB size error
+        return fail(SNMF_ERR_DIM,
+                    "partial h_update_ind (%d of %d rows): dimension mismatch in src/sparse_nmf.m:192/197/202", n_h, r);
+    }
+    pl->upd_h = n_h > 0;
+    pl->upd_w = n_w > 0;
+    pl->bm = (p->beta == 1.0) ? BM_KL : (p->beta == 2.0 ? BM_EUC : BM_GEN);
+    pl->n_mat = pl->bm == BM_KL ? 1 : 2;
+
+    pl->Fp = (int)roundup(F, 32);
+    pl->rp = (int)roundup(r, 32);
+    pl->Tp = (int)roundup(T, 64);
+    pl->nf = pl->Fp / 32;
+    pl->nk = pl->rp / 32;
+    pl->ldh = pl->rp + 4;
+    pl->ldr = pl->Fp + 4;
+    // k_hstep: widest frame tile whose H image + ratio image fit the LDS
+    const size_t per_col = (size_t)(pl->ldh + pl->ldr) * 4;
+    const size_t lds_cap = 160 * 1024;  // gfx950: 160 KiB per CU, one workgroup may take all of it
+    if (64 * per_col <= lds_cap && pl->Tp / 64 >= ctx->n_cu) pl->NT = 2;
+    else if (32 * per_col <= lds_cap) pl->NT = 1;
+    else {
+        delete pl;
+        return fail(SNMF_ERR_UNSUPPORTED, "F + r = %d too large for the %zu-byte LDS tile (limit F+r <= %zu)", F + r,
+                    lds_cap, lds_cap / 128 - 8);
+    }
+    pl->lds_h = std::max<size_t>((size_t)32 * pl->NT * per_col, 2 * kNW * 64 * sizeof(double));
+    const int n_tiles_h = pl->Tp / (32 * pl->NT);
+    const int wg_per_cu = pl->lds_h * 2 <= lds_cap ? 2 : 1;
+    pl->grid_h = std::max(1, std::min(n_tiles_h, ctx->n_cu * wg_per_cu));
+    // k_wstats geometry
+    if (pl->nk <= 4) { pl->NKT = 4; pl->NWB = 8; }
+    else if (pl->nk <= 8) { pl->NKT = 8; pl->NWB = 8; }
+    else { pl->NKT = 16; pl->NWB = 4; }
+    pl->n_kg = (pl->nk + pl->NKT - 1) / pl->NKT;
+    pl->n_fg = (pl->nf + pl->NWB - 1) / pl->NWB;
+    if (pl->rp > 2 * pl->NWB * 64 * 1 && pl->n_kg == 1) { /* unreachable: NKT=16 -> rp<=512=2*4*64 */ }
+    const int n_tiles_w = pl->Tp / 32;
+    pl->n_chunks = std::max(1, std::min(n_tiles_w, ctx->n_cu / std::max(1, pl->n_fg * pl->n_kg)));
+    pl->lds_w = std::max<size_t>((size_t)32 * pl->ldh * 4, (size_t)pl->NWB * 64 * sizeof(double));
+    if (pl->lds_w > lds_cap) {
+        delete pl;
+        return fail(SNMF_ERR_UNSUPPORTED, "r = %d too large for the LDS H tile", r);
+    }
+    if (pl->rp > 2 * pl->NWB * 64 && pl->upd_w && pl->bm == BM_KL) {
+        delete pl;
+        return fail(SNMF_ERR_UNSUPPORTED, "r = %d > %d not supported for KL W updates yet", r, 2 * pl->NWB * 64);
+    }
+
+    // allocations
+    const size_t nV = (size_t)pl->Fp * pl->Tp, nH = (size_t)pl->rp * pl->Tp, nW = (size_t)pl->Fp * pl->rp;
+    int s = SNMF_OK;
+    auto A = [&](int st) { if (s == SNMF_OK) s = st; };
+    A(dalloc(&pl->V, nV));
+    A(dalloc(&pl->H[0], nH));
+    A(dalloc(&pl->H[1], nH));
+    A(dalloc(&pl->Wc, nW));
+    A(dalloc(&pl->Wt4, nW));
+    A(dalloc(&pl->Wk4, nW));
+    A(dalloc(&pl->dphv, (size_t)pl->rp));
+    A(dalloc(&pl->colsum, (size_t)pl->rp));
+    A(dalloc(&pl->lamk, (size_t)pl->rp));
+    if (p->sparsity_kind == SNMF_SPARSITY_FULL) A(dalloc(&pl->S, nH));
+    if (pl->upd_w) {
+        A(dalloc(&pl->slabs, (size_t)pl->n_chunks * pl->n_mat * nW));
+        A(dalloc(&pl->spart, (size_t)pl->n_chunks * pl->rp));
+    }
+    pl->n_part = std::max(pl->grid_h, pl->n_chunks * pl->n_fg);
+    pl->n_part = std::max(pl->n_part, 1024);
+    A(dalloc(&pl->part, (size_t)2 * pl->n_part));
+    A(dalloc(&pl->stats, (size_t)pl->n_mat * nW + pl->rp + 2));
+    A(dalloc(&pl->divh, (size_t)std::max(1, p->max_iter)));
+    A(dalloc(&pl->costh, (size_t)std::max(1, p->max_iter)));
+    A(dalloc(&pl->wn, (size_t)pl->rp));
+    A(dalloc(&pl->st, (size_t)1));
+    A(dalloc(&pl->w_ind, (size_t)pl->rp));
+    if (s != SNMF_OK) {
+        snmf_plan_destroy(pl);
+        return s;
+    }
+    hipStream_t st = ctx->stream;
+    hipMemsetAsync(pl->Wc, 0, nW * 4, st);
+    hipMemsetAsync(pl->Wt4, 0, nW * 4, st);
+    hipMemsetAsync(pl->Wk4, 0, nW * 4, st);
+    hipMemsetAsync(pl->H[0], 0, nH * 4, st);
+    hipMemsetAsync(pl->H[1], 0, nH * 4, st);
+    hipMemsetAsync(pl->colsum, 0, pl->rp * 4, st);
+    hipMemsetAsync(pl->stats, 0, ((size_t)pl->n_mat * nW + pl->rp + 2) * 8, st);
+    hipMemsetAsync(pl->w_ind, 0, pl->rp, st);
+    hipMemcpyAsync(pl->w_ind, pl->h_w_ind.data(), r, hipMemcpyHostToDevice, st);
+    {
+        std::vector<float> lk(pl->rp, 0.f);
+        if (p->sparsity_kind == SNMF_SPARSITY_SCALAR)
+            for (int k = 0; k < r; ++k) lk[k] = (float)p->sparsity_scalar;
+        hipMemcpyAsync(pl->lamk, lk.data(), pl->rp * 4, hipMemcpyHostToDevice, st);
+        // pad rows of H divide by dphv: keep it positive there (0 * acc / 1 = 0, never 0/0)
+        std::vector<float> ones(pl->rp, 1.f);
+        hipMemcpyAsync(pl->dphv, ones.data(), pl->rp * 4, hipMemcpyHostToDevice, st);
+        hipStreamSynchronize(st);
+    }
+    pl->have_s = p->sparsity_kind == SNMF_SPARSITY_SCALAR;
+    *out = pl;
+    return SNMF_OK;
+}
+
+extern "C" int64_t snmf_plan_stats_len(const snmf_plan* pl) {
+    if (!pl) return 0;
+    return (int64_t)pl->n_mat * pl->Fp * pl->rp + pl->rp + 2;
+}
+
+extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
+    if (!pl || !buf) return fail(SNMF_ERR_INVALID, "NULL argument");
+    snprintf(buf, n,
+             "F=%d T=%d r=%d beta=%g | Fp=%d rp=%d Tp=%d | hstep: tile=%d frames, grid=%d x %d thr, lds=%zu B | "
+             "wstats: NK=%d waves=%d grid=(%d chunks,%d fgroups,%d kgroups) lds=%zu B | n_cu=%d",
+             pl->p.F, pl->p.T, pl->p.r, pl->p.beta, pl->Fp, pl->rp, pl->Tp, 32 * pl->NT, pl->grid_h, kNW * 64,
+             pl->lds_h, pl->NKT, pl->NWB, pl->n_chunks, pl->n_fg, pl->n_kg, pl->lds_w, pl->ctx->n_cu);
+    return SNMF_OK;
+}
+
+// ---- data movement ---------------------------------------------------------------------------
+static int ensure_staging(snmf_plan* pl, size_t bytes) {
+    if (pl->staging_bytes >= bytes) return SNMF_OK;
+    if (pl->staging) {
+        hipStreamSynchronize(pl->ctx->stream);
+        hipFree(pl->staging);
+        pl->staging = nullptr;
+        pl->staging_bytes = 0;
+    }
+    hipError_t e = hipMalloc(&pl->staging, bytes);
+    if (e != hipSuccess) return fail(SNMF_ERR_NOMEM, "hipMalloc(staging %zu): %s", bytes, hipGetErrorString(e));
+    pl->staging_bytes = bytes;
+    return SNMF_OK;
+}
+
+static int grid_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 4096); }
+
+template <typename TIn>
+static int pack_in(snmf_plan* pl, const TIn* src, int64_t ld, int rows, int cols, float* dst, int rowsP, int colsP,
+                   bool do_floor, int is_device) {
+    if (!src) return fail(SNMF_ERR_INVALID, "source pointer is NULL");
+    if (ld < rows) return fail(SNMF_ERR_INVALID, "leading dimension %lld < rows %d", (long long)ld, rows);
+    HIP_TRY(hipSetDevice(pl->ctx->device));
+    hipStream_t st = pl->ctx->stream;
+    const TIn* dsrc = src;
+    if (!is_device) {
+        const size_t bytes = ((size_t)(cols - 1) * ld + rows) * sizeof(TIn);
+        SN_TRY(ensure_staging(pl, bytes));
+        HIP_TRY(hipMemcpyAsync(pl->staging, src, bytes, hipMemcpyHostToDevice, st));
+        dsrc = (const TIn*)pl->staging;
+    }
+    const size_t n = (size_t)rowsP * colsP;
+    hipLaunchKernelGGL(k_pack<TIn>, dim3(grid_for(n)), dim3(256), 0, st, dsrc, ld, rows, cols, dst, rowsP, colsP, kFlr,
+                       do_floor ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    if (!is_device) HIP_TRY(hipStreamSynchronize(st));  // staging / host buffer reusable on return
+    return SNMF_OK;
+}
+
+template <typename TOut>
+static int unpack_out(snmf_plan* pl, const float* src, int rowsP, int rows, int cols, TOut* dst, int64_t ld,
+                      int is_device) {
+    if (!dst) return fail(SNMF_ERR_INVALID, "destination pointer is NULL");
+    if (ld < rows) return fail(SNMF_ERR_INVALID, "leading dimension %lld < rows %d", (long long)ld, rows);
+    HIP_TRY(hipSetDevice(pl->ctx->device));
+    hipStream_t st = pl->ctx->stream;
+    const size_t n = (size_t)rows * cols;
+    if (is_device) {
+        hipLaunchKernelGGL(k_unpack<TOut>, dim3(grid_for(n)), dim3(256), 0, st, src, rowsP, rows, cols, dst, ld);
+        HIP_TRY(hipGetLastError());
+        return SNMF_OK;
+    }
+    SN_TRY(ensure_staging(pl, n * sizeof(TOut)));
+    hipLaunchKernelGGL(k_unpack<TOut>, dim3(grid_for(n)), dim3(256), 0, st, src, rowsP, rows, cols,
+                       (TOut*)pl->staging, (int64_t)rows);
+    HIP_TRY(hipGetLastError());
+    if (ld == rows) {
+        HIP_TRY(hipMemcpyAsync(dst, pl->staging, n * sizeof(TOut), hipMemcpyDeviceToHost, st));
+    } else {
+        HIP_TRY(hipMemcpy2DAsync(dst, ld * sizeof(TOut), pl->staging, rows * sizeof(TOut), rows * sizeof(TOut), cols,
+                                 hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return SNMF_OK;
+}
+
+#define PLAN_CHECK(pl) \
+    if (!(pl)) return fail(SNMF_ERR_INVALID, "plan is NULL")
+
+template <typename T>
+static int set_v(snmf_plan* pl, const T* V, int64_t ld, int dev) {
+    PLAN_CHECK(pl);
+    SN_TRY(pack_in<T>(pl, V, ld, pl->p.F, pl->p.T, pl->V, pl->Fp, pl->Tp, pl->p.floor_v != 0, dev));
+    pl->have_v = true;
+    return SNMF_OK;
+}
+template <typename T>
+static int set_w(snmf_plan* pl, const T* W, int64_t ld, int dev) {
+    PLAN_CHECK(pl);
+    SN_TRY(pack_in<T>(pl, W, ld, pl->p.F, pl->p.r, pl->Wc, pl->Fp, pl->rp, false, dev));
+    pl->have_w = true;
+    pl->inited = false;
+    return SNMF_OK;
+}
+template <typename T>
+static int set_h(snmf_plan* pl, const T* H, int64_t ld, int dev) {
+    PLAN_CHECK(pl);
+    SN_TRY(pack_in<T>(pl, H, ld, pl->p.r, pl->p.T, pl->H[0], pl->rp, pl->Tp, false, dev));
+    pl->have_h = true;
+    pl->inited = false;
+    pl->cur = 0;
+    return SNMF_OK;
+}
+template <typename T>
+static int set_s(snmf_plan* pl, const T* S, int dev) {
+    PLAN_CHECK(pl);
+    if (pl->p.sparsity_kind == SNMF_SPARSITY_SCALAR) return fail(SNMF_ERR_STATE, "plan has scalar sparsity");
+    if (pl->p.sparsity_kind == SNMF_SPARSITY_RVEC)
+        SN_TRY(pack_in<T>(pl, S, pl->p.r, pl->p.r, 1, pl->lamk, pl->rp, 1, false, dev));
+    else
+        SN_TRY(pack_in<T>(pl, S, pl->p.r, pl->p.r, pl->p.T, pl->S, pl->rp, pl->Tp, false, dev));
+    pl->have_s = true;
+    pl->inited = false;
+    return SNMF_OK;
+}
+
+extern "C" int snmf_plan_set_v_f64(snmf_plan* pl, const double* V, int64_t ld, int d) { return set_v(pl, V, ld, d); }
+extern "C" int snmf_plan_set_v_f32(snmf_plan* pl, const float* V, int64_t ld, int d) { return set_v(pl, V, ld, d); }
+extern "C" int snmf_plan_set_w_f64(snmf_plan* pl, const double* W, int64_t ld, int d) { return set_w(pl, W, ld, d); }
+extern "C" int snmf_plan_set_w_f32(snmf_plan* pl, const float* W, int64_t ld, int d) { return set_w(pl, W, ld, d); }
+extern "C" int snmf_plan_set_h_f64(snmf_plan* pl, const double* H, int64_t ld, int d) { return set_h(pl, H, ld, d); }
+extern "C" int snmf_plan_set_h_f32(snmf_plan* pl, const float* H, int64_t ld, int d) { return set_h(pl, H, ld, d); }
+extern "C" int snmf_plan_set_sparsity_f64(snmf_plan* pl, const double* S, int d) { return set_s(pl, S, d); }
+extern "C" int snmf_plan_set_sparsity_f32(snmf_plan* pl, const float* S, int d) { return set_s(pl, S, d); }
+
+extern "C" int snmf_plan_get_w_f64(snmf_plan* pl, double* W, int64_t ld, int d) {
+    PLAN_CHECK(pl);
+    return unpack_out<double>(pl, pl->Wc, pl->Fp, pl->p.F, pl->p.r, W, ld, d);
+}
+extern "C" int snmf_plan_get_w_f32(snmf_plan* pl, float* W, int64_t ld, int d) {
+    PLAN_CHECK(pl);
+    return unpack_out<float>(pl, pl->Wc, pl->Fp, pl->p.F, pl->p.r, W, ld, d);
+}
+
+// ---- launch helpers --------------------------------------------------------------------------
+static StepArgs make_args(snmf_plan* pl) {
+    StepArgs a{};
+    a.V = pl->V;
+    a.Hin = pl->H[pl->cur];
+    a.Hout = pl->H[pl->cur ^ 1];
+    a.Wt4 = pl->Wt4;
+    a.Wk4 = pl->Wk4;
+    a.dphv = pl->dphv;
+    a.colsum = pl->colsum;
+    a.lamk = pl->lamk;
+    a.S = pl->S;
+    a.slabs = pl->slabs;
+    a.spart = pl->spart;
+    a.part = pl->part;
+    a.stop = &pl->st->stop;
+    a.F = pl->p.F;
+    a.T = pl->p.T;
+    a.Fp = pl->Fp;
+    a.rp = pl->rp;
+    a.Tp = pl->Tp;
+    a.nf = pl->nf;
+    a.nk = pl->nk;
+    a.ldh = pl->ldh;
+    a.ldr = pl->ldr;
+    a.beta = (float)pl->p.beta;
+    const double bb1 = pl->p.beta * (pl->p.beta - 1.0);
+    a.inv_bb1 = bb1 != 0.0 ? (float)(1.0 / bb1) : 0.f;
+    return a;
+}
+
+template <typename K>
+static int launch_big(K kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, StepArgs a) {
+    static std::map<const void*, size_t> attr_set;
+    const void* key = (const void*)kern;
+    auto it = attr_set.find(key);
+    if (lds > 64 * 1024 && (it == attr_set.end() || it->second < lds)) {
+        HIP_TRY(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[key] = lds;
+    }
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return SNMF_OK;
+}
+
+// k_hstep dispatch over (NT, BM, OBJ, UPD)
+template <int NT, int BM>
+static int launch_hstep_nb(snmf_plan* pl, const StepArgs& a, bool obj, bool upd) {
+    dim3 g(pl->grid_h), b(kNW * 64);
+    hipStream_t st = pl->ctx->stream;
+    if (obj && upd) return launch_big(k_hstep<NT, BM, true, true>, g, b, pl->lds_h, st, a);
+    if (!obj && upd) return launch_big(k_hstep<NT, BM, false, true>, g, b, pl->lds_h, st, a);
+    if (obj && !upd) return launch_big(k_hstep<NT, BM, true, false>, g, b, pl->lds_h, st, a);
+    return SNMF_OK;
+}
+static int launch_hstep(snmf_plan* pl, bool obj, bool upd) {
+    StepArgs a = make_args(pl);
+    a.n_tiles = pl->Tp / (32 * pl->NT);
+    ScopedTimer tm(pl->ctx, FAM_HSTEP);
+    if (pl->NT == 2) {
+        if (pl->bm == BM_KL) return launch_hstep_nb<2, BM_KL>(pl, a, obj, upd);
+        if (pl->bm == BM_EUC) return launch_hstep_nb<2, BM_EUC>(pl, a, obj, upd);
+        return launch_hstep_nb<2, BM_GEN>(pl, a, obj, upd);
+    }
+    if (pl->bm == BM_KL) return launch_hstep_nb<1, BM_KL>(pl, a, obj, upd);
+    if (pl->bm == BM_EUC) return launch_hstep_nb<1, BM_EUC>(pl, a, obj, upd);
+    return launch_hstep_nb<1, BM_GEN>(pl, a, obj, upd);
+}
+
+// k_wstats dispatch
+template <int NK, int NWB, int WM, int BM, bool OBJ>
+static int launch_wstats_one(snmf_plan* pl, const StepArgs& a, int mat_index) {
+    dim3 g(pl->n_chunks, pl->n_fg, pl->n_kg), b(NWB * 64);
+    static std::map<const void*, size_t> attr_set;
+    auto kern = k_wstats<NK, NWB, WM, BM, OBJ>;
+    const void* key = (const void*)kern;
+    if (pl->lds_w > 64 * 1024 && attr_set[key] < pl->lds_w) {
+        HIP_TRY(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_w));
+        attr_set[key] = pl->lds_w;
+    }
+    hipLaunchKernelGGL(kern, g, b, pl->lds_w, pl->ctx->stream, a, pl->n_chunks, mat_index, pl->n_mat);
+    HIP_TRY(hipGetLastError());
+    return SNMF_OK;
+}
+template <int NK, int NWB>
+static int launch_wstats_geo(snmf_plan* pl, const StepArgs& a, bool obj) {
+    if (pl->bm == BM_KL) {
+        return obj ? launch_wstats_one<NK, NWB, 0, BM_KL, true>(pl, a, 0)
+                   : launch_wstats_one<NK, NWB, 0, BM_KL, false>(pl, a, 0);
+    }
+    if (pl->bm == BM_EUC) {
+        SN_TRY(obj ? (launch_wstats_one<NK, NWB, 1, BM_EUC, true>(pl, a, 1))
+                   : (launch_wstats_one<NK, NWB, 1, BM_EUC, false>(pl, a, 1)));
+        return launch_wstats_one<NK, NWB, 3, BM_EUC, false>(pl, a, 0);
+    }
+    SN_TRY(obj ? (launch_wstats_one<NK, NWB, 1, BM_GEN, true>(pl, a, 1))
+               : (launch_wstats_one<NK, NWB, 1, BM_GEN, false>(pl, a, 1)));
+    return launch_wstats_one<NK, NWB, 2, BM_GEN, false>(pl, a, 0);
+}
+static int launch_wstats(snmf_plan* pl, bool obj) {
+    StepArgs a = make_args(pl);
+    a.n_tiles = pl->Tp / 32;
+    ScopedTimer tm(pl->ctx, FAM_WSTATS);
+    if (pl->NKT == 4) return launch_wstats_geo<4, 8>(pl, a, obj);
+    if (pl->NKT == 8) return launch_wstats_geo<8, 8>(pl, a, obj);
+    return launch_wstats_geo<16, 4>(pl, a, obj);
+}
+
+static int launch_reduce(snmf_plan* pl, double* stats, bool do_mats, bool do_obj, int n_part, bool sh_const) {
+    ReduceArgs ra{};
+    ra.slabs = pl->slabs;
+    ra.spart = pl->spart;
+    ra.part = pl->part;
+    ra.stats = stats;
+    ra.stop = &pl->st->stop;
+    ra.n_chunks = pl->n_chunks;
+    ra.n_mat = pl->n_mat;
+    ra.n_part = n_part;
+    ra.rp = pl->rp;
+    ra.Fp = pl->Fp;
+    ra.do_mats = do_mats;
+    ra.do_obj = do_obj;
+    ra.sh_const = pl->sh_const;
+    ra.use_sh_const = sh_const;
+    const size_t tot = do_mats ? (size_t)pl->n_mat * pl->rp * pl->Fp + pl->rp : 1;
+    ScopedTimer tm(pl->ctx, FAM_REDUCE);
+    hipLaunchKernelGGL(k_reduce, dim3((int)std::min<size_t>((tot + 255) / 256, 2048)), dim3(256), 0, pl->ctx->stream,
+                       ra);
+    HIP_TRY(hipGetLastError());
+    return SNMF_OK;
+}
+
+static int launch_wapply(snmf_plan* pl, const double* stats, int check_it, bool do_update, bool init_mode) {
+    ApplyArgs aa{};
+    aa.stats = stats;
+    aa.Wc = pl->Wc;
+    aa.Wt4 = pl->Wt4;
+    aa.Wk4 = pl->Wk4;
+    aa.dphv = pl->dphv;
+    aa.colsum = pl->colsum;
+    aa.lamk = pl->lamk;
+    aa.w_ind = pl->w_ind;
+    aa.divh = pl->divh;
+    aa.costh = pl->costh;
+    aa.st = pl->st;
+    aa.F = pl->p.F;
+    aa.r = pl->p.r;
+    aa.Fp = pl->Fp;
+    aa.rp = pl->rp;
+    aa.n_mat = pl->n_mat;
+    aa.check_it = check_it;
+    aa.do_update = do_update;
+    aa.init_mode = init_mode;
+    aa.conv_eps = pl->p.conv_eps;
+    aa.wn = pl->wn;
+    ScopedTimer tm(pl->ctx, FAM_WAPPLY);
+    hipLaunchKernelGGL(k_wapply, dim3(pl->p.r), dim3(256), 0, pl->ctx->stream, aa);
+    HIP_TRY(hipGetLastError());
+    return SNMF_OK;
+}
+
+static int launch_check(snmf_plan* pl, const double* stats, int it) {
+    const size_t off = (size_t)pl->n_mat * pl->rp * pl->Fp + pl->rp;
+    hipLaunchKernelGGL(k_check, dim3(1), dim3(64), 0, pl->ctx->stream, stats, off, pl->divh, pl->costh, pl->st, it,
+                       pl->p.conv_eps);
+    HIP_TRY(hipGetLastError());
+    return SNMF_OK;
+}
+
+// ---- init: src/sparse_nmf.m:157-173 ----------------------------------------------------------
+extern "C" int snmf_plan_init(snmf_plan* pl) {
+    PLAN_CHECK(pl);
+    if (!pl->have_v || !pl->have_w || !pl->have_h) return fail(SNMF_ERR_STATE, "set_v, set_w and set_h must precede init");
+    if (!pl->have_s) return fail(SNMF_ERR_STATE, "set_sparsity must precede init for this sparsity kind");
+    HIP_TRY(hipSetDevice(pl->ctx->device));
+    hipStream_t st = pl->ctx->stream;
+    HIP_TRY(hipMemsetAsync(pl->st, 0, sizeof(DevState), st));
+    HIP_TRY(hipMemsetAsync(pl->divh, 0, sizeof(double) * std::max(1, pl->p.max_iter), st));
+    HIP_TRY(hipMemsetAsync(pl->costh, 0, sizeof(double) * std::max(1, pl->p.max_iter), st));
+    // wn = sqrt(sum(w.^2)); w = w./wn  (+ operand images, colsum, dphv)
+    SN_TRY(launch_wapply(pl, pl->stats, 0, false, true));
+    // h = h .* wn'
+    const size_t nH = (size_t)pl->rp * pl->Tp;
+    hipLaunchKernelGGL(k_scale_h, dim3(grid_for(nH)), dim3(256), 0, st, pl->H[pl->cur], pl->wn, pl->rp, pl->p.r, nH);
+    HIP_TRY(hipGetLastError());
+    pl->it_done = 0;
+    pl->final_done = false;
+    pl->inited = true;
+    pl->sh_const = 0.0;
+    if (!pl->upd_h && pl->p.cost_check) {
+        // H never changes: sum(sum(sparsity .* h)) (:261) is a constant of the solve
+        const int g = 256;
+        hipLaunchKernelGGL(k_sum_sh, dim3(g), dim3(256), 0, st, pl->H[pl->cur], pl->S, pl->lamk, pl->rp, pl->p.r,
+                           pl->p.T, pl->part);
+        HIP_TRY(hipGetLastError());
+        std::vector<double> hp(g);
+        HIP_TRY(hipMemcpyAsync(hp.data(), pl->part, g * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        double s = 0.0;
+        for (double x : hp) s += x;
+        pl->sh_const = s;
+    }
+    return SNMF_OK;
+}
+
+// ---- the iteration, split so that an all-reduce can sit between wstats and wapply ----------
+// Iteration j (1-based) = hstep(j) -> wstats(j) -> [reduce] -> wapply(j).  The objective of
+// iterate j-1 is produced by the first pass of iteration j that forms Lam = W_{j-1} * H_{j-1}.
+static bool want_obj(const snmf_plan* pl, int j) { return pl->p.cost_check && j > 1; }
+
+extern "C" int snmf_plan_hstep(snmf_plan* pl) {
+    PLAN_CHECK(pl);
+    if (!pl->inited) return fail(SNMF_ERR_STATE, "plan not initialised");
+    HIP_TRY(hipSetDevice(pl->ctx->device));
+    if (!pl->upd_h) return SNMF_OK;
+    const int j = pl->it_done + 1;
+    SN_TRY(launch_hstep(pl, want_obj(pl, j), true));
+    pl->cur ^= 1;
+    return SNMF_OK;
+}
+
+// after hstep(j): H[cur] = H_j.  NOTE: when the device-side stop flag is set the kernels are
+// no-ops and the H buffers keep H_{n_iter}; get_h accounts for that.
+extern "C" int snmf_plan_wstats(snmf_plan* pl, double* stats) {
+    PLAN_CHECK(pl);
+    if (!pl->inited) return fail(SNMF_ERR_STATE, "plan not initialised");
+    if (!stats) return fail(SNMF_ERR_INVALID, "stats is NULL");
+    HIP_TRY(hipSetDevice(pl->ctx->device));
+    const int j = pl->it_done + 1;
+    const bool obj = want_obj(pl, j);
+    if (pl->upd_w) {
+        // W-only mode: the divergence of iterate j-1 comes from this pass (Lam' = W_{j-1} * H)
+        SN_TRY(launch_wstats(pl, obj && !pl->upd_h));
+    }
+    const int n_part = pl->upd_h ? pl->grid_h : pl->n_chunks * pl->n_fg;
+    if (!pl->upd_h && !pl->upd_w && obj) {
+        // neither factor is updated: the loop only re-evaluates the objective
+        SN_TRY(launch_hstep(pl, true, false));
+        SN_TRY(launch_reduce(pl, stats, false, true, pl->grid_h, true));
+        return SNMF_OK;
+    }
+    SN_TRY(launch_reduce(pl, stats, pl->upd_w, obj, n_part, !pl->upd_h));
+    return SNMF_OK;
+}
+
+extern "C" int snmf_plan_wapply(snmf_plan* pl, const double* stats) {
+    PLAN_CHECK(pl);
+    if (!pl->inited) return fail(SNMF_ERR_STATE, "plan not initialised");
+    if (!stats) return fail(SNMF_ERR_INVALID, "stats is NULL");
+    HIP_TRY(hipSetDevice(pl->ctx->device));
+    const int j = pl->it_done + 1;
+    const bool obj = want_obj(pl, j);
+    if (pl->upd_w) SN_TRY(launch_wapply(pl, stats, obj ? j - 1 : 0, true, false));
+    else if (obj) SN_TRY(launch_check(pl, stats, j - 1));
+    pl->it_done = j;
+    return SNMF_OK;
+}
+
+extern "C" int snmf_plan_objstats(snmf_plan* pl, double* stats) {
+    PLAN_CHECK(pl);
+    if (!pl->inited) return fail(SNMF_ERR_STATE, "plan not initialised");
+    if (!stats) return fail(SNMF_ERR_INVALID, "stats is NULL");
+    HIP_TRY(hipSetDevice(pl->ctx->device));
+    SN_TRY(launch_hstep(pl, true, false));
+    // sum(S.*H) of the final iterate: the objective-only pass does not visit H's rows, so take it
+    // from a dedicated reduction over the current H.
+    const int g = 256;
+    hipLaunchKernelGGL(k_sum_sh, dim3(g), dim3(256), 0, pl->ctx->stream, pl->H[pl->cur], pl->S, pl->lamk, pl->rp,
+                       pl->p.r, pl->p.T, pl->part + 2 * (size_t)pl->grid_h);
+    HIP_TRY(hipGetLastError());
+    SN_TRY(launch_reduce(pl, stats, false, true, pl->grid_h, false));
+    const size_t off = (size_t)pl->n_mat * pl->rp * pl->Fp + pl->rp;
+    hipLaunchKernelGGL(k_fold_sh, dim3(1), dim3(64), 0, pl->ctx->stream, pl->part + 2 * (size_t)pl->grid_h, 256,
+                       stats + off, &pl->st->stop);
+    HIP_TRY(hipGetLastError());
+    return SNMF_OK;
+}
+
+extern "C" int snmf_plan_objapply(snmf_plan* pl, const double* stats) {
+    PLAN_CHECK(pl);
+    if (!pl->inited) return fail(SNMF_ERR_STATE, "plan not initialised");
+    HIP_TRY(hipSetDevice(pl->ctx->device));
+    if (pl->it_done < 1) return SNMF_OK;
+    SN_TRY(launch_check(pl, stats, pl->it_done));
+    pl->final_done = true;
+    return SNMF_OK;
+}
+
+static int read_state(snmf_plan* pl, DevState* hs) {
+    HIP_TRY(hipMemcpyAsync(hs, pl->st, sizeof(DevState), hipMemcpyDeviceToHost, pl->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(pl->ctx->stream));
+    return SNMF_OK;
+}
+
+extern "C" int snmf_plan_stopped(snmf_plan* pl, int32_t* stopped) {
+    PLAN_CHECK(pl);
+    DevState hs{};
+    SN_TRY(read_state(pl, &hs));
+    if (stopped) *stopped = hs.stop;
+    return SNMF_OK;
+}
+
+// final objective (iterate max_iter): objective-only pass + sum(S.*H) + check
+static int finalize_objective(snmf_plan* pl) {
+    if (pl->final_done || !pl->p.cost_check || pl->it_done < 1) return SNMF_OK;
+    SN_TRY(snmf_plan_objstats(pl, pl->stats));
+    return snmf_plan_objapply(pl, pl->stats);
+}
+
+extern "C" int snmf_plan_run(snmf_plan* pl, int32_t n_iters, int32_t* iters_done) {
+    PLAN_CHECK(pl);
+    if (!pl->inited) return fail(SNMF_ERR_STATE, "plan not initialised");
+    HIP_TRY(hipSetDevice(pl->ctx->device));
+    const int target = std::min(pl->p.max_iter, pl->it_done + std::max(0, n_iters));
+    const bool can_stop = pl->p.cost_check && pl->p.conv_eps > 0.0;
+    int since_poll = 0;
+    bool stopped = false;
+    while (pl->it_done < target) {
+        SN_TRY(snmf_plan_hstep(pl));
+        SN_TRY(snmf_plan_wstats(pl, pl->stats));
+        SN_TRY(snmf_plan_wapply(pl, pl->stats));
+        if (can_stop && ++since_poll >= 4) {
+            since_poll = 0;
+            DevState hs{};
+            SN_TRY(read_state(pl, &hs));
+            if (hs.stop) {
+                stopped = true;
+                break;
+            }
+        }
+    }
+    if (!stopped && pl->it_done >= pl->p.max_iter) SN_TRY(finalize_objective(pl));
+    if (iters_done) {
+        DevState hs{};
+        SN_TRY(read_state(pl, &hs));
+        *iters_done = hs.stop ? hs.n_iter : pl->it_done;
+    }
+    return SNMF_OK;
+}
+
+// Which H buffer holds the result?  Without a stop: H[cur].  With a stop recorded at iteration
+// n (detected while iteration n+1 was in flight): hstep(n+1) already wrote H_{n+1} into the
+// other buffer before the flag was raised, later launches were no-ops although the host kept
+// flipping `cur`; H_n is the buffer with index parity n (H_0 lives in buffer 0 after set_h).
+static int result_h_index(snmf_plan* pl, int* idx) {
+    DevState hs{};
+    SN_TRY(read_state(pl, &hs));
+    if (hs.stop && pl->upd_h) *idx = hs.n_iter & 1;
+    else *idx = pl->cur;
+    return SNMF_OK;
+}
+
+extern "C" int snmf_plan_get_h_f64(snmf_plan* pl, double* H, int64_t ld, int d) {
+    PLAN_CHECK(pl);
+    int idx = 0;
+    SN_TRY(result_h_index(pl, &idx));
+    return unpack_out<double>(pl, pl->H[idx], pl->rp, pl->p.r, pl->p.T, H, ld, d);
+}
+extern "C" int snmf_plan_get_h_f32(snmf_plan* pl, float* H, int64_t ld, int d) {
+    PLAN_CHECK(pl);
+    int idx = 0;
+    SN_TRY(result_h_index(pl, &idx));
+    return unpack_out<float>(pl, pl->H[idx], pl->rp, pl->p.r, pl->p.T, H, ld, d);
+}
+
+extern "C" int snmf_plan_get_objective(snmf_plan* pl, double* div_out, double* cost_out, int32_t* n_iter_out) {
+    PLAN_CHECK(pl);
+    HIP_TRY(hipSetDevice(pl->ctx->device));
+    DevState hs{};
+    SN_TRY(read_state(pl, &hs));
+    const int mi = pl->p.max_iter;
+    // iterations executed: the stop index (:279-281) or every launched iteration
+    const int n_exec = hs.stop ? hs.n_iter : pl->it_done;
+    if (n_iter_out) *n_iter_out = n_exec;
+    if (div_out) {
+        std::fill(div_out, div_out + mi, 0.0);
+        if (pl->p.cost_check && hs.n_iter > 0)
+            HIP_TRY(hipMemcpy(div_out, pl->divh, sizeof(double) * std::min(mi, hs.n_iter), hipMemcpyDeviceToHost));
+    }
+    if (cost_out) {
+        std::fill(cost_out, cost_out + mi, 0.0);
+        if (pl->p.cost_check && hs.n_iter > 0)
+            HIP_TRY(hipMemcpy(cost_out, pl->costh, sizeof(double) * std::min(mi, hs.n_iter), hipMemcpyDeviceToHost));
+    }
+    return SNMF_OK;
+}
+
+// ---- one-shot drop-in ------------------------------------------------------------------------
+template <typename T>
+static int sparse_nmf_impl(snmf_ctx* ctx, const snmf_params* p, const T* V, int64_t ldV, T* W, T* H,
+                           const T* sparsity, double* div_out, double* cost_out, int32_t* n_iter_out) {
+    if (!ctx) return fail(SNMF_ERR_INVALID, "ctx is NULL");
+    if (!V || !W || !H) return fail(SNMF_ERR_INVALID, "V, W and H must be non-NULL");
+    snmf_plan* pl = nullptr;
+    SN_TRY(snmf_plan_create(ctx, p, &pl));
+    int s = SNMF_OK;
+    auto step = [&](int st) { if (s == SNMF_OK) s = st; };
+    step(set_v<T>(pl, V, ldV, 0));
+    step(set_w<T>(pl, W, p->F, 0));
+    step(set_h<T>(pl, H, p->r, 0));
+    if (p->sparsity_kind != SNMF_SPARSITY_SCALAR) {
+        if (!sparsity) step(fail(SNMF_ERR_INVALID, "sparsity array required for this sparsity_kind"));
+        else step(set_s<T>(pl, sparsity, 0));
+    }
+    step(snmf_plan_init(pl));
+    if (s == SNMF_OK) step(snmf_plan_run(pl, p->max_iter, nullptr));
+    if (s == SNMF_OK) {
+        if (sizeof(T) == 8) {
+            step(snmf_plan_get_w_f64(pl, (double*)W, p->F, 0));
+            step(snmf_plan_get_h_f64(pl, (double*)H, p->r, 0));
+        } else {
+            step(snmf_plan_get_w_f32(pl, (float*)W, p->F, 0));
+            step(snmf_plan_get_h_f32(pl, (float*)H, p->r, 0));
+        }
+    }
+    if (s == SNMF_OK) step(snmf_plan_get_objective(pl, div_out, cost_out, n_iter_out));
+    snmf_plan_destroy(pl);
+    return s;
+}
+
+extern "C" int snmf_sparse_nmf_f64(snmf_ctx* ctx, const snmf_params* p, const double* V, int64_t ldV, double* W,
+                                   double* H, const double* sparsity, double* div_out, double* cost_out,
+                                   int32_t* n_iter_out) {
+    return sparse_nmf_impl<double>(ctx, p, V, ldV, W, H, sparsity, div_out, cost_out, n_iter_out);
+}
+extern "C" int snmf_sparse_nmf_f32(snmf_ctx* ctx, const snmf_params* p, const float* V, int64_t ldV, float* W,
+                                   float* H, const float* sparsity, double* div_out, double* cost_out,
+                                   int32_t* n_iter_out) {
+    return sparse_nmf_impl<float>(ctx, p, V, ldV, W, H, sparsity, div_out, cost_out, n_iter_out);
+}

@@ -1,0 +1,745 @@
+// snmf_kernels.h -- gfx950 (MI355X / CDNA4) device code of the sparse-NMF engine.
+//
+// Reference algorithm: lordet01/SE_SNMF_NAT  src/sparse_nmf.m:186-286 (multiplicative updates
+// of H and W for the beta-divergence with an L1 penalty on H, W kept column-normalised).
+//
+// Design: everything is built from fp32 MFMA 32x32x2 tiles
+// (v_mfma_f32_32x32x2_f32, exact f32, 64 cycles / SIMD).  A workgroup of NW waves owns a tile of
+// Tt = 32*NT spectrogram frames.  The chain of contractions of one half-iteration runs inside
+// ONE kernel, the F x Tt ratio tile lives only in LDS / registers and never goes to HBM:
+//
+//   k_hstep : Lam = W*H (P1) -> ratio tile in LDS -> W^T*ratio (P2) -> H <- H .* dmh ./ dph
+//             (+ the divergence / cost sums of the PREVIOUS iterate, which P1's Lam is)
+//   k_wstats: Lam'^T = H^T*W^T (P3) -> ratio in registers (already the A operand of) ->
+//             G += ratio * H^T (P4), accumulated in registers over the workgroup's whole frame
+//             chunk and written once as a split-T partial slab
+//   k_reduce: partial slabs + partial objective sums -> fp64 statistics (fixed order)
+//   k_wapply: F x r epilogue (dpw, dmw, update, column normalise) + convergence test
+//
+// MFMA 32x32x2 f32 operand map (lane l, fl = l&31, h = l>>5):
+//   A[i=fl][k=h], B[k=h][j=fl], D[row=(reg&3)+8*(reg>>2)+4*h][col=fl]  (reg in [0,16)).
+// The contraction index is visited in the permuted order k(q,h,e) = 8q+4h+e so that one 16-byte
+// read per lane feeds four MFMAs, and so that a D tile can be handed to the next product as an
+// operand without any lane movement (its row index IS that order).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace snmf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float kFlr = 1e-9f;  // src/sparse_nmf.m:166
+constexpr int kNW = 8;         // waves per workgroup in k_hstep (2 per SIMD)
+
+// beta modes (template parameter BM)
+constexpr int BM_GEN = 0;  // generic beta (incl. IS, beta = 0)
+constexpr int BM_KL = 1;   // beta == 1
+constexpr int BM_EUC = 2;  // beta == 2
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_pow(float x, float y) {
+    // x > 0 always here (clamped at 1e-9).  exp2(y*log2 x) on the transcendental unit.
+    return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+}
+__device__ __forceinline__ float fast_ln(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }
+
+// D-tile register -> row inside the 32-row tile
+__device__ __forceinline__ constexpr int drow(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// den = lam^(beta-1), and the map den -> lam^(beta-2) used to form num = v * lam^(beta-2)
+template <int BM>
+__device__ __forceinline__ float den_of_lam(float lam, float beta) {
+    if (BM == BM_EUC) return lam;
+    return fast_pow(lam, beta - 1.f);
+}
+template <int BM>
+__device__ __forceinline__ float numfac_of_lam(float lam, float beta) {
+    if (BM == BM_EUC) return 1.f;
+    return fast_pow(lam, beta - 2.f);
+}
+
+// one element of the divergence sum, src/sparse_nmf.m:248-258
+template <int BM>
+__device__ __forceinline__ float div_term(float v, float lam, float beta, float inv_bb1) {
+    if (BM == BM_KL) {
+        // v*log(v/lam) - v + lam
+        return v * (fast_ln(v * fast_rcp(lam)) - 1.f) + lam;
+    } else if (BM == BM_EUC) {
+        float d = v - lam;
+        return d * d;
+    } else {
+        if (beta == 0.f) {
+            float q = v * fast_rcp(lam);
+            return q - fast_ln(q) - 1.f;
+        }
+        float lb1 = fast_pow(lam, beta - 1.f);
+        return (fast_pow(v, beta) + (beta - 1.f) * lb1 * lam - beta * v * lb1) * inv_bb1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Arguments shared by the two big kernels.  Layouts (all fp32, zero padded):
+//   V   [Tp][Fp]            column-major F x T, Fp = 32*nf
+//   H   [Tp][rp]            column-major r x T, rp = 32*nk
+//   Wt4 [nf][rp/8][2][32][4] = W[32*phi+f][8q+4h+e]   (A operand of W*H, B operand of H^T*W^T)
+//   Wk4 [nk][Fp/8][2][32][4] = W[8q+4h+e][32*kap+k]   (A operand of W^T*ratio)
+// ------------------------------------------------------------------------------------------
+struct StepArgs {
+    const float* V;
+    const float* Hin;
+    float* Hout;
+    const float* Wt4;
+    const float* Wk4;
+    const float* dphv;    // KL, scalar/rvec sparsity: max(colsum(W)+lambda_k, flr)  [rp]
+    const float* colsum;  // KL, full sparsity: colsum(W) [rp]
+    const float* lamk;    // lambda_k [rp] (scalar/rvec kinds)
+    const float* S;       // full sparsity r x T in H layout, or nullptr
+    float* slabs;         // k_wstats: [n_chunks][n_mat][rp][Fp]
+    float* spart;         // k_wstats: [n_chunks][rp]  partial row sums of H
+    double* part;         // [grid][2] partial (div, sum S.*H)
+    const int* stop;      // device flag: convergence reached -> kernels become no-ops
+    int F, T, Fp, rp, Tp, nf, nk;
+    int n_tiles;          // tiles of this kernel's tile width
+    int ldh, ldr;         // LDS leading dimensions (floats)
+    float beta, inv_bb1;
+};
+
+// Cooperative copy of a [cols][rp] tile of H (contiguous in HBM) into the padded LDS image.
+template <int NTHREADS>
+__device__ __forceinline__ void stage_h_tile(const float* __restrict__ src, float* Hs, int cols, int rp, int ldh) {
+    const int n4 = cols * rp / 4;
+    const int rp4 = rp / 4;
+    for (int i = threadIdx.x; i < n4; i += NTHREADS) {
+        f32x4 x = *reinterpret_cast<const f32x4*>(src + 4 * (size_t)i);
+        int t = i / rp4, k4 = i - t * rp4;
+        *reinterpret_cast<f32x4*>(Hs + t * ldh + 4 * k4) = x;
+    }
+}
+
+// ============================================================================================
+// k_hstep: H half-step, src/sparse_nmf.m:189-208, fused with the objective of the previous
+// iterate (:248-261).  UPD=false gives the objective-only pass.
+// ============================================================================================
+template <int NT, int BM, bool OBJ, bool UPD>
+__global__ __launch_bounds__(kNW * 64, 2) void k_hstep(StepArgs a) {
+    if (a.stop && *a.stop) return;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int Tt = 32 * NT;
+    float* Hs = lds;                   // [Tt][ldh]
+    float* Rs = lds + Tt * a.ldh;      // [Tt][ldr]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int fl = lane & 31, h = lane >> 5;
+    const int rp = a.rp, Fp = a.Fp, ldh = a.ldh, ldr = a.ldr;
+    double acc_div = 0.0, acc_sh = 0.0;
+
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const int t0 = tile * Tt;
+        __syncthreads();  // previous tile's readers of Hs / Rs are done
+        stage_h_tile<kNW * 64>(a.Hin + (size_t)t0 * rp, Hs, Tt, rp, ldh);
+        __syncthreads();
+
+        // ---- P1: Lam[phi] = W[phi,:] * H[:, tile]  -> ratio / den image ----------------------
+        for (int phi = w; phi < a.nf; phi += kNW) {
+            f32x16 acc[NT];
+#pragma unroll
+            for (int tau = 0; tau < NT; ++tau) acc[tau] = zero16();
+            const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)phi * rp * 32) + lane;
+            const float* hs = Hs + fl * ldh + 4 * h;
+            const int nq = rp / 8;
+            f32x4 wa = wp[0];
+            for (int q = 0; q < nq; ++q) {
+                f32x4 wn = wp[(q + 1 < nq ? q + 1 : q) * 64];  // prefetch next 1 KiB W slice
+                f32x4 hb[NT];
+#pragma unroll
+                for (int tau = 0; tau < NT; ++tau)
+                    hb[tau] = *reinterpret_cast<const f32x4*>(hs + tau * 32 * ldh + 8 * q);
+#pragma unroll
+                for (int tau = 0; tau < NT; ++tau) {
+                    acc[tau] = mfma32(wa.x, hb[tau].x, acc[tau]);
+                    acc[tau] = mfma32(wa.y, hb[tau].y, acc[tau]);
+                    acc[tau] = mfma32(wa.z, hb[tau].z, acc[tau]);
+                    acc[tau] = mfma32(wa.w, hb[tau].w, acc[tau]);
+                }
+                wa = wn;
+            }
+            // epilogue: lane (t = fl, h), reg -> f = 32*phi + drow(reg,h)
+            float dsum = 0.f;
+#pragma unroll
+            for (int tau = 0; tau < NT; ++tau) {
+                const int t = t0 + tau * 32 + fl;
+                const float* vp = a.V + (size_t)t * Fp + phi * 32 + 4 * h;
+                float* rsp = Rs + (tau * 32 + fl) * ldr + phi * 32 + 4 * h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(vp + 8 * g);
+                    f32x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float lam = fmaxf(acc[tau][4 * g + j], kFlr);
+                        if (OBJ) {
+                            const int f = phi * 32 + 8 * g + 4 * h + j;
+                            float d = div_term<BM>(v[j], lam, a.beta, a.inv_bb1);
+                            dsum += (f < a.F && t < a.T) ? d : 0.f;
+                        }
+                        if (BM == BM_KL) o[j] = v[j] * fast_rcp(lam);
+                        else o[j] = den_of_lam<BM>(lam, a.beta);
+                    }
+                    if (UPD) *reinterpret_cast<f32x4*>(rsp + 8 * g) = o;
+                }
+            }
+            if (OBJ) acc_div += (double)dsum;
+        }
+        if (!UPD) continue;
+        __syncthreads();
+
+        // ---- P2: contraction over f with W^T ------------------------------------------------
+        // KL : dmh = W^T * ratio ;            H <- H .* dmh ./ dphv
+        // else: pass a: dph = W^T*den + S ;    Hs <- H ./ max(dph, flr)
+        //       in-place image transform den -> num = V .* lam^(beta-2)
+        //       pass b: dmh = W^T*num ;        H <- Hs .* dmh
+        constexpr int NPASS = (BM == BM_KL) ? 1 : 2;
+#pragma unroll 1
+        for (int pass = 0; pass < NPASS; ++pass) {
+            if (pass == 1) {
+                __syncthreads();  // all waves finished reading the den image
+                for (int phi = w; phi < a.nf; phi += kNW) {
+#pragma unroll
+                    for (int tau = 0; tau < NT; ++tau) {
+                        const int t = t0 + tau * 32 + fl;
+                        const float* vp = a.V + (size_t)t * Fp + phi * 32 + 4 * h;
+                        float* rsp = Rs + (tau * 32 + fl) * ldr + phi * 32 + 4 * h;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4 v = *reinterpret_cast<const f32x4*>(vp + 8 * g);
+                            f32x4 d = *reinterpret_cast<f32x4*>(rsp + 8 * g);
+                            f32x4 o;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                if (BM == BM_EUC) o[j] = v[j];
+                                else {
+                                    // den = lam^(b-1)  ->  lam^(b-2) = den^((b-2)/(b-1))
+                                    float lf = (a.beta == 0.f) ? d[j] * d[j]
+                                                               : fast_pow(d[j], (a.beta - 2.f) / (a.beta - 1.f));
+                                    o[j] = v[j] * lf;
+                                }
+                            }
+                            *reinterpret_cast<f32x4*>(rsp + 8 * g) = o;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            for (int kap = w; kap < a.nk; kap += kNW) {
+                f32x16 acc[NT];
+#pragma unroll
+                for (int tau = 0; tau < NT; ++tau) acc[tau] = zero16();
+                const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wk4 + (size_t)kap * Fp * 32) + lane;
+                const float* rs = Rs + fl * ldr + 4 * h;
+                const int nq = Fp / 8;
+                f32x4 wa = wp[0];
+                for (int q = 0; q < nq; ++q) {
+                    f32x4 wn = wp[(q + 1 < nq ? q + 1 : q) * 64];
+                    f32x4 rb[NT];
+#pragma unroll
+                    for (int tau = 0; tau < NT; ++tau)
+                        rb[tau] = *reinterpret_cast<const f32x4*>(rs + tau * 32 * ldr + 8 * q);
+#pragma unroll
+                    for (int tau = 0; tau < NT; ++tau) {
+                        acc[tau] = mfma32(wa.x, rb[tau].x, acc[tau]);
+                        acc[tau] = mfma32(wa.y, rb[tau].y, acc[tau]);
+                        acc[tau] = mfma32(wa.z, rb[tau].z, acc[tau]);
+                        acc[tau] = mfma32(wa.w, rb[tau].w, acc[tau]);
+                    }
+                    wa = wn;
+                }
+                // epilogue: lane (t = fl, h), reg -> k = 32*kap + drow(reg,h)
+                float shsum = 0.f;
+#pragma unroll
+                for (int tau = 0; tau < NT; ++tau) {
+                    const int t = t0 + tau * 32 + fl;
+                    float* hsp = Hs + (tau * 32 + fl) * ldh + kap * 32 + 4 * h;
+                    float* hop = a.Hout + (size_t)t * rp + kap * 32 + 4 * h;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int k0 = kap * 32 + 8 * g + 4 * h;
+                        f32x4 ho = *reinterpret_cast<f32x4*>(hsp + 8 * g);
+                        f32x4 sp;
+                        if (a.S) sp = *reinterpret_cast<const f32x4*>(a.S + (size_t)t * rp + k0);
+                        else sp = *reinterpret_cast<const f32x4*>(a.lamk + k0);
+                        f32x4 o;
+                        if (BM == BM_KL) {
+                            f32x4 dp;
+                            if (a.S) {
+                                f32x4 cs = *reinterpret_cast<const f32x4*>(a.colsum + k0);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) dp[j] = fmaxf(cs[j] + sp[j], kFlr);
+                            } else {
+                                dp = *reinterpret_cast<const f32x4*>(a.dphv + k0);
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                o[j] = ho[j] * acc[tau][4 * g + j] * fast_rcp(dp[j]);
+                                if (OBJ) shsum += sp[j] * ho[j];
+                            }
+                            *reinterpret_cast<f32x4*>(hop + 8 * g) = o;
+                        } else if (pass == 0) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                float dp = fmaxf(acc[tau][4 * g + j] + sp[j], kFlr);
+                                o[j] = ho[j] * fast_rcp(dp);
+                                if (OBJ) shsum += sp[j] * ho[j];
+                            }
+                            *reinterpret_cast<f32x4*>(hsp + 8 * g) = o;
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) o[j] = ho[j] * acc[tau][4 * g + j];
+                            *reinterpret_cast<f32x4*>(hop + 8 * g) = o;
+                        }
+                    }
+                }
+                if (OBJ) acc_sh += (double)shsum;
+            }
+        }
+    }
+
+    if (OBJ) {
+        // deterministic workgroup reduction of the two fp64 partial sums
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(lds);
+        red[threadIdx.x] = acc_div;
+        red[kNW * 64 + threadIdx.x] = acc_sh;
+        __syncthreads();
+        for (int s = kNW * 32; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) {
+                red[threadIdx.x] += red[threadIdx.x + s];
+                red[kNW * 64 + threadIdx.x] += red[kNW * 64 + threadIdx.x + s];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            a.part[2 * blockIdx.x] = red[0];
+            a.part[2 * blockIdx.x + 1] = red[kNW * 64];
+        }
+    }
+}
+
+// ============================================================================================
+// k_wstats: the T-reductions of the W half-step, src/sparse_nmf.m:215-239.
+//   WM 0 (KL)      : slab = (V ./ Lam') * H^T        and s = rowsum(H)
+//   WM 1 (P)       : slab = Lam'^(beta-1) * H^T
+//   WM 2 (Q)       : slab = (V .* Lam'^(beta-2)) * H^T
+//   WM 3 (Q, EUC)  : slab = V * H^T                  (no Lam' needed)
+// grid = (n_chunks, n_fgroups); wave w of a workgroup owns f-tile phi = fgroup*NWB + w and keeps
+// its NK x (32x32) accumulators in registers over the whole chunk of frames.
+// OBJ: additionally sums the divergence of (W, H) (W-only mode: Lam' IS the objective's Lam).
+// ============================================================================================
+template <int NK, int NWB, int WM, int BM, bool OBJ>
+__global__ __launch_bounds__(NWB * 64, (NWB == 8 ? 2 : 1)) void k_wstats(StepArgs a, int n_chunks, int mat_index,
+                                                                          int n_mat) {
+    if (a.stop && *a.stop) return;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Hs = lds;  // [32][ldh]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int fl = lane & 31, h = lane >> 5;
+    const int rp = a.rp, Fp = a.Fp, ldh = a.ldh;
+    const int chunk = blockIdx.x;
+    const int phi = blockIdx.y * NWB + w;
+    const bool active = phi < a.nf;
+    const int kap_base = blockIdx.z * NK;  // kappa-group (r > 32*NK: P3 is recomputed per group)
+    const bool do_obj = OBJ && blockIdx.z == 0;
+    // contiguous, balanced range of 32-frame tiles for this chunk
+    const int tb = (int)(((long long)a.n_tiles * chunk) / n_chunks);
+    const int te = (int)(((long long)a.n_tiles * (chunk + 1)) / n_chunks);
+
+    f32x16 G[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) G[k] = zero16();
+    float ssum[2] = {0.f, 0.f};  // thread <-> k = tid + j*NWB*64 (rp <= 2*NWB*64 checked on the host)
+    double acc_div = 0.0;
+
+    for (int tile = tb; tile < te; ++tile) {
+        const int t0 = tile * 32;
+        __syncthreads();
+        stage_h_tile<NWB * 64>(a.Hin + (size_t)t0 * rp, Hs, 32, rp, ldh);
+        __syncthreads();
+        if (WM == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int k = threadIdx.x + j * NWB * 64;
+                if (k < rp) {
+                    float s = 0.f;
+                    for (int t = 0; t < 32; ++t) s += Hs[t * ldh + k];
+                    ssum[j] += s;
+                }
+            }
+        }
+        if (!active) continue;
+
+        float R[16];
+        if (WM != 3) {
+            // ---- P3: Lam'^T[t, f] = sum_k H[k,t] W[f,k]  (A = H from LDS, B = W from L2) -----
+            f32x16 acc = zero16();
+            const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)phi * rp * 32) + lane;
+            const float* hs = Hs + fl * ldh + 4 * h;
+            const int nq = rp / 8;
+            f32x4 wa = wp[0];
+            for (int q = 0; q < nq; ++q) {
+                f32x4 wn = wp[(q + 1 < nq ? q + 1 : q) * 64];
+                f32x4 hb = *reinterpret_cast<const f32x4*>(hs + 8 * q);
+                acc = mfma32(hb.x, wa.x, acc);
+                acc = mfma32(hb.y, wa.y, acc);
+                acc = mfma32(hb.z, wa.z, acc);
+                acc = mfma32(hb.w, wa.w, acc);
+                wa = wn;
+            }
+            // lane (f = fl, h), reg -> t = t0 + drow(reg,h)
+            const int f = phi * 32 + fl;
+            float dsum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int t = t0 + drow(i, h);
+                float v = a.V[(size_t)t * Fp + f];
+                float lam = fmaxf(acc[i], kFlr);
+                if (OBJ) {
+                    if (do_obj) {
+                        float d = div_term<BM>(v, lam, a.beta, a.inv_bb1);
+                        dsum += (f < a.F && t < a.T) ? d : 0.f;
+                    }
+                }
+                if (WM == 0) R[i] = v * fast_rcp(lam);
+                else if (WM == 1) R[i] = den_of_lam<BM>(lam, a.beta);
+                else R[i] = v * numfac_of_lam<BM>(lam, a.beta);
+            }
+            if (OBJ) acc_div += (double)dsum;
+        } else {
+            const int f = phi * 32 + fl;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) R[i] = a.V[(size_t)(t0 + drow(i, h)) * Fp + f];
+        }
+        // ---- P4: G[phi, kap] += ratio[f, t] * H[k, t]  (A = ratio registers, B = H from LDS)
+        const float* hb = Hs + (4 * h) * ldh + fl;
+#pragma unroll
+        for (int kap = 0; kap < NK; ++kap) {
+            if (kap_base + kap < a.nk) {  // wave-uniform
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float b = hb[((i & 3) + 8 * (i >> 2)) * ldh + (kap_base + kap) * 32];
+                    G[kap] = mfma32(R[i], b, G[kap]);
+                }
+            }
+        }
+    }
+
+    // ---- write the partial slab: D tile lane (k = fl, h), reg -> f = 32*phi + drow(reg,h)
+    if (active) {
+        float* slab = a.slabs + ((size_t)chunk * n_mat + mat_index) * rp * Fp;
+#pragma unroll
+        for (int kap = 0; kap < NK; ++kap) {
+            if (kap_base + kap < a.nk) {
+                float* dst = slab + (size_t)((kap_base + kap) * 32 + fl) * Fp + phi * 32 + 4 * h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 o = {G[kap][4 * g], G[kap][4 * g + 1], G[kap][4 * g + 2], G[kap][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(dst + 8 * g) = o;
+                }
+            }
+        }
+    }
+    if (WM == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = threadIdx.x + j * NWB * 64;
+            if (k < rp) a.spart[(size_t)chunk * rp + k] = ssum[j];
+        }
+    }
+    if (OBJ) {
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(lds);
+        red[threadIdx.x] = acc_div;
+        __syncthreads();
+        for (int s = NWB * 32; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0 && blockIdx.z == 0) {
+            a.part[2 * (blockIdx.y * n_chunks + blockIdx.x)] = red[0];
+            a.part[2 * (blockIdx.y * n_chunks + blockIdx.x) + 1] = 0.0;
+        }
+    }
+}
+
+// ============================================================================================
+// Statistics buffer (fp64, device), the unit that is all-reduced across ranks:
+//   [ M0 (rp*Fp) | M1 (rp*Fp, beta != 1) | s (rp) | div | sh ]
+// M0 = G (KL) or Q;  M1 = P.  Element (f,k) at k*Fp + f.
+// ============================================================================================
+struct ReduceArgs {
+    const float* slabs;   // [n_chunks][n_mat][rp*Fp]
+    const float* spart;   // [n_chunks][rp]
+    const double* part;   // [n_part][2]
+    double* stats;
+    const int* stop;
+    int n_chunks, n_mat, n_part, rp, Fp;
+    int do_mats;          // reduce slabs + s
+    int do_obj;           // reduce objective partials
+    double sh_const;      // W-only mode: sum(S.*H) is constant, added here
+    int use_sh_const;
+};
+
+__global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
+    if (a.stop && *a.stop) return;
+    const size_t nel = (size_t)a.rp * a.Fp;
+    const size_t tot = a.do_mats ? nel * a.n_mat + a.rp : 0;
+    double* sc = a.stats + nel * a.n_mat + a.rp;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (size_t)gridDim.x * 256) {
+        double s = 0.0;
+        if (i < nel * a.n_mat) {
+            const size_t m = i / nel, e = i - m * nel;
+            const float* p = a.slabs + m * nel + e;
+            for (int c = 0; c < a.n_chunks; ++c) s += (double)p[(size_t)c * a.n_mat * nel];
+        } else {
+            const size_t k = i - nel * a.n_mat;
+            for (int c = 0; c < a.n_chunks; ++c) s += (double)a.spart[(size_t)c * a.rp + k];
+        }
+        a.stats[i] = s;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 2) {
+        double s = 0.0;
+        if (a.do_obj) {
+            if (threadIdx.x == 1 && a.use_sh_const) s = a.sh_const;
+            else
+                for (int c = 0; c < a.n_part; ++c) s += a.part[2 * c + threadIdx.x];
+        }
+        sc[threadIdx.x] = s;
+    }
+}
+
+// Device-side solver state (fp64 objective history and the convergence flag).
+struct DevState {
+    int stop;      // set by the convergence test, src/sparse_nmf.m:275-281
+    int n_iter;    // iterations whose objective has been recorded
+    int pad0, pad1;
+};
+
+// Convergence test of src/sparse_nmf.m:260-285 for iteration `it` (1-based) whose (div, sh) sit
+// in the reduced statistics.  Every workgroup evaluates it identically (no races: it reads only
+// the statistics and the cost of iteration it-1, written by an earlier launch); one thread
+// records.  Returns true when the loop must stop at `it`.
+__device__ __forceinline__ bool conv_test(const double* sc, double* divh, double* costh, DevState* st, int it,
+                                          double conv_eps, bool recorder) {
+    const double div = sc[0], cost = sc[0] + sc[1];
+    bool stopnow = false;
+    if (it > 1 && conv_eps > 0.0) {
+        const double last = costh[it - 2];
+        const double e = fabs(cost - last) / last;
+        stopnow = e < conv_eps;
+    }
+    if (recorder) {
+        divh[it - 1] = div;
+        costh[it - 1] = cost;
+        st->n_iter = it;
+        if (stopnow) st->stop = 1;
+    }
+    return stopnow;
+}
+
+struct ApplyArgs {
+    const double* stats;
+    float* Wc;        // [rp][Fp] master copy, column-major
+    float* Wt4;
+    float* Wk4;
+    float* dphv;
+    float* colsum;
+    const float* lamk;
+    const uint8_t* w_ind;  // [rp] (pads 0)
+    double* divh;
+    double* costh;
+    DevState* st;
+    int F, r, Fp, rp, n_mat;
+    int check_it;     // >0: run the convergence test for that iteration first
+    int do_update;    // apply the W update (0: check only)
+    int init_mode;    // 1: normalise the given W only (src/sparse_nmf.m:157-159), write wn
+    double conv_eps;
+    double* wn;       // init_mode: column norms out [rp]
+};
+
+// One workgroup (256 threads) per column k of W.  src/sparse_nmf.m:215-244.
+__global__ __launch_bounds__(256) void k_wapply(ApplyArgs a) {
+    __shared__ double red[3][256];
+    if (a.st->stop) return;
+    const int k = blockIdx.x;
+    const int tid = threadIdx.x;
+    const size_t nel = (size_t)a.rp * a.Fp;
+    if (a.check_it > 0) {
+        const double* sc = a.stats + nel * a.n_mat + a.rp;
+        bool stopnow = conv_test(sc, a.divh, a.costh, a.st, a.check_it, a.conv_eps, k == 0 && tid == 0);
+        if (stopnow) return;
+    }
+    if (!a.do_update && !a.init_mode) return;
+    if (k >= a.r) return;
+
+    float* wc = a.Wc + (size_t)k * a.Fp;
+    const bool upd = a.init_mode ? false : (a.w_ind[k] != 0);
+    // pass 1: column sums needed by the update
+    double cQW = 0.0, cPW = 0.0, cW = 0.0;
+    if (upd) {
+        const double* Q = a.stats + (size_t)k * a.Fp;
+        const double* P = (a.n_mat == 2) ? a.stats + nel + (size_t)k * a.Fp : nullptr;
+        const double sk = (a.n_mat == 2) ? 0.0 : a.stats[nel * a.n_mat + k];
+        for (int f = tid; f < a.F; f += 256) {
+            double wv = (double)wc[f];
+            cQW += Q[f] * wv;
+            cPW += (P ? P[f] : sk) * wv;
+        }
+        red[0][tid] = cQW;
+        red[1][tid] = cPW;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) {
+                red[0][tid] += red[0][tid + s];
+                red[1][tid] += red[1][tid + s];
+            }
+            __syncthreads();
+        }
+        cQW = red[0][0];
+        cPW = red[1][0];
+        __syncthreads();
+    }
+    // updated (un-normalised) entry: dpw = max(P + W.*colsum(Q.*W), flr); dmw = Q + W.*colsum(P.*W)
+    auto updated = [&](int f) -> double {
+        double wv = (double)wc[f];
+        if (upd) {
+            const double Qv = a.stats[(size_t)k * a.Fp + f];
+            const double Pv = (a.n_mat == 2) ? a.stats[nel + (size_t)k * a.Fp + f] : a.stats[nel * a.n_mat + k];
+            double dpw = Pv + wv * cQW;
+            dpw = dpw > 1e-9 ? dpw : 1e-9;
+            wv = wv * (Qv + wv * cPW) / dpw;
+        }
+        return wv;
+    };
+    // pass 2: squared norm of the updated column
+    double ssq = 0.0;
+    for (int f = tid; f < a.F; f += 256) {
+        const double wv = updated(f);
+        ssq += wv * wv;
+    }
+    red[0][tid] = ssq;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[0][tid] += red[0][tid + s];
+        __syncthreads();
+    }
+    const double nrm = sqrt(red[0][0]);
+    __syncthreads();
+    // pass 3: normalise (ALL columns, :242), write the three images, column sum
+    for (int f = tid; f < a.F; f += 256) {
+        const float wf = (float)(updated(f) / nrm);
+        cW += (double)wf;
+        wc[f] = wf;
+        {   // Wt4[phi][q][h][f32][e] = W[32phi+f32][8q+4h+e]
+            const int phi = f >> 5, f32 = f & 31, q = k >> 3, hh = (k >> 2) & 1, e = k & 3;
+            a.Wt4[(((size_t)phi * (a.rp / 8) + q) * 2 + hh) * 128 + f32 * 4 + e] = wf;
+        }
+        {   // Wk4[kap][q][h][k32][e] = W[8q+4h+e][32kap+k32]
+            const int kap = k >> 5, k32 = k & 31, q = f >> 3, hh = (f >> 2) & 1, e = f & 3;
+            a.Wk4[(((size_t)kap * (a.Fp / 8) + q) * 2 + hh) * 128 + k32 * 4 + e] = wf;
+        }
+    }
+    red[1][tid] = cW;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[1][tid] += red[1][tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float cs = (float)red[1][0];
+        a.colsum[k] = cs;
+        a.dphv[k] = fmaxf(cs + a.lamk[k], kFlr);
+        if (a.init_mode) a.wn[k] = nrm;
+    }
+}
+
+// Convergence check alone (H-only mode and the final objective pass): one thread.
+__global__ void k_check(const double* stats, size_t sc_off, double* divh, double* costh, DevState* st, int it,
+                        double conv_eps) {
+    if (st->stop) return;
+    if (threadIdx.x == 0 && blockIdx.x == 0) conv_test(stats + sc_off, divh, costh, st, it, conv_eps, true);
+}
+
+// ---- small utility kernels -------------------------------------------------------------------
+// h = h .* wn'  (src/sparse_nmf.m:160), H in [Tp][rp] layout
+__global__ void k_scale_h(float* H, const double* wn, int rp, int r, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        int k = (int)(i % rp);
+        if (k < r) H[i] = (float)((double)H[i] * wn[k]);
+    }
+}
+
+// partial sums of S.*H over the real entries (W-only mode: constant over the iterations)
+__global__ __launch_bounds__(256) void k_sum_sh(const float* H, const float* S, const float* lamk, int rp, int r, int T,
+                                                double* out /*[grid]*/) {
+    __shared__ double red[256];
+    double s = 0.0;
+    const size_t n = (size_t)rp * T;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        int k = (int)(i % rp);
+        if (k < r) s += (double)(S ? S[i] : lamk[k]) * (double)H[i];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+
+// k_sum_sh partials -> stats.sh (tiny kernel: 256 doubles)
+__global__ void k_fold_sh(const double* part, int n, double* sc, const int* stop) {
+    if (*stop) return;
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += part[i];
+        sc[1] = s;
+    }
+}
+
+// Layout conversion: user column-major (rows x cols, ld) -> padded [colsP][rowsP] fp32, optional floor.
+template <typename TIn>
+__global__ void k_pack(const TIn* __restrict__ src, int64_t ld, int rows, int cols, float* __restrict__ dst, int rowsP,
+                       int colsP, float floor_val, int do_floor) {
+    const size_t n = (size_t)rowsP * colsP;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int rr = (int)(i % rowsP);
+        const size_t c = i / rowsP;
+        float v = 0.f;
+        if (rr < rows && c < (size_t)cols) {
+            v = (float)src[(size_t)c * ld + rr];
+            if (do_floor) v = fmaxf(v, floor_val);
+        }
+        dst[i] = v;
+    }
+}
+template <typename TOut>
+__global__ void k_unpack(const float* __restrict__ src, int rowsP, int rows, int cols, TOut* __restrict__ dst,
+                         int64_t ld) {
+    const size_t n = (size_t)rows * cols;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int rr = (int)(i % rows);
+        const size_t c = i / rows;
+        dst[c * ld + rr] = (TOut)src[c * rowsP + rr];
+    }
+}
+
+}  // namespace snmf
