@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- NMF multiplicative-update iterations/s on MI355X (BASELINE.json metric).
+
+Workload at N=1: BASELINE.json configs[1] = single-MI355X sparse NMF basis training,
+257 x 100 000 frames, r = 256, KL divergence, L1 sparsity 5 (SURVEY.md §8d "C2").  A "step" is one
+full iteration of src/sparse_nmf.m:186-286: H half-step + W half-step + objective, on synthetic
+|STFT|-like data that is already resident in HBM when the timed region starts.
+
+N>1 (launched by torch.distributed.run, one rank per GPU over RCCL): the SAME total problem with
+the frame axis sharded across ranks (strong scaling), one all-reduce of the W statistics per
+iteration (se_snmf_nat_amd/dist.py).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+_ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, _ROOT)
+
+import numpy as np  # noqa: E402
+
+F_, T_, R_ = 257, 100_000, 256
+SPARSITY = 5.0
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense f32 MFMA
+
+
+def make_problem(F, T, r, t0=0, t1=None):
+    """Deterministic synthetic input: V = Gamma(.5)*Gamma(.3) + 1e-9, U(0,1) inits.
+    Generated in frame blocks so that every rank can draw exactly its own columns."""
+    t1 = T if t1 is None else t1
+    rd = np.random.default_rng(0)
+    Wt = rd.gamma(0.5, 1.0, size=(F, r))
+    ri = np.random.default_rng(1)
+    W0 = ri.random((F, r))
+    # per-block streams keyed by the block index keep shards reproducible for any world size
+    blk = 1000
+    Vs, Hs = [], []
+    for b in range(t0 // blk, (t1 + blk - 1) // blk):
+        g = np.random.default_rng([2, b])
+        Ht = g.gamma(0.3, 1.0, size=(r, blk))
+        H0 = g.random((r, blk))
+        lo, hi = max(t0, b * blk) - b * blk, min(t1, (b + 1) * blk) - b * blk
+        Vs.append((Wt @ Ht[:, lo:hi]) + 1e-9)
+        Hs.append(H0[:, lo:hi])
+    return np.concatenate(Vs, axis=1), W0, np.concatenate(Hs, axis=1)
+
+
+def cpu_baseline(F, T, r, budget_iters=2):
+    """The reference's CPU path, represented by the fp64 oracle restatement (MATLAB is not
+    available): same operation sequence as src/sparse_nmf.m including MATLAB's duplicated
+    (V./Lam)*H' product, BLAS-backed, all host cores.  Bounded sample: `budget_iters` iterations
+    of the SAME 257 x 100000, r = 256 workload."""
+    from oracle.sparse_nmf_oracle import sparse_nmf as oracle_nmf
+    V, W0, H0 = make_problem(F, T, r)
+    p = dict(cf="kl", sparsity=SPARSITY, max_iter=budget_iters, conv_eps=0, init_w=W0, init_h=H0, cost_check=1)
+    t = time.perf_counter()
+    oracle_nmf(V, p, mimic_matlab_flops=True)
+    dt = time.perf_counter() - t
+    return {"value": budget_iters / dt, "unit": "iterations/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{budget_iters} iterations of the same {F}x{T} r={r} KL workload, fp64 NumPy/BLAS oracle "
+                      f"(stand-in for MATLAB sparse_nmf.m, not MATLAB itself), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--F", type=int, default=F_)
+    ap.add_argument("--T", type=int, default=T_)
+    ap.add_argument("--r", type=int, default=R_)
+    args = ap.parse_args()
+    F, T, r = args.F, args.T, args.r
+    K, W = args.steps, args.warmup
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    flops_half = 4.0 * F * T * r  # per launch of k_hstep or k_wstats (2 contractions each), whole problem
+
+    if world == 1 and args.gpus == 1:
+        # single GPU: plain C-ABI path, no torch needed
+        from se_snmf_nat_amd import Context, Plan
+        ctx = Context(0)
+        V, W0, H0 = make_problem(F, T, r)
+        plan = Plan(ctx, F, T, r, beta=1.0, max_iter=W + K + 1, conv_eps=0.0, cost_check=True, sparsity=SPARSITY)
+        plan.set_v(V.astype(np.float32))
+        plan.set_w(W0)
+        plan.set_h(H0.astype(np.float32))
+        plan.init()
+        desc = plan.describe()
+        plan.run_async(W)
+        ctx.sync()
+        ctx.timing(True)
+        t = time.perf_counter()
+        plan.run_async(K)
+        ctx.sync()
+        dt = time.perf_counter() - t
+        fam = {f: ctx.timing_get(f) for f in ("hstep", "wstats", "reduce", "wapply")}
+        ctx.timing(False)
+        # untimed-instrumentation rerun for the headline number (events add a little host work)
+        plan2 = Plan(ctx, F, T, r, beta=1.0, max_iter=W + K + 1, conv_eps=0.0, cost_check=True, sparsity=SPARSITY)
+        plan2.set_v(V.astype(np.float32))
+        plan2.set_w(W0)
+        plan2.set_h(H0.astype(np.float32))
+        plan2.init()
+        plan2.run_async(W)
+        ctx.sync()
+        t = time.perf_counter()
+        plan2.run_async(K)
+        ctx.sync()
+        dt = time.perf_counter() - t
+        div, cost, n_it = plan2.get_objective()
+        ms = dt / K * 1e3
+        dom = max(("hstep", "wstats"), key=lambda f: fam[f][0])
+        ach = flops_half / (fam[dom][0] * 1e-3) / 1e12 if fam[dom][0] > 0 else 0.0
+        out = {
+            "metric": "NMF multiplicative-update iterations/sec (FxTxr)", "value": K / dt, "unit": "iterations/s",
+            "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"single-MI355X sparse NMF basis train (BASELINE configs[1]): {F}x{T} frames, "
+                                   f"r={r}, KL, sparsity={SPARSITY}, full W+H update + objective per step",
+                       "F": F, "T": T, "r": r, "beta": 1, "geometry": desc},
+            "roofline": {"bound": "mfma", "kernel": f"k_{dom}", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "algorithmic_flops_per_launch": flops_half,
+                         "kernel_ms": {f: fam[f][0] for f in fam}, "launches": {f: fam[f][1] for f in fam},
+                         "whole_iteration_TFLOPs": 2 * flops_half / (ms * 1e-3) / 1e12},
+            "final_cost": float(cost[n_it - 1]) if n_it > 0 else None,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(F, T, r)
+        print(json.dumps(out))
+        return
+
+    # ---- multi-GPU: one rank per GPU, frames sharded, RCCL all-reduce of the W statistics ----
+    import torch
+    import torch.distributed as dist
+    from se_snmf_nat_amd.dist import ShardedTrainer, shard_bounds
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    t0, t1 = shard_bounds(T, world, rank)
+    V, W0, H0 = make_problem(F, T, r, t0, t1)
+    tr = ShardedTrainer(V.astype(np.float32), W0, H0.astype(np.float32), beta=1.0, sparsity=SPARSITY,
+                        max_iter=W + K + 1, conv_eps=0.0, cost_check=True, device=local_rank)
+    desc = tr.plan.describe()
+    tr.run(W)
+    tr.sync()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    tr.run(K)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    dtt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(dtt, op=dist.ReduceOp.MAX)
+    dt = float(dtt.item())
+    if rank == 0:
+        ms = dt / K * 1e3
+        tot = 2 * flops_half / (ms * 1e-3) / 1e12
+        out = {
+            "metric": "NMF multiplicative-update iterations/sec (FxTxr)", "value": K / dt, "unit": "iterations/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{world}xMI355X frame-sharded sparse NMF basis train: {F}x{T} frames total, r={r}, "
+                                   f"KL, sparsity={SPARSITY}, one RCCL all-reduce of the W statistics per step",
+                       "F": F, "T": T, "r": r, "beta": 1, "parallelism": f"frames/{world}", "geometry": desc},
+            "roofline": {"bound": "mfma", "kernel": "whole iteration (all ranks)", "achieved": tot,
+                         "peak": PEAK_F32_MFMA_TFLOPS * world, "unit": "TFLOP/s",
+                         "frac": tot / (PEAK_F32_MFMA_TFLOPS * world), "traffic": None},
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

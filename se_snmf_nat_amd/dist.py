@@ -1,0 +1,127 @@
+"""Frame-sharded multi-GPU basis training.
+
+The reference is single-process MATLAB (run_basis_train.m:80-91, run_basis_DNMF.m:36-55 call
+sparse_nmf on one concatenated spectrogram).  Columns (frames) of V and H are independent given
+W, so the frame axis is partitioned into contiguous blocks, one process per GPU, W replicated.
+Per iteration there is exactly ONE exchange: a sum-all-reduce (RCCL over xGMI through
+torch.distributed) of the fp64 statistics buffer
+
+    [ (V./Lam)H' or Q (F*r) | P (F*r, beta != 1) | rowsum(H) (r) | div | sum(S.*H) ]
+
+after which every rank applies the identical deterministic W epilogue + convergence test
+(src/sparse_nmf.m:215-244, :272-284), so the replicas of W stay bit-identical.  H-only solves
+need no exchange except the two cost scalars.
+
+The loop below is engine-agnostic: `engine` is anything with the step interface of
+`se_snmf_nat_amd.api.Plan` (hstep / wstats / wapply / objstats / objapply / stopped).  The product
+engine is the HIP plan; tests/ drive the same loop over gloo with an oracle-backed engine to pin
+the sharding algebra on CPU.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_bounds(T, world_size, rank):
+    """Contiguous, balanced frame range [t0, t1) of `rank`."""
+    t0 = (T * rank) // world_size
+    t1 = (T * (rank + 1)) // world_size
+    return t0, t1
+
+
+class ShardedLoop:
+    """for it = 1:max_iter of src/sparse_nmf.m:186 with the frame axis sharded over ranks."""
+
+    def __init__(self, engine, stats, all_reduce, *, max_iter, can_stop, cost_check, poll_every=4):
+        """engine: step interface; stats: buffer object the engine fills (torch tensor or numpy);
+        all_reduce(stats): in-place sum over ranks (no-op for world_size 1)."""
+        self.e = engine
+        self.stats = stats
+        self.all_reduce = all_reduce
+        self.max_iter = int(max_iter)
+        self.can_stop = bool(can_stop)
+        self.cost_check = bool(cost_check)
+        self.poll_every = int(poll_every)
+        self.it = 0
+        self.finalized = False
+
+    def _ptr(self):
+        s = self.stats
+        return s.data_ptr() if hasattr(s, "data_ptr") else s.ctypes.data
+
+    def step(self):
+        self.e.hstep()
+        self.e.wstats(self._ptr())
+        self.all_reduce(self.stats)
+        self.e.wapply(self._ptr())
+        self.it += 1
+
+    def run(self, n_iters=None):
+        target = self.max_iter if n_iters is None else min(self.max_iter, self.it + int(n_iters))
+        since = 0
+        stopped = False
+        while self.it < target:
+            self.step()
+            since += 1
+            if self.can_stop and since >= self.poll_every:
+                since = 0
+                if self.e.stopped():
+                    stopped = True
+                    break
+        if not stopped and self.it >= self.max_iter and self.cost_check and not self.finalized and self.it > 0:
+            self.e.objstats(self._ptr())
+            self.all_reduce(self.stats)
+            self.e.objapply(self._ptr())
+            self.finalized = True
+        return self.it
+
+
+class ShardedTrainer:
+    """One rank of a frame-sharded solve on its own MI355X (one process per GPU).
+
+    v_local: F x T_local block of the spectrogram (numpy, or a torch CUDA tensor shaped
+    (T_local, F) i.e. column-major), w0: F x r (replicated), h0_local: r x T_local.
+    `group`: torch.distributed process group (None = default).  world_size 1 needs no init.
+    """
+
+    def __init__(self, v_local, w0, h0_local, *, beta=1.0, sparsity=0.0, max_iter=100, conv_eps=0.0,
+                 cost_check=True, floor_v=True, w_update_ind=None, h_update_ind=None, device=0, group=None,
+                 use_torch_stream=True):
+        import torch
+        import torch.distributed as dist
+        from .api import Context, Plan
+        self.torch = torch
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.ctx = Context(device)
+        if use_torch_stream:
+            self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        F = w0.shape[0] if not hasattr(w0, "data_ptr") else w0.shape[1]
+        r = w0.shape[1] if not hasattr(w0, "data_ptr") else w0.shape[0]
+        T = v_local.shape[1] if not hasattr(v_local, "data_ptr") else v_local.shape[0]
+        self.plan = Plan(self.ctx, F, T, r, beta=beta, max_iter=max_iter, conv_eps=conv_eps, cost_check=cost_check,
+                         floor_v=floor_v, sparsity=sparsity, w_update_ind=w_update_ind, h_update_ind=h_update_ind)
+        self.plan.set_v(v_local)
+        self.plan.set_w(w0)
+        self.plan.set_h(h0_local)
+        self.plan.init()
+        self.stats = torch.zeros(self.plan.stats_len(), dtype=torch.float64, device=self.device)
+        self.loop = ShardedLoop(self.plan, self.stats, self._all_reduce, max_iter=max_iter,
+                                can_stop=bool(cost_check) and conv_eps > 0, cost_check=cost_check)
+
+    def _all_reduce(self, t):
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def run(self, n_iters=None):
+        return self.loop.run(n_iters)
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.device)
+
+    def result(self):
+        """(W, H_local, (div, cost, n_iter)) as numpy."""
+        return self.plan.get_w(), self.plan.get_h(), self.plan.get_objective()

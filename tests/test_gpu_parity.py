@@ -1,0 +1,254 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes), against the fp64 oracle.
+
+Tolerances (north_star: "W/H within 1e-4 relative of reference", fp32 MFMA vs fp64 oracle):
+  REL_WH   = 1e-4  Frobenius-relative error on W and on H after identical (V, r, init, iters)
+  REL_COST = 1e-5  relative error on every recorded objective value (fp64 accumulation on device)
+and the early-stop iteration index must match EXACTLY on the golden cases.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle.sparse_nmf_oracle import run_basis_dnmf_solves, sparse_nmf as oracle_nmf, synth_problem
+from test_oracle import GOLD, SOLVE_CASES, load_case
+
+pytestmark = pytest.mark.gpu
+REL_WH = 1e-4
+REL_COST = 1e-5
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def check(res, ref, *, cost=True):
+    w, h, o = res
+    wr, hr, orf = ref
+    assert o["n_iter"] == orf["n_iter"]
+    assert np.isfinite(w).all() and np.isfinite(h).all()
+    assert rel(w, wr) < REL_WH, rel(w, wr)
+    assert rel(h, hr) < REL_WH, rel(h, hr)
+    if cost:
+        assert len(o["cost"]) == len(orf["cost"])
+        np.testing.assert_allclose(o["cost"], orf["cost"], rtol=REL_COST)
+        np.testing.assert_allclose(o["div"], orf["div"], rtol=REL_COST)
+
+
+@pytest.mark.parametrize("path", SOLVE_CASES, ids=lambda p: os.path.basename(p)[:-4])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_golden_vectors_through_c_abi(gpu_ctx, path, dtype):
+    from se_snmf_nat_amd import sparse_nmf
+    d, p = load_case(path)
+    w, h, o = sparse_nmf(d["V"], p, ctx=gpu_ctx, dtype=dtype)
+    assert o["n_iter"] == int(d["n_iter"])  # exact stop index
+    if "W" in d:
+        assert rel(w, d["W"]) < REL_WH
+    assert rel(h, d["H"]) < REL_WH
+    np.testing.assert_allclose(o["cost"], d["cost"], rtol=REL_COST)
+    np.testing.assert_allclose(o["div"], d["div"], rtol=REL_COST)
+    np.testing.assert_allclose(np.sqrt((w.astype(np.float64) ** 2).sum(0)), 1.0, rtol=1e-6)
+
+
+def test_golden_dnmf_three_solve_loop(gpu_ctx):
+    """run_basis_DNMF.m:36-55 through the host mirror."""
+    from se_snmf_nat_amd import run_basis_dnmf
+    ref = dict(np.load(os.path.join(GOLD, "ref_data.npz")))
+    d = dict(np.load(os.path.join(GOLD, "dnmf_loop_513x64_r20_20.npz")))
+    Y = ref["Y"]
+    X = (Y * d["mask"] + 1e-9).astype(np.float32)
+    D = (Y - X + 2e-9).astype(np.float32)
+    Bs = np.concatenate([ref["B"][:, :20], ref["B"][:, 100:120]], axis=1)
+    p = dict(cf="kl", sparsity=5, max_iter=30, conv_eps=1e-3, cost_check=1)
+    B_hat, A_hat = run_basis_dnmf(Y, X, D, Bs, 20, 20, p, ctx=gpu_ctx)
+    assert rel(B_hat, d["B_hat"]) < REL_WH
+    assert rel(A_hat, d["A_hat"]) < REL_WH
+
+
+CASES = [
+    # name, F, T, r, params, w_ind, h_ind
+    ("kl_aligned", 64, 96, 32, dict(cf="kl", sparsity=5, max_iter=20), None, None),
+    ("kl_c1_257x2000_r40_50it", 257, 2000, 40, dict(cf="kl", sparsity=5, max_iter=50), None, None),
+    ("kl_stop", 257, 2000, 40, dict(cf="kl", sparsity=5, max_iter=100, conv_eps=1e-3), None, None),
+    ("kl_honly", 257, 640, 40, dict(cf="kl", sparsity=5, max_iter=20), "none", None),
+    ("kl_wonly", 257, 640, 40, dict(cf="kl", sparsity=5, max_iter=20), None, "none"),
+    ("kl_wonly_stop", 257, 640, 40, dict(cf="kl", sparsity=5, max_iter=100, conv_eps=1e-3), None, "none"),
+    ("kl_honly_stop", 257, 640, 40, dict(cf="kl", sparsity=5, max_iter=100, conv_eps=1e-3), "none", None),
+    ("kl_semi", 257, 640, 40, dict(cf="kl", sparsity=5, max_iter=20), "half", None),
+    ("kl_neither", 65, 100, 8, dict(cf="kl", sparsity=5, max_iter=6, conv_eps=1e-3), "none", "none"),
+    ("kl_513x100_r50", 513, 100, 50, dict(cf="kl", sparsity=5, max_iter=20), None, None),
+    ("kl_T1", 513, 1, 200, dict(cf="kl", sparsity=5, max_iter=100, conv_eps=1e-3), "none", None),
+    ("kl_F1", 1, 50, 3, dict(cf="kl", sparsity=0.1, max_iter=10), None, None),
+    ("kl_r1", 40, 50, 1, dict(cf="kl", sparsity=0.1, max_iter=10), None, None),
+    ("kl_ragged", 37, 131, 13, dict(cf="kl", sparsity=0.5, max_iter=15), None, None),
+    ("kl_r256", 257, 4096, 256, dict(cf="kl", sparsity=5, max_iter=5), None, None),
+    ("kl_r512", 130, 700, 512, dict(cf="kl", sparsity=1, max_iter=4), None, None),
+    ("kl_r600_honly", 100, 200, 600, dict(cf="kl", sparsity=5, max_iter=5), "none", None),
+    ("kl_F1025", 1025, 300, 20, dict(cf="kl", sparsity=5, max_iter=5), None, None),
+    ("kl_nocheck", 257, 640, 40, dict(cf="kl", sparsity=5, max_iter=20, cost_check=0), None, None),
+    ("kl_maxiter1", 65, 100, 8, dict(cf="kl", sparsity=5, max_iter=1, conv_eps=1e-3), None, None),
+    ("kl_maxiter2", 65, 100, 8, dict(cf="kl", sparsity=5, max_iter=2, conv_eps=1e-3), None, None),
+    ("kl_lambda0", 65, 100, 8, dict(cf="kl", sparsity=0, max_iter=10), None, None),
+    ("ed_full", 257, 640, 40, dict(cf="ed", sparsity=5, max_iter=20), None, None),
+    ("ed_wonly", 257, 640, 40, dict(cf="ed", sparsity=5, max_iter=20), None, "none"),
+    ("ed_honly", 257, 640, 40, dict(cf="ed", sparsity=5, max_iter=20), "none", None),
+    ("ed_c5_scaled_513x2048_r512", 513, 2048, 512, dict(cf="ed", sparsity=50, max_iter=4), None, None),
+    ("is_full", 257, 640, 40, dict(cf="is", sparsity=0.1, max_iter=20), None, None),
+    ("b05_full", 257, 640, 40, dict(cf="beta", beta=0.5, sparsity=1, max_iter=20), None, None),
+    ("b15_r300", 129, 300, 300, dict(cf="beta", beta=1.5, sparsity=1, max_iter=10), None, None),
+    ("b3_full", 65, 200, 16, dict(cf="beta", beta=3.0, sparsity=1, max_iter=10), None, None),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c[0])
+def test_synthetic_cases_against_oracle(gpu_ctx, case):
+    from se_snmf_nat_amd import sparse_nmf
+    name, F, T, r, params, wi, hi = case
+    V, W0, H0 = synth_problem(F, T, r)
+    p = dict(params, init_w=W0, init_h=H0)
+    p.setdefault("cost_check", 1)
+    if wi == "none":
+        p["w_update_ind"] = np.zeros(r, bool)
+    elif wi == "half":
+        p["w_update_ind"] = np.arange(r) >= r // 2
+    if hi == "none":
+        p["h_update_ind"] = np.zeros(r, bool)
+    check(sparse_nmf(V, p, ctx=gpu_ctx), oracle_nmf(V, p))
+
+
+def test_power_domain_dynamic_range(gpu_ctx):
+    """|STFT|^2 of int16 audio reaches ~1e10: fp32 range/precision check."""
+    from se_snmf_nat_amd import sparse_nmf
+    V, W0, H0 = synth_problem(257, 2000, 40, scale="power")
+    p = dict(cf="kl", sparsity=5, max_iter=30, init_w=W0, init_h=H0, cost_check=1)
+    check(sparse_nmf(V, p, ctx=gpu_ctx), oracle_nmf(V, p))
+
+
+def test_sparsity_argument_forms(gpu_ctx):
+    """scalar / r x 1 column / full r x n forms of p.sparsity (src/sparse_nmf.m:150-155)."""
+    from se_snmf_nat_amd import sparse_nmf
+    V, W0, H0 = synth_problem(129, 300, 24)
+    rs = np.random.RandomState(3)
+    for sp in (np.linspace(0, 9, 24).reshape(-1, 1), np.abs(rs.randn(24, 300)) * 4, np.full((24, 300), 2.0)):
+        for cf in ("kl", "ed"):
+            p = dict(cf=cf, sparsity=sp, max_iter=15, init_w=W0, init_h=H0, cost_check=1)
+            check(sparse_nmf(V, p, ctx=gpu_ctx), oracle_nmf(V, p))
+
+
+def test_gpu_variant_entry_point(gpu_ctx):
+    """sparse_nmf_GPU.m deltas: no V floor, objective vectors left zero, cost_check ignored."""
+    from se_snmf_nat_amd import sparse_nmf_GPU
+    V, W0, H0 = synth_problem(65, 200, 12)
+    p = dict(cf="kl", sparsity=1, max_iter=200, conv_eps=1e-3, init_w=W0, init_h=H0)
+    w, h, o = sparse_nmf_GPU(V, p, ctx=gpu_ctx)
+    wr, hr, orf = oracle_nmf(V, p, gpu_variant=True)
+    assert o["n_iter"] == orf["n_iter"] < 200
+    assert len(o["div"]) == 200 and not o["div"].any() and not o["cost"].any()
+    assert rel(w, wr) < REL_WH and rel(h, hr) < REL_WH
+
+
+def test_inputs_are_not_mutated_and_random_init_path(gpu_ctx):
+    from se_snmf_nat_amd import sparse_nmf
+    V, W0, H0 = synth_problem(40, 60, 6)
+    Vc, Wc, Hc = V.copy(), W0.copy(), H0.copy()
+    sparse_nmf(V, dict(init_w=W0, init_h=H0, max_iter=3, cost_check=1), ctx=gpu_ctx)
+    assert np.array_equal(V, Vc) and np.array_equal(W0, Wc) and np.array_equal(H0, Hc)
+    # p.r only: random factors from the seeded stand-in generator; r > size(init_w,2): appended columns
+    w, h, o = sparse_nmf(V, dict(r=5, max_iter=30, cost_check=1, random_seed=7), ctx=gpu_ctx)
+    assert w.shape == (40, 5) and h.shape == (5, 60) and np.all(np.diff(o["cost"]) <= 0)
+    w2, h2, _ = sparse_nmf(V, dict(r=5, max_iter=30, cost_check=1, random_seed=7), ctx=gpu_ctx)
+    assert np.array_equal(w, w2) and np.array_equal(h, h2)  # deterministic
+    w, h, _ = sparse_nmf(V, dict(init_w=W0, r=9, init_h="ones", max_iter=3, cost_check=1), ctx=gpu_ctx)
+    assert w.shape == (40, 9)
+
+
+def test_partial_h_update_ind_is_a_dimension_error(gpu_ctx):
+    from se_snmf_nat_amd import SnmfError, sparse_nmf
+    V, W0, H0 = synth_problem(40, 60, 6)
+    with pytest.raises(SnmfError, match="DIM"):
+        sparse_nmf(V, dict(init_w=W0, init_h=H0, h_update_ind=np.array([1, 1, 0, 1, 1, 1], bool), cost_check=1),
+                   ctx=gpu_ctx)
+
+
+def test_runs_are_bitwise_reproducible(gpu_ctx):
+    """Fixed-order partial sums everywhere: two runs give identical bits (needed so that W replicas
+    stay identical across ranks)."""
+    from se_snmf_nat_amd import sparse_nmf
+    V, W0, H0 = synth_problem(257, 3000, 64)
+    p = dict(cf="kl", sparsity=5, max_iter=10, init_w=W0, init_h=H0, cost_check=1)
+    a = sparse_nmf(V, p, ctx=gpu_ctx)
+    b = sparse_nmf(V, p, ctx=gpu_ctx)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2]["cost"], b[2]["cost"])
+
+
+def test_full_size_c2_properties(gpu_ctx):
+    """BASELINE C2 (257 x 100000, r = 256, KL): too big for the oracle in seconds, so check
+    size-independent properties: non-increasing cost, unit-norm non-negative W, finite H, and frame
+    locality: the H-only solve of a column block equals the same columns of the full H-only solve."""
+    from se_snmf_nat_amd import Plan
+    F, T, r = 257, 100_000, 256
+    rs = np.random.default_rng(0)
+    Wt = rs.gamma(0.5, 1.0, (F, r)).astype(np.float32)
+    Ht = rs.gamma(0.3, 1.0, (r, T)).astype(np.float32)
+    V = Wt @ Ht + 1e-9
+    W0 = rs.random((F, r)).astype(np.float32)
+    H0 = rs.random((r, T)).astype(np.float32)
+    plan = Plan(gpu_ctx, F, T, r, beta=1.0, max_iter=12, conv_eps=0.0, cost_check=True, sparsity=5.0)
+    plan.set_v(V); plan.set_w(W0); plan.set_h(H0); plan.init()
+    assert plan.run() == 12
+    w, h = plan.get_w(), plan.get_h()
+    div, cost, n = plan.get_objective()
+    assert n == 12 and np.all(np.diff(cost) <= 0) and np.all(cost > 0)
+    np.testing.assert_allclose(np.sqrt((w ** 2).sum(0)), 1.0, rtol=1e-6)
+    assert (w >= 0).all() and (h >= 0).all() and np.isfinite(h).all()
+    plan.close()
+    # frame locality of the H-only solve (the property that makes frame sharding exact)
+    hp = dict(beta=1.0, max_iter=5, conv_eps=0.0, cost_check=True, sparsity=5.0, w_update_ind=np.zeros(r, bool))
+    full = Plan(gpu_ctx, F, T, r, **hp)
+    full.set_v(V); full.set_w(W0); full.set_h(H0); full.init(); full.run()
+    hf = full.get_h(np.float32)
+    full.close()
+    t0, t1 = 33_333, 41_111
+    part = Plan(gpu_ctx, F, t1 - t0, r, **hp)
+    part.set_v(V[:, t0:t1]); part.set_w(W0); part.set_h(H0[:, t0:t1]); part.init(); part.run()
+    hpart = part.get_h(np.float32)
+    part.close()
+    assert rel(hpart, hf[:, t0:t1]) < 1e-6
+
+
+def test_plan_step_api_equals_run(gpu_ctx):
+    """hstep / wstats / wapply with a device statistics buffer (the multi-GPU path at world size 1,
+    driven by se_snmf_nat_amd.dist.ShardedTrainer over torch) gives the same bits as plan.run."""
+    torch = pytest.importorskip("torch")
+    from se_snmf_nat_amd import sparse_nmf
+    from se_snmf_nat_amd.dist import ShardedTrainer
+    V, W0, H0 = synth_problem(257, 1000, 48)
+    for conv_eps, kw in ((0.0, {}), (1e-3, {}), (1e-3, dict(w_update_ind=np.zeros(48, bool)))):
+        p = dict(cf="kl", sparsity=5, max_iter=60, conv_eps=conv_eps, init_w=W0, init_h=H0, cost_check=1, **kw)
+        w, h, o = sparse_nmf(V, p, ctx=gpu_ctx)
+        tr = ShardedTrainer(V, W0, H0, beta=1.0, sparsity=5.0, max_iter=60, conv_eps=conv_eps, cost_check=True,
+                            device=0, **kw)
+        tr.run()
+        tr.sync()
+        w2, h2, (div, cost, n) = tr.result()
+        assert n == o["n_iter"]
+        assert np.array_equal(w, w2) and np.array_equal(h, h2)
+        np.testing.assert_array_equal(cost[:n], o["cost"][:n])
+
+
+def test_device_resident_inputs(gpu_ctx):
+    """V/W/H handed over as device pointers (torch CUDA tensors, column-major)."""
+    torch = pytest.importorskip("torch")
+    from se_snmf_nat_amd import Plan, sparse_nmf
+    V, W0, H0 = synth_problem(129, 500, 24)
+    p = dict(cf="kl", sparsity=2, max_iter=10, init_w=W0, init_h=H0, cost_check=1)
+    w, h, o = sparse_nmf(V, p, ctx=gpu_ctx, dtype=np.float32)
+    dev = torch.device("cuda", 0)
+    tV = torch.tensor(np.ascontiguousarray(V.T), dtype=torch.float32, device=dev)   # (T, F) = column-major F x T
+    tW = torch.tensor(np.ascontiguousarray(W0.T), dtype=torch.float64, device=dev)
+    tH = torch.tensor(np.ascontiguousarray(H0.T), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    plan = Plan(gpu_ctx, 129, 500, 24, beta=1.0, max_iter=10, sparsity=2.0)
+    plan.set_v(tV); plan.set_w(tW); plan.set_h(tH); plan.init(); plan.run()
+    assert rel(plan.get_w(), w) < 1e-6 and rel(plan.get_h(), h) < 1e-6
