@@ -76,6 +76,27 @@ def build(force=False, verbose=False):
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """One process must hold ONE HIP runtime.  The PyTorch wheel ships its own libamdhip64.so.7
+    (same soname as /opt/rocm's); whichever is loaded first wins for the whole process, and torch
+    cannot initialise its devices on top of the other copy.  torch.distributed (RCCL) is the
+    multi-GPU transport of this package, so when the wheel is present its copy is loaded first --
+    without importing torch (slow).  Without torch the system runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load the shared library (building nothing).  Raises if it is missing: no fallback."""
     global _lib
@@ -85,6 +106,7 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  The engine has no CPU fallback.")
+    _preload_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     PP = C.POINTER(SnmfParams)

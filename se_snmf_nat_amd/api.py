@@ -12,6 +12,7 @@ initial factors (:112-140) and marshalling.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -34,6 +35,7 @@ class Context:
         _lib.check(self._lib.snmf_ctx_create(C.byref(h), int(device)))
         self._h = h
         self.device = int(device)
+        self._plans = weakref.WeakSet()  # plans must die before their context (C side keeps a raw pointer)
 
     def set_stream(self, hip_stream_ptr):
         _lib.check(self._lib.snmf_ctx_set_stream(self._h, C.c_void_p(hip_stream_ptr or 0)))
@@ -51,6 +53,8 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None):
+            for pl in list(self._plans):
+                pl.close()
             self._lib.snmf_ctx_destroy(self._h)
             self._h = None
 
@@ -263,6 +267,7 @@ class Plan:
         h = C.c_void_p()
         _lib.check(self._lib.snmf_plan_create(ctx._h, C.byref(sp), C.byref(h)))
         self._h = h
+        ctx._plans.add(self)
         if self._sarr is not None:
             _lib.check(self._lib.snmf_plan_set_sparsity_f64(self._h, _ptr(self._sarr), 0))
 
@@ -362,7 +367,8 @@ class Plan:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.snmf_plan_destroy(self._h)
+            if getattr(self.ctx, "_h", None):  # a destroyed context has already destroyed its plans
+                self._lib.snmf_plan_destroy(self._h)
             self._h = None
 
     def __del__(self):

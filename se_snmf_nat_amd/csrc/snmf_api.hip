@@ -207,6 +207,7 @@ struct snmf_plan {
     snmf_params p{};
     // geometry
     int Fp = 0, rp = 0, Tp = 0, nf = 0, nk = 0;
+    int Fm = 0, Fq = 0, xr = 0;
     int NT = 1;            // k_hstep frame tile = 32*NT
     int NKT = 8, NWB = 8;  // k_wstats template geometry
     int n_fg = 1, n_kg = 1, n_chunks = 1;
@@ -218,7 +219,7 @@ struct snmf_plan {
     bool upd_h = true, upd_w = true;
     // device buffers
     float *V = nullptr, *H[2] = {nullptr, nullptr}, *Wc = nullptr, *Wt4 = nullptr, *Wk4 = nullptr;
-    float *dphv = nullptr, *colsum = nullptr, *lamk = nullptr, *S = nullptr;
+    float *dphv = nullptr, *colsum = nullptr, *lamk = nullptr, *S = nullptr, *wx = nullptr;
     float *slabs = nullptr, *spart = nullptr;
     double *part = nullptr, *stats = nullptr, *divh = nullptr, *costh = nullptr, *wn = nullptr;
     DevState* st = nullptr;
@@ -263,7 +264,7 @@ extern "C" void snmf_plan_destroy(snmf_plan* pl) {
     hipStreamSynchronize(pl->ctx->stream);
     void* ptrs[] = {pl->V,     pl->H[0],  pl->H[1], pl->Wc,   pl->Wt4,   pl->Wk4,  pl->dphv, pl->colsum, pl->lamk,
                     pl->S,     pl->slabs, pl->spart, pl->part, pl->stats, pl->divh, pl->costh, pl->wn,    pl->st,
-                    pl->w_ind, pl->staging};
+                    pl->w_ind, pl->staging, pl->wx};
     for (void* q : ptrs)
         if (q) hipFree(q);
     delete pl;
@@ -301,24 +302,29 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     pl->bm = (p->beta == 1.0) ? BM_KL : (p->beta == 2.0 ? BM_EUC : BM_GEN);
     pl->n_mat = pl->bm == BM_KL ? 1 : 2;
 
-    pl->Fp = (int)roundup(F, 32);
+    // row geometry (see snmf_kernels.h): F = 32*nf + 1 (257, 513, ...) -> extra-row mode
+    pl->xr = (F % 32 == 1 && F > 32) ? 1 : 0;
+    pl->nf = pl->xr ? F / 32 : (int)roundup(F, 32) / 32;
+    pl->Fm = 32 * pl->nf;
+    pl->Fp = pl->Fm + 4 * pl->xr;
+    pl->Fq = pl->Fm + 8 * pl->xr;
     pl->rp = (int)roundup(r, 32);
     pl->Tp = (int)roundup(T, 64);
-    pl->nf = pl->Fp / 32;
     pl->nk = pl->rp / 32;
     pl->ldh = pl->rp + 4;
-    pl->ldr = pl->Fp + 4;
+    pl->ldr = pl->Fq + 4;
     // k_hstep: widest frame tile whose H image + ratio image fit the LDS
     const size_t per_col = (size_t)(pl->ldh + pl->ldr) * 4;
     const size_t lds_cap = 160 * 1024;  // gfx950: 160 KiB per CU, one workgroup may take all of it
-    if (64 * per_col <= lds_cap && pl->Tp / 64 >= ctx->n_cu) pl->NT = 2;
-    else if (32 * per_col <= lds_cap) pl->NT = 1;
+    const size_t lds_extra = (size_t)pl->rp * 4;
+    if (64 * per_col + lds_extra <= lds_cap && pl->Tp / 64 >= ctx->n_cu) pl->NT = 2;
+    else if (32 * per_col + lds_extra <= lds_cap) pl->NT = 1;
     else {
         delete pl;
         return fail(SNMF_ERR_UNSUPPORTED, "F + r = %d too large for the %zu-byte LDS tile (limit F+r <= %zu)", F + r,
                     lds_cap, lds_cap / 128 - 8);
     }
-    pl->lds_h = std::max<size_t>((size_t)32 * pl->NT * per_col, 2 * kNW * 64 * sizeof(double));
+    pl->lds_h = std::max<size_t>((size_t)32 * pl->NT * per_col + (size_t)pl->rp * 4, 2 * kNW * 64 * sizeof(double));
     const int n_tiles_h = pl->Tp / (32 * pl->NT);
     const int wg_per_cu = pl->lds_h * 2 <= lds_cap ? 2 : 1;
     pl->grid_h = std::max(1, std::min(n_tiles_h, ctx->n_cu * wg_per_cu));
@@ -331,7 +337,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     if (pl->rp > 2 * pl->NWB * 64 * 1 && pl->n_kg == 1) { /* unreachable: NKT=16 -> rp<=512=2*4*64 */ }
     const int n_tiles_w = pl->Tp / 32;
     pl->n_chunks = std::max(1, std::min(n_tiles_w, ctx->n_cu / std::max(1, pl->n_fg * pl->n_kg)));
-    pl->lds_w = std::max<size_t>((size_t)32 * pl->ldh * 4, (size_t)pl->NWB * 64 * sizeof(double));
+    pl->lds_w = std::max<size_t>((size_t)32 * pl->ldh * 4 + (size_t)pl->rp * 4, (size_t)pl->NWB * 64 * sizeof(double));
     if (pl->lds_w > lds_cap) {
         delete pl;
         return fail(SNMF_ERR_UNSUPPORTED, "r = %d too large for the LDS H tile", r);
@@ -343,14 +349,16 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
 
     // allocations
     const size_t nV = (size_t)pl->Fp * pl->Tp, nH = (size_t)pl->rp * pl->Tp, nW = (size_t)pl->Fp * pl->rp;
+    const size_t nWt = (size_t)pl->Fm * pl->rp, nWk = (size_t)pl->Fq * pl->rp;
     int s = SNMF_OK;
     auto A = [&](int st) { if (s == SNMF_OK) s = st; };
     A(dalloc(&pl->V, nV));
     A(dalloc(&pl->H[0], nH));
     A(dalloc(&pl->H[1], nH));
     A(dalloc(&pl->Wc, nW));
-    A(dalloc(&pl->Wt4, nW));
-    A(dalloc(&pl->Wk4, nW));
+    A(dalloc(&pl->Wt4, nWt));
+    A(dalloc(&pl->Wk4, nWk));
+    A(dalloc(&pl->wx, (size_t)pl->rp));
     A(dalloc(&pl->dphv, (size_t)pl->rp));
     A(dalloc(&pl->colsum, (size_t)pl->rp));
     A(dalloc(&pl->lamk, (size_t)pl->rp));
@@ -374,8 +382,10 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     }
     hipStream_t st = ctx->stream;
     hipMemsetAsync(pl->Wc, 0, nW * 4, st);
-    hipMemsetAsync(pl->Wt4, 0, nW * 4, st);
-    hipMemsetAsync(pl->Wk4, 0, nW * 4, st);
+    hipMemsetAsync(pl->Wt4, 0, nWt * 4, st);
+    hipMemsetAsync(pl->Wk4, 0, nWk * 4, st);
+    hipMemsetAsync(pl->wx, 0, (size_t)pl->rp * 4, st);
+    if (pl->slabs) hipMemsetAsync(pl->slabs, 0, (size_t)pl->n_chunks * pl->n_mat * nW * 4, st);
     hipMemsetAsync(pl->H[0], 0, nH * 4, st);
     hipMemsetAsync(pl->H[1], 0, nH * 4, st);
     hipMemsetAsync(pl->colsum, 0, pl->rp * 4, st);
@@ -405,9 +415,9 @@ extern "C" int64_t snmf_plan_stats_len(const snmf_plan* pl) {
 extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
     if (!pl || !buf) return fail(SNMF_ERR_INVALID, "NULL argument");
     snprintf(buf, n,
-             "F=%d T=%d r=%d beta=%g | Fp=%d rp=%d Tp=%d | hstep: tile=%d frames, grid=%d x %d thr, lds=%zu B | "
+             "F=%d T=%d r=%d beta=%g | Fm=%d(+%d VALU row) rp=%d Tp=%d | hstep: tile=%d frames, grid=%d x %d thr, lds=%zu B | "
              "wstats: NK=%d waves=%d grid=(%d chunks,%d fgroups,%d kgroups) lds=%zu B | n_cu=%d",
-             pl->p.F, pl->p.T, pl->p.r, pl->p.beta, pl->Fp, pl->rp, pl->Tp, 32 * pl->NT, pl->grid_h, kNW * 64,
+             pl->p.F, pl->p.T, pl->p.r, pl->p.beta, pl->Fm, pl->xr, pl->rp, pl->Tp, 32 * pl->NT, pl->grid_h, kNW * 64,
              pl->lds_h, pl->NKT, pl->NWB, pl->n_chunks, pl->n_fg, pl->n_kg, pl->lds_w, pl->ctx->n_cu);
     return SNMF_OK;
 }
@@ -552,6 +562,10 @@ static StepArgs make_args(snmf_plan* pl) {
     a.spart = pl->spart;
     a.part = pl->part;
     a.stop = &pl->st->stop;
+    a.wx = pl->wx;
+    a.Fm = pl->Fm;
+    a.Fq = pl->Fq;
+    a.xr = pl->xr;
     a.F = pl->p.F;
     a.T = pl->p.T;
     a.Fp = pl->Fp;
@@ -686,6 +700,10 @@ static int launch_wapply(snmf_plan* pl, const double* stats, int check_it, bool 
     aa.Fp = pl->Fp;
     aa.rp = pl->rp;
     aa.n_mat = pl->n_mat;
+    aa.wx = pl->wx;
+    aa.Fm = pl->Fm;
+    aa.Fq = pl->Fq;
+    aa.xr = pl->xr;
     aa.check_it = check_it;
     aa.do_update = do_update;
     aa.init_mode = init_mode;

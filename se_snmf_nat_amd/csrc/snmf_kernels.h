@@ -49,8 +49,10 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_pow(float x, float y) {
-    // x > 0 always here (clamped at 1e-9).  exp2(y*log2 x) on the transcendental unit.
-    return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+    // Generic-beta path only (x > 0 always: clamped at 1e-9).  The bare transcendental-unit form
+    // exp2(y*log2 x) carries a systematic ~1e-5 relative bias at |y*log2 x| ~ 30, which showed up
+    // in the objective; the OCML powf is accurate to ~1 ulp.
+    return powf(x, y);
 }
 __device__ __forceinline__ float fast_ln(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }
 
@@ -90,10 +92,16 @@ __device__ __forceinline__ float div_term(float v, float lam, float beta, float 
 
 // ------------------------------------------------------------------------------------------
 // Arguments shared by the two big kernels.  Layouts (all fp32, zero padded):
-//   V   [Tp][Fp]            column-major F x T, Fp = 32*nf
+//   V   [Tp][Fp]            column-major F x T, leading dimension Fp
 //   H   [Tp][rp]            column-major r x T, rp = 32*nk
 //   Wt4 [nf][rp/8][2][32][4] = W[32*phi+f][8q+4h+e]   (A operand of W*H, B operand of H^T*W^T)
-//   Wk4 [nk][Fp/8][2][32][4] = W[8q+4h+e][32*kap+k]   (A operand of W^T*ratio)
+//   Wk4 [nk][Fq/8][2][32][4] = W[8q+4h+e][32*kap+k]   (A operand of W^T*ratio)
+// Row geometry.  Spectrograms have F = 2^n + 1 rows (257, 513): padding that to a multiple of 32
+// would waste a whole 32-row MFMA tile (+12.5 % flops at 257) and, worse, leave 9 tiles for 8
+// waves.  In "extra-row" mode (xr = 1, F = 32*nf + 1) the MFMA tiles cover Fm = 32*nf rows and the
+// last row is a 1 x r x Tt dot product on the VALU (1/257 of the flops, hidden under the MFMAs);
+// it re-enters the W^T*ratio contraction as one more 8-deep k-block (Fq = Fm + 8).
+//   xr = 0: Fm = Fp = Fq = 32*ceil(F/32).     xr = 1: Fp = Fm + 4, Fq = Fm + 8.
 // ------------------------------------------------------------------------------------------
 struct StepArgs {
     const float* V;
@@ -109,7 +117,11 @@ struct StepArgs {
     float* spart;         // k_wstats: [n_chunks][rp]  partial row sums of H
     double* part;         // [grid][2] partial (div, sum S.*H)
     const int* stop;      // device flag: convergence reached -> kernels become no-ops
+    const float* wx;      // extra-row mode: W[Fm, k]  [rp]
     int F, T, Fp, rp, Tp, nf, nk;
+    int Fm;               // rows covered by MFMA tiles = 32*nf
+    int Fq;               // contraction length of W^T*ratio = Fm + 8*xr
+    int xr;               // 1: F = Fm + 1, the last row ("Nyquist bin") is handled on the VALU
     int n_tiles;          // tiles of this kernel's tile width
     int ldh, ldr;         // LDS leading dimensions (floats)
     float beta, inv_bb1;
@@ -138,10 +150,16 @@ __global__ __launch_bounds__(kNW * 64, 2) void k_hstep(StepArgs a) {
     constexpr int Tt = 32 * NT;
     float* Hs = lds;                   // [Tt][ldh]
     float* Rs = lds + Tt * a.ldh;      // [Tt][ldr]
+    float* wxs = Rs + Tt * a.ldr;      // [rp]  extra row of W
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int fl = lane & 31, h = lane >> 5;
     const int rp = a.rp, Fp = a.Fp, ldh = a.ldh, ldr = a.ldr;
     double acc_div = 0.0, acc_sh = 0.0;
+    if (a.xr) {
+        for (int k = threadIdx.x; k < rp; k += kNW * 64) wxs[k] = a.wx[k];
+        // the 7 unused cells of the extra 8-deep k-block stay zero for the whole kernel
+        for (int i = threadIdx.x; i < Tt * 8; i += kNW * 64) Rs[(i >> 3) * ldr + a.Fm + (i & 7)] = 0.f;
+    }
 
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const int t0 = tile * Tt;
@@ -200,6 +218,31 @@ __global__ __launch_bounds__(kNW * 64, 2) void k_hstep(StepArgs a) {
             }
             if (OBJ) acc_div += (double)dsum;
         }
+        if (a.xr) {
+            // extra row: lam_x[t] = sum_k W[Fm,k] H[k,t]; 4 columns x 16 lanes at a time
+            constexpr int CPW = Tt / kNW;
+            float dsum = 0.f;
+#pragma unroll
+            for (int c0 = 0; c0 < CPW; c0 += 4) {
+                const int tl = w * CPW + c0 + (lane >> 4);
+                const int kl = lane & 15;
+                const float* hrow = Hs + tl * ldh;
+                float s = 0.f;
+                for (int k = kl; k < rp; k += 16) s += wxs[k] * hrow[k];
+                s += __shfl_xor(s, 1);
+                s += __shfl_xor(s, 2);
+                s += __shfl_xor(s, 4);
+                s += __shfl_xor(s, 8);
+                if (kl == 0) {
+                    const int t = t0 + tl;
+                    const float v = a.V[(size_t)t * Fp + a.Fm];
+                    const float lam = fmaxf(s, kFlr);
+                    if (OBJ) dsum += (t < a.T) ? div_term<BM>(v, lam, a.beta, a.inv_bb1) : 0.f;
+                    if (UPD) Rs[tl * ldr + a.Fm] = (BM == BM_KL) ? v * fast_rcp(lam) : den_of_lam<BM>(lam, a.beta);
+                }
+            }
+            if (OBJ) acc_div += (double)dsum;
+        }
         if (!UPD) continue;
         __syncthreads();
 
@@ -238,15 +281,30 @@ __global__ __launch_bounds__(kNW * 64, 2) void k_hstep(StepArgs a) {
                         }
                     }
                 }
+                if (a.xr) {
+                    constexpr int CPW = Tt / kNW;
+                    if ((lane & 15) == 0) {
+#pragma unroll
+                        for (int c0 = 0; c0 < CPW; c0 += 4) {
+                            const int tl = w * CPW + c0 + (lane >> 4);
+                            const float v = a.V[(size_t)(t0 + tl) * Fp + a.Fm];
+                            const float d = Rs[tl * ldr + a.Fm];
+                            float o;
+                            if (BM == BM_EUC) o = v;
+                            else o = v * ((a.beta == 0.f) ? d * d : fast_pow(d, (a.beta - 2.f) / (a.beta - 1.f)));
+                            Rs[tl * ldr + a.Fm] = o;
+                        }
+                    }
+                }
                 __syncthreads();
             }
             for (int kap = w; kap < a.nk; kap += kNW) {
                 f32x16 acc[NT];
 #pragma unroll
                 for (int tau = 0; tau < NT; ++tau) acc[tau] = zero16();
-                const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wk4 + (size_t)kap * Fp * 32) + lane;
+                const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wk4 + (size_t)kap * a.Fq * 32) + lane;
                 const float* rs = Rs + fl * ldr + 4 * h;
-                const int nq = Fp / 8;
+                const int nq = a.Fq / 8;
                 f32x4 wa = wp[0];
                 for (int q = 0; q < nq; ++q) {
                     f32x4 wn = wp[(q + 1 < nq ? q + 1 : q) * 64];
@@ -349,11 +407,19 @@ __global__ __launch_bounds__(NWB * 64, (NWB == 8 ? 2 : 1)) void k_wstats(StepArg
                                                                           int n_mat) {
     if (a.stop && *a.stop) return;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Hs = lds;  // [32][ldh]
+    float* Hs = lds;             // [32][ldh]
+    float* wxs = lds + 32 * a.ldh;  // [rp] extra row of W
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int fl = lane & 31, h = lane >> 5;
     const int rp = a.rp, Fp = a.Fp, ldh = a.ldh;
     const int chunk = blockIdx.x;
+    const bool do_x = a.xr && blockIdx.y == 0 && blockIdx.z == 0;  // extra row: one f-group only
+    constexpr int CPW = 32 / NWB;  // columns of the extra-row dot product per wave
+    float gx[8];                   // extra row of the slab: lane <-> k = lane + 64*i
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gx[i] = 0.f;
+    if (do_x && WM != 3)
+        for (int k = threadIdx.x; k < rp; k += NWB * 64) wxs[k] = a.wx[k];
     const int phi = blockIdx.y * NWB + w;
     const bool active = phi < a.nf;
     const int kap_base = blockIdx.z * NK;  // kappa-group (r > 32*NK: P3 is recomputed per group)
@@ -381,6 +447,49 @@ __global__ __launch_bounds__(NWB * 64, (NWB == 8 ? 2 : 1)) void k_wstats(StepArg
                     float s = 0.f;
                     for (int t = 0; t < 32; ++t) s += Hs[t * ldh + k];
                     ssum[j] += s;
+                }
+            }
+        }
+        if (do_x) {
+            // extra row: ratio_x[t] for this wave's CPW columns, then gx[k] += ratio_x[t] * H[k,t]
+            float rxv[CPW];
+            float dsum = 0.f;
+#pragma unroll
+            for (int c0 = 0; c0 < CPW; c0 += 4) {
+                const int tl = w * CPW + c0 + (lane >> 4);
+                const int kl = lane & 15;
+                const float* hrow = Hs + tl * ldh;
+                const int t = t0 + tl;
+                const float v = a.V[(size_t)t * Fp + a.Fm];
+                float rv;
+                if (WM != 3) {
+                    float s = 0.f;
+                    for (int k = kl; k < rp; k += 16) s += wxs[k] * hrow[k];
+                    s += __shfl_xor(s, 1);
+                    s += __shfl_xor(s, 2);
+                    s += __shfl_xor(s, 4);
+                    s += __shfl_xor(s, 8);
+                    const float lam = fmaxf(s, kFlr);
+                    if (OBJ && kl == 0) dsum += (t < a.T) ? div_term<BM>(v, lam, a.beta, a.inv_bb1) : 0.f;
+                    if (WM == 0) rv = v * fast_rcp(lam);
+                    else if (WM == 1) rv = den_of_lam<BM>(lam, a.beta);
+                    else rv = v * numfac_of_lam<BM>(lam, a.beta);
+                } else {
+                    rv = v;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    rxv[c0 + c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv), 16 * c));
+            }
+            if (OBJ) acc_div += (double)dsum;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = lane + 64 * i;
+                if (k < rp) {
+                    float g = gx[i];
+#pragma unroll
+                    for (int c = 0; c < CPW; ++c) g += rxv[c] * Hs[(w * CPW + c) * ldh + k];
+                    gx[i] = g;
                 }
             }
         }
@@ -462,6 +571,24 @@ __global__ __launch_bounds__(NWB * 64, (NWB == 8 ? 2 : 1)) void k_wstats(StepArg
             const int k = threadIdx.x + j * NWB * 64;
             if (k < rp) a.spart[(size_t)chunk * rp + k] = ssum[j];
         }
+    }
+    if (do_x) {
+        // fixed-order sum of the per-wave partial extra rows, through LDS
+        __syncthreads();
+        float* red = lds;  // [NWB][rp]  (NWB*rp <= 32*ldh)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = lane + 64 * i;
+            if (k < rp) red[w * rp + k] = gx[i];
+        }
+        __syncthreads();
+        float* slab = a.slabs + ((size_t)chunk * n_mat + mat_index) * rp * Fp;
+        for (int k = threadIdx.x; k < rp; k += NWB * 64) {
+            float s = 0.f;
+            for (int ww = 0; ww < NWB; ++ww) s += red[ww * rp + k];
+            slab[(size_t)k * Fp + a.Fm] = s;
+        }
+        __syncthreads();
     }
     if (OBJ) {
         __syncthreads();
@@ -566,7 +693,9 @@ struct ApplyArgs {
     double* divh;
     double* costh;
     DevState* st;
+    float* wx;        // extra-row mode: W[Fm, :]
     int F, r, Fp, rp, n_mat;
+    int Fm, Fq, xr;
     int check_it;     // >0: run the convergence test for that iteration first
     int do_update;    // apply the W update (0: check only)
     int init_mode;    // 1: normalise the given W only (src/sparse_nmf.m:157-159), write wn
@@ -647,13 +776,15 @@ __global__ __launch_bounds__(256) void k_wapply(ApplyArgs a) {
         const float wf = (float)(updated(f) / nrm);
         cW += (double)wf;
         wc[f] = wf;
-        {   // Wt4[phi][q][h][f32][e] = W[32phi+f32][8q+4h+e]
+        if (f < a.Fm) {  // Wt4[phi][q][h][f32][e] = W[32phi+f32][8q+4h+e]
             const int phi = f >> 5, f32 = f & 31, q = k >> 3, hh = (k >> 2) & 1, e = k & 3;
             a.Wt4[(((size_t)phi * (a.rp / 8) + q) * 2 + hh) * 128 + f32 * 4 + e] = wf;
+        } else {
+            a.wx[k] = wf;  // extra row
         }
         {   // Wk4[kap][q][h][k32][e] = W[8q+4h+e][32kap+k32]
             const int kap = k >> 5, k32 = k & 31, q = f >> 3, hh = (f >> 2) & 1, e = f & 3;
-            a.Wk4[(((size_t)kap * (a.Fp / 8) + q) * 2 + hh) * 128 + k32 * 4 + e] = wf;
+            a.Wk4[(((size_t)kap * (a.Fq / 8) + q) * 2 + hh) * 128 + k32 * 4 + e] = wf;
         }
     }
     red[1][tid] = cW;

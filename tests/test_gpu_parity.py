@@ -3,7 +3,10 @@
 Tolerances (north_star: "W/H within 1e-4 relative of reference", fp32 MFMA vs fp64 oracle):
   REL_WH   = 1e-4  Frobenius-relative error on W and on H after identical (V, r, init, iters)
   REL_COST = 1e-5  relative error on every recorded objective value (fp64 accumulation on device)
-and the early-stop iteration index must match EXACTLY on the golden cases.
+  ABS_DIV  = 2e-7 * sum(V): each divergence term v*log(v/lam) - v + lam is evaluated in fp32 and
+             cancels to O((v-lam)^2/lam), so the absolute error floor of the sum is ~eps_f32 * sum(V)
+             (only visible when the fit is near-perfect, div << sum(V))
+and the early-stop iteration index must match EXACTLY.
 """
 import glob
 import os
@@ -23,7 +26,7 @@ def rel(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
-def check(res, ref, *, cost=True):
+def check(res, ref, *, cost=True, vsum=0.0):
     w, h, o = res
     wr, hr, orf = ref
     assert o["n_iter"] == orf["n_iter"]
@@ -32,8 +35,8 @@ def check(res, ref, *, cost=True):
     assert rel(h, hr) < REL_WH, rel(h, hr)
     if cost:
         assert len(o["cost"]) == len(orf["cost"])
-        np.testing.assert_allclose(o["cost"], orf["cost"], rtol=REL_COST)
-        np.testing.assert_allclose(o["div"], orf["div"], rtol=REL_COST)
+        np.testing.assert_allclose(o["cost"], orf["cost"], rtol=REL_COST, atol=2e-7 * vsum)
+        np.testing.assert_allclose(o["div"], orf["div"], rtol=REL_COST, atol=2e-7 * vsum)
 
 
 @pytest.mark.parametrize("path", SOLVE_CASES, ids=lambda p: os.path.basename(p)[:-4])
@@ -114,7 +117,7 @@ def test_synthetic_cases_against_oracle(gpu_ctx, case):
         p["w_update_ind"] = np.arange(r) >= r // 2
     if hi == "none":
         p["h_update_ind"] = np.zeros(r, bool)
-    check(sparse_nmf(V, p, ctx=gpu_ctx), oracle_nmf(V, p))
+    check(sparse_nmf(V, p, ctx=gpu_ctx), oracle_nmf(V, p), vsum=float(V.sum()))
 
 
 def test_power_domain_dynamic_range(gpu_ctx):
