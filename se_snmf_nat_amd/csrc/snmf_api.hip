@@ -208,11 +208,12 @@ struct snmf_plan {
     // geometry
     int Fp = 0, rp = 0, Tp = 0, nf = 0, nk = 0;
     int Fm = 0, Fq = 0, xr = 0;
-    int NT = 1;            // k_hstep frame tile = 32*NT
-    int NKT = 8, NWB = 8;  // k_wstats template geometry
+    int NT = 1, NWH = 8;   // k_hstep: frame tile = 32*NT, NWH waves per workgroup
+    int NKT = 8, NWB = 4, WPS = 2;  // k_wstats template geometry
     int n_fg = 1, n_kg = 1, n_chunks = 1;
     int grid_h = 1;
-    int ldh = 0, ldr = 0;
+    int ldh = 0, ldr = 0, ldhw = 0;
+    int stagger_h = 0, stagger_w = 0;
     size_t lds_h = 0, lds_w = 0;
     int bm = BM_KL;
     int n_mat = 1;
@@ -223,6 +224,7 @@ struct snmf_plan {
     float *slabs = nullptr, *spart = nullptr;
     double *part = nullptr, *stats = nullptr, *divh = nullptr, *costh = nullptr, *wn = nullptr;
     DevState* st = nullptr;
+    unsigned long long* prof = nullptr;
     uint8_t* w_ind = nullptr;
     void* staging = nullptr;
     size_t staging_bytes = 0;
@@ -262,6 +264,24 @@ extern "C" void snmf_plan_destroy(snmf_plan* pl) {
     if (!pl) return;
     hipSetDevice(pl->ctx->device);
     hipStreamSynchronize(pl->ctx->stream);
+#ifdef SNMF_PROF
+    if (pl->prof) {  // diagnostic build: phase shares of the LAST k_hstep launch
+        const int nw = pl->grid_h * pl->NWH;
+        std::vector<unsigned long long> hp((size_t)nw * 12);
+        hipMemcpy(hp.data(), pl->prof, hp.size() * 8, hipMemcpyDeviceToHost);
+        double tot[12] = {0};
+        for (int i = 0; i < nw; ++i)
+            for (int j = 0; j < 12; ++j) tot[j] += (double)hp[(size_t)i * 12 + j];
+        double all = 0;
+        for (int j = 0; j < 12; ++j) all += tot[j];
+        static const char* nm[12] = {"bar_top", "stage", "bar_stage", "p1_pre", "p1_mfma", "p1_epi", "xrow", "bar_p2",
+                                     "p2_pre", "p2_mfma", "p2_epi", "stage_out"};
+        fprintf(stderr, "[SNMF_PROF] k_hstep phase shares (avg cycles/wave = %.0f):", all / nw);
+        for (int j = 0; j < 12; ++j) fprintf(stderr, " %s=%.1f%%", nm[j], 100.0 * tot[j] / all);
+        fprintf(stderr, "\n");
+        hipFree(pl->prof);
+    }
+#endif
     void* ptrs[] = {pl->V,     pl->H[0],  pl->H[1], pl->Wc,   pl->Wt4,   pl->Wk4,  pl->dphv, pl->colsum, pl->lamk,
                     pl->S,     pl->slabs, pl->spart, pl->part, pl->stats, pl->divh, pl->costh, pl->wn,    pl->st,
                     pl->w_ind, pl->staging, pl->wx};
@@ -313,31 +333,65 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     pl->nk = pl->rp / 32;
     pl->ldh = pl->rp + 4;
     pl->ldr = pl->Fq + 4;
-    // k_hstep: widest frame tile whose H image + ratio image fit the LDS
+    // k_hstep geometry: prefer two 4-wave workgroups per CU on 32-frame tiles (their phases
+    // de-synchronise and keep the matrix pipe fed); otherwise one 8-wave workgroup per CU on the
+    // widest tile whose H image + ratio image fit the 160 KiB LDS.  SNMF_HSTEP_CFG=NWxNT overrides.
     const size_t per_col = (size_t)(pl->ldh + pl->ldr) * 4;
     const size_t lds_cap = 160 * 1024;  // gfx950: 160 KiB per CU, one workgroup may take all of it
     const size_t lds_extra = (size_t)pl->rp * 4;
-    if (64 * per_col + lds_extra <= lds_cap && pl->Tp / 64 >= ctx->n_cu) pl->NT = 2;
-    else if (32 * per_col + lds_extra <= lds_cap) pl->NT = 1;
+    const size_t lds1 = 32 * per_col + lds_extra, lds2 = 64 * per_col + lds_extra;
+    if (2 * lds1 <= lds_cap) { pl->NWH = 4; pl->NT = 1; }
+    else if (lds2 <= lds_cap && pl->Tp / 64 >= ctx->n_cu) { pl->NWH = 8; pl->NT = 2; }
+    else if (lds1 <= lds_cap) { pl->NWH = 8; pl->NT = 1; }
     else {
         delete pl;
         return fail(SNMF_ERR_UNSUPPORTED, "F + r = %d too large for the %zu-byte LDS tile (limit F+r <= %zu)", F + r,
                     lds_cap, lds_cap / 128 - 8);
     }
-    pl->lds_h = std::max<size_t>((size_t)32 * pl->NT * per_col + (size_t)pl->rp * 4, 2 * kNW * 64 * sizeof(double));
+    if (const char* e = getenv("SNMF_HSTEP_CFG")) {
+        int nw = 0, nt = 0;
+        if (sscanf(e, "%dx%d", &nw, &nt) == 2 && (nw == 4 || nw == 8) && (nt == 1 || nt == 2) &&
+            (nt == 1 ? lds1 : lds2) <= lds_cap) {
+            pl->NWH = nw;
+            pl->NT = nt;
+        }
+    }
+    pl->lds_h = std::max<size_t>(pl->NT == 1 ? lds1 : lds2, 2 * kMaxNW * 64 * sizeof(double));
     const int n_tiles_h = pl->Tp / (32 * pl->NT);
-    const int wg_per_cu = pl->lds_h * 2 <= lds_cap ? 2 : 1;
+    // NT == 1 kernels are register-bounded for two workgroups per CU (4x1: 2 waves/SIMD, 8x1: 4)
+    int wg_per_cu = (pl->lds_h * 2 <= lds_cap && pl->NT == 1) ? 2 : 1;
+    if (const char* e = getenv("SNMF_WGPCU")) wg_per_cu = std::max(1, std::min(wg_per_cu, atoi(e)));  // experiments
     pl->grid_h = std::max(1, std::min(n_tiles_h, ctx->n_cu * wg_per_cu));
-    // k_wstats geometry
-    if (pl->nk <= 4) { pl->NKT = 4; pl->NWB = 8; }
-    else if (pl->nk <= 8) { pl->NKT = 8; pl->NWB = 8; }
-    else { pl->NKT = 16; pl->NWB = 4; }
+    // k_wstats geometry: 4-wave workgroups, each wave owns one 32-row tile x NKT 32-column tiles of
+    // the statistics in registers.  NKT <= 8 (128 accumulator VGPRs): two workgroups per CU.
+    if (pl->nk <= 4) { pl->NKT = 4; pl->WPS = 2; }
+    else if (pl->nk <= 8) { pl->NKT = 8; pl->WPS = 2; }
+    else { pl->NKT = 16; pl->WPS = 1; }
+    pl->NWB = 4;
     pl->n_kg = (pl->nk + pl->NKT - 1) / pl->NKT;
     pl->n_fg = (pl->nf + pl->NWB - 1) / pl->NWB;
-    if (pl->rp > 2 * pl->NWB * 64 * 1 && pl->n_kg == 1) { /* unreachable: NKT=16 -> rp<=512=2*4*64 */ }
     const int n_tiles_w = pl->Tp / 32;
-    pl->n_chunks = std::max(1, std::min(n_tiles_w, ctx->n_cu / std::max(1, pl->n_fg * pl->n_kg)));
-    pl->lds_w = std::max<size_t>((size_t)32 * pl->ldh * 4 + (size_t)pl->rp * 4, (size_t)pl->NWB * 64 * sizeof(double));
+    pl->n_chunks = std::max(1, std::min(n_tiles_w, ctx->n_cu * pl->WPS / std::max(1, pl->n_fg * pl->n_kg)));
+    // H image of k_wstats: rows padded to whole NKT-tile groups (branch-free P4, see the kernel)
+    pl->ldhw = std::max(pl->rp, 32 * pl->NKT * pl->n_kg) + 4;
+    pl->lds_w = std::max<size_t>(((size_t)32 * pl->ldhw + (size_t)32 * pl->Fp + pl->rp) * 4,
+                                 (size_t)pl->NWB * 64 * sizeof(double));
+    // start-up stagger (cycles) of the second half of each grid: about half a tile period when two
+    // workgroups share a CU.  SNMF_STAGGER=<h>,<w> overrides (0 disables).
+    {
+        const int mf_h = (pl->nf + pl->NWH - 1) / pl->NWH * pl->NT * (pl->rp / 2) +
+                         (pl->nk + pl->NWH - 1) / pl->NWH * pl->NT * (pl->Fq / 2);
+        pl->stagger_h = (pl->grid_h > ctx->n_cu) ? mf_h * 64 : 0;
+        const int mf_w = pl->rp / 2 + 16 * pl->NKT;
+        pl->stagger_w = (pl->WPS == 2 && pl->n_chunks * pl->n_fg * pl->n_kg > ctx->n_cu) ? mf_w * 64 : 0;
+        if (const char* e = getenv("SNMF_STAGGER")) {
+            int sh = 0, sw = 0;
+            if (sscanf(e, "%d,%d", &sh, &sw) == 2) {
+                pl->stagger_h = sh;
+                pl->stagger_w = sw;
+            }
+        }
+    }
     if (pl->lds_w > lds_cap) {
         delete pl;
         return fail(SNMF_ERR_UNSUPPORTED, "r = %d too large for the LDS H tile", r);
@@ -376,6 +430,9 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     A(dalloc(&pl->wn, (size_t)pl->rp));
     A(dalloc(&pl->st, (size_t)1));
     A(dalloc(&pl->w_ind, (size_t)pl->rp));
+#ifdef SNMF_PROF
+    A(dalloc(&pl->prof, (size_t)1024 * 8 * 12));
+#endif
     if (s != SNMF_OK) {
         snmf_plan_destroy(pl);
         return s;
@@ -417,7 +474,7 @@ extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
     snprintf(buf, n,
              "F=%d T=%d r=%d beta=%g | Fm=%d(+%d VALU row) rp=%d Tp=%d | hstep: tile=%d frames, grid=%d x %d thr, lds=%zu B | "
              "wstats: NK=%d waves=%d grid=(%d chunks,%d fgroups,%d kgroups) lds=%zu B | n_cu=%d",
-             pl->p.F, pl->p.T, pl->p.r, pl->p.beta, pl->Fm, pl->xr, pl->rp, pl->Tp, 32 * pl->NT, pl->grid_h, kNW * 64,
+             pl->p.F, pl->p.T, pl->p.r, pl->p.beta, pl->Fm, pl->xr, pl->rp, pl->Tp, 32 * pl->NT, pl->grid_h, pl->NWH * 64,
              pl->lds_h, pl->NKT, pl->NWB, pl->n_chunks, pl->n_fg, pl->n_kg, pl->lds_w, pl->ctx->n_cu);
     return SNMF_OK;
 }
@@ -562,6 +619,9 @@ static StepArgs make_args(snmf_plan* pl) {
     a.spart = pl->spart;
     a.part = pl->part;
     a.stop = &pl->st->stop;
+    a.stagger_shift = -1;
+    if (const char* e = getenv("SNMF_STAGGER_SHIFT")) a.stagger_shift = atoi(e);
+    a.prof = pl->prof;
     a.wx = pl->wx;
     a.Fm = pl->Fm;
     a.Fq = pl->Fq;
@@ -595,36 +655,37 @@ static int launch_big(K kern, dim3 grid, dim3 block, size_t lds, hipStream_t st,
     return SNMF_OK;
 }
 
-// k_hstep dispatch over (NT, BM, OBJ, UPD)
-template <int NT, int BM>
+// k_hstep dispatch over (NW, NT, BM, OBJ, UPD)
+template <int NW, int NT, int BM>
 static int launch_hstep_nb(snmf_plan* pl, const StepArgs& a, bool obj, bool upd) {
-    dim3 g(pl->grid_h), b(kNW * 64);
+    dim3 g(pl->grid_h), b(NW * 64);
     hipStream_t st = pl->ctx->stream;
-    if (obj && upd) return launch_big(k_hstep<NT, BM, true, true>, g, b, pl->lds_h, st, a);
-    if (!obj && upd) return launch_big(k_hstep<NT, BM, false, true>, g, b, pl->lds_h, st, a);
-    if (obj && !upd) return launch_big(k_hstep<NT, BM, true, false>, g, b, pl->lds_h, st, a);
+    if (obj && upd) return launch_big(k_hstep<NW, NT, BM, true, true>, g, b, pl->lds_h, st, a);
+    if (!obj && upd) return launch_big(k_hstep<NW, NT, BM, false, true>, g, b, pl->lds_h, st, a);
+    if (obj && !upd) return launch_big(k_hstep<NW, NT, BM, true, false>, g, b, pl->lds_h, st, a);
     return SNMF_OK;
+}
+template <int NW, int NT>
+static int launch_hstep_g(snmf_plan* pl, const StepArgs& a, bool obj, bool upd) {
+    if (pl->bm == BM_KL) return launch_hstep_nb<NW, NT, BM_KL>(pl, a, obj, upd);
+    if (pl->bm == BM_EUC) return launch_hstep_nb<NW, NT, BM_EUC>(pl, a, obj, upd);
+    return launch_hstep_nb<NW, NT, BM_GEN>(pl, a, obj, upd);
 }
 static int launch_hstep(snmf_plan* pl, bool obj, bool upd) {
     StepArgs a = make_args(pl);
     a.n_tiles = pl->Tp / (32 * pl->NT);
+    a.stagger = pl->stagger_h;
     ScopedTimer tm(pl->ctx, FAM_HSTEP);
-    if (pl->NT == 2) {
-        if (pl->bm == BM_KL) return launch_hstep_nb<2, BM_KL>(pl, a, obj, upd);
-        if (pl->bm == BM_EUC) return launch_hstep_nb<2, BM_EUC>(pl, a, obj, upd);
-        return launch_hstep_nb<2, BM_GEN>(pl, a, obj, upd);
-    }
-    if (pl->bm == BM_KL) return launch_hstep_nb<1, BM_KL>(pl, a, obj, upd);
-    if (pl->bm == BM_EUC) return launch_hstep_nb<1, BM_EUC>(pl, a, obj, upd);
-    return launch_hstep_nb<1, BM_GEN>(pl, a, obj, upd);
+    if (pl->NWH == 4) return pl->NT == 2 ? launch_hstep_g<4, 2>(pl, a, obj, upd) : launch_hstep_g<4, 1>(pl, a, obj, upd);
+    return pl->NT == 2 ? launch_hstep_g<8, 2>(pl, a, obj, upd) : launch_hstep_g<8, 1>(pl, a, obj, upd);
 }
 
 // k_wstats dispatch
-template <int NK, int NWB, int WM, int BM, bool OBJ>
+template <int NK, int NWB, int WPS, int WM, int BM, bool OBJ>
 static int launch_wstats_one(snmf_plan* pl, const StepArgs& a, int mat_index) {
     dim3 g(pl->n_chunks, pl->n_fg, pl->n_kg), b(NWB * 64);
     static std::map<const void*, size_t> attr_set;
-    auto kern = k_wstats<NK, NWB, WM, BM, OBJ>;
+    auto kern = k_wstats<NK, NWB, WPS, WM, BM, OBJ>;
     const void* key = (const void*)kern;
     if (pl->lds_w > 64 * 1024 && attr_set[key] < pl->lds_w) {
         HIP_TRY(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_w));
@@ -634,28 +695,30 @@ static int launch_wstats_one(snmf_plan* pl, const StepArgs& a, int mat_index) {
     HIP_TRY(hipGetLastError());
     return SNMF_OK;
 }
-template <int NK, int NWB>
+template <int NK, int NWB, int WPS>
 static int launch_wstats_geo(snmf_plan* pl, const StepArgs& a, bool obj) {
     if (pl->bm == BM_KL) {
-        return obj ? launch_wstats_one<NK, NWB, 0, BM_KL, true>(pl, a, 0)
-                   : launch_wstats_one<NK, NWB, 0, BM_KL, false>(pl, a, 0);
+        return obj ? launch_wstats_one<NK, NWB, WPS, 0, BM_KL, true>(pl, a, 0)
+                   : launch_wstats_one<NK, NWB, WPS, 0, BM_KL, false>(pl, a, 0);
     }
     if (pl->bm == BM_EUC) {
-        SN_TRY(obj ? (launch_wstats_one<NK, NWB, 1, BM_EUC, true>(pl, a, 1))
-                   : (launch_wstats_one<NK, NWB, 1, BM_EUC, false>(pl, a, 1)));
-        return launch_wstats_one<NK, NWB, 3, BM_EUC, false>(pl, a, 0);
+        SN_TRY(obj ? (launch_wstats_one<NK, NWB, WPS, 1, BM_EUC, true>(pl, a, 1))
+                   : (launch_wstats_one<NK, NWB, WPS, 1, BM_EUC, false>(pl, a, 1)));
+        return launch_wstats_one<NK, NWB, WPS, 3, BM_EUC, false>(pl, a, 0);
     }
-    SN_TRY(obj ? (launch_wstats_one<NK, NWB, 1, BM_GEN, true>(pl, a, 1))
-               : (launch_wstats_one<NK, NWB, 1, BM_GEN, false>(pl, a, 1)));
-    return launch_wstats_one<NK, NWB, 2, BM_GEN, false>(pl, a, 0);
+    SN_TRY(obj ? (launch_wstats_one<NK, NWB, WPS, 1, BM_GEN, true>(pl, a, 1))
+               : (launch_wstats_one<NK, NWB, WPS, 1, BM_GEN, false>(pl, a, 1)));
+    return launch_wstats_one<NK, NWB, WPS, 2, BM_GEN, false>(pl, a, 0);
 }
 static int launch_wstats(snmf_plan* pl, bool obj) {
     StepArgs a = make_args(pl);
     a.n_tiles = pl->Tp / 32;
+    a.ldh = pl->ldhw;
+    a.stagger = pl->stagger_w;
     ScopedTimer tm(pl->ctx, FAM_WSTATS);
-    if (pl->NKT == 4) return launch_wstats_geo<4, 8>(pl, a, obj);
-    if (pl->NKT == 8) return launch_wstats_geo<8, 8>(pl, a, obj);
-    return launch_wstats_geo<16, 4>(pl, a, obj);
+    if (pl->NKT == 4) return launch_wstats_geo<4, 4, 2>(pl, a, obj);
+    if (pl->NKT == 8) return launch_wstats_geo<8, 4, 2>(pl, a, obj);
+    return launch_wstats_geo<16, 4, 1>(pl, a, obj);
 }
 
 static int launch_reduce(snmf_plan* pl, double* stats, bool do_mats, bool do_obj, int n_part, bool sh_const) {
@@ -674,10 +737,10 @@ static int launch_reduce(snmf_plan* pl, double* stats, bool do_mats, bool do_obj
     ra.do_obj = do_obj;
     ra.sh_const = pl->sh_const;
     ra.use_sh_const = sh_const;
-    const size_t tot = do_mats ? (size_t)pl->n_mat * pl->rp * pl->Fp + pl->rp : 1;
+    const size_t tot = do_mats ? ((size_t)pl->n_mat * pl->rp * pl->Fp) / 4 : 1;
     ScopedTimer tm(pl->ctx, FAM_REDUCE);
-    hipLaunchKernelGGL(k_reduce, dim3((int)std::min<size_t>((tot + 255) / 256, 2048)), dim3(256), 0, pl->ctx->stream,
-                       ra);
+    hipLaunchKernelGGL(k_reduce, dim3((int)std::max<size_t>(1, std::min<size_t>((tot + 31) / 32, 4096))), dim3(256),
+                       0, pl->ctx->stream, ra);
     HIP_TRY(hipGetLastError());
     return SNMF_OK;
 }

@@ -31,7 +31,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr float kFlr = 1e-9f;  // src/sparse_nmf.m:166
-constexpr int kNW = 8;         // waves per workgroup in k_hstep (2 per SIMD)
+constexpr int kMaxNW = 8;      // most waves per workgroup (reduction scratch sizing)
 
 // beta modes (template parameter BM)
 constexpr int BM_GEN = 0;  // generic beta (incl. IS, beta = 0)
@@ -117,6 +117,7 @@ struct StepArgs {
     float* spart;         // k_wstats: [n_chunks][rp]  partial row sums of H
     double* part;         // [grid][2] partial (div, sum S.*H)
     const int* stop;      // device flag: convergence reached -> kernels become no-ops
+    unsigned long long* prof;  // -DSNMF_PROF diagnostic builds only: per-wave phase cycle sums
     const float* wx;      // extra-row mode: W[Fm, k]  [rp]
     int F, T, Fp, rp, Tp, nf, nk;
     int Fm;               // rows covered by MFMA tiles = 32*nf
@@ -124,18 +125,162 @@ struct StepArgs {
     int xr;               // 1: F = Fm + 1, the last row ("Nyquist bin") is handled on the VALU
     int n_tiles;          // tiles of this kernel's tile width
     int ldh, ldr;         // LDS leading dimensions (floats)
+    int stagger;          // cycles by which half of the workgroups start late (0 = off)
+    int stagger_shift;    // which half: bit `shift` of the linear block id (-1: upper half of the grid)
     float beta, inv_bb1;
 };
 
-// Cooperative copy of a [cols][rp] tile of H (contiguous in HBM) into the padded LDS image.
+
+// Compiler fence for software pipelining.  hipcc otherwise sinks a prefetching load into the
+// iteration that consumes it (observed: global_load -> s_waitcnt vmcnt(0) -> MFMA, i.e. the full
+// L2 latency exposed every k-step).  Loads cannot move across this statement, so everything issued
+// before it stays in flight while the MFMAs after it run.
+// The asm statement pins loads at the IR level; sched_barrier(0) additionally stops the machine
+// scheduler from hoisting the (memory-free) MFMAs above the loads, which has the same effect.
+// Phase stamps (diagnostic build -DSNMF_PROF only; the shipped kernels contain none).
+#ifdef SNMF_PROF
+#define SNMF_STAMP_DECL unsigned long long pf_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long pl_ = __builtin_amdgcn_s_memtime();
+#define SNMF_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pf_[i] += t_ - pl_; pl_ = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SNMF_STAMP_OUT(base, nph) do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < nph; ++i_) (base)[i_] = pf_[i_]; } while (0)
+#else
+#define SNMF_STAMP_DECL
+#define SNMF_STAMP(i)
+#define SNMF_STAMP_OUT(base, nph)
+#endif
+
+#define SNMF_PIN()                          \
+    do {                                    \
+        asm volatile("" ::: "memory");      \
+        __builtin_amdgcn_sched_barrier(0);  \
+    } while (0)
+
+// acc[tau] += sum over k-blocks q of  Wfrag(q) (x) Sfrag_tau(q)
+//   wp : this lane's f32x4 of the W operand image, consecutive k-blocks 64 f32x4 apart (L2/HBM)
+//   sp : this lane's row of the LDS image (H tile or ratio tile), k-block q at sp + 8q,
+//        frame sub-tile tau a further tau*sstride floats on
+//   SWAP=false: W is the MFMA A operand (P1, P2);  SWAP=true: the LDS tile is A (P3).
+// W fragments are prefetched two k-blocks ahead, LDS fragments one ahead.
+template <int NT, bool SWAP>
+__device__ __forceinline__ void mfma_block(f32x16 (&acc)[NT], const f32x4& w, const f32x4 (&sf)[NT]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau) {
+            if (SWAP) acc[tau] = mfma32(sf[tau][e], w[e], acc[tau]);
+            else acc[tau] = mfma32(w[e], sf[tau][e], acc[tau]);
+        }
+    }
+}
+
+// The loop is unrolled by two 2-block stages held in NAMED registers (A, B): rotating buffers with
+// register copies would make the copy wait for the load it has just issued.  Stage X+1's loads are
+// issued before stage X's 8*NT MFMAs (512*NT cycles), which is what hides the L2 latency.
+template <int NT, bool SWAP>
+__device__ __forceinline__ void contract(f32x16 (&acc)[NT], const f32x4* __restrict__ wp, const float* sp,
+                                         int sstride, int nq) {
+    f32x4 wA0, wA1, wB0, wB1;
+    f32x4 sA0[NT], sA1[NT], sB0[NT], sB1[NT];
+    const int last = nq - 1;
+    auto ldw = [&](int q) { return wp[(size_t)(q < last ? q : last) * 64]; };
+    auto lds_ = [&](f32x4 (&d)[NT], int q) {
+        const int qq = q < last ? q : last;
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau) d[tau] = *reinterpret_cast<const f32x4*>(sp + tau * sstride + 8 * qq);
+    };
+    wA0 = ldw(0);
+    wA1 = ldw(1);
+    lds_(sA0, 0);
+    lds_(sA1, 1);
+    const int nq4 = nq & ~3;
+    int q = 0;
+    for (; q < nq4; q += 4) {
+        wB0 = ldw(q + 2);
+        wB1 = ldw(q + 3);
+        lds_(sB0, q + 2);
+        lds_(sB1, q + 3);
+        SNMF_PIN();
+        mfma_block<NT, SWAP>(acc, wA0, sA0);
+        mfma_block<NT, SWAP>(acc, wA1, sA1);
+        wA0 = ldw(q + 4);
+        wA1 = ldw(q + 5);
+        lds_(sA0, q + 4);
+        lds_(sA1, q + 5);
+        SNMF_PIN();
+        mfma_block<NT, SWAP>(acc, wB0, sB0);
+        mfma_block<NT, SWAP>(acc, wB1, sB1);
+    }
+    // remainder (nq % 4 blocks: only the W^T*ratio contraction in extra-row mode has one)
+    if (q < nq) {
+        mfma_block<NT, SWAP>(acc, wA0, sA0);
+        if (q + 1 < nq) mfma_block<NT, SWAP>(acc, wA1, sA1);
+        if (q + 2 < nq) {
+            wB0 = ldw(q + 2);
+            lds_(sB0, q + 2);
+            mfma_block<NT, SWAP>(acc, wB0, sB0);
+        }
+    }
+}
+
+// Two workgroups share a CU.  Launched together with identical work they would run in lockstep:
+// both staging (HBM burst, matrix pipe idle), then both issuing MFMAs (pipe contended).  Starting
+// the second half of the grid half a tile period late makes one workgroup's staging / epilogues
+// coincide with the other's MFMA phase for the rest of the kernel.  Purely a speed matter.
+__device__ __forceinline__ void stagger_start(int cycles, unsigned linear_block, unsigned n_blocks, int shift) {
+    const bool late = shift >= 0 ? ((linear_block >> shift) & 1u) != 0 : linear_block >= n_blocks / 2;
+    if (cycles > 0 && late) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)cycles) __builtin_amdgcn_s_sleep(32);
+    }
+}
+
+// Cooperative copy of a contiguous [cols][rowlen] global tile into an LDS image with leading
+// dimension ld (rowlen, ld multiples of 4 floats), and back.  Staging BOTH the H tile and the V
+// tile through LDS keeps every HBM-latency access out of the MFMA loops: vmcnt retires in issue
+// order, so a single outstanding HBM load (or store) in front of the W-fragment loads would stall
+// the first wait of the loop for the whole HBM latency.
 template <int NTHREADS>
-__device__ __forceinline__ void stage_h_tile(const float* __restrict__ src, float* Hs, int cols, int rp, int ldh) {
-    const int n4 = cols * rp / 4;
-    const int rp4 = rp / 4;
-    for (int i = threadIdx.x; i < n4; i += NTHREADS) {
-        f32x4 x = *reinterpret_cast<const f32x4*>(src + 4 * (size_t)i);
-        int t = i / rp4, k4 = i - t * rp4;
-        *reinterpret_cast<f32x4*>(Hs + t * ldh + 4 * k4) = x;
+__device__ __forceinline__ void stage_in(const float* __restrict__ src, float* dst, int cols, int rowlen, int ld) {
+    const int r4 = rowlen / 4;
+    const int n4 = cols * r4;
+    constexpr int B = 8;  // loads in flight per thread and batch
+    for (int i0 = threadIdx.x; i0 < n4; i0 += B * NTHREADS) {
+        f32x4 x[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            const int i = i0 + b * NTHREADS;
+            if (i < n4) x[b] = *reinterpret_cast<const f32x4*>(src + 4 * (size_t)i);
+        }
+        SNMF_PIN();
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            const int i = i0 + b * NTHREADS;
+            if (i < n4) {
+                const int t = i / r4, k4 = i - t * r4;
+                *reinterpret_cast<f32x4*>(dst + t * ld + 4 * k4) = x[b];
+            }
+        }
+    }
+}
+template <int NTHREADS>
+__device__ __forceinline__ void stage_out(float* __restrict__ dst, const float* src, int cols, int rowlen, int ld) {
+    const int r4 = rowlen / 4;
+    const int n4 = cols * r4;
+    constexpr int B = 8;
+    for (int i0 = threadIdx.x; i0 < n4; i0 += B * NTHREADS) {
+        f32x4 x[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            const int i = i0 + b * NTHREADS;
+            if (i < n4) {
+                const int t = i / r4, k4 = i - t * r4;
+                x[b] = *reinterpret_cast<const f32x4*>(src + t * ld + 4 * k4);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            const int i = i0 + b * NTHREADS;
+            if (i < n4) *reinterpret_cast<f32x4*>(dst + 4 * (size_t)i) = x[b];
+        }
     }
 }
 
@@ -143,8 +288,14 @@ __device__ __forceinline__ void stage_h_tile(const float* __restrict__ src, floa
 // k_hstep: H half-step, src/sparse_nmf.m:189-208, fused with the objective of the previous
 // iterate (:248-261).  UPD=false gives the objective-only pass.
 // ============================================================================================
-template <int NT, int BM, bool OBJ, bool UPD>
-__global__ __launch_bounds__(kNW * 64, 2) void k_hstep(StepArgs a) {
+// Geometry: NW waves per workgroup, NT 32-frame sub-tiles per tile.  Two shapes are used:
+//   (NW=4, NT=1): TWO independent workgroups per CU (one wave of each per SIMD).  Their barriers,
+//                 H-tile staging and VALU epilogues de-synchronise, so one workgroup's MFMAs fill
+//                 the matrix pipe while the other is staging / in an epilogue.
+//   (NW=8, NT=2): one workgroup per CU, W fragments shared by two sub-tiles (half the L2 traffic).
+template <int NW, int NT, int BM, bool OBJ, bool UPD>
+__global__ __launch_bounds__(NW * 64, 2) void k_hstep(StepArgs a) {
+    constexpr int kNW = NW;
     if (a.stop && *a.stop) return;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int Tt = 32 * NT;
@@ -161,11 +312,17 @@ __global__ __launch_bounds__(kNW * 64, 2) void k_hstep(StepArgs a) {
         for (int i = threadIdx.x; i < Tt * 8; i += kNW * 64) Rs[(i >> 3) * ldr + a.Fm + (i & 7)] = 0.f;
     }
 
+    stagger_start(a.stagger, blockIdx.x, gridDim.x, a.stagger_shift);
+    SNMF_STAMP_DECL
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
         const int t0 = tile * Tt;
         __syncthreads();  // previous tile's readers of Hs / Rs are done
-        stage_h_tile<kNW * 64>(a.Hin + (size_t)t0 * rp, Hs, Tt, rp, ldh);
+        SNMF_STAMP(0);
+        stage_in<kNW * 64>(a.Hin + (size_t)t0 * rp, Hs, Tt, rp, ldh);
+        stage_in<kNW * 64>(a.V + (size_t)t0 * Fp, Rs, Tt, Fp, ldr);  // the ratio is formed in place
+        SNMF_STAMP(1);
         __syncthreads();
+        SNMF_STAMP(2);
 
         // ---- P1: Lam[phi] = W[phi,:] * H[:, tile]  -> ratio / den image ----------------------
         for (int phi = w; phi < a.nf; phi += kNW) {
@@ -173,34 +330,18 @@ __global__ __launch_bounds__(kNW * 64, 2) void k_hstep(StepArgs a) {
 #pragma unroll
             for (int tau = 0; tau < NT; ++tau) acc[tau] = zero16();
             const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)phi * rp * 32) + lane;
-            const float* hs = Hs + fl * ldh + 4 * h;
-            const int nq = rp / 8;
-            f32x4 wa = wp[0];
-            for (int q = 0; q < nq; ++q) {
-                f32x4 wn = wp[(q + 1 < nq ? q + 1 : q) * 64];  // prefetch next 1 KiB W slice
-                f32x4 hb[NT];
-#pragma unroll
-                for (int tau = 0; tau < NT; ++tau)
-                    hb[tau] = *reinterpret_cast<const f32x4*>(hs + tau * 32 * ldh + 8 * q);
-#pragma unroll
-                for (int tau = 0; tau < NT; ++tau) {
-                    acc[tau] = mfma32(wa.x, hb[tau].x, acc[tau]);
-                    acc[tau] = mfma32(wa.y, hb[tau].y, acc[tau]);
-                    acc[tau] = mfma32(wa.z, hb[tau].z, acc[tau]);
-                    acc[tau] = mfma32(wa.w, hb[tau].w, acc[tau]);
-                }
-                wa = wn;
-            }
+            SNMF_STAMP(3);
+            contract<NT, false>(acc, wp, Hs + fl * ldh + 4 * h, 32 * ldh, rp / 8);
+            SNMF_STAMP(4);
             // epilogue: lane (t = fl, h), reg -> f = 32*phi + drow(reg,h)
             float dsum = 0.f;
 #pragma unroll
             for (int tau = 0; tau < NT; ++tau) {
                 const int t = t0 + tau * 32 + fl;
-                const float* vp = a.V + (size_t)t * Fp + phi * 32 + 4 * h;
                 float* rsp = Rs + (tau * 32 + fl) * ldr + phi * 32 + 4 * h;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(vp + 8 * g);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(rsp + 8 * g);  // staged V
                     f32x4 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -217,6 +358,7 @@ __global__ __launch_bounds__(kNW * 64, 2) void k_hstep(StepArgs a) {
                 }
             }
             if (OBJ) acc_div += (double)dsum;
+            SNMF_STAMP(5);
         }
         if (a.xr) {
             // extra row: lam_x[t] = sum_k W[Fm,k] H[k,t]; 4 columns x 16 lanes at a time
@@ -227,15 +369,21 @@ __global__ __launch_bounds__(kNW * 64, 2) void k_hstep(StepArgs a) {
                 const int tl = w * CPW + c0 + (lane >> 4);
                 const int kl = lane & 15;
                 const float* hrow = Hs + tl * ldh;
-                float s = 0.f;
-                for (int k = kl; k < rp; k += 16) s += wxs[k] * hrow[k];
+                float s0 = 0.f, s1 = 0.f;
+                for (int k = 4 * kl; k < rp; k += 64) {  // 16 lanes x 4 consecutive k per step
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wxs + k);
+                    const f32x4 hv = *reinterpret_cast<const f32x4*>(hrow + k);
+                    s0 += wv[0] * hv[0] + wv[1] * hv[1];
+                    s1 += wv[2] * hv[2] + wv[3] * hv[3];
+                }
+                float s = s0 + s1;
                 s += __shfl_xor(s, 1);
                 s += __shfl_xor(s, 2);
                 s += __shfl_xor(s, 4);
                 s += __shfl_xor(s, 8);
                 if (kl == 0) {
                     const int t = t0 + tl;
-                    const float v = a.V[(size_t)t * Fp + a.Fm];
+                    const float v = Rs[tl * ldr + a.Fm];  // staged V
                     const float lam = fmaxf(s, kFlr);
                     if (OBJ) dsum += (t < a.T) ? div_term<BM>(v, lam, a.beta, a.inv_bb1) : 0.f;
                     if (UPD) Rs[tl * ldr + a.Fm] = (BM == BM_KL) ? v * fast_rcp(lam) : den_of_lam<BM>(lam, a.beta);
@@ -243,8 +391,10 @@ __global__ __launch_bounds__(kNW * 64, 2) void k_hstep(StepArgs a) {
             }
             if (OBJ) acc_div += (double)dsum;
         }
+        SNMF_STAMP(6);
         if (!UPD) continue;
         __syncthreads();
+        SNMF_STAMP(7);
 
         // ---- P2: contraction over f with W^T ------------------------------------------------
         // KL : dmh = W^T * ratio ;            H <- H .* dmh ./ dphv
@@ -303,38 +453,32 @@ __global__ __launch_bounds__(kNW * 64, 2) void k_hstep(StepArgs a) {
 #pragma unroll
                 for (int tau = 0; tau < NT; ++tau) acc[tau] = zero16();
                 const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wk4 + (size_t)kap * a.Fq * 32) + lane;
-                const float* rs = Rs + fl * ldr + 4 * h;
-                const int nq = a.Fq / 8;
-                f32x4 wa = wp[0];
-                for (int q = 0; q < nq; ++q) {
-                    f32x4 wn = wp[(q + 1 < nq ? q + 1 : q) * 64];
-                    f32x4 rb[NT];
+                // per-k constants of the epilogue, issued before the MFMA loop
+                f32x4 dpf[4], spf[4];
+                if (!a.S) {
 #pragma unroll
-                    for (int tau = 0; tau < NT; ++tau)
-                        rb[tau] = *reinterpret_cast<const f32x4*>(rs + tau * 32 * ldr + 8 * q);
-#pragma unroll
-                    for (int tau = 0; tau < NT; ++tau) {
-                        acc[tau] = mfma32(wa.x, rb[tau].x, acc[tau]);
-                        acc[tau] = mfma32(wa.y, rb[tau].y, acc[tau]);
-                        acc[tau] = mfma32(wa.z, rb[tau].z, acc[tau]);
-                        acc[tau] = mfma32(wa.w, rb[tau].w, acc[tau]);
+                    for (int g = 0; g < 4; ++g) {
+                        const int k0 = kap * 32 + 8 * g + 4 * h;
+                        if (BM == BM_KL) dpf[g] = *reinterpret_cast<const f32x4*>(a.dphv + k0);
+                        if (OBJ || BM != BM_KL) spf[g] = *reinterpret_cast<const f32x4*>(a.lamk + k0);
                     }
-                    wa = wn;
                 }
+                SNMF_STAMP(8);
+                contract<NT, false>(acc, wp, Rs + fl * ldr + 4 * h, 32 * ldr, a.Fq / 8);
+                SNMF_STAMP(9);
                 // epilogue: lane (t = fl, h), reg -> k = 32*kap + drow(reg,h)
                 float shsum = 0.f;
 #pragma unroll
                 for (int tau = 0; tau < NT; ++tau) {
                     const int t = t0 + tau * 32 + fl;
                     float* hsp = Hs + (tau * 32 + fl) * ldh + kap * 32 + 4 * h;
-                    float* hop = a.Hout + (size_t)t * rp + kap * 32 + 4 * h;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int k0 = kap * 32 + 8 * g + 4 * h;
                         f32x4 ho = *reinterpret_cast<f32x4*>(hsp + 8 * g);
                         f32x4 sp;
                         if (a.S) sp = *reinterpret_cast<const f32x4*>(a.S + (size_t)t * rp + k0);
-                        else sp = *reinterpret_cast<const f32x4*>(a.lamk + k0);
+                        else sp = spf[g];
                         f32x4 o;
                         if (BM == BM_KL) {
                             f32x4 dp;
@@ -343,14 +487,14 @@ __global__ __launch_bounds__(kNW * 64, 2) void k_hstep(StepArgs a) {
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) dp[j] = fmaxf(cs[j] + sp[j], kFlr);
                             } else {
-                                dp = *reinterpret_cast<const f32x4*>(a.dphv + k0);
+                                dp = dpf[g];
                             }
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 o[j] = ho[j] * acc[tau][4 * g + j] * fast_rcp(dp[j]);
                                 if (OBJ) shsum += sp[j] * ho[j];
                             }
-                            *reinterpret_cast<f32x4*>(hop + 8 * g) = o;
+                            *reinterpret_cast<f32x4*>(hsp + 8 * g) = o;  // in place; copied out after P2
                         } else if (pass == 0) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
@@ -362,19 +506,25 @@ __global__ __launch_bounds__(kNW * 64, 2) void k_hstep(StepArgs a) {
                         } else {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) o[j] = ho[j] * acc[tau][4 * g + j];
-                            *reinterpret_cast<f32x4*>(hop + 8 * g) = o;
+                            *reinterpret_cast<f32x4*>(hsp + 8 * g) = o;
                         }
                     }
                 }
                 if (OBJ) acc_sh += (double)shsum;
+                SNMF_STAMP(10);
             }
         }
+        // the updated H tile leaves through one coalesced copy
+        __syncthreads();
+        stage_out<kNW * 64>(a.Hout + (size_t)t0 * rp, Hs, Tt, rp, ldh);
+        SNMF_STAMP(11);
     }
+    SNMF_STAMP_OUT(a.prof + ((size_t)blockIdx.x * kNW + w) * 12, 12);
 
     if (OBJ) {
         // deterministic workgroup reduction of the two fp64 partial sums
         __syncthreads();
-        double* red = reinterpret_cast<double*>(lds);
+        double* red = reinterpret_cast<double*>(lds);  // [2][NW*64]
         red[threadIdx.x] = acc_div;
         red[kNW * 64 + threadIdx.x] = acc_sh;
         __syncthreads();
@@ -402,13 +552,14 @@ __global__ __launch_bounds__(kNW * 64, 2) void k_hstep(StepArgs a) {
 // its NK x (32x32) accumulators in registers over the whole chunk of frames.
 // OBJ: additionally sums the divergence of (W, H) (W-only mode: Lam' IS the objective's Lam).
 // ============================================================================================
-template <int NK, int NWB, int WM, int BM, bool OBJ>
-__global__ __launch_bounds__(NWB * 64, (NWB == 8 ? 2 : 1)) void k_wstats(StepArgs a, int n_chunks, int mat_index,
+template <int NK, int NWB, int WPS, int WM, int BM, bool OBJ>
+__global__ __launch_bounds__(NWB * 64, WPS) void k_wstats(StepArgs a, int n_chunks, int mat_index,
                                                                           int n_mat) {
     if (a.stop && *a.stop) return;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Hs = lds;             // [32][ldh]
-    float* wxs = lds + 32 * a.ldh;  // [rp] extra row of W
+    float* Hs = lds;                  // [32][ldh]
+    float* Vs = lds + 32 * a.ldh;     // [32][Fp]  V tile (no HBM access inside the MFMA loops)
+    float* wxs = Vs + 32 * a.Fp;      // [rp] extra row of W
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int fl = lane & 31, h = lane >> 5;
     const int rp = a.rp, Fp = a.Fp, ldh = a.ldh;
@@ -432,12 +583,15 @@ __global__ __launch_bounds__(NWB * 64, (NWB == 8 ? 2 : 1)) void k_wstats(StepArg
 #pragma unroll
     for (int k = 0; k < NK; ++k) G[k] = zero16();
     float ssum[2] = {0.f, 0.f};  // thread <-> k = tid + j*NWB*64 (rp <= 2*NWB*64 checked on the host)
+    stagger_start(a.stagger, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
+                  gridDim.x * gridDim.y * gridDim.z, a.stagger_shift);
     double acc_div = 0.0;
 
     for (int tile = tb; tile < te; ++tile) {
         const int t0 = tile * 32;
         __syncthreads();
-        stage_h_tile<NWB * 64>(a.Hin + (size_t)t0 * rp, Hs, 32, rp, ldh);
+        stage_in<NWB * 64>(a.Hin + (size_t)t0 * rp, Hs, 32, rp, ldh);
+        stage_in<NWB * 64>(a.V + (size_t)t0 * Fp, Vs, 32, Fp, Fp);
         __syncthreads();
         if (WM == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
 #pragma unroll
@@ -460,11 +614,17 @@ __global__ __launch_bounds__(NWB * 64, (NWB == 8 ? 2 : 1)) void k_wstats(StepArg
                 const int kl = lane & 15;
                 const float* hrow = Hs + tl * ldh;
                 const int t = t0 + tl;
-                const float v = a.V[(size_t)t * Fp + a.Fm];
+                const float v = Vs[tl * Fp + a.Fm];
                 float rv;
                 if (WM != 3) {
-                    float s = 0.f;
-                    for (int k = kl; k < rp; k += 16) s += wxs[k] * hrow[k];
+                    float s0 = 0.f, s1 = 0.f;
+                    for (int k = 4 * kl; k < rp; k += 64) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(wxs + k);
+                        const f32x4 hv = *reinterpret_cast<const f32x4*>(hrow + k);
+                        s0 += wv[0] * hv[0] + wv[1] * hv[1];
+                        s1 += wv[2] * hv[2] + wv[3] * hv[3];
+                    }
+                    float s = s0 + s1;
                     s += __shfl_xor(s, 1);
                     s += __shfl_xor(s, 2);
                     s += __shfl_xor(s, 4);
@@ -498,27 +658,17 @@ __global__ __launch_bounds__(NWB * 64, (NWB == 8 ? 2 : 1)) void k_wstats(StepArg
         float R[16];
         if (WM != 3) {
             // ---- P3: Lam'^T[t, f] = sum_k H[k,t] W[f,k]  (A = H from LDS, B = W from L2) -----
-            f32x16 acc = zero16();
+            f32x16 acc1[1] = {zero16()};
             const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)phi * rp * 32) + lane;
-            const float* hs = Hs + fl * ldh + 4 * h;
-            const int nq = rp / 8;
-            f32x4 wa = wp[0];
-            for (int q = 0; q < nq; ++q) {
-                f32x4 wn = wp[(q + 1 < nq ? q + 1 : q) * 64];
-                f32x4 hb = *reinterpret_cast<const f32x4*>(hs + 8 * q);
-                acc = mfma32(hb.x, wa.x, acc);
-                acc = mfma32(hb.y, wa.y, acc);
-                acc = mfma32(hb.z, wa.z, acc);
-                acc = mfma32(hb.w, wa.w, acc);
-                wa = wn;
-            }
+            contract<1, true>(acc1, wp, Hs + fl * ldh + 4 * h, 0, rp / 8);
+            const f32x16 acc = acc1[0];
             // lane (f = fl, h), reg -> t = t0 + drow(reg,h)
             const int f = phi * 32 + fl;
             float dsum = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int t = t0 + drow(i, h);
-                float v = a.V[(size_t)t * Fp + f];
+                const float v = Vs[drow(i, h) * Fp + f];
                 float lam = fmaxf(acc[i], kFlr);
                 if (OBJ) {
                     if (do_obj) {
@@ -534,20 +684,50 @@ __global__ __launch_bounds__(NWB * 64, (NWB == 8 ? 2 : 1)) void k_wstats(StepArg
         } else {
             const int f = phi * 32 + fl;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) R[i] = a.V[(size_t)(t0 + drow(i, h)) * Fp + f];
+            for (int i = 0; i < 16; ++i) R[i] = Vs[drow(i, h) * Fp + f];
         }
         // ---- P4: G[phi, kap] += ratio[f, t] * H[k, t]  (A = ratio registers, B = H from LDS)
-        const float* hb = Hs + (4 * h) * ldh + fl;
+        // B fragments (one ds_read_b32 per MFMA) are fetched a whole kappa-tile (16 reads) ahead.
+        // kappa-tiles beyond nk (NK is a template bound) are clamped: they recompute the last real
+        // tile into an accumulator that is never stored, which keeps the loop branch-free.
+        // The H image of this kernel is padded to 32*NK columns per kappa-group (host: ldh), so tiles
+        // beyond nk read finite padding into accumulators that are never stored -- no clamps, and
+        // every read is (one of 16 row bases) + an immediate offset.
+        const float* hb = Hs + (4 * h) * ldh + fl + kap_base * 32;
+        const float* hrow[16];
 #pragma unroll
-        for (int kap = 0; kap < NK; ++kap) {
-            if (kap_base + kap < a.nk) {  // wave-uniform
+        for (int i = 0; i < 16; ++i) hrow[i] = hb + ((i & 3) + 8 * (i >> 2)) * ldh;
+        float b0[16], b1[16];
+        auto ldb = [&](float (&b)[16], int kap) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    float b = hb[((i & 3) + 8 * (i >> 2)) * ldh + (kap_base + kap) * 32];
-                    G[kap] = mfma32(R[i], b, G[kap]);
-                }
-            }
-        }
+            for (int i = 0; i < 16; ++i) b[i] = hrow[i][kap * 32];
+        };
+        // two named buffers alternate (a register copy would have to wait for the load it follows);
+        // the tile index is a compile-time constant so that G[] is never indexed dynamically
+#define SNMF_KTILE(KP, CUR, NXT)                                                  \
+    if constexpr ((KP) < NK) {                                                    \
+        if constexpr ((KP) + 1 < NK) ldb(NXT, (KP) + 1);                          \
+        SNMF_PIN();                                                               \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) G[KP] = mfma32(R[i], CUR[i], G[KP]); \
+    }
+        ldb(b0, 0);
+        SNMF_KTILE(0, b0, b1)
+        SNMF_KTILE(1, b1, b0)
+        SNMF_KTILE(2, b0, b1)
+        SNMF_KTILE(3, b1, b0)
+        SNMF_KTILE(4, b0, b1)
+        SNMF_KTILE(5, b1, b0)
+        SNMF_KTILE(6, b0, b1)
+        SNMF_KTILE(7, b1, b0)
+        SNMF_KTILE(8, b0, b1)
+        SNMF_KTILE(9, b1, b0)
+        SNMF_KTILE(10, b0, b1)
+        SNMF_KTILE(11, b1, b0)
+        SNMF_KTILE(12, b0, b1)
+        SNMF_KTILE(13, b1, b0)
+        SNMF_KTILE(14, b0, b1)
+        SNMF_KTILE(15, b1, b0)
+#undef SNMF_KTILE
     }
 
     // ---- write the partial slab: D tile lane (k = fl, h), reg -> f = 32*phi + drow(reg,h)
@@ -626,29 +806,107 @@ struct ReduceArgs {
 
 __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
     if (a.stop && *a.stop) return;
-    const size_t nel = (size_t)a.rp * a.Fp;
-    const size_t tot = a.do_mats ? nel * a.n_mat + a.rp : 0;
-    double* sc = a.stats + nel * a.n_mat + a.rp;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (size_t)gridDim.x * 256) {
-        double s = 0.0;
-        if (i < nel * a.n_mat) {
-            const size_t m = i / nel, e = i - m * nel;
-            const float* p = a.slabs + m * nel + e;
-            for (int c = 0; c < a.n_chunks; ++c) s += (double)p[(size_t)c * a.n_mat * nel];
-        } else {
-            const size_t k = i - nel * a.n_mat;
-            for (int c = 0; c < a.n_chunks; ++c) s += (double)a.spart[(size_t)c * a.rp + k];
+    const size_t nel = (size_t)a.rp * a.Fp;   // multiple of 4
+    const size_t nmat = nel * a.n_mat;
+    double* sc = a.stats + nmat + a.rp;
+    if (a.do_mats) {
+        // slabs: a block owns 32 x 4 consecutive elements; its 8 thread groups each add a contiguous
+        // eighth of the chunks (8 loads in flight), then the 8 partial sums are added in group
+        // order.  Every order is fixed => bitwise reproducible and identical on every rank.
+        __shared__ double part[8][32][4];
+        const size_t n4 = nmat / 4;
+        const size_t cstride = nmat;  // floats between consecutive chunks
+        const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+        const int cb = (int)(((long long)a.n_chunks * g) / 8), ce = (int)(((long long)a.n_chunks * (g + 1)) / 8);
+        for (size_t b4 = (size_t)blockIdx.x * 32; b4 < n4; b4 += (size_t)gridDim.x * 32) {
+            const size_t i4 = b4 + e;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            if (i4 < n4) {
+                const float* p = a.slabs + 4 * i4;
+                int c = cb;
+                for (; c + 8 <= ce; c += 8) {
+                    f32x4 x[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const f32x4*>(p + (size_t)(c + j) * cstride);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        s0 += (double)x[j][0];
+                        s1 += (double)x[j][1];
+                        s2 += (double)x[j][2];
+                        s3 += (double)x[j][3];
+                    }
+                }
+                for (; c < ce; ++c) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(p + (size_t)c * cstride);
+                    s0 += (double)x[0];
+                    s1 += (double)x[1];
+                    s2 += (double)x[2];
+                    s3 += (double)x[3];
+                }
+            }
+            __syncthreads();
+            part[g][e][0] = s0;
+            part[g][e][1] = s1;
+            part[g][e][2] = s2;
+            part[g][e][3] = s3;
+            __syncthreads();
+            if (threadIdx.x < 128) {
+                const int ee = threadIdx.x >> 2, j = threadIdx.x & 3;
+                if (b4 + ee < n4) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int gg = 0; gg < 8; ++gg) t += part[gg][ee][j];
+                    a.stats[4 * (b4 + ee) + j] = t;
+                }
+            }
         }
-        a.stats[i] = s;
+        // row sums of H (KL only; zeros otherwise): same two-level fixed-order scheme, 32 rows a block
+        for (int k0 = blockIdx.x * 32; k0 < a.rp; k0 += gridDim.x * 32) {
+            double sk = 0.0;
+            int c = cb;
+            for (; c + 8 <= ce; c += 8) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = a.spart[(size_t)(c + j) * a.rp + k0 + e];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sk += (double)x[j];
+            }
+            for (; c < ce; ++c) sk += (double)a.spart[(size_t)c * a.rp + k0 + e];
+            __syncthreads();
+            part[g][e][0] = sk;
+            __syncthreads();
+            if (threadIdx.x < 32) {
+                double t = 0.0;
+#pragma unroll
+                for (int gg = 0; gg < 8; ++gg) t += part[gg][threadIdx.x][0];
+                a.stats[nmat + k0 + threadIdx.x] = t;
+            }
+        }
     }
-    if (blockIdx.x == 0 && threadIdx.x < 2) {
-        double s = 0.0;
+    // objective partial sums: the LAST block folds them (fixed strided + tree order)
+    if (blockIdx.x == gridDim.x - 1) {
+        __shared__ double red2[2][256];
+        double d = 0.0, h = 0.0;
         if (a.do_obj) {
-            if (threadIdx.x == 1 && a.use_sh_const) s = a.sh_const;
-            else
-                for (int c = 0; c < a.n_part; ++c) s += a.part[2 * c + threadIdx.x];
+            for (int c = threadIdx.x; c < a.n_part; c += 256) {
+                d += a.part[2 * c];
+                h += a.part[2 * c + 1];
+            }
         }
-        sc[threadIdx.x] = s;
+        red2[0][threadIdx.x] = d;
+        red2[1][threadIdx.x] = h;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) {
+                red2[0][threadIdx.x] += red2[0][threadIdx.x + st];
+                red2[1][threadIdx.x] += red2[1][threadIdx.x + st];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            sc[0] = a.do_obj ? red2[0][0] : 0.0;
+            sc[1] = a.do_obj ? (a.use_sh_const ? a.sh_const : red2[1][0]) : 0.0;
+        }
     }
 }
 
