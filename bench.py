@@ -49,7 +49,16 @@ def make_problem(F, T, r, t0=0, t1=None):
     return np.concatenate(Vs, axis=1), W0, np.concatenate(Hs, axis=1)
 
 
-def cpu_baseline(F, T, r, budget_iters=2):
+def blas_threads():
+    try:
+        from threadpoolctl import threadpool_info
+        n = [d.get("num_threads", 0) for d in threadpool_info() if d.get("user_api") == "blas"]
+        return max(n) if n else os.cpu_count()
+    except Exception:
+        return os.cpu_count()
+
+
+def cpu_baseline(F, T, r, budget_iters=12):
     """The reference's CPU path, represented by the fp64 oracle restatement (MATLAB is not
     available): same operation sequence as src/sparse_nmf.m including MATLAB's duplicated
     (V./Lam)*H' product, BLAS-backed, all host cores.  Bounded sample: `budget_iters` iterations
@@ -60,9 +69,10 @@ def cpu_baseline(F, T, r, budget_iters=2):
     t = time.perf_counter()
     oracle_nmf(V, p, mimic_matlab_flops=True)
     dt = time.perf_counter() - t
-    return {"value": budget_iters / dt, "unit": "iterations/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{budget_iters} iterations of the same {F}x{T} r={r} KL workload, fp64 NumPy/BLAS oracle "
-                      f"(stand-in for MATLAB sparse_nmf.m, not MATLAB itself), {dt:.1f} s"}
+    return {"value": budget_iters / dt, "unit": "iterations/s", "cores": blas_threads(), "kind": "port",
+            "sample": f"{budget_iters} iterations of the same {F}x{T} r={r} KL workload, fp64 NumPy/OpenBLAS oracle "
+                      f"(stand-in for MATLAB sparse_nmf.m, not MATLAB itself; BLAS threads = cores used, "
+                      f"host has {os.cpu_count()} logical CPUs), {dt:.1f} s"}
 
 
 def main():
@@ -117,6 +127,18 @@ def main():
         div, cost, n_it = plan2.get_objective()
         ms = dt / K * 1e3
         dom = max(("hstep", "wstats"), key=lambda f: fam[f][0])
+        # HBM bytes per launch of the dominant kernel: from the SEPARATE rocprofv3 --pmc passes of the
+        # same command (scripts/prof.sh -> scripts/summarize_prof.py -> profiles/*_traffic.json);
+        # a profiler cannot run inside this process, so the committed measurement is quoted.
+        traffic = None
+        if (F, T, r) == (F_, T_, R_):
+            import glob
+            for fn in sorted(glob.glob(os.path.join(_ROOT, "profiles", "r*_traffic.json")))[-1:]:
+                tj = json.load(open(fn))
+                for k, v in tj.items():
+                    if k.startswith("k_" + dom) and ("true, true" in k or dom == "wstats"):
+                        traffic = v["total_bytes"]
+        last_cost = [c for c in cost if c != 0.0]
         ach = flops_half / (fam[dom][0] * 1e-3) / 1e12 if fam[dom][0] > 0 else 0.0
         out = {
             "metric": "NMF multiplicative-update iterations/sec (FxTxr)", "value": K / dt, "unit": "iterations/s",
@@ -126,11 +148,12 @@ def main():
                                    f"r={r}, KL, sparsity={SPARSITY}, full W+H update + objective per step",
                        "F": F, "T": T, "r": r, "beta": 1, "geometry": desc},
             "roofline": {"bound": "mfma", "kernel": f"k_{dom}", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE/WRITE_SIZE passes)",
                          "algorithmic_flops_per_launch": flops_half,
                          "kernel_ms": {f: fam[f][0] for f in fam}, "launches": {f: fam[f][1] for f in fam},
                          "whole_iteration_TFLOPs": 2 * flops_half / (ms * 1e-3) / 1e12},
-            "final_cost": float(cost[n_it - 1]) if n_it > 0 else None,
+            "final_cost": float(last_cost[-1]) if last_cost else None,
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(F, T, r)
