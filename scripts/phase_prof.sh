@@ -8,7 +8,7 @@ for l in sys.stdin:
     if l.startswith('[SNMF'): last=l
     elif l.startswith('{'): d=json.loads(l); print(last.strip()); print({k:round(v,4) for k,v in d['roofline']['kernel_ms'].items()})
 "; }
-run SNMF_HSTEP_CFG=4x1
-run SNMF_HSTEP_CFG=4x1 SNMF_WGPCU=1
-run SNMF_HSTEP_CFG=8x1 SNMF_WGPCU=1
+run SNMF_X=1
+run SNMF_PROF_W=1
+run SNMF_PROF_W=1 SNMF_WSTATS_NL=0
 cp /tmp/libsnmf_hip.so.bak se_snmf_nat_amd/libsnmf_hip.so

@@ -208,8 +208,8 @@ struct snmf_plan {
     // geometry
     int Fp = 0, rp = 0, Tp = 0, nf = 0, nk = 0;
     int Fm = 0, Fq = 0, xr = 0;
-    int NT = 1, NWH = 8;   // k_hstep: frame tile = 32*NT, NWH waves per workgroup
-    int NKT = 8, NWB = 4, WPS = 2;  // k_wstats template geometry
+    int NT = 1, NWH = 8, NLH = 0;  // k_hstep: frame tile = 32*NT, NWH consumer + NLH loader waves
+    int NKT = 8, NWB = 4, WPS = 2, NLW = 0;  // k_wstats template geometry (NLW loader waves)
     int n_fg = 1, n_kg = 1, n_chunks = 1;
     int grid_h = 1;
     int ldh = 0, ldr = 0, ldhw = 0;
@@ -265,18 +265,21 @@ extern "C" void snmf_plan_destroy(snmf_plan* pl) {
     hipSetDevice(pl->ctx->device);
     hipStreamSynchronize(pl->ctx->stream);
 #ifdef SNMF_PROF
-    if (pl->prof) {  // diagnostic build: phase shares of the LAST k_hstep launch
-        const int nw = pl->grid_h * pl->NWH;
+    if (pl->prof) {  // diagnostic build: phase shares of the LAST big-kernel launch
+        const bool wlast = getenv("SNMF_PROF_W") != nullptr;
+        const int nw = wlast ? pl->n_chunks * pl->n_fg * pl->NWB : pl->grid_h * pl->NWH;
         std::vector<unsigned long long> hp((size_t)nw * 12);
-        hipMemcpy(hp.data(), pl->prof, hp.size() * 8, hipMemcpyDeviceToHost);
+        hipMemcpy(hp.data(), pl->prof + (wlast ? (size_t)4096 * 12 : 0), hp.size() * 8, hipMemcpyDeviceToHost);
         double tot[12] = {0};
         for (int i = 0; i < nw; ++i)
             for (int j = 0; j < 12; ++j) tot[j] += (double)hp[(size_t)i * 12 + j];
         double all = 0;
         for (int j = 0; j < 12; ++j) all += tot[j];
-        static const char* nm[12] = {"bar_top", "stage", "bar_stage", "p1_pre", "p1_mfma", "p1_epi", "xrow", "bar_p2",
-                                     "p2_pre", "p2_mfma", "p2_epi", "stage_out"};
-        fprintf(stderr, "[SNMF_PROF] k_hstep phase shares (avg cycles/wave = %.0f):", all / nw);
+        static const char* nmh[12] = {"bar_top", "stage", "bar_stage", "p1_pre", "p1_mfma", "p1_epi", "xrow", "bar_p2",
+                                      "p2_pre", "p2_mfma", "p2_epi", "stage_out"};
+        static const char* nmw[12] = {"loop", "barrier", "ssum+xrow", "p3_mfma", "p3_epi", "p4_mfma", "-", "-", "-", "-", "-", "-"};
+        const char* const* nm = wlast ? nmw : nmh;
+        fprintf(stderr, "[SNMF_PROF] %s phase shares (avg cycles/wave = %.0f):", wlast ? "k_wstats" : "k_hstep", all / nw);
         for (int j = 0; j < 12; ++j) fprintf(stderr, " %s=%.1f%%", nm[j], 100.0 * tot[j] / all);
         fprintf(stderr, "\n");
         hipFree(pl->prof);
@@ -340,7 +343,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     const size_t lds_cap = 160 * 1024;  // gfx950: 160 KiB per CU, one workgroup may take all of it
     const size_t lds_extra = (size_t)pl->rp * 4;
     const size_t lds1 = 32 * per_col + lds_extra, lds2 = 64 * per_col + lds_extra;
-    if (2 * lds1 <= lds_cap) { pl->NWH = 4; pl->NT = 1; }
+    if (2 * lds1 - lds_extra <= lds_cap) { pl->NWH = 8; pl->NT = 1; pl->NLH = 4; }  // double-buffered
     else if (lds2 <= lds_cap && pl->Tp / 64 >= ctx->n_cu) { pl->NWH = 8; pl->NT = 2; }
     else if (lds1 <= lds_cap) { pl->NWH = 8; pl->NT = 1; }
     else {
@@ -350,16 +353,19 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     }
     if (const char* e = getenv("SNMF_HSTEP_CFG")) {
         int nw = 0, nt = 0;
-        if (sscanf(e, "%dx%d", &nw, &nt) == 2 && (nw == 4 || nw == 8) && (nt == 1 || nt == 2) &&
-            (nt == 1 ? lds1 : lds2) <= lds_cap) {
+        int nl = 0;
+        const int got = sscanf(e, "%dx%dx%d", &nw, &nt, &nl);
+        if (got >= 2 && (nw == 4 || nw == 8) && (nt == 1 || nt == 2) && (nt == 1 ? lds1 : lds2) <= lds_cap) {
             pl->NWH = nw;
             pl->NT = nt;
+            pl->NLH = (got == 3 && nl == 4 && nw == 8 && nt == 1 && 2 * lds1 - lds_extra <= lds_cap) ? 4 : 0;
         }
     }
-    pl->lds_h = std::max<size_t>(pl->NT == 1 ? lds1 : lds2, 2 * kMaxNW * 64 * sizeof(double));
+    pl->lds_h = std::max<size_t>(pl->NLH ? 2 * lds1 - lds_extra : (pl->NT == 1 ? lds1 : lds2),
+                                 2 * kMaxNW * 64 * sizeof(double));
     const int n_tiles_h = pl->Tp / (32 * pl->NT);
-    // NT == 1 kernels are register-bounded for two workgroups per CU (4x1: 2 waves/SIMD, 8x1: 4)
-    int wg_per_cu = (pl->lds_h * 2 <= lds_cap && pl->NT == 1) ? 2 : 1;
+    // without loaders the NT == 1 kernels are register-bounded for two workgroups per CU
+    int wg_per_cu = (pl->lds_h * 2 <= lds_cap && pl->NT == 1 && !pl->NLH) ? 2 : 1;
     if (const char* e = getenv("SNMF_WGPCU")) wg_per_cu = std::max(1, std::min(wg_per_cu, atoi(e)));  // experiments
     pl->grid_h = std::max(1, std::min(n_tiles_h, ctx->n_cu * wg_per_cu));
     // k_wstats geometry: 4-wave workgroups, each wave owns one 32-row tile x NKT 32-column tiles of
@@ -371,11 +377,18 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     pl->n_kg = (pl->nk + pl->NKT - 1) / pl->NKT;
     pl->n_fg = (pl->nf + pl->NWB - 1) / pl->NWB;
     const int n_tiles_w = pl->Tp / 32;
-    pl->n_chunks = std::max(1, std::min(n_tiles_w, ctx->n_cu * pl->WPS / std::max(1, pl->n_fg * pl->n_kg)));
     // H image of k_wstats: rows padded to whole NKT-tile groups (branch-free P4, see the kernel)
     pl->ldhw = std::max(pl->rp, 32 * pl->NKT * pl->n_kg) + 4;
-    pl->lds_w = std::max<size_t>(((size_t)32 * pl->ldhw + (size_t)32 * pl->Fp + pl->rp) * 4,
-                                 (size_t)pl->NWB * 64 * sizeof(double));
+    {
+        const size_t buf = ((size_t)32 * pl->ldhw + (size_t)32 * pl->Fp) * 4;
+        // loaders + double buffering when the accumulators allow 2 waves per SIMD and LDS has room
+        pl->NLW = (pl->WPS == 2 && 2 * buf + (size_t)pl->rp * 4 <= lds_cap) ? 4 : 0;
+        if (const char* e = getenv("SNMF_WSTATS_NL")) pl->NLW = (atoi(e) == 4 && pl->NLW == 4) ? 4 : 0;
+        pl->lds_w = std::max<size_t>((pl->NLW ? 2 : 1) * buf + (size_t)pl->rp * 4,
+                                     (size_t)(pl->NWB + pl->NLW) * 64 * sizeof(double));
+    }
+    const int wg_w = pl->NLW ? 1 : pl->WPS;  // workgroups per CU
+    pl->n_chunks = std::max(1, std::min(n_tiles_w, ctx->n_cu * wg_w / std::max(1, pl->n_fg * pl->n_kg)));
     // start-up stagger (cycles) of the second half of each grid: about half a tile period when two
     // workgroups share a CU.  SNMF_STAGGER=<h>,<w> overrides (0 disables).
     {
@@ -383,7 +396,8 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
                          (pl->nk + pl->NWH - 1) / pl->NWH * pl->NT * (pl->Fq / 2);
         pl->stagger_h = (pl->grid_h > ctx->n_cu) ? mf_h * 64 : 0;
         const int mf_w = pl->rp / 2 + 16 * pl->NKT;
-        pl->stagger_w = (pl->WPS == 2 && pl->n_chunks * pl->n_fg * pl->n_kg > ctx->n_cu) ? mf_w * 64 : 0;
+        pl->stagger_w = 0;
+        (void)mf_w;
         if (const char* e = getenv("SNMF_STAGGER")) {
             int sh = 0, sw = 0;
             if (sscanf(e, "%d,%d", &sh, &sw) == 2) {
@@ -473,9 +487,9 @@ extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
     if (!pl || !buf) return fail(SNMF_ERR_INVALID, "NULL argument");
     snprintf(buf, n,
              "F=%d T=%d r=%d beta=%g | Fm=%d(+%d VALU row) rp=%d Tp=%d | hstep: tile=%d frames, grid=%d x %d thr, lds=%zu B | "
-             "wstats: NK=%d waves=%d grid=(%d chunks,%d fgroups,%d kgroups) lds=%zu B | n_cu=%d",
-             pl->p.F, pl->p.T, pl->p.r, pl->p.beta, pl->Fm, pl->xr, pl->rp, pl->Tp, 32 * pl->NT, pl->grid_h, pl->NWH * 64,
-             pl->lds_h, pl->NKT, pl->NWB, pl->n_chunks, pl->n_fg, pl->n_kg, pl->lds_w, pl->ctx->n_cu);
+             "wstats: NK=%d waves=%d+%d grid=(%d chunks,%d fgroups,%d kgroups) lds=%zu B | n_cu=%d",
+             pl->p.F, pl->p.T, pl->p.r, pl->p.beta, pl->Fm, pl->xr, pl->rp, pl->Tp, 32 * pl->NT, pl->grid_h, (pl->NWH + pl->NLH) * 64,
+             pl->lds_h, pl->NKT, pl->NWB, pl->NLW, pl->n_chunks, pl->n_fg, pl->n_kg, pl->lds_w, pl->ctx->n_cu);
     return SNMF_OK;
 }
 
@@ -655,37 +669,38 @@ static int launch_big(K kern, dim3 grid, dim3 block, size_t lds, hipStream_t st,
     return SNMF_OK;
 }
 
-// k_hstep dispatch over (NW, NT, BM, OBJ, UPD)
-template <int NW, int NT, int BM>
+// k_hstep dispatch over (NW, NT, NL, BM, OBJ, UPD)
+template <int NW, int NT, int NL, int BM>
 static int launch_hstep_nb(snmf_plan* pl, const StepArgs& a, bool obj, bool upd) {
-    dim3 g(pl->grid_h), b(NW * 64);
+    dim3 g(pl->grid_h), b((NW + NL) * 64);
     hipStream_t st = pl->ctx->stream;
-    if (obj && upd) return launch_big(k_hstep<NW, NT, BM, true, true>, g, b, pl->lds_h, st, a);
-    if (!obj && upd) return launch_big(k_hstep<NW, NT, BM, false, true>, g, b, pl->lds_h, st, a);
-    if (obj && !upd) return launch_big(k_hstep<NW, NT, BM, true, false>, g, b, pl->lds_h, st, a);
+    if (obj && upd) return launch_big(k_hstep<NW, NT, NL, BM, true, true>, g, b, pl->lds_h, st, a);
+    if (!obj && upd) return launch_big(k_hstep<NW, NT, NL, BM, false, true>, g, b, pl->lds_h, st, a);
+    if (obj && !upd) return launch_big(k_hstep<NW, NT, NL, BM, true, false>, g, b, pl->lds_h, st, a);
     return SNMF_OK;
 }
-template <int NW, int NT>
+template <int NW, int NT, int NL>
 static int launch_hstep_g(snmf_plan* pl, const StepArgs& a, bool obj, bool upd) {
-    if (pl->bm == BM_KL) return launch_hstep_nb<NW, NT, BM_KL>(pl, a, obj, upd);
-    if (pl->bm == BM_EUC) return launch_hstep_nb<NW, NT, BM_EUC>(pl, a, obj, upd);
-    return launch_hstep_nb<NW, NT, BM_GEN>(pl, a, obj, upd);
+    if (pl->bm == BM_KL) return launch_hstep_nb<NW, NT, NL, BM_KL>(pl, a, obj, upd);
+    if (pl->bm == BM_EUC) return launch_hstep_nb<NW, NT, NL, BM_EUC>(pl, a, obj, upd);
+    return launch_hstep_nb<NW, NT, NL, BM_GEN>(pl, a, obj, upd);
 }
 static int launch_hstep(snmf_plan* pl, bool obj, bool upd) {
     StepArgs a = make_args(pl);
     a.n_tiles = pl->Tp / (32 * pl->NT);
     a.stagger = pl->stagger_h;
     ScopedTimer tm(pl->ctx, FAM_HSTEP);
-    if (pl->NWH == 4) return pl->NT == 2 ? launch_hstep_g<4, 2>(pl, a, obj, upd) : launch_hstep_g<4, 1>(pl, a, obj, upd);
-    return pl->NT == 2 ? launch_hstep_g<8, 2>(pl, a, obj, upd) : launch_hstep_g<8, 1>(pl, a, obj, upd);
+    if (pl->NWH == 8 && pl->NLH == 4) return launch_hstep_g<8, 1, 4>(pl, a, obj, upd);
+    if (pl->NWH == 4) return pl->NT == 2 ? launch_hstep_g<4, 2, 0>(pl, a, obj, upd) : launch_hstep_g<4, 1, 0>(pl, a, obj, upd);
+    return pl->NT == 2 ? launch_hstep_g<8, 2, 0>(pl, a, obj, upd) : launch_hstep_g<8, 1, 0>(pl, a, obj, upd);
 }
 
 // k_wstats dispatch
-template <int NK, int NWB, int WPS, int WM, int BM, bool OBJ>
+template <int NK, int NWB, int NL, int WPS, int WM, int BM, bool OBJ>
 static int launch_wstats_one(snmf_plan* pl, const StepArgs& a, int mat_index) {
-    dim3 g(pl->n_chunks, pl->n_fg, pl->n_kg), b(NWB * 64);
+    dim3 g(pl->n_chunks, pl->n_fg, pl->n_kg), b((NWB + NL) * 64);
     static std::map<const void*, size_t> attr_set;
-    auto kern = k_wstats<NK, NWB, WPS, WM, BM, OBJ>;
+    auto kern = k_wstats<NK, NWB, NL, WPS, WM, BM, OBJ>;
     const void* key = (const void*)kern;
     if (pl->lds_w > 64 * 1024 && attr_set[key] < pl->lds_w) {
         HIP_TRY(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_w));
@@ -695,20 +710,20 @@ static int launch_wstats_one(snmf_plan* pl, const StepArgs& a, int mat_index) {
     HIP_TRY(hipGetLastError());
     return SNMF_OK;
 }
-template <int NK, int NWB, int WPS>
+template <int NK, int NWB, int NL, int WPS>
 static int launch_wstats_geo(snmf_plan* pl, const StepArgs& a, bool obj) {
     if (pl->bm == BM_KL) {
-        return obj ? launch_wstats_one<NK, NWB, WPS, 0, BM_KL, true>(pl, a, 0)
-                   : launch_wstats_one<NK, NWB, WPS, 0, BM_KL, false>(pl, a, 0);
+        return obj ? launch_wstats_one<NK, NWB, NL, WPS, 0, BM_KL, true>(pl, a, 0)
+                   : launch_wstats_one<NK, NWB, NL, WPS, 0, BM_KL, false>(pl, a, 0);
     }
     if (pl->bm == BM_EUC) {
-        SN_TRY(obj ? (launch_wstats_one<NK, NWB, WPS, 1, BM_EUC, true>(pl, a, 1))
-                   : (launch_wstats_one<NK, NWB, WPS, 1, BM_EUC, false>(pl, a, 1)));
-        return launch_wstats_one<NK, NWB, WPS, 3, BM_EUC, false>(pl, a, 0);
+        SN_TRY(obj ? (launch_wstats_one<NK, NWB, NL, WPS, 1, BM_EUC, true>(pl, a, 1))
+                   : (launch_wstats_one<NK, NWB, NL, WPS, 1, BM_EUC, false>(pl, a, 1)));
+        return launch_wstats_one<NK, NWB, NL, WPS, 3, BM_EUC, false>(pl, a, 0);
     }
-    SN_TRY(obj ? (launch_wstats_one<NK, NWB, WPS, 1, BM_GEN, true>(pl, a, 1))
-               : (launch_wstats_one<NK, NWB, WPS, 1, BM_GEN, false>(pl, a, 1)));
-    return launch_wstats_one<NK, NWB, WPS, 2, BM_GEN, false>(pl, a, 0);
+    SN_TRY(obj ? (launch_wstats_one<NK, NWB, NL, WPS, 1, BM_GEN, true>(pl, a, 1))
+               : (launch_wstats_one<NK, NWB, NL, WPS, 1, BM_GEN, false>(pl, a, 1)));
+    return launch_wstats_one<NK, NWB, NL, WPS, 2, BM_GEN, false>(pl, a, 0);
 }
 static int launch_wstats(snmf_plan* pl, bool obj) {
     StepArgs a = make_args(pl);
@@ -716,9 +731,9 @@ static int launch_wstats(snmf_plan* pl, bool obj) {
     a.ldh = pl->ldhw;
     a.stagger = pl->stagger_w;
     ScopedTimer tm(pl->ctx, FAM_WSTATS);
-    if (pl->NKT == 4) return launch_wstats_geo<4, 4, 2>(pl, a, obj);
-    if (pl->NKT == 8) return launch_wstats_geo<8, 4, 2>(pl, a, obj);
-    return launch_wstats_geo<16, 4, 1>(pl, a, obj);
+    if (pl->NKT == 4) return pl->NLW ? launch_wstats_geo<4, 4, 4, 2>(pl, a, obj) : launch_wstats_geo<4, 4, 0, 2>(pl, a, obj);
+    if (pl->NKT == 8) return pl->NLW ? launch_wstats_geo<8, 4, 4, 2>(pl, a, obj) : launch_wstats_geo<8, 4, 0, 2>(pl, a, obj);
+    return launch_wstats_geo<16, 4, 0, 1>(pl, a, obj);
 }
 
 static int launch_reduce(snmf_plan* pl, double* stats, bool do_mats, bool do_obj, int n_part, bool sh_const) {

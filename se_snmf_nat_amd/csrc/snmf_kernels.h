@@ -31,7 +31,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr float kFlr = 1e-9f;  // src/sparse_nmf.m:166
-constexpr int kMaxNW = 8;      // most waves per workgroup (reduction scratch sizing)
+constexpr int kMaxNW = 12;     // most waves per workgroup (reduction scratch sizing)
 
 // beta modes (template parameter BM)
 constexpr int BM_GEN = 0;  // generic beta (incl. IS, beta = 0)
@@ -172,53 +172,65 @@ __device__ __forceinline__ void mfma_block(f32x16 (&acc)[NT], const f32x4& w, co
     }
 }
 
-// The loop is unrolled by two 2-block stages held in NAMED registers (A, B): rotating buffers with
+// The loop is unrolled by two SB-block stages held in NAMED registers (A, B): rotating buffers with
 // register copies would make the copy wait for the load it has just issued.  Stage X+1's loads are
-// issued before stage X's 8*NT MFMAs (512*NT cycles), which is what hides the L2 latency.
+// issued before stage X's 4*SB*NT MFMAs (256*SB*NT cycles alone), which is what hides the L2 latency.
+template <int NT, bool SWAP, int SB>
+__device__ __forceinline__ void contract_sb(f32x16 (&acc)[NT], const f32x4* __restrict__ wp, const float* sp,
+                                            int sstride, int nq) {
+    f32x4 wA[SB], wB[SB];
+    f32x4 sA[SB][NT], sB[SB][NT];
+    const int last = nq - 1;
+    auto ldstage = [&](f32x4 (&w)[SB], f32x4 (&sf)[SB][NT], int q0) {
+#pragma unroll
+        for (int j = 0; j < SB; ++j) {
+            const int qq = (q0 + j) < last ? (q0 + j) : last;
+            w[j] = wp[(size_t)qq * 64];
+#pragma unroll
+            for (int tau = 0; tau < NT; ++tau)
+                sf[j][tau] = *reinterpret_cast<const f32x4*>(sp + tau * sstride + 8 * qq);
+        }
+    };
+    auto mmstage = [&](const f32x4 (&w)[SB], const f32x4 (&sf)[SB][NT]) {
+#pragma unroll
+        for (int j = 0; j < SB; ++j) mfma_block<NT, SWAP>(acc, w[j], sf[j]);
+    };
+    const int nmain = nq - nq % (2 * SB);
+    int q = 0;
+    if (nmain > 0) {
+        ldstage(wA, sA, 0);
+        for (; q < nmain; q += 2 * SB) {
+            ldstage(wB, sB, q + SB);
+            SNMF_PIN();
+            mmstage(wA, sA);
+            ldstage(wA, sA, q + 2 * SB);  // clamped past the end; harmless re-read of the last block
+            SNMF_PIN();
+            mmstage(wB, sB);
+        }
+    }
+    // remainder (fewer than 2*SB blocks): simple two-deep pipeline
+    if (q < nq) {
+        f32x4 w0 = wp[(size_t)q * 64];
+        f32x4 s0[NT];
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau) s0[tau] = *reinterpret_cast<const f32x4*>(sp + tau * sstride + 8 * q);
+        for (; q < nq; ++q) {
+            const int qn = q + 1 < nq ? q + 1 : q;
+            const f32x4 w1 = wp[(size_t)qn * 64];
+            f32x4 s1[NT];
+#pragma unroll
+            for (int tau = 0; tau < NT; ++tau) s1[tau] = *reinterpret_cast<const f32x4*>(sp + tau * sstride + 8 * qn);
+            mfma_block<NT, SWAP>(acc, w0, s0);
+            w0 = w1;
+#pragma unroll
+            for (int tau = 0; tau < NT; ++tau) s0[tau] = s1[tau];
+        }
+    }
+}
 template <int NT, bool SWAP>
 __device__ __forceinline__ void contract(f32x16 (&acc)[NT], const f32x4* __restrict__ wp, const float* sp,
                                          int sstride, int nq) {
-    f32x4 wA0, wA1, wB0, wB1;
-    f32x4 sA0[NT], sA1[NT], sB0[NT], sB1[NT];
-    const int last = nq - 1;
-    auto ldw = [&](int q) { return wp[(size_t)(q < last ? q : last) * 64]; };
-    auto lds_ = [&](f32x4 (&d)[NT], int q) {
-        const int qq = q < last ? q : last;
-#pragma unroll
-        for (int tau = 0; tau < NT; ++tau) d[tau] = *reinterpret_cast<const f32x4*>(sp + tau * sstride + 8 * qq);
-    };
-    wA0 = ldw(0);
-    wA1 = ldw(1);
-    lds_(sA0, 0);
-    lds_(sA1, 1);
-    const int nq4 = nq & ~3;
-    int q = 0;
-    for (; q < nq4; q += 4) {
-        wB0 = ldw(q + 2);
-        wB1 = ldw(q + 3);
-        lds_(sB0, q + 2);
-        lds_(sB1, q + 3);
-        SNMF_PIN();
-        mfma_block<NT, SWAP>(acc, wA0, sA0);
-        mfma_block<NT, SWAP>(acc, wA1, sA1);
-        wA0 = ldw(q + 4);
-        wA1 = ldw(q + 5);
-        lds_(sA0, q + 4);
-        lds_(sA1, q + 5);
-        SNMF_PIN();
-        mfma_block<NT, SWAP>(acc, wB0, sB0);
-        mfma_block<NT, SWAP>(acc, wB1, sB1);
-    }
-    // remainder (nq % 4 blocks: only the W^T*ratio contraction in extra-row mode has one)
-    if (q < nq) {
-        mfma_block<NT, SWAP>(acc, wA0, sA0);
-        if (q + 1 < nq) mfma_block<NT, SWAP>(acc, wA1, sA1);
-        if (q + 2 < nq) {
-            wB0 = ldw(q + 2);
-            lds_(sB0, q + 2);
-            mfma_block<NT, SWAP>(acc, wB0, sB0);
-        }
-    }
+    contract_sb<NT, SWAP, 2>(acc, wp, sp, sstride, nq);  // SB = 4 measured slower (registers, no latency win)
 }
 
 // Two workgroups share a CU.  Launched together with identical work they would run in lockstep:
@@ -239,11 +251,12 @@ __device__ __forceinline__ void stagger_start(int cycles, unsigned linear_block,
 // order, so a single outstanding HBM load (or store) in front of the W-fragment loads would stall
 // the first wait of the loop for the whole HBM latency.
 template <int NTHREADS>
-__device__ __forceinline__ void stage_in(const float* __restrict__ src, float* dst, int cols, int rowlen, int ld) {
+__device__ __forceinline__ void stage_in(const float* __restrict__ src, float* dst, int cols, int rowlen, int ld,
+                                         int tid) {
     const int r4 = rowlen / 4;
     const int n4 = cols * r4;
     constexpr int B = 8;  // loads in flight per thread and batch
-    for (int i0 = threadIdx.x; i0 < n4; i0 += B * NTHREADS) {
+    for (int i0 = tid; i0 < n4; i0 += B * NTHREADS) {
         f32x4 x[B];
 #pragma unroll
         for (int b = 0; b < B; ++b) {
@@ -262,11 +275,12 @@ __device__ __forceinline__ void stage_in(const float* __restrict__ src, float* d
     }
 }
 template <int NTHREADS>
-__device__ __forceinline__ void stage_out(float* __restrict__ dst, const float* src, int cols, int rowlen, int ld) {
+__device__ __forceinline__ void stage_out(float* __restrict__ dst, const float* src, int cols, int rowlen, int ld,
+                                          int tid) {
     const int r4 = rowlen / 4;
     const int n4 = cols * r4;
     constexpr int B = 8;
-    for (int i0 = threadIdx.x; i0 < n4; i0 += B * NTHREADS) {
+    for (int i0 = tid; i0 < n4; i0 += B * NTHREADS) {
         f32x4 x[B];
 #pragma unroll
         for (int b = 0; b < B; ++b) {
@@ -284,260 +298,355 @@ __device__ __forceinline__ void stage_out(float* __restrict__ dst, const float* 
     }
 }
 
-// ============================================================================================
-// k_hstep: H half-step, src/sparse_nmf.m:189-208, fused with the objective of the previous
-// iterate (:248-261).  UPD=false gives the objective-only pass.
-// ============================================================================================
-// Geometry: NW waves per workgroup, NT 32-frame sub-tiles per tile.  Two shapes are used:
-//   (NW=4, NT=1): TWO independent workgroups per CU (one wave of each per SIMD).  Their barriers,
-//                 H-tile staging and VALU epilogues de-synchronise, so one workgroup's MFMAs fill
-//                 the matrix pipe while the other is staging / in an epilogue.
-//   (NW=8, NT=2): one workgroup per CU, W fragments shared by two sub-tiles (half the L2 traffic).
-template <int NW, int NT, int BM, bool OBJ, bool UPD>
-__global__ __launch_bounds__(NW * 64, 2) void k_hstep(StepArgs a) {
-    constexpr int kNW = NW;
-    if (a.stop && *a.stop) return;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+// Geometry.  A workgroup has NW CONSUMER waves (they issue every MFMA) and NL LOADER waves.
+// Loaders keep HBM latency away from the matrix pipe: while the consumers work on tile i they bring
+// tile i+1 (its H and V blocks) into the other LDS buffer and copy the updated H tile i-1 out;
+// consumer waves never touch HBM (their only global loads are L2-resident W fragments).
+// vmcnt retires in issue order per wave, so this split -- not an async copy issued by the consumer
+// itself -- is what keeps the W-fragment waits short.  NL = 0: consumers stage synchronously (used
+// when the LDS budget of the shape leaves no room for a second buffer).
+//   (NW=8, NT=1, NL=4): one workgroup per CU, 3 waves per SIMD, two LDS buffers   <- default
+//   (NW=4, NT=1, NL=0): two workgroups per CU, synchronous staging
+//   (NW=8, NT=2, NL=0): one workgroup per CU, W fragments shared by two frame sub-tiles
+constexpr int kPF = 20;  // f32x4 a loader thread keeps in flight (covers 32*(rp+Fp) <= 20480 floats at NL=4)
+
+template <int NW, int NT, int BM, bool OBJ>
+__device__ __forceinline__ void hstep_p1_tiles(const StepArgs& a, float* Hs, float* Rs, int t0, int w, int lane,
+                                               bool upd, double& acc_div) {
     constexpr int Tt = 32 * NT;
-    float* Hs = lds;                   // [Tt][ldh]
-    float* Rs = lds + Tt * a.ldh;      // [Tt][ldr]
-    float* wxs = Rs + Tt * a.ldr;      // [rp]  extra row of W
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int fl = lane & 31, h = lane >> 5;
-    const int rp = a.rp, Fp = a.Fp, ldh = a.ldh, ldr = a.ldr;
-    double acc_div = 0.0, acc_sh = 0.0;
-    if (a.xr) {
-        for (int k = threadIdx.x; k < rp; k += kNW * 64) wxs[k] = a.wx[k];
-        // the 7 unused cells of the extra 8-deep k-block stay zero for the whole kernel
-        for (int i = threadIdx.x; i < Tt * 8; i += kNW * 64) Rs[(i >> 3) * ldr + a.Fm + (i & 7)] = 0.f;
-    }
-
-    stagger_start(a.stagger, blockIdx.x, gridDim.x, a.stagger_shift);
-    SNMF_STAMP_DECL
-    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-        const int t0 = tile * Tt;
-        __syncthreads();  // previous tile's readers of Hs / Rs are done
-        SNMF_STAMP(0);
-        stage_in<kNW * 64>(a.Hin + (size_t)t0 * rp, Hs, Tt, rp, ldh);
-        stage_in<kNW * 64>(a.V + (size_t)t0 * Fp, Rs, Tt, Fp, ldr);  // the ratio is formed in place
-        SNMF_STAMP(1);
-        __syncthreads();
-        SNMF_STAMP(2);
-
-        // ---- P1: Lam[phi] = W[phi,:] * H[:, tile]  -> ratio / den image ----------------------
-        for (int phi = w; phi < a.nf; phi += kNW) {
-            f32x16 acc[NT];
+    const int rp = a.rp, ldh = a.ldh, ldr = a.ldr;
+    // ---- P1: Lam[phi] = W[phi,:] * H[:, tile]  -> ratio / den image (in place over the staged V)
+    for (int phi = w; phi < a.nf; phi += NW) {
+        f32x16 acc[NT];
 #pragma unroll
-            for (int tau = 0; tau < NT; ++tau) acc[tau] = zero16();
-            const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)phi * rp * 32) + lane;
-            SNMF_STAMP(3);
-            contract<NT, false>(acc, wp, Hs + fl * ldh + 4 * h, 32 * ldh, rp / 8);
-            SNMF_STAMP(4);
-            // epilogue: lane (t = fl, h), reg -> f = 32*phi + drow(reg,h)
-            float dsum = 0.f;
+        for (int tau = 0; tau < NT; ++tau) acc[tau] = zero16();
+        const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)phi * rp * 32) + lane;
+        contract<NT, false>(acc, wp, Hs + fl * ldh + 4 * h, 32 * ldh, rp / 8);
+        // epilogue: lane (t = fl, h), reg -> f = 32*phi + drow(reg,h)
+        float dsum = 0.f;
 #pragma unroll
-            for (int tau = 0; tau < NT; ++tau) {
-                const int t = t0 + tau * 32 + fl;
-                float* rsp = Rs + (tau * 32 + fl) * ldr + phi * 32 + 4 * h;
+        for (int tau = 0; tau < NT; ++tau) {
+            const int t = t0 + tau * 32 + fl;
+            float* rsp = Rs + (tau * 32 + fl) * ldr + phi * 32 + 4 * h;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(rsp + 8 * g);  // staged V
-                    f32x4 o;
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(rsp + 8 * g);  // staged V
+                f32x4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float lam = fmaxf(acc[tau][4 * g + j], kFlr);
-                        if (OBJ) {
-                            const int f = phi * 32 + 8 * g + 4 * h + j;
-                            float d = div_term<BM>(v[j], lam, a.beta, a.inv_bb1);
-                            dsum += (f < a.F && t < a.T) ? d : 0.f;
-                        }
-                        if (BM == BM_KL) o[j] = v[j] * fast_rcp(lam);
-                        else o[j] = den_of_lam<BM>(lam, a.beta);
+                for (int j = 0; j < 4; ++j) {
+                    float lam = fmaxf(acc[tau][4 * g + j], kFlr);
+                    if (OBJ) {
+                        const int f = phi * 32 + 8 * g + 4 * h + j;
+                        float d = div_term<BM>(v[j], lam, a.beta, a.inv_bb1);
+                        dsum += (f < a.F && t < a.T) ? d : 0.f;
                     }
-                    if (UPD) *reinterpret_cast<f32x4*>(rsp + 8 * g) = o;
+                    if (BM == BM_KL) o[j] = v[j] * fast_rcp(lam);
+                    else o[j] = den_of_lam<BM>(lam, a.beta);
                 }
+                if (upd) *reinterpret_cast<f32x4*>(rsp + 8 * g) = o;
             }
-            if (OBJ) acc_div += (double)dsum;
-            SNMF_STAMP(5);
         }
-        if (a.xr) {
-            // extra row: lam_x[t] = sum_k W[Fm,k] H[k,t]; 4 columns x 16 lanes at a time
-            constexpr int CPW = Tt / kNW;
-            float dsum = 0.f;
+        if (OBJ) acc_div += (double)dsum;
+    }
+}
+
+// extra row (F = 32*nf + 1): lam_x[t] = sum_k W[Fm,k] H[k,t] on the VALU, 4 columns x 16 lanes at a time
+template <int NW, int NT, int BM, bool OBJ>
+__device__ __forceinline__ void hstep_p1_xrow(const StepArgs& a, float* Hs, float* Rs, const float* wxs, int t0, int w,
+                                              int lane, bool upd, double& acc_div) {
+    constexpr int Tt = 32 * NT;
+    const int rp = a.rp, ldh = a.ldh, ldr = a.ldr;
+    if (a.xr) {
+        // extra row: lam_x[t] = sum_k W[Fm,k] H[k,t]; 4 columns x 16 lanes at a time
+        constexpr int CPW = Tt / NW;
+        float dsum = 0.f;
+#pragma unroll
+        for (int c0 = 0; c0 < CPW; c0 += 4) {
+            const int tl = w * CPW + c0 + (lane >> 4);
+            const int kl = lane & 15;
+            const float* hrow = Hs + tl * ldh;
+            float s0 = 0.f, s1 = 0.f;
+            for (int k = 4 * kl; k < rp; k += 64) {  // 16 lanes x 4 consecutive k per step
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wxs + k);
+                const f32x4 hv = *reinterpret_cast<const f32x4*>(hrow + k);
+                s0 += wv[0] * hv[0] + wv[1] * hv[1];
+                s1 += wv[2] * hv[2] + wv[3] * hv[3];
+            }
+            float s = s0 + s1;
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 4);
+            s += __shfl_xor(s, 8);
+            if (kl == 0) {
+                const int t = t0 + tl;
+                const float v = Rs[tl * ldr + a.Fm];  // staged V
+                const float lam = fmaxf(s, kFlr);
+                if (OBJ) dsum += (t < a.T) ? div_term<BM>(v, lam, a.beta, a.inv_bb1) : 0.f;
+                if (upd) Rs[tl * ldr + a.Fm] = (BM == BM_KL) ? v * fast_rcp(lam) : den_of_lam<BM>(lam, a.beta);
+            }
+        }
+        if (OBJ) acc_div += (double)dsum;
+    }
+}
+
+// P1 of one wave.  The second half of the waves (the SIMD partners of the first half) run their
+// VALU-only extra-row work FIRST: the two waves of a SIMD then reach their MFMA loops, and later
+// their VALU epilogues, at different times instead of colliding on both.
+template <int NW, int NT, int BM, bool OBJ>
+__device__ __forceinline__ void hstep_p1(const StepArgs& a, float* Hs, float* Rs, const float* wxs, int t0, int w,
+                                         int lane, bool upd, double& acc_div) {
+    const bool xfirst = a.xr && (w >= NW / 2);
+    if (xfirst) hstep_p1_xrow<NW, NT, BM, OBJ>(a, Hs, Rs, wxs, t0, w, lane, upd, acc_div);
+    hstep_p1_tiles<NW, NT, BM, OBJ>(a, Hs, Rs, t0, w, lane, upd, acc_div);
+    if (a.xr && !xfirst) hstep_p1_xrow<NW, NT, BM, OBJ>(a, Hs, Rs, wxs, t0, w, lane, upd, acc_div);
+}
+
+// beta != 1: in-place transform of this wave's part of the image, den = lam^(b-1) -> num = V .* lam^(b-2)
+template <int NW, int NT, int BM>
+__device__ __forceinline__ void hstep_den_to_num(const StepArgs& a, float* Rs, int t0, int w, int lane) {
+    constexpr int Tt = 32 * NT;
+    const int fl = lane & 31, h = lane >> 5;
+    const int Fp = a.Fp, ldr = a.ldr;
+    for (int phi = w; phi < a.nf; phi += NW) {
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau) {
+            const int t = t0 + tau * 32 + fl;
+            const float* vp = a.V + (size_t)t * Fp + phi * 32 + 4 * h;
+            float* rsp = Rs + (tau * 32 + fl) * ldr + phi * 32 + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(vp + 8 * g);
+                f32x4 d = *reinterpret_cast<f32x4*>(rsp + 8 * g);
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (BM == BM_EUC) o[j] = v[j];
+                    else {
+                        // den = lam^(b-1)  ->  lam^(b-2) = den^((b-2)/(b-1))
+                        float lf = (a.beta == 0.f) ? d[j] * d[j] : fast_pow(d[j], (a.beta - 2.f) / (a.beta - 1.f));
+                        o[j] = v[j] * lf;
+                    }
+                }
+                *reinterpret_cast<f32x4*>(rsp + 8 * g) = o;
+            }
+        }
+    }
+    if (a.xr) {
+        constexpr int CPW = Tt / NW;
+        if ((lane & 15) == 0) {
 #pragma unroll
             for (int c0 = 0; c0 < CPW; c0 += 4) {
                 const int tl = w * CPW + c0 + (lane >> 4);
-                const int kl = lane & 15;
-                const float* hrow = Hs + tl * ldh;
-                float s0 = 0.f, s1 = 0.f;
-                for (int k = 4 * kl; k < rp; k += 64) {  // 16 lanes x 4 consecutive k per step
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wxs + k);
-                    const f32x4 hv = *reinterpret_cast<const f32x4*>(hrow + k);
-                    s0 += wv[0] * hv[0] + wv[1] * hv[1];
-                    s1 += wv[2] * hv[2] + wv[3] * hv[3];
-                }
-                float s = s0 + s1;
-                s += __shfl_xor(s, 1);
-                s += __shfl_xor(s, 2);
-                s += __shfl_xor(s, 4);
-                s += __shfl_xor(s, 8);
-                if (kl == 0) {
-                    const int t = t0 + tl;
-                    const float v = Rs[tl * ldr + a.Fm];  // staged V
-                    const float lam = fmaxf(s, kFlr);
-                    if (OBJ) dsum += (t < a.T) ? div_term<BM>(v, lam, a.beta, a.inv_bb1) : 0.f;
-                    if (UPD) Rs[tl * ldr + a.Fm] = (BM == BM_KL) ? v * fast_rcp(lam) : den_of_lam<BM>(lam, a.beta);
-                }
+                const float v = a.V[(size_t)(t0 + tl) * Fp + a.Fm];
+                const float d = Rs[tl * ldr + a.Fm];
+                float o;
+                if (BM == BM_EUC) o = v;
+                else o = v * ((a.beta == 0.f) ? d * d : fast_pow(d, (a.beta - 2.f) / (a.beta - 1.f)));
+                Rs[tl * ldr + a.Fm] = o;
             }
-            if (OBJ) acc_div += (double)dsum;
         }
-        SNMF_STAMP(6);
-        if (!UPD) continue;
-        __syncthreads();
-        SNMF_STAMP(7);
+    }
+}
 
-        // ---- P2: contraction over f with W^T ------------------------------------------------
-        // KL : dmh = W^T * ratio ;            H <- H .* dmh ./ dphv
-        // else: pass a: dph = W^T*den + S ;    Hs <- H ./ max(dph, flr)
-        //       in-place image transform den -> num = V .* lam^(beta-2)
-        //       pass b: dmh = W^T*num ;        H <- Hs .* dmh
-        constexpr int NPASS = (BM == BM_KL) ? 1 : 2;
-#pragma unroll 1
-        for (int pass = 0; pass < NPASS; ++pass) {
-            if (pass == 1) {
-                __syncthreads();  // all waves finished reading the den image
-                for (int phi = w; phi < a.nf; phi += kNW) {
+// ---- P2: contraction over f with W^T.  KL: dmh = W^T*ratio; H <- H .* dmh ./ dphv.
+// beta != 1, pass 0: dph = W^T*den + S; Hs <- H ./ max(dph, flr);   pass 1: dmh = W^T*num; H <- Hs .* dmh
+template <int NW, int NT, int BM, bool OBJ>
+__device__ __forceinline__ void hstep_p2(const StepArgs& a, float* Hs, const float* Rs, int t0, int w, int lane,
+                                         int pass, double& acc_sh) {
+    const int fl = lane & 31, h = lane >> 5;
+    const int rp = a.rp, ldh = a.ldh, ldr = a.ldr;
+    for (int kap = w; kap < a.nk; kap += NW) {
+        f32x16 acc[NT];
 #pragma unroll
-                    for (int tau = 0; tau < NT; ++tau) {
-                        const int t = t0 + tau * 32 + fl;
-                        const float* vp = a.V + (size_t)t * Fp + phi * 32 + 4 * h;
-                        float* rsp = Rs + (tau * 32 + fl) * ldr + phi * 32 + 4 * h;
+        for (int tau = 0; tau < NT; ++tau) acc[tau] = zero16();
+        const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wk4 + (size_t)kap * a.Fq * 32) + lane;
+        // per-k constants of the epilogue, issued before the MFMA loop
+        f32x4 dpf[4], spf[4];
+        if (!a.S) {
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            f32x4 v = *reinterpret_cast<const f32x4*>(vp + 8 * g);
-                            f32x4 d = *reinterpret_cast<f32x4*>(rsp + 8 * g);
-                            f32x4 o;
+            for (int g = 0; g < 4; ++g) {
+                const int k0 = kap * 32 + 8 * g + 4 * h;
+                if (BM == BM_KL) dpf[g] = *reinterpret_cast<const f32x4*>(a.dphv + k0);
+                if (OBJ || BM != BM_KL) spf[g] = *reinterpret_cast<const f32x4*>(a.lamk + k0);
+            }
+        }
+        contract<NT, false>(acc, wp, Rs + fl * ldr + 4 * h, 32 * ldr, a.Fq / 8);
+        // epilogue: lane (t = fl, h), reg -> k = 32*kap + drow(reg,h)
+        float shsum = 0.f;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                if (BM == BM_EUC) o[j] = v[j];
-                                else {
-                                    // den = lam^(b-1)  ->  lam^(b-2) = den^((b-2)/(b-1))
-                                    float lf = (a.beta == 0.f) ? d[j] * d[j]
-                                                               : fast_pow(d[j], (a.beta - 2.f) / (a.beta - 1.f));
-                                    o[j] = v[j] * lf;
-                                }
-                            }
-                            *reinterpret_cast<f32x4*>(rsp + 8 * g) = o;
-                        }
+        for (int tau = 0; tau < NT; ++tau) {
+            const int t = t0 + tau * 32 + fl;
+            float* hsp = Hs + (tau * 32 + fl) * ldh + kap * 32 + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int k0 = kap * 32 + 8 * g + 4 * h;
+                f32x4 ho = *reinterpret_cast<f32x4*>(hsp + 8 * g);
+                f32x4 sp;
+                if (a.S) sp = *reinterpret_cast<const f32x4*>(a.S + (size_t)t * rp + k0);
+                else sp = spf[g];
+                f32x4 o;
+                if (BM == BM_KL) {
+                    f32x4 dp;
+                    if (a.S) {
+                        f32x4 cs = *reinterpret_cast<const f32x4*>(a.colsum + k0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) dp[j] = fmaxf(cs[j] + sp[j], kFlr);
+                    } else {
+                        dp = dpf[g];
                     }
-                }
-                if (a.xr) {
-                    constexpr int CPW = Tt / kNW;
-                    if ((lane & 15) == 0) {
 #pragma unroll
-                        for (int c0 = 0; c0 < CPW; c0 += 4) {
-                            const int tl = w * CPW + c0 + (lane >> 4);
-                            const float v = a.V[(size_t)(t0 + tl) * Fp + a.Fm];
-                            const float d = Rs[tl * ldr + a.Fm];
-                            float o;
-                            if (BM == BM_EUC) o = v;
-                            else o = v * ((a.beta == 0.f) ? d * d : fast_pow(d, (a.beta - 2.f) / (a.beta - 1.f)));
-                            Rs[tl * ldr + a.Fm] = o;
-                        }
+                    for (int j = 0; j < 4; ++j) {
+                        o[j] = ho[j] * acc[tau][4 * g + j] * fast_rcp(dp[j]);
+                        if (OBJ) shsum += sp[j] * ho[j];
                     }
+                } else if (pass == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float dp = fmaxf(acc[tau][4 * g + j] + sp[j], kFlr);
+                        o[j] = ho[j] * fast_rcp(dp);
+                        if (OBJ) shsum += sp[j] * ho[j];
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = ho[j] * acc[tau][4 * g + j];
                 }
+                *reinterpret_cast<f32x4*>(hsp + 8 * g) = o;  // in place; copied out after P2
+            }
+        }
+        if (OBJ) acc_sh += (double)shsum;
+    }
+}
+
+// ============================================================================================
+// k_hstep: H half-step, src/sparse_nmf.m:189-208, fused with the objective of the previous
+// iterate (:248-261).  UPD=false gives the objective-only pass.
+//
+// NL = 0: NW consumer waves, one LDS buffer, the consumers stage each tile synchronously.
+// NL > 0: NW consumers + NL loaders, TWO LDS buffers.  Barrier schedule of tile i (every wave,
+//         whatever its role, executes the same sequence; buffers cur = i&1, nxt = cur^1):
+//   B1 | consumers: P1(cur)            loaders: copy H tile i-1 out of nxt, issue tile i+1 -> regs
+//   B2 | consumers: P2(cur) [+2 barriers for beta != 1]     loaders: regs -> nxt
+// so the only thing the consumers ever wait for is each other.
+// ============================================================================================
+template <int NW, int NT, int NL, int BM, bool OBJ, bool UPD>
+__global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(StepArgs a) {
+    constexpr int NTHR = (NW + NL) * 64;
+    constexpr int NBUF = NL > 0 ? 2 : 1;
+    if (a.stop && *a.stop) return;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int Tt = 32 * NT;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int rp = a.rp, Fp = a.Fp, ldh = a.ldh, ldr = a.ldr;
+    const int bufsz = Tt * (ldh + ldr);  // floats per buffer: Hs [Tt][ldh] then Rs [Tt][ldr]
+    float* wxs = lds + NBUF * bufsz;     // [rp]  extra row of W
+    double acc_div = 0.0, acc_sh = 0.0;
+    if (a.xr) {
+        for (int k = threadIdx.x; k < rp; k += NTHR) wxs[k] = a.wx[k];
+        // the 7 unused cells of the extra 8-deep k-block stay zero for the whole kernel
+        for (int i = threadIdx.x; i < NBUF * Tt * 8; i += NTHR) {
+            const int bsel = i / (Tt * 8), ii = i - bsel * Tt * 8;
+            lds[bsel * bufsz + Tt * ldh + (ii >> 3) * ldr + a.Fm + (ii & 7)] = 0.f;
+        }
+    }
+    constexpr int NPASS = (BM == BM_KL) ? 1 : 2;
+
+    if (NL > 0 && w >= NW) {
+        // ================================ loader role =========================================
+        // Same index -> (row, column) map for the copy-out and the load of an H image, so a loader
+        // thread only ever re-writes cells it has itself read: no loader-loader barrier is needed.
+        constexpr int NLT = NL * 64;
+        const int lt = threadIdx.x - NW * 64;
+        int tile = blockIdx.x, it = 0, prev = -1;
+        if (tile < a.n_tiles) {
+            stage_in<NLT>(a.Hin + (size_t)tile * Tt * rp, lds, Tt, rp, ldh, lt);
+            stage_in<NLT>(a.V + (size_t)tile * Tt * Fp, lds + Tt * ldh, Tt, Fp, ldr, lt);
+        }
+        for (; tile < a.n_tiles; tile += gridDim.x, ++it) {
+            float* nH = lds + ((it & 1) ^ 1) * bufsz;
+            const int nt = tile + (int)gridDim.x;
+            __syncthreads();  // B1
+            if (UPD && prev >= 0) stage_out<NLT>(a.Hout + (size_t)prev * Tt * rp, nH, Tt, rp, ldh, lt);
+            if (nt < a.n_tiles) stage_in<NLT>(a.Hin + (size_t)nt * Tt * rp, nH, Tt, rp, ldh, lt);
+            __syncthreads();  // B2
+            if (nt < a.n_tiles) stage_in<NLT>(a.V + (size_t)nt * Tt * Fp, nH + Tt * ldh, Tt, Fp, ldr, lt);
+            if (UPD && NPASS == 2) {
+                __syncthreads();
                 __syncthreads();
             }
-            for (int kap = w; kap < a.nk; kap += kNW) {
-                f32x16 acc[NT];
-#pragma unroll
-                for (int tau = 0; tau < NT; ++tau) acc[tau] = zero16();
-                const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wk4 + (size_t)kap * a.Fq * 32) + lane;
-                // per-k constants of the epilogue, issued before the MFMA loop
-                f32x4 dpf[4], spf[4];
-                if (!a.S) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int k0 = kap * 32 + 8 * g + 4 * h;
-                        if (BM == BM_KL) dpf[g] = *reinterpret_cast<const f32x4*>(a.dphv + k0);
-                        if (OBJ || BM != BM_KL) spf[g] = *reinterpret_cast<const f32x4*>(a.lamk + k0);
-                    }
-                }
-                SNMF_STAMP(8);
-                contract<NT, false>(acc, wp, Rs + fl * ldr + 4 * h, 32 * ldr, a.Fq / 8);
+            prev = tile;
+        }
+        __syncthreads();  // the last tile's P2 is complete
+        if (UPD && prev >= 0)
+            stage_out<NLT>(a.Hout + (size_t)prev * Tt * rp, lds + ((it - 1) & 1) * bufsz, Tt, rp, ldh, lt);
+    } else {
+        // ================================ consumer role =======================================
+        if (NL == 0) stagger_start(a.stagger, blockIdx.x, gridDim.x, a.stagger_shift);
+        SNMF_STAMP_DECL
+        int it = 0;
+        for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x, ++it) {
+            const int t0 = tile * Tt;
+            float* Hs = lds + (NL > 0 ? (it & 1) * bufsz : 0);
+            float* Rs = Hs + Tt * ldh;  // V tile, overwritten in place by the ratio tile
+            if (NL == 0) {
+                __syncthreads();  // previous tile fully consumed / copied out
+                SNMF_STAMP(0);
+                stage_in<NTHR>(a.Hin + (size_t)t0 * rp, Hs, Tt, rp, ldh, threadIdx.x);
+                stage_in<NTHR>(a.V + (size_t)t0 * Fp, Rs, Tt, Fp, ldr, threadIdx.x);
+                SNMF_STAMP(1);
+            }
+            __syncthreads();  // B1
+            SNMF_STAMP(2);
+            hstep_p1<NW, NT, BM, OBJ>(a, Hs, Rs, wxs, t0, w, lane, UPD, acc_div);
+            SNMF_STAMP(4);
+            if (UPD || NL > 0) __syncthreads();  // B2
+            SNMF_STAMP(7);
+            if (UPD) {
+                hstep_p2<NW, NT, BM, OBJ>(a, Hs, Rs, t0, w, lane, 0, acc_sh);
                 SNMF_STAMP(9);
-                // epilogue: lane (t = fl, h), reg -> k = 32*kap + drow(reg,h)
-                float shsum = 0.f;
-#pragma unroll
-                for (int tau = 0; tau < NT; ++tau) {
-                    const int t = t0 + tau * 32 + fl;
-                    float* hsp = Hs + (tau * 32 + fl) * ldh + kap * 32 + 4 * h;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int k0 = kap * 32 + 8 * g + 4 * h;
-                        f32x4 ho = *reinterpret_cast<f32x4*>(hsp + 8 * g);
-                        f32x4 sp;
-                        if (a.S) sp = *reinterpret_cast<const f32x4*>(a.S + (size_t)t * rp + k0);
-                        else sp = spf[g];
-                        f32x4 o;
-                        if (BM == BM_KL) {
-                            f32x4 dp;
-                            if (a.S) {
-                                f32x4 cs = *reinterpret_cast<const f32x4*>(a.colsum + k0);
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) dp[j] = fmaxf(cs[j] + sp[j], kFlr);
-                            } else {
-                                dp = dpf[g];
-                            }
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                o[j] = ho[j] * acc[tau][4 * g + j] * fast_rcp(dp[j]);
-                                if (OBJ) shsum += sp[j] * ho[j];
-                            }
-                            *reinterpret_cast<f32x4*>(hsp + 8 * g) = o;  // in place; copied out after P2
-                        } else if (pass == 0) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                float dp = fmaxf(acc[tau][4 * g + j] + sp[j], kFlr);
-                                o[j] = ho[j] * fast_rcp(dp);
-                                if (OBJ) shsum += sp[j] * ho[j];
-                            }
-                            *reinterpret_cast<f32x4*>(hsp + 8 * g) = o;
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) o[j] = ho[j] * acc[tau][4 * g + j];
-                            *reinterpret_cast<f32x4*>(hsp + 8 * g) = o;
-                        }
-                    }
+                if (NPASS == 2) {
+                    __syncthreads();  // every wave finished reading the den image
+                    hstep_den_to_num<NW, NT, BM>(a, Rs, t0, w, lane);
+                    __syncthreads();
+                    double dummy = 0.0;
+                    hstep_p2<NW, NT, BM, false>(a, Hs, Rs, t0, w, lane, 1, dummy);
                 }
-                if (OBJ) acc_sh += (double)shsum;
-                SNMF_STAMP(10);
+                if (NL == 0) {
+                    __syncthreads();  // the updated H tile leaves through one coalesced copy
+                    SNMF_STAMP(10);
+                    stage_out<NTHR>(a.Hout + (size_t)t0 * rp, Hs, Tt, rp, ldh, threadIdx.x);
+                    SNMF_STAMP(11);
+                }
             }
         }
-        // the updated H tile leaves through one coalesced copy
-        __syncthreads();
-        stage_out<kNW * 64>(a.Hout + (size_t)t0 * rp, Hs, Tt, rp, ldh);
-        SNMF_STAMP(11);
+        if (NL > 0) __syncthreads();  // matches the loaders' final barrier
+        SNMF_STAMP_OUT(a.prof + ((size_t)blockIdx.x * NW + w) * 12, 12);
     }
-    SNMF_STAMP_OUT(a.prof + ((size_t)blockIdx.x * kNW + w) * 12, 12);
 
     if (OBJ) {
         // deterministic workgroup reduction of the two fp64 partial sums
         __syncthreads();
-        double* red = reinterpret_cast<double*>(lds);  // [2][NW*64]
+        double* red = reinterpret_cast<double*>(lds);  // [2][NTHR]
         red[threadIdx.x] = acc_div;
-        red[kNW * 64 + threadIdx.x] = acc_sh;
+        red[NTHR + threadIdx.x] = acc_sh;
         __syncthreads();
-        for (int s = kNW * 32; s > 0; s >>= 1) {
+        // NTHR is 256, 512 or 768: fold the tail above the largest power of two first
+        constexpr int P2 = NTHR >= 512 ? 512 : 256;
+        if ((int)threadIdx.x + P2 < NTHR) {
+            red[threadIdx.x] += red[threadIdx.x + P2];
+            red[NTHR + threadIdx.x] += red[NTHR + threadIdx.x + P2];
+        }
+        __syncthreads();
+        for (int s = P2 / 2; s > 0; s >>= 1) {
             if ((int)threadIdx.x < s) {
                 red[threadIdx.x] += red[threadIdx.x + s];
-                red[kNW * 64 + threadIdx.x] += red[kNW * 64 + threadIdx.x + s];
+                red[NTHR + threadIdx.x] += red[NTHR + threadIdx.x + s];
             }
             __syncthreads();
         }
         if (threadIdx.x == 0) {
             a.part[2 * blockIdx.x] = red[0];
-            a.part[2 * blockIdx.x + 1] = red[kNW * 64];
+            a.part[2 * blockIdx.x + 1] = red[NTHR];
         }
     }
 }
@@ -552,15 +661,21 @@ __global__ __launch_bounds__(NW * 64, 2) void k_hstep(StepArgs a) {
 // its NK x (32x32) accumulators in registers over the whole chunk of frames.
 // OBJ: additionally sums the divergence of (W, H) (W-only mode: Lam' IS the objective's Lam).
 // ============================================================================================
-template <int NK, int NWB, int WPS, int WM, int BM, bool OBJ>
-__global__ __launch_bounds__(NWB * 64, WPS) void k_wstats(StepArgs a, int n_chunks, int mat_index,
-                                                                          int n_mat) {
+// NL > 0: NL loader waves stage tile i+1 into the second LDS buffer (and keep the row sums of H)
+// while the NWB consumer waves -- ONE per SIMD, so nothing contends for the matrix pipe -- run
+// P3/P4 on tile i; one barrier per tile.  NL = 0: consumers stage synchronously (two workgroups per
+// CU when the accumulators leave room).
+template <int NK, int NWB, int NL, int WPS, int WM, int BM, bool OBJ>
+__global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int n_chunks, int mat_index,
+                                                                 int n_mat) {
+    constexpr int NTHR = (NWB + NL) * 64;
+    constexpr int NBUF = NL > 0 ? 2 : 1;
     if (a.stop && *a.stop) return;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Hs = lds;                  // [32][ldh]
-    float* Vs = lds + 32 * a.ldh;     // [32][Fp]  V tile (no HBM access inside the MFMA loops)
-    float* wxs = Vs + 32 * a.Fp;      // [rp] extra row of W
+    const int bufsz = 32 * (a.ldh + a.Fp);  // floats per buffer: Hs [32][ldh] then Vs [32][Fp]
+    float* wxs = lds + NBUF * bufsz;        // [rp] extra row of W
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool is_loader = NL > 0 && w >= NWB;
     const int fl = lane & 31, h = lane >> 5;
     const int rp = a.rp, Fp = a.Fp, ldh = a.ldh;
     const int chunk = blockIdx.x;
@@ -570,9 +685,9 @@ __global__ __launch_bounds__(NWB * 64, WPS) void k_wstats(StepArgs a, int n_chun
 #pragma unroll
     for (int i = 0; i < 8; ++i) gx[i] = 0.f;
     if (do_x && WM != 3)
-        for (int k = threadIdx.x; k < rp; k += NWB * 64) wxs[k] = a.wx[k];
+        for (int k = threadIdx.x; k < rp; k += NTHR) wxs[k] = a.wx[k];
     const int phi = blockIdx.y * NWB + w;
-    const bool active = phi < a.nf;
+    const bool active = !is_loader && phi < a.nf;
     const int kap_base = blockIdx.z * NK;  // kappa-group (r > 32*NK: P3 is recomputed per group)
     const bool do_obj = OBJ && blockIdx.z == 0;
     // contiguous, balanced range of 32-frame tiles for this chunk
@@ -582,25 +697,63 @@ __global__ __launch_bounds__(NWB * 64, WPS) void k_wstats(StepArgs a, int n_chun
     f32x16 G[NK];
 #pragma unroll
     for (int k = 0; k < NK; ++k) G[k] = zero16();
-    float ssum[2] = {0.f, 0.f};  // thread <-> k = tid + j*NWB*64 (rp <= 2*NWB*64 checked on the host)
-    stagger_start(a.stagger, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
-                  gridDim.x * gridDim.y * gridDim.z, a.stagger_shift);
+    // row sums of H: kept by the staging threads (loaders, or everybody when NL = 0);
+    // thread <-> k = sid + j*NST (rp <= 2*NST checked on the host)
+    constexpr int NST = NL > 0 ? NL * 64 : NWB * 64;
+    const int sid = NL > 0 ? (int)threadIdx.x - NWB * 64 : (int)threadIdx.x;
+    const bool do_s = WM == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+    float ssum[2] = {0.f, 0.f};
     double acc_div = 0.0;
 
-    for (int tile = tb; tile < te; ++tile) {
+    if (is_loader) {
+        // ================================ loader role =========================================
+        if (tb < te) {
+            stage_in<NST>(a.Hin + (size_t)tb * 32 * rp, lds, 32, rp, ldh, sid);
+            stage_in<NST>(a.V + (size_t)tb * 32 * Fp, lds + 32 * ldh, 32, Fp, Fp, sid);
+        }
+        for (int tile = tb, it = 0; tile < te; ++tile, ++it) {
+            const float* cH = lds + (it & 1) * bufsz;
+            float* nH = lds + ((it & 1) ^ 1) * bufsz;
+            __syncthreads();  // tile `tile` is complete in buffer it&1; buffer (it&1)^1 is free
+            if (do_s) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int k = sid + j * NST;
+                    if (k < rp) {
+                        float sacc = 0.f;
+                        for (int t = 0; t < 32; ++t) sacc += cH[t * ldh + k];
+                        ssum[j] += sacc;
+                    }
+                }
+            }
+            if (tile + 1 < te) {
+                stage_in<NST>(a.Hin + (size_t)(tile + 1) * 32 * rp, nH, 32, rp, ldh, sid);
+                stage_in<NST>(a.V + (size_t)(tile + 1) * 32 * Fp, nH + 32 * ldh, 32, Fp, Fp, sid);
+            }
+        }
+    }
+
+    SNMF_STAMP_DECL
+    for (int tile = tb, it = 0; tile < te && !is_loader; ++tile, ++it) {
         const int t0 = tile * 32;
+        SNMF_STAMP(0);
+        float* Hs = lds + (NL > 0 ? (it & 1) * bufsz : 0);  // [32][ldh]
+        float* Vs = Hs + 32 * ldh;                            // [32][Fp]  (no HBM access in the MFMA loops)
+        if (NL == 0) {
+            __syncthreads();
+            stage_in<NST>(a.Hin + (size_t)t0 * rp, Hs, 32, rp, ldh, sid);
+            stage_in<NST>(a.V + (size_t)t0 * Fp, Vs, 32, Fp, Fp, sid);
+        }
         __syncthreads();
-        stage_in<NWB * 64>(a.Hin + (size_t)t0 * rp, Hs, 32, rp, ldh);
-        stage_in<NWB * 64>(a.V + (size_t)t0 * Fp, Vs, 32, Fp, Fp);
-        __syncthreads();
-        if (WM == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+        SNMF_STAMP(1);
+        if (NL == 0 && do_s) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int k = threadIdx.x + j * NWB * 64;
+                const int k = sid + j * NST;
                 if (k < rp) {
-                    float s = 0.f;
-                    for (int t = 0; t < 32; ++t) s += Hs[t * ldh + k];
-                    ssum[j] += s;
+                    float sacc = 0.f;
+                    for (int t = 0; t < 32; ++t) sacc += Hs[t * ldh + k];
+                    ssum[j] += sacc;
                 }
             }
         }
@@ -653,6 +806,7 @@ __global__ __launch_bounds__(NWB * 64, WPS) void k_wstats(StepArgs a, int n_chun
                 }
             }
         }
+        SNMF_STAMP(2);
         if (!active) continue;
 
         float R[16];
@@ -661,6 +815,7 @@ __global__ __launch_bounds__(NWB * 64, WPS) void k_wstats(StepArgs a, int n_chun
             f32x16 acc1[1] = {zero16()};
             const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)phi * rp * 32) + lane;
             contract<1, true>(acc1, wp, Hs + fl * ldh + 4 * h, 0, rp / 8);
+            SNMF_STAMP(3);
             const f32x16 acc = acc1[0];
             // lane (f = fl, h), reg -> t = t0 + drow(reg,h)
             const int f = phi * 32 + fl;
@@ -690,6 +845,7 @@ __global__ __launch_bounds__(NWB * 64, WPS) void k_wstats(StepArgs a, int n_chun
         // B fragments (one ds_read_b32 per MFMA) are fetched a whole kappa-tile (16 reads) ahead.
         // kappa-tiles beyond nk (NK is a template bound) are clamped: they recompute the last real
         // tile into an accumulator that is never stored, which keeps the loop branch-free.
+        SNMF_STAMP(4);
         // The H image of this kernel is padded to 32*NK columns per kappa-group (host: ldh), so tiles
         // beyond nk read finite padding into accumulators that are never stored -- no clamps, and
         // every read is (one of 16 row bases) + an immediate offset.
@@ -728,7 +884,14 @@ __global__ __launch_bounds__(NWB * 64, WPS) void k_wstats(StepArgs a, int n_chun
         SNMF_KTILE(14, b0, b1)
         SNMF_KTILE(15, b1, b0)
 #undef SNMF_KTILE
+        SNMF_STAMP(5);
     }
+#ifdef SNMF_PROF
+    if (!is_loader && a.prof) {
+        const size_t wv = ((size_t)(blockIdx.x + gridDim.x * blockIdx.y)) * NWB + w;
+        if (wv < 4096) SNMF_STAMP_OUT(a.prof + (4096 + wv) * 12, 12);
+    }
+#endif
 
     // ---- write the partial slab: D tile lane (k = fl, h), reg -> f = 32*phi + drow(reg,h)
     if (active) {
@@ -745,25 +908,27 @@ __global__ __launch_bounds__(NWB * 64, WPS) void k_wstats(StepArgs a, int n_chun
             }
         }
     }
-    if (WM == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+    if (do_s && sid >= 0) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int k = threadIdx.x + j * NWB * 64;
+            const int k = sid + j * NST;
             if (k < rp) a.spart[(size_t)chunk * rp + k] = ssum[j];
         }
     }
     if (do_x) {
-        // fixed-order sum of the per-wave partial extra rows, through LDS
+        // fixed-order sum of the consumers' partial extra rows, through LDS
         __syncthreads();
         float* red = lds;  // [NWB][rp]  (NWB*rp <= 32*ldh)
+        if (!is_loader) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int k = lane + 64 * i;
-            if (k < rp) red[w * rp + k] = gx[i];
+            for (int i = 0; i < 8; ++i) {
+                const int k = lane + 64 * i;
+                if (k < rp) red[w * rp + k] = gx[i];
+            }
         }
         __syncthreads();
         float* slab = a.slabs + ((size_t)chunk * n_mat + mat_index) * rp * Fp;
-        for (int k = threadIdx.x; k < rp; k += NWB * 64) {
+        for (int k = threadIdx.x; k < rp; k += NTHR) {
             float s = 0.f;
             for (int ww = 0; ww < NWB; ++ww) s += red[ww * rp + k];
             slab[(size_t)k * Fp + a.Fm] = s;
@@ -775,7 +940,7 @@ __global__ __launch_bounds__(NWB * 64, WPS) void k_wstats(StepArgs a, int n_chun
         double* red = reinterpret_cast<double*>(lds);
         red[threadIdx.x] = acc_div;
         __syncthreads();
-        for (int s = NWB * 32; s > 0; s >>= 1) {
+        for (int s = NTHR / 2; s > 0; s >>= 1) {  // NTHR is 256 or 512
             if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
             __syncthreads();
         }
