@@ -114,10 +114,9 @@ int snmf_plan_set_h_f32(snmf_plan* plan, const float* H, int64_t ld, int is_devi
 int snmf_plan_set_sparsity_f64(snmf_plan* plan, const double* S, int is_device);
 int snmf_plan_set_sparsity_f32(snmf_plan* plan, const float* S, int is_device);
 
-/* src/sparse_nmf.m:157-169: normalise W columns, rescale H rows, floor V; resets the iteration
- * counter and the objective history.  `wnorm_dev` (optional, r doubles, DEVICE) overrides the
- * locally computed column norms -- unused for frame sharding (W is replicated) and kept for
- * symmetry. */
+/* src/sparse_nmf.m:157-169: normalise W columns, rescale H rows (V is floored at set_v); resets
+ * the iteration counter and the objective history.  If W was not set again since the last init its
+ * normalised form and norms are reused (same bits as normalising the same input again). */
 int snmf_plan_init(snmf_plan* plan);
 
 /* The hot loop src/sparse_nmf.m:186-286: up to `n_iters` more iterations (bounded by
@@ -145,6 +144,27 @@ int snmf_plan_objstats(snmf_plan* plan, double* stats_dev);
 int snmf_plan_objapply(snmf_plan* plan, const double* stats_dev);
 /* 1 when the device-side convergence test has fired (synchronises the stream). */
 int snmf_plan_stopped(snmf_plan* plan, int32_t* stopped);
+
+/* Online separation stream (src/NTF_sep_event_RT.m:67-107 -> src/bnmf_sep_event_RT_IS16.m:138-154):
+ * the SAME dictionary W and the SAME initial activations H0 (the reference re-seeds its generator
+ * in every call, src/sparse_nmf.m:112-114, so H0 is identical for every frame) are used for
+ * n_solves INDEPENDENT H-only solves, one per group of `frames_per_solve` (<= 32) consecutive
+ * columns of V; each has its own objective and its own convergence test (:272-284).
+ * Result-identical to n_solves calls of snmf_sparse_nmf_* with w_update_ind all false, but W stays
+ * resident and normalised, V is uploaded once, and every solve is ONE persistent workgroup (all of
+ * its iterations inside one launch), the solves running concurrently across the CUs.
+ *   plan    : H-only plan whose T >= n_solves*frames_per_solve (capacity); snmf_plan_set_w called
+ *   V       : F x (n_solves*frames_per_solve) host matrix, leading dimension ldV
+ *   H0      : r x frames_per_solve host matrix
+ *   H_out   : r x (n_solves*frames_per_solve) host matrix (leading dimension r)
+ *   n_iter_out[n_solves], cost_out[n_solves] (last recorded cost, 0 without cost_check): optional
+ * Scalar / r-vector sparsity only. */
+int snmf_plan_solve_frames_f64(snmf_plan* plan, int32_t frames_per_solve, const double* V, int64_t ldV,
+                               int32_t n_solves, const double* H0, double* H_out, int32_t* n_iter_out,
+                               double* cost_out);
+int snmf_plan_solve_frames_f32(snmf_plan* plan, int32_t frames_per_solve, const float* V, int64_t ldV,
+                               int32_t n_solves, const float* H0, float* H_out, int32_t* n_iter_out,
+                               double* cost_out);
 
 /* Results.  W: F x r, H: r x T(local).  Host or device destinations. */
 int snmf_plan_get_w_f64(snmf_plan* plan, double* W, int64_t ld, int is_device);

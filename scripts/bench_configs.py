@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Secondary measurements of the other BASELINE.json configs (bench.py is C2, the headline):
+  C1  257x2000 r=40 KL 50 it            (reference's own CPU-runnable plumbing case)
+  C3  online: 513x1 r=200 H-only per frame, early stop 1e-3 (frames/s), W resident
+      + noise-dictionary adaptation shape: W-only 513x100 r=50
+  C4  run_basis_DNMF 3-solve loop, F=513, R_x=R_d=100, single GPU (T = 100000)
+  C5  513x500000 r=512 beta=2 (it/s)
+Prints one JSON line per config.  Usage: python scripts/bench_configs.py [c1 c3 c4 c5] [--cpu]"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+from se_snmf_nat_amd import Context, Plan, run_basis_dnmf, sparse_nmf  # noqa: E402
+
+which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["c1", "c3", "c4", "c5"]
+with_cpu = "--cpu" in sys.argv
+ctx = Context(0)
+
+
+def synth(F, T, r, seed=0):
+    rd = np.random.default_rng(seed)
+    Wt = rd.gamma(0.5, 1.0, size=(F, r)).astype(np.float32)
+    Ht = rd.gamma(0.3, 1.0, size=(r, T)).astype(np.float32)
+    V = Wt @ Ht + 1e-9
+    return V, rd.random((F, r)).astype(np.float32), rd.random((r, T)).astype(np.float32)
+
+
+def timed_plan(F, T, r, iters, warm, **kw):
+    V, W0, H0 = synth(F, T, r)
+    plan = Plan(ctx, F, T, r, max_iter=warm + iters + 1, conv_eps=0.0, cost_check=True, **kw)
+    plan.set_v(V); plan.set_w(W0); plan.set_h(H0); plan.init()
+    plan.run_async(warm); ctx.sync()
+    t = time.perf_counter(); plan.run_async(iters); ctx.sync(); dt = time.perf_counter() - t
+    d = plan.describe(); plan.close()
+    return iters / dt, d, (V, W0, H0)
+
+
+if "c1" in which:
+    ips, d, (V, W0, H0) = timed_plan(257, 2000, 40, 200, 20, beta=1.0, sparsity=5.0)
+    out = {"config": "C1 257x2000 r=40 KL", "value": ips, "unit": "iterations/s", "geometry": d}
+    if with_cpu:
+        from oracle.sparse_nmf_oracle import sparse_nmf as onmf
+        t = time.perf_counter()
+        onmf(V.astype(np.float64), dict(cf="kl", sparsity=5, max_iter=50, init_w=W0, init_h=H0, cost_check=1), mimic_matlab_flops=True)
+        out["cpu_oracle_its"] = 50 / (time.perf_counter() - t)
+    print(json.dumps(out), flush=True)
+
+if "c3" in which:
+    ref = dict(np.load(os.path.join(ROOT, "tests", "golden", "ref_data.npz")))
+    B, Y = ref["B"].astype(np.float64), ref["Y"].astype(np.float64)
+    H0 = np.random.RandomState(1).random_sample((200, 1))
+    # (a) latency: one frame per call (real-time use), dictionary resident
+    one = Plan(ctx, 513, 1, 200, beta=1.0, max_iter=100, conv_eps=1e-3, cost_check=True, sparsity=5.0,
+               w_update_ind=np.zeros(200, bool))
+    one.set_w(B)
+    for rep in range(3):
+        if rep == 1:
+            t = time.perf_counter()
+        for col in range(Y.shape[1]):
+            one.solve_frames(Y[:, col:col + 1], H0)
+    lat = (time.perf_counter() - t) / (2 * Y.shape[1])
+    # (b) throughput: a whole file's frames in one stream call (one persistent workgroup per frame)
+    Yl = np.tile(Y, (1, 64))  # 4096 frames
+    plan = Plan(ctx, 513, Yl.shape[1], 200, beta=1.0, max_iter=100, conv_eps=1e-3, cost_check=True, sparsity=5.0,
+                w_update_ind=np.zeros(200, bool))
+    plan.set_w(B)
+    plan.solve_frames(Yl[:, :256], H0)
+    t = time.perf_counter()
+    Hs, nit, lc = plan.solve_frames(Yl, H0, dtype=np.float32)
+    dt = time.perf_counter() - t
+    nframes, its = Yl.shape[1], int(nit.sum())
+    out = {"config": "C3 online H-only 513x1 r=200 (shipped dictionaries, real |STFT|^2 frames), eps=1e-3",
+           "value": nframes / dt, "unit": "frames/s (4096-frame stream call, host buffers in/out)",
+           "single_frame_call_latency_ms": lat * 1e3, "single_frame_calls_per_s": 1 / lat,
+           "inner_iterations_per_frame": its / nframes, "iterations_per_s": its / dt}
+    if with_cpu:
+        from oracle.sparse_nmf_oracle import sparse_nmf as onmf
+        t = time.perf_counter()
+        for col in range(Y.shape[1]):
+            onmf(Y[:, col:col + 1], dict(cf="kl", sparsity=5, max_iter=100, conv_eps=1e-3, init_w=B, init_h=H0,
+                                         cost_check=1, w_update_ind=np.zeros(200, bool)))
+        out["cpu_oracle_frames_s"] = Y.shape[1] / (time.perf_counter() - t)
+    print(json.dumps(out), flush=True)
+    # adaptation shape: W-only 513 x 100, r = 50
+    Bu = ref["Bu"].astype(np.float64)
+    Yd = np.concatenate([Y, Y[:, :36]], axis=1)
+    Hd = np.random.RandomState(2).random_sample((50, 100)) * 1e6
+    p = dict(cf="kl", sparsity=5, max_iter=100, conv_eps=1e-3, init_w=Bu, init_h=Hd, cost_check=1,
+             w_update_ind=np.ones(50, bool), h_update_ind=np.zeros(50, bool))
+    sparse_nmf(Yd, p, ctx=ctx)
+    t = time.perf_counter(); n = 20
+    for _ in range(n):
+        w, h, o = sparse_nmf(Yd, p, ctx=ctx)
+    dt = time.perf_counter() - t
+    print(json.dumps({"config": "C3 adaptation W-only 513x100 r=50, eps=1e-3", "value": n / dt, "unit": "solves/s",
+                      "iterations_per_solve": o["n_iter"]}), flush=True)
+
+if "c4" in which:
+    F, T, Rx, Rd = 513, 100_000, 100, 100
+    X, _, _ = synth(F, T, Rx, 1); D, _, _ = synth(F, T, Rd, 2)
+    Y = X + D + 1e-9
+    B = np.random.default_rng(3).random((F, Rx + Rd))
+    p = dict(cf="kl", sparsity=5, max_iter=50, conv_eps=0, cost_check=1)
+    run_basis_dnmf(Y[:, :4096], X[:, :4096], D[:, :4096], B, Rx, Rd, p, ctx=ctx)
+    t = time.perf_counter(); Bh, Ah = run_basis_dnmf(Y, X, D, B, Rx, Rd, p, ctx=ctx, dtype=np.float32); dt = time.perf_counter() - t
+    print(json.dumps({"config": f"C4 run_basis_DNMF 3 solves x 50 it, {F}x{T}, R_x=R_d=100, 1 GPU, host buffers in/out",
+                      "value": 150 / dt, "unit": "solver iterations/s (incl. PCIe + layout conversion)",
+                      "seconds": dt}), flush=True)
+
+if "c5" in which:
+    ips, d, _ = timed_plan(513, 500_000, 512, 10, 2, beta=2.0, sparsity=50.0)
+    fl = 12.0 * 513 * 500_000 * 512
+    print(json.dumps({"config": "C5 513x500000 r=512 beta=2 lambda=50", "value": ips, "unit": "iterations/s",
+                      "TFLOPs_algorithmic(12FTr)": fl * ips / 1e12, "geometry": d}), flush=True)

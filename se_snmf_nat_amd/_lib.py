@@ -29,7 +29,7 @@ SYMBOLS = [
     "snmf_plan_hstep", "snmf_plan_wstats", "snmf_plan_wapply", "snmf_plan_objstats", "snmf_plan_objapply",
     "snmf_plan_stopped",
     "snmf_plan_get_w_f64", "snmf_plan_get_w_f32", "snmf_plan_get_h_f64", "snmf_plan_get_h_f32",
-    "snmf_plan_get_objective",
+    "snmf_plan_get_objective", "snmf_plan_solve_frames_f64", "snmf_plan_solve_frames_f32",
     "snmf_ctx_timing", "snmf_ctx_timing_get", "snmf_plan_describe",
 ]
 
@@ -136,6 +136,8 @@ def load():
         "snmf_ctx_timing_get": (C.c_int, [vp, C.c_char_p, C.POINTER(dbl), C.POINTER(i64)]),
         "snmf_plan_describe": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
     }
+    for ty in ("f64", "f32"):
+        sig[f"snmf_plan_solve_frames_{ty}"] = (C.c_int, [vp, i32, vp, i64, i32, vp, vp, vp, vp])
     for nm in ("v", "w", "h"):
         for ty in ("f64", "f32"):
             sig[f"snmf_plan_set_{nm}_{ty}"] = (C.c_int, [vp, vp, i64, C.c_int])

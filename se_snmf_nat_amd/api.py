@@ -353,6 +353,26 @@ class Plan:
         _lib.check(fn(self._h, _ptr(out), self.r, 0))
         return out
 
+    def solve_frames(self, v, h0, dtype=np.float64):
+        """Online stream: independent H-only solves of consecutive groups of h0.shape[1] (<= 32) columns
+        of `v` with the resident dictionary and the same H0 each time
+        (src/bnmf_sep_event_RT_IS16.m:138-154, called once per hop by src/NTF_sep_event_RT.m:67-107).
+        The plan's T is the capacity in columns.  Returns (H, n_iter, last_cost)."""
+        dt = np.dtype(dtype)
+        v = np.asfortranarray(v, dtype=dt)
+        h0 = np.asfortranarray(h0, dtype=dt)
+        tps = h0.shape[1]
+        n = v.shape[1] // tps
+        if v.shape[0] != self.F or n * tps != v.shape[1] or h0.shape[0] != self.r:
+            raise SnmfError(3, "solve_frames: v must be F x (n*tps) and h0 r x tps")
+        H = np.empty((self.r, n * tps), dtype=dt, order="F")
+        nit = np.zeros(n, np.int32)
+        cost = np.zeros(n)
+        fn = self._lib.snmf_plan_solve_frames_f64 if dt == np.float64 else self._lib.snmf_plan_solve_frames_f32
+        _lib.check(fn(self._h, tps, _ptr(v), v.strides[1] // dt.itemsize if v.shape[1] > 1 else self.F, n, _ptr(h0),
+                      _ptr(H), _ptr(nit), _ptr(cost)))
+        return H, nit, cost
+
     def get_objective(self):
         div = np.zeros(max(self.max_iter, 1))
         cost = np.zeros(max(self.max_iter, 1))

@@ -231,6 +231,11 @@ struct snmf_plan {
     int n_part = 0;
     // state
     bool have_v = false, have_w = false, have_h = false, have_s = false, inited = false;
+    bool w_dirty = true;      // W changed since its last normalisation (online: W stays, only V/H change)
+    bool small = false;       // T <= 32 H-only solve: one persistent single-workgroup launch
+    bool small_ok = false;
+    size_t lds_small = 0;
+    bool small_done = false;
     int cur = 0;          // H[cur] holds the current iterate
     int it_done = 0;      // update iterations launched
     bool final_done = false;
@@ -332,7 +337,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     pl->Fp = pl->Fm + 4 * pl->xr;
     pl->Fq = pl->Fm + 8 * pl->xr;
     pl->rp = (int)roundup(r, 32);
-    pl->Tp = (int)roundup(T, 64);
+    pl->Tp = (int)roundup(T + 32, 64);  // >= 32 zero columns of slack: a 32-frame tile may start at any frame
     pl->nk = pl->rp / 32;
     pl->ldh = pl->rp + 4;
     pl->ldr = pl->Fq + 4;
@@ -415,6 +420,13 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         return fail(SNMF_ERR_UNSUPPORTED, "r = %d > %d not supported for KL W updates yet", r, 2 * pl->NWB * 64);
     }
 
+    // persistent single-launch path for the online shape (H-only, at most one 32-frame tile)
+    {
+        const size_t need = ((size_t)32 * (pl->ldh + pl->ldr) + ((pl->rp + 3) & ~3)) * 4 + 2 * 512 * sizeof(double);
+        pl->small_ok = pl->upd_h && !pl->upd_w && need <= lds_cap;   // shape admits the persistent kernel
+        pl->small = pl->small_ok && T <= 32 && !getenv("SNMF_NO_SMALL");
+        pl->lds_small = need;
+    }
     // allocations
     const size_t nV = (size_t)pl->Fp * pl->Tp, nH = (size_t)pl->rp * pl->Tp, nW = (size_t)pl->Fp * pl->rp;
     const size_t nWt = (size_t)pl->Fm * pl->rp, nWk = (size_t)pl->Fq * pl->rp;
@@ -574,6 +586,7 @@ static int set_w(snmf_plan* pl, const T* W, int64_t ld, int dev) {
     PLAN_CHECK(pl);
     SN_TRY(pack_in<T>(pl, W, ld, pl->p.F, pl->p.r, pl->Wc, pl->Fp, pl->rp, false, dev));
     pl->have_w = true;
+    pl->w_dirty = true;
     pl->inited = false;
     return SNMF_OK;
 }
@@ -811,8 +824,12 @@ extern "C" int snmf_plan_init(snmf_plan* pl) {
     HIP_TRY(hipMemsetAsync(pl->st, 0, sizeof(DevState), st));
     HIP_TRY(hipMemsetAsync(pl->divh, 0, sizeof(double) * std::max(1, pl->p.max_iter), st));
     HIP_TRY(hipMemsetAsync(pl->costh, 0, sizeof(double) * std::max(1, pl->p.max_iter), st));
-    // wn = sqrt(sum(w.^2)); w = w./wn  (+ operand images, colsum, dphv)
-    SN_TRY(launch_wapply(pl, pl->stats, 0, false, true));
+    // wn = sqrt(sum(w.^2)); w = w./wn  (+ operand images, colsum, dphv).  When only V / H changed since
+    // the last init (online separation: the dictionary stays) the normalised W and wn are reused:
+    // normalising an already-identical input would reproduce them bit for bit.
+    if (pl->w_dirty) SN_TRY(launch_wapply(pl, pl->stats, 0, false, true));
+    pl->w_dirty = false;
+    pl->small_done = false;
     // h = h .* wn'
     const size_t nH = (size_t)pl->rp * pl->Tp;
     hipLaunchKernelGGL(k_scale_h, dim3(grid_for(nH)), dim3(256), 0, st, pl->H[pl->cur], pl->wn, pl->rp, pl->p.r, nH);
@@ -941,10 +958,53 @@ static int finalize_objective(snmf_plan* pl) {
     return snmf_plan_objapply(pl, pl->stats);
 }
 
+// persistent single-launch H-only solves: n_solves independent workgroups of tps <= 32 frames each
+static int launch_small(snmf_plan* pl, int n_solves, int tps, double* divh, double* costh, DevState* st) {
+    StepArgs a = make_args(pl);
+    a.Hout = pl->H[pl->cur];  // in place
+    a.n_tiles = 1;
+    SmallArgs sa{};
+    sa.max_iter = pl->p.max_iter;
+    sa.cost_check = pl->p.cost_check;
+    sa.conv_eps = pl->p.conv_eps;
+    sa.divh = divh;
+    sa.costh = costh;
+    sa.st = st;
+    sa.tps = tps;
+    auto launch = [&](auto kern) -> int {
+        static std::map<const void*, size_t> attr_set;
+        const void* key = (const void*)kern;
+        if (pl->lds_small > 64 * 1024 && attr_set[key] < pl->lds_small) {
+            HIP_TRY(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_small));
+            attr_set[key] = pl->lds_small;
+        }
+        hipLaunchKernelGGL(kern, dim3(n_solves), dim3(512), pl->lds_small, pl->ctx->stream, a, sa);
+        HIP_TRY(hipGetLastError());
+        return SNMF_OK;
+    };
+    ScopedTimer tm(pl->ctx, FAM_HSTEP);
+    const bool obj = pl->p.cost_check != 0;
+    if (pl->bm == BM_KL) return obj ? launch(k_hsolve_small<BM_KL, true>) : launch(k_hsolve_small<BM_KL, false>);
+    if (pl->bm == BM_EUC) return obj ? launch(k_hsolve_small<BM_EUC, true>) : launch(k_hsolve_small<BM_EUC, false>);
+    return obj ? launch(k_hsolve_small<BM_GEN, true>) : launch(k_hsolve_small<BM_GEN, false>);
+}
+
 extern "C" int snmf_plan_run(snmf_plan* pl, int32_t n_iters, int32_t* iters_done) {
     PLAN_CHECK(pl);
     if (!pl->inited) return fail(SNMF_ERR_STATE, "plan not initialised");
     HIP_TRY(hipSetDevice(pl->ctx->device));
+    if (pl->small && pl->it_done == 0 && n_iters >= pl->p.max_iter && !pl->small_done) {
+        SN_TRY(launch_small(pl, 1, pl->p.T, pl->divh, pl->costh, pl->st));
+        pl->it_done = pl->p.max_iter;
+        pl->final_done = true;
+        pl->small_done = true;
+        if (iters_done) {
+            DevState hs{};
+            SN_TRY(read_state(pl, &hs));
+            *iters_done = hs.stop ? hs.n_iter : pl->it_done;
+        }
+        return SNMF_OK;
+    }
     const int target = std::min(pl->p.max_iter, pl->it_done + std::max(0, n_iters));
     const bool can_stop = pl->p.cost_check && pl->p.conv_eps > 0.0;
     int since_poll = 0;
@@ -979,7 +1039,7 @@ extern "C" int snmf_plan_run(snmf_plan* pl, int32_t n_iters, int32_t* iters_done
 static int result_h_index(snmf_plan* pl, int* idx) {
     DevState hs{};
     SN_TRY(read_state(pl, &hs));
-    if (hs.stop && pl->upd_h) *idx = hs.n_iter & 1;
+    if (hs.stop && pl->upd_h && !pl->small_done) *idx = hs.n_iter & 1;
     else *idx = pl->cur;
     return SNMF_OK;
 }
@@ -1017,6 +1077,75 @@ extern "C" int snmf_plan_get_objective(snmf_plan* pl, double* div_out, double* c
             HIP_TRY(hipMemcpy(cost_out, pl->costh, sizeof(double) * std::min(mi, hs.n_iter), hipMemcpyDeviceToHost));
     }
     return SNMF_OK;
+}
+
+// ---- online stream ---------------------------------------------------------------------------
+template <typename T>
+static int solve_frames_impl(snmf_plan* pl, int32_t tps, const T* V, int64_t ldV, int32_t n_solves, const T* H0,
+                             T* H_out, int32_t* n_iter_out, double* cost_out) {
+    PLAN_CHECK(pl);
+    if (!V || !H0 || !H_out || n_solves <= 0) return fail(SNMF_ERR_INVALID, "V, H0, H_out and n_solves are required");
+    if (pl->upd_w || !pl->upd_h) return fail(SNMF_ERR_STATE, "solve_frames needs an H-only plan (w_update_ind all false)");
+    if (!pl->have_w) return fail(SNMF_ERR_STATE, "snmf_plan_set_w must precede solve_frames");
+    if (!pl->have_s) return fail(SNMF_ERR_STATE, "set_sparsity must precede solve_frames for this sparsity kind");
+    if (pl->p.sparsity_kind == SNMF_SPARSITY_FULL) return fail(SNMF_ERR_UNSUPPORTED, "solve_frames: full sparsity matrix");
+    if (tps < 1 || tps > 32) return fail(SNMF_ERR_UNSUPPORTED, "frames per solve must be in [1,32] (got %d)", tps);
+    if (!pl->small_ok) return fail(SNMF_ERR_UNSUPPORTED, "F + r too large for the persistent online kernel");
+    const int F = pl->p.F, r = pl->p.r;
+    const size_t ncols = (size_t)n_solves * tps;
+    if (ncols > (size_t)pl->p.T) return fail(SNMF_ERR_INVALID, "n_solves*frames_per_solve = %zu exceeds the plan's T = %d", ncols, pl->p.T);
+    if (ldV < F) return fail(SNMF_ERR_INVALID, "ldV < F");
+    HIP_TRY(hipSetDevice(pl->ctx->device));
+    hipStream_t st = pl->ctx->stream;
+    const int mi = std::max(1, pl->p.max_iter);
+    // device staging: [V | H0 | H_all] as T, then per-solve state, objective histories, outputs
+    const size_t bV = ((ncols - 1) * (size_t)ldV + F) * sizeof(T), bH0 = (size_t)r * tps * sizeof(T),
+                 bHo = (size_t)r * ncols * sizeof(T);
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t oH0 = al(bV), oHo = oH0 + al(bH0), oSt = oHo + al(bHo), oDv = oSt + al((size_t)n_solves * sizeof(DevState)),
+                 oCs = oDv + al((size_t)n_solves * mi * 8), oNi = oCs + al((size_t)n_solves * mi * 8),
+                 oCo = oNi + al((size_t)n_solves * 4), tot = oCo + al((size_t)n_solves * 8);
+    SN_TRY(ensure_staging(pl, tot));
+    char* sb = (char*)pl->staging;
+    HIP_TRY(hipMemcpyAsync(sb, V, bV, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(sb + oH0, H0, bH0, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(sb + oSt, 0, oNi - oSt, st));
+    // V: all frames at once; floor as src/sparse_nmf.m:169
+    const size_t nVp = (size_t)pl->Fp * pl->Tp;
+    hipLaunchKernelGGL(k_pack<T>, dim3(grid_for(nVp)), dim3(256), 0, st, (const T*)sb, ldV, F, (int)ncols, pl->V, pl->Fp,
+                       pl->Tp, kFlr, pl->p.floor_v ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    pl->have_v = true;
+    // W: normalised once per set_w (:157-159)
+    if (pl->w_dirty) SN_TRY(launch_wapply(pl, pl->stats, 0, false, true));
+    pl->w_dirty = false;
+    // H0 .* wn' replicated for every solve (:160)
+    pl->cur = 0;
+    hipLaunchKernelGGL(k_tile_h0<T>, dim3(grid_for(ncols * pl->rp)), dim3(256), 0, st, (const T*)(sb + oH0), pl->wn, r,
+                       pl->rp, tps, n_solves, pl->H[0]);
+    HIP_TRY(hipGetLastError());
+    pl->have_h = true;
+    pl->inited = false;  // the plan's single-solve state is not valid after a stream call
+    SN_TRY(launch_small(pl, n_solves, tps, (double*)(sb + oDv), (double*)(sb + oCs), (DevState*)(sb + oSt)));
+    hipLaunchKernelGGL(k_unpack<T>, dim3(grid_for((size_t)r * ncols)), dim3(256), 0, st, pl->H[0], pl->rp, r, (int)ncols,
+                       (T*)(sb + oHo), (int64_t)r);
+    hipLaunchKernelGGL(k_collect, dim3((n_solves + 255) / 256), dim3(256), 0, st, (const DevState*)(sb + oSt),
+                       (const double*)(sb + oCs), n_solves, pl->p.max_iter, pl->p.cost_check, (int*)(sb + oNi),
+                       (double*)(sb + oCo));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(H_out, sb + oHo, bHo, hipMemcpyDeviceToHost, st));
+    if (n_iter_out) HIP_TRY(hipMemcpyAsync(n_iter_out, sb + oNi, (size_t)n_solves * 4, hipMemcpyDeviceToHost, st));
+    if (cost_out) HIP_TRY(hipMemcpyAsync(cost_out, sb + oCo, (size_t)n_solves * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return SNMF_OK;
+}
+extern "C" int snmf_plan_solve_frames_f64(snmf_plan* pl, int32_t tps, const double* V, int64_t ldV, int32_t n,
+                                          const double* H0, double* H_out, int32_t* n_iter_out, double* cost_out) {
+    return solve_frames_impl<double>(pl, tps, V, ldV, n, H0, H_out, n_iter_out, cost_out);
+}
+extern "C" int snmf_plan_solve_frames_f32(snmf_plan* pl, int32_t tps, const float* V, int64_t ldV, int32_t n,
+                                          const float* H0, float* H_out, int32_t* n_iter_out, double* cost_out) {
+    return solve_frames_impl<float>(pl, tps, V, ldV, n, H0, H_out, n_iter_out, cost_out);
 }
 
 // ---- one-shot drop-in ------------------------------------------------------------------------

@@ -90,6 +90,13 @@ __device__ __forceinline__ float div_term(float v, float lam, float beta, float 
     }
 }
 
+// Device-side solver state (fp64 objective history and the convergence flag).
+struct DevState {
+    int stop;      // set by the convergence test, src/sparse_nmf.m:275-281
+    int n_iter;    // iterations whose objective has been recorded
+    int pad0, pad1;
+};
+
 // ------------------------------------------------------------------------------------------
 // Arguments shared by the two big kernels.  Layouts (all fp32, zero padded):
 //   V   [Tp][Fp]            column-major F x T, leading dimension Fp
@@ -310,7 +317,9 @@ __device__ __forceinline__ void stage_out(float* __restrict__ dst, const float* 
 //   (NW=8, NT=2, NL=0): one workgroup per CU, W fragments shared by two frame sub-tiles
 constexpr int kPF = 20;  // f32x4 a loader thread keeps in flight (covers 32*(rp+Fp) <= 20480 floats at NL=4)
 
-template <int NW, int NT, int BM, bool OBJ>
+// VG: V is read from global memory (persistent small-problem kernel: the LDS V image would be
+// destroyed by the in-place ratio, and V is L2-resident there) instead of the staged LDS image.
+template <int NW, int NT, int BM, bool OBJ, bool VG = false>
 __device__ __forceinline__ void hstep_p1_tiles(const StepArgs& a, float* Hs, float* Rs, int t0, int w, int lane,
                                                bool upd, double& acc_div) {
     constexpr int Tt = 32 * NT;
@@ -322,6 +331,15 @@ __device__ __forceinline__ void hstep_p1_tiles(const StepArgs& a, float* Hs, flo
 #pragma unroll
         for (int tau = 0; tau < NT; ++tau) acc[tau] = zero16();
         const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)phi * rp * 32) + lane;
+        f32x4 vfr[NT][4];
+        if (VG) {
+#pragma unroll
+            for (int tau = 0; tau < NT; ++tau)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    vfr[tau][g] = *reinterpret_cast<const f32x4*>(a.V + (size_t)(t0 + tau * 32 + fl) * a.Fp + phi * 32 +
+                                                                  4 * h + 8 * g);
+        }
         contract<NT, false>(acc, wp, Hs + fl * ldh + 4 * h, 32 * ldh, rp / 8);
         // epilogue: lane (t = fl, h), reg -> f = 32*phi + drow(reg,h)
         float dsum = 0.f;
@@ -331,7 +349,7 @@ __device__ __forceinline__ void hstep_p1_tiles(const StepArgs& a, float* Hs, flo
             float* rsp = Rs + (tau * 32 + fl) * ldr + phi * 32 + 4 * h;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(rsp + 8 * g);  // staged V
+                const f32x4 v = VG ? vfr[tau][g] : *reinterpret_cast<const f32x4*>(rsp + 8 * g);  // staged V
                 f32x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -352,7 +370,7 @@ __device__ __forceinline__ void hstep_p1_tiles(const StepArgs& a, float* Hs, flo
 }
 
 // extra row (F = 32*nf + 1): lam_x[t] = sum_k W[Fm,k] H[k,t] on the VALU, 4 columns x 16 lanes at a time
-template <int NW, int NT, int BM, bool OBJ>
+template <int NW, int NT, int BM, bool OBJ, bool VG = false>
 __device__ __forceinline__ void hstep_p1_xrow(const StepArgs& a, float* Hs, float* Rs, const float* wxs, int t0, int w,
                                               int lane, bool upd, double& acc_div) {
     constexpr int Tt = 32 * NT;
@@ -380,7 +398,7 @@ __device__ __forceinline__ void hstep_p1_xrow(const StepArgs& a, float* Hs, floa
             s += __shfl_xor(s, 8);
             if (kl == 0) {
                 const int t = t0 + tl;
-                const float v = Rs[tl * ldr + a.Fm];  // staged V
+                const float v = VG ? a.V[(size_t)t * a.Fp + a.Fm] : Rs[tl * ldr + a.Fm];  // staged V
                 const float lam = fmaxf(s, kFlr);
                 if (OBJ) dsum += (t < a.T) ? div_term<BM>(v, lam, a.beta, a.inv_bb1) : 0.f;
                 if (upd) Rs[tl * ldr + a.Fm] = (BM == BM_KL) ? v * fast_rcp(lam) : den_of_lam<BM>(lam, a.beta);
@@ -393,13 +411,13 @@ __device__ __forceinline__ void hstep_p1_xrow(const StepArgs& a, float* Hs, floa
 // P1 of one wave.  The second half of the waves (the SIMD partners of the first half) run their
 // VALU-only extra-row work FIRST: the two waves of a SIMD then reach their MFMA loops, and later
 // their VALU epilogues, at different times instead of colliding on both.
-template <int NW, int NT, int BM, bool OBJ>
+template <int NW, int NT, int BM, bool OBJ, bool VG = false>
 __device__ __forceinline__ void hstep_p1(const StepArgs& a, float* Hs, float* Rs, const float* wxs, int t0, int w,
                                          int lane, bool upd, double& acc_div) {
     const bool xfirst = a.xr && (w >= NW / 2);
-    if (xfirst) hstep_p1_xrow<NW, NT, BM, OBJ>(a, Hs, Rs, wxs, t0, w, lane, upd, acc_div);
-    hstep_p1_tiles<NW, NT, BM, OBJ>(a, Hs, Rs, t0, w, lane, upd, acc_div);
-    if (a.xr && !xfirst) hstep_p1_xrow<NW, NT, BM, OBJ>(a, Hs, Rs, wxs, t0, w, lane, upd, acc_div);
+    if (xfirst) hstep_p1_xrow<NW, NT, BM, OBJ, VG>(a, Hs, Rs, wxs, t0, w, lane, upd, acc_div);
+    hstep_p1_tiles<NW, NT, BM, OBJ, VG>(a, Hs, Rs, t0, w, lane, upd, acc_div);
+    if (a.xr && !xfirst) hstep_p1_xrow<NW, NT, BM, OBJ, VG>(a, Hs, Rs, wxs, t0, w, lane, upd, acc_div);
 }
 
 // beta != 1: in-place transform of this wave's part of the image, den = lam^(b-1) -> num = V .* lam^(b-2)
@@ -649,6 +667,119 @@ __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(Step
             a.part[2 * blockIdx.x + 1] = red[NTHR];
         }
     }
+}
+
+// ============================================================================================
+// k_hsolve_small: the WHOLE H-only solve of src/sparse_nmf.m:186-286 for T <= 32 frames in ONE
+// launch by ONE workgroup: the online separation call (src/bnmf_sep_event_RT_IS16.m:138-154,
+// T = 1, W = [B_x, B_d] fixed) is latency-bound -- ~27 iterations of two GEMV-sized products --
+// so per-iteration kernel launches and host-side convergence polling would dominate.  H lives in
+// LDS across the iterations; the objective sums, the convergence test (:272-284) and the
+// objective vectors are produced on the device; W fragments stream from L2.
+// Iteration j: P1 on H_{j-1} gives cost_{j-1} (tested BEFORE H moves, so a stop leaves H_{j-1}).
+// ============================================================================================
+struct SmallArgs {
+    int max_iter;
+    int cost_check;
+    double conv_eps;
+    double* divh;   // [gridDim.x][max_iter]
+    double* costh;  // [gridDim.x][max_iter]
+    DevState* st;   // [gridDim.x]
+    int tps;        // frames per solve (<= 32); workgroup b solves columns [b*tps, (b+1)*tps)
+};
+
+// One workgroup = one independent solve (gridDim.x solves run concurrently: the batched online
+// stream, one frame per CU).
+template <int BM, bool OBJ>
+__global__ __launch_bounds__(512, 2) void k_hsolve_small(StepArgs a, SmallArgs sa) {
+    constexpr int NW = 8, NT = 1, NTHR = 512, Tt = 32;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    {   // re-base everything on this workgroup's columns
+        const size_t c0 = (size_t)blockIdx.x * sa.tps;
+        a.V += c0 * a.Fp;
+        a.Hin += c0 * a.rp;
+        a.Hout += c0 * a.rp;
+        if (a.S) a.S += c0 * a.rp;
+        a.T = sa.tps;
+        sa.divh += (size_t)blockIdx.x * sa.max_iter;
+        sa.costh += (size_t)blockIdx.x * sa.max_iter;
+        sa.st += blockIdx.x;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int rp = a.rp, ldh = a.ldh, ldr = a.ldr;
+    float* Hs = lds;                 // [32][ldh]
+    float* Rs = Hs + Tt * ldh;       // [32][ldr] ratio / den / num image
+    float* wxs = Rs + Tt * ldr;      // [rp]
+    double* red = reinterpret_cast<double*>(wxs + ((rp + 3) & ~3));  // [2][512]
+    if (a.xr)
+        for (int k = threadIdx.x; k < rp; k += NTHR) wxs[k] = a.wx[k];
+    for (int i = threadIdx.x; i < Tt * ldr; i += NTHR) Rs[i] = 0.f;
+    stage_in<NTHR>(a.Hin, Hs, Tt, rp, ldh, threadIdx.x);
+    __syncthreads();
+    constexpr int NPASS = (BM == BM_KL) ? 1 : 2;
+    double last_cost = 0.0;
+    int n_rec = 0;
+    bool stopped = false;
+    for (int j = 1; j <= sa.max_iter + 1; ++j) {
+        if (j > sa.max_iter && !(OBJ && sa.max_iter >= 1)) break;
+        const bool upd = j <= sa.max_iter;
+        double acc_div = 0.0, acc_sh = 0.0;
+        hstep_p1<NW, NT, BM, OBJ, true>(a, Hs, Rs, wxs, 0, w, lane, upd, acc_div);
+        if (OBJ && j > 1) {
+            // sum(S .* H_{j-1}) over the real entries (pad rows of H are zero)
+            float sh = 0.f;
+            for (int i = threadIdx.x; i < a.T * rp; i += NTHR) {
+                const int t = i / rp, k = i - t * rp;
+                const float sv = a.S ? a.S[(size_t)t * rp + k] : a.lamk[k];
+                sh += sv * Hs[t * ldh + k];
+            }
+            acc_sh = (double)sh;
+        }
+        __syncthreads();
+        if (OBJ && j > 1) {
+            red[threadIdx.x] = acc_div;
+            red[NTHR + threadIdx.x] = acc_sh;
+            __syncthreads();
+            for (int s2 = NTHR / 2; s2 > 0; s2 >>= 1) {
+                if ((int)threadIdx.x < s2) {
+                    red[threadIdx.x] += red[threadIdx.x + s2];
+                    red[NTHR + threadIdx.x] += red[NTHR + threadIdx.x + s2];
+                }
+                __syncthreads();
+            }
+            const double div = red[0], cost = red[0] + red[NTHR];
+            __syncthreads();  // everyone has read red[] before it is reused
+            const int it = j - 1;
+            bool stopnow = false;
+            if (it > 1 && sa.conv_eps > 0.0) stopnow = fabs(cost - last_cost) / last_cost < sa.conv_eps;
+            if (threadIdx.x == 0) {
+                sa.divh[it - 1] = div;
+                sa.costh[it - 1] = cost;
+            }
+            n_rec = it;
+            last_cost = cost;
+            if (stopnow) {
+                stopped = true;
+                break;
+            }
+        }
+        if (!upd) break;
+        double dummy = 0.0;
+        hstep_p2<NW, NT, BM, false>(a, Hs, Rs, 0, w, lane, 0, dummy);
+        if (NPASS == 2) {
+            __syncthreads();
+            hstep_den_to_num<NW, NT, BM>(a, Rs, 0, w, lane);
+            __syncthreads();
+            hstep_p2<NW, NT, BM, false>(a, Hs, Rs, 0, w, lane, 1, dummy);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        sa.st->n_iter = n_rec;
+        sa.st->stop = stopped ? 1 : 0;
+    }
+    __syncthreads();
+    stage_out<NTHR>(a.Hout, Hs, sa.tps, rp, ldh, threadIdx.x);  // only this solve's columns
 }
 
 // ============================================================================================
@@ -1075,13 +1206,6 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
     }
 }
 
-// Device-side solver state (fp64 objective history and the convergence flag).
-struct DevState {
-    int stop;      // set by the convergence test, src/sparse_nmf.m:275-281
-    int n_iter;    // iterations whose objective has been recorded
-    int pad0, pad1;
-};
-
 // Convergence test of src/sparse_nmf.m:260-285 for iteration `it` (1-based) whose (div, sh) sit
 // in the reduced statistics.  Every workgroup evaluates it identically (no races: it reads only
 // the statistics and the cost of iteration it-1, written by an earlier launch); one thread
@@ -1266,6 +1390,30 @@ __global__ void k_fold_sh(const double* part, int n, double* sc, const int* stop
         double s = 0.0;
         for (int i = 0; i < n; ++i) s += part[i];
         sc[1] = s;
+    }
+}
+
+// per-solve bookkeeping of the online stream: iteration count and last recorded cost
+__global__ void k_collect(const DevState* st, const double* costh, int n_solves, int max_iter, int cost_check,
+                          int* n_iter_out, double* cost_out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n_solves) {
+        n_iter_out[b] = st[b].stop ? st[b].n_iter : max_iter;
+        cost_out[b] = (cost_check && st[b].n_iter > 0) ? costh[(size_t)b * max_iter + st[b].n_iter - 1] : 0.0;
+    }
+}
+// H[0][(s*tps + t)*rp + k] = H0[t*r + k] * wn[k]: the same initial activations for every solve,
+// already rescaled by the column norms of init_w (src/sparse_nmf.m:160)
+template <typename TIn>
+__global__ void k_tile_h0(const TIn* __restrict__ H0, const double* __restrict__ wn, int r, int rp, int tps,
+                          int n_solves, float* __restrict__ H) {
+    const size_t n = (size_t)n_solves * tps * rp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % rp);
+        const size_t col = i / rp;
+        const int t = (int)(col % tps);
+        // same two roundings as the single-solve path (pack to fp32, then scale in fp64)
+        H[i] = k < r ? (float)((double)(float)H0[(size_t)t * r + k] * wn[k]) : 0.f;
     }
 }
 

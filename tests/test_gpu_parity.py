@@ -255,3 +255,83 @@ def test_device_resident_inputs(gpu_ctx):
     plan = Plan(gpu_ctx, 129, 500, 24, beta=1.0, max_iter=10, sparsity=2.0)
     plan.set_v(tV); plan.set_w(tW); plan.set_h(tH); plan.init(); plan.run()
     assert rel(plan.get_w(), w) < 1e-6 and rel(plan.get_h(), h) < 1e-6
+
+
+def test_persistent_small_solve_matches_generic_path_and_oracle(gpu_ctx, monkeypatch):
+    """T <= 32 H-only solves (the online call, src/bnmf_sep_event_RT_IS16.m:138-154) run as ONE
+    persistent launch; it must agree with the per-iteration path and with the oracle, including the
+    stop index, for every divergence."""
+    from se_snmf_nat_amd import sparse_nmf
+    for (F, T, r, cf, beta) in [(513, 1, 200, "kl", 1), (257, 7, 40, "kl", 1), (129, 32, 24, "ed", 2),
+                                (65, 5, 8, "is", 0), (129, 20, 33, "beta", 0.5)]:
+        V, W0, H0 = synth_problem(F, T, r)
+        p = dict(cf=cf, beta=beta, sparsity=0.5, max_iter=60, conv_eps=1e-3, init_w=W0, init_h=H0, cost_check=1,
+                 w_update_ind=np.zeros(r, bool))
+        ref = oracle_nmf(V, p)
+        monkeypatch.delenv("SNMF_NO_SMALL", raising=False)
+        small = sparse_nmf(V, p, ctx=gpu_ctx)
+        monkeypatch.setenv("SNMF_NO_SMALL", "1")
+        generic = sparse_nmf(V, p, ctx=gpu_ctx)
+        monkeypatch.delenv("SNMF_NO_SMALL")
+        check(small, ref, vsum=float(V.sum()))
+        check(generic, ref, vsum=float(V.sum()))
+        assert small[2]["n_iter"] == generic[2]["n_iter"]
+        assert rel(small[1], generic[1]) < 1e-5
+        # no cost_check: fixed iteration count, zero objective vectors
+        p2 = dict(p, cost_check=0, max_iter=9)
+        a = sparse_nmf(V, p2, ctx=gpu_ctx)
+        b = oracle_nmf(V, p2)
+        assert a[2]["n_iter"] == 9 and not a[2]["cost"].any() and rel(a[1], b[1]) < REL_WH
+
+
+def test_online_stream_reuses_the_resident_dictionary(gpu_ctx):
+    """Frame loop of the online path: W is set and normalised once, each frame only sets V and H0.
+    Every frame must equal an independent sparse_nmf call (the reference re-seeds and re-normalises
+    per call, src/sparse_nmf.m:112-114,:157-160)."""
+    from se_snmf_nat_amd import Plan, sparse_nmf
+    ref = dict(np.load(os.path.join(GOLD, "ref_data.npz")))
+    B, Y = ref["B"].astype(np.float64), ref["Y"].astype(np.float64)
+    H0 = np.random.RandomState(1).random_sample((200, 1))
+    plan = Plan(gpu_ctx, 513, 1, 200, beta=1.0, max_iter=100, conv_eps=1e-3, cost_check=True, sparsity=5.0,
+                w_update_ind=np.zeros(200, bool))
+    plan.set_w(B)
+    for col in (0, 17, 40, 3):
+        plan.set_v(Y[:, col:col + 1])
+        plan.set_h(H0)
+        plan.init()
+        n = plan.run()
+        h = plan.get_h()
+        w1, h1, o1 = sparse_nmf(Y[:, col:col + 1], dict(cf="kl", sparsity=5, max_iter=100, conv_eps=1e-3, init_w=B,
+                                                         init_h=H0, cost_check=1, w_update_ind=np.zeros(200, bool)),
+                                ctx=gpu_ctx)
+        assert n == o1["n_iter"]
+        assert np.array_equal(h, h1)
+        div, cost, nn = plan.get_objective()
+        np.testing.assert_array_equal(cost[:nn], o1["cost"])
+    # the stream entry point: all frames in one call, one persistent workgroup per frame
+    stream = Plan(gpu_ctx, 513, 64, 200, beta=1.0, max_iter=100, conv_eps=1e-3, cost_check=True, sparsity=5.0,
+                  w_update_ind=np.zeros(200, bool))
+    stream.set_w(B)
+    cols = [0, 17, 40, 3, 63]
+    for dtype in (np.float64, np.float32):
+        Hs, nit, lc = stream.solve_frames(Y[:, cols], H0, dtype=dtype)
+        for j, col in enumerate(cols):
+            w1, h1, o1 = sparse_nmf(Y[:, col:col + 1], dict(cf="kl", sparsity=5, max_iter=100, conv_eps=1e-3, init_w=B,
+                                                             init_h=H0, cost_check=1, w_update_ind=np.zeros(200, bool)),
+                                    ctx=gpu_ctx, dtype=dtype)
+            assert nit[j] == o1["n_iter"] and np.array_equal(Hs[:, j:j + 1], h1) and lc[j] == o1["cost"][-1]
+    # all 64 frames against the oracle (stop index exact, H within tolerance)
+    Hs, nit, lc = stream.solve_frames(Y, H0)
+    for col in range(0, 64, 7):
+        wr, hr, orf = oracle_nmf(Y[:, col:col + 1], dict(cf="kl", sparsity=5, max_iter=100, conv_eps=1e-3, init_w=B,
+                                                          init_h=H0, cost_check=1, w_update_ind=np.zeros(200, bool)))
+        assert nit[col] == orf["n_iter"] and rel(Hs[:, col:col + 1], hr) < REL_WH
+        assert abs(lc[col] - orf["cost"][-1]) <= REL_COST * orf["cost"][-1]
+    # two frames per solve (joint cost over the pair, like a 513 x 2 call)
+    H02 = np.random.RandomState(2).random_sample((200, 2))
+    Hs2, nit2, _ = stream.solve_frames(Y[:, :6], H02)
+    for j in range(3):
+        w1, h1, o1 = sparse_nmf(Y[:, 2 * j:2 * j + 2], dict(cf="kl", sparsity=5, max_iter=100, conv_eps=1e-3, init_w=B,
+                                                             init_h=H02, cost_check=1, w_update_ind=np.zeros(200, bool)),
+                                ctx=gpu_ctx)
+        assert nit2[j] == o1["n_iter"] and np.array_equal(Hs2[:, 2 * j:2 * j + 2], h1)
