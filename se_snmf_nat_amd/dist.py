@@ -109,12 +109,15 @@ class ShardedTrainer:
         self.plan.set_h(h0_local)
         self.plan.init()
         self.stats = torch.zeros(self.plan.stats_len(), dtype=torch.float64, device=self.device)
+        # H-only solves exchange nothing but the two cost scalars at the tail of the buffer
+        w_any = True if w_update_ind is None else bool(np.asarray(w_update_ind).any())
+        self._ar_view = self.stats if w_any else self.stats[-2:]
         self.loop = ShardedLoop(self.plan, self.stats, self._all_reduce, max_iter=max_iter,
                                 can_stop=bool(cost_check) and conv_eps > 0, cost_check=cost_check)
 
     def _all_reduce(self, t):
         if self.world > 1:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            self.dist.all_reduce(self._ar_view, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def run(self, n_iters=None):
         return self.loop.run(n_iters)
@@ -125,3 +128,37 @@ class ShardedTrainer:
     def result(self):
         """(W, H_local, (div, cost, n_iter)) as numpy."""
         return self.plan.get_w(), self.plan.get_h(), self.plan.get_objective()
+
+
+def run_basis_dnmf_sharded(Y_local, X_local, D_local, B, R_x, R_d, p, *, device=0, group=None):
+    """The 3-solve loop of run_basis_DNMF.m:36-55 with the frame axis sharded over the ranks of
+    `group` (BASELINE config 4): every rank passes ITS columns of the mixture / clean / noise
+    features and the replicated exemplar basis B (F x (R_x+R_d)).
+
+      1. H-only on Y (:37-40)  -- no data exchange but the two cost scalars
+      2. W-only on X with H = A_hat(1:R_x,:) (:43-47)   -- one all-reduce of the statistics / iteration
+      3. W-only on D with H = A_hat(R_x+1:end,:) (:49-53)
+
+    Returns (B_hat [replicated, bit-identical on every rank], A_hat_local)."""
+    def beta_of(p):
+        cf = p.get("cf", "kl")
+        return {"is": 0.0, "kl": 1.0, "ed": 2.0}.get(cf, float(p.get("beta", 1.0)))
+
+    common = dict(beta=beta_of(p), sparsity=p.get("sparsity", 0), max_iter=int(p.get("max_iter", 100)),
+                  conv_eps=float(p.get("conv_eps", 0)), cost_check=bool(p["cost_check"]), device=device, group=group)
+    B = np.asarray(B, dtype=np.float64)
+    r = R_x + R_d
+    rs = np.random.RandomState(int(p.get("random_seed", 1)) or None)
+    H0 = rs.random_sample((r, np.asarray(Y_local).shape[1]))  # stand-in for rand(r,n) (src/sparse_nmf.m:133-134)
+    t1 = ShardedTrainer(Y_local, B, H0, w_update_ind=np.zeros(r, bool), h_update_ind=np.ones(r, bool), **common)
+    t1.run()
+    _, A_hat, _ = t1.result()
+    t2 = ShardedTrainer(X_local, B[:, :R_x], A_hat[:R_x, :], w_update_ind=np.ones(R_x, bool),
+                        h_update_ind=np.zeros(R_x, bool), **common)
+    t2.run()
+    B_hat_x, _, _ = t2.result()
+    t3 = ShardedTrainer(D_local, B[:, R_x:r], A_hat[R_x:r, :], w_update_ind=np.ones(R_d, bool),
+                        h_update_ind=np.zeros(R_d, bool), **common)
+    t3.run()
+    B_hat_d, _, _ = t3.result()
+    return np.concatenate([B_hat_x, B_hat_d], axis=1), A_hat

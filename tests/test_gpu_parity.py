@@ -335,3 +335,21 @@ def test_online_stream_reuses_the_resident_dictionary(gpu_ctx):
                                                              init_h=H02, cost_check=1, w_update_ind=np.zeros(200, bool)),
                                 ctx=gpu_ctx)
         assert nit2[j] == o1["n_iter"] and np.array_equal(Hs2[:, 2 * j:2 * j + 2], h1)
+
+
+def test_sharded_dnmf_loop_world1_equals_host_mirror(gpu_ctx):
+    """run_basis_dnmf_sharded (the multi-GPU form of run_basis_DNMF.m:36-55) at world size 1 must give the
+    same bits as the unsharded host mirror when fed the same initial activations."""
+    pytest.importorskip("torch")
+    from se_snmf_nat_amd import run_basis_dnmf
+    from se_snmf_nat_amd.dist import run_basis_dnmf_sharded
+    ref = dict(np.load(os.path.join(GOLD, "ref_data.npz")))
+    d = dict(np.load(os.path.join(GOLD, "dnmf_loop_513x64_r20_20.npz")))
+    Y = ref["Y"].astype(np.float64)
+    X = (ref["Y"] * d["mask"] + 1e-9).astype(np.float32).astype(np.float64)
+    D = (ref["Y"] - X.astype(np.float32) + 2e-9).astype(np.float32).astype(np.float64)
+    Bs = np.concatenate([ref["B"][:, :20], ref["B"][:, 100:120]], axis=1).astype(np.float64)
+    p = dict(cf="kl", sparsity=5, max_iter=30, conv_eps=1e-3, cost_check=1, random_seed=1)
+    B1, A1 = run_basis_dnmf(Y, X, D, Bs, 20, 20, p, ctx=gpu_ctx)
+    B2, A2 = run_basis_dnmf_sharded(Y, X, D, Bs, 20, 20, p, device=0)
+    assert np.array_equal(B1, B2) and np.array_equal(A1, A2)
