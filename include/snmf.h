@@ -176,6 +176,39 @@ int snmf_plan_get_h_f32(snmf_plan* plan, float* H, int64_t ld, int is_device);
 int snmf_plan_get_objective(snmf_plan* plan, double* div_out, double* cost_out,
                             int32_t* n_iter_out);
 
+/* ---- spectrogram front-end on the device (the step before the path in every call stack) ---- */
+/* Parameters of src/stft_fft.m + run_basis_train.m:60-63 (shipped values:
+ * settings/initial_setting_SNMF_NAT.m:21-37,53,88-90). */
+typedef struct snmf_stft_params {
+    int32_t framelength;   /* sz,    p.framelength (640) */
+    int32_t frameshift;    /* shift, p.frameshift  (160) */
+    int32_t fftlength;     /* power of two in [64, 4096], p.fftlength (1024) */
+    int32_t dcbin;         /* first DCbin magnitudes are set to 1e-6 (src/stft_fft.m:31); must be >= 1 */
+    int32_t splice;        /* p.Splice (src/frame_splice.m), 0 = none */
+    double preemph;        /* p.preemph */
+    double pow;            /* p.pow: features are |STFT|.^pow + nonzerofloor */
+    double nonzerofloor;   /* p.nonzerofloor */
+    const double* window;  /* framelength values, p.win_STFT */
+} snmf_stft_params;
+
+/* Number of frames src/stft_fft.m:21 processes for an n_samples signal (its trailing all-zero
+ * columns are the ones run_basis_train.m:61 removes).  Pure host arithmetic, never fails. */
+int64_t snmf_stft_num_frames(const snmf_stft_params* sp, int64_t n_samples);
+
+/* TF_mag of run_basis_train.m:60-63 / run_basis_DNMF.m:13-16: F x n_frames, F = (2*splice+1)*(fftlength/2+1).
+ * samples: float audio (host or device); V_out: host or device, leading dimension ld >= F. */
+int snmf_stft_features_f32(snmf_ctx* ctx, const snmf_stft_params* sp, const float* samples, int64_t n_samples,
+                           int samples_on_device, float* V_out, int64_t ld, int out_on_device,
+                           int32_t* n_frames_out);
+/* Same, written straight into a plan's resident V (plan F must equal the feature rows and plan T the
+ * frame count); the V floor of src/sparse_nmf.m:169 is applied as in snmf_plan_set_v. */
+int snmf_plan_set_v_from_audio_f32(snmf_plan* plan, const snmf_stft_params* sp, const float* samples,
+                                   int64_t n_samples, int samples_on_device);
+/* Mel projection of run_basis_train.m:70-78: out (K*M x T) = blockdiag(mel) * V (K*n x T);
+ * mel: M x n ROW-major host matrix (mel_matrix(...)'), V / out host or device (both the same side). */
+int snmf_mel_features_f32(snmf_ctx* ctx, const float* mel, int32_t M, int32_t n, int32_t K, const float* V,
+                          int64_t ldv, int32_t T, float* out, int64_t ldo, int on_device);
+
 /* ---- instrumentation (bench.py: HIP-event timing on the engine's own stream) ------------ */
 /* Average device time in milliseconds per launch of the named kernel family over the launches
  * recorded since snmf_ctx_timing(ctx, 1) was switched on.  Families: "hstep", "wstats",

@@ -17,7 +17,7 @@ import numpy as np  # noqa: E402
 
 from se_snmf_nat_amd import Context, Plan, run_basis_dnmf, sparse_nmf  # noqa: E402
 
-which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["c1", "c3", "c4", "c5"]
+which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["c1", "c3", "c4", "c5", "fe"]
 with_cpu = "--cpu" in sys.argv
 ctx = Context(0)
 
@@ -117,3 +117,33 @@ if "c5" in which:
     fl = 12.0 * 513 * 500_000 * 512
     print(json.dumps({"config": "C5 513x500000 r=512 beta=2 lambda=50", "value": ips, "unit": "iterations/s",
                       "TFLOPs_algorithmic(12FTr)": fl * ips / 1e12, "geometry": d}), flush=True)
+
+if "fe" in which:
+    # front-end: 12 min of audio (run_basis_train.m's train_seq_len_max) -> 513 x ~72k power spectra in HBM
+    import torch
+    from se_snmf_nat_amd import frontend as fe, _lib
+    import ctypes as C
+    p = fe.default_params()
+    n = 16000 * 60 * 12
+    rs = np.random.RandomState(0)
+    s = (rs.randn(n) * 3000).astype(np.float32)
+    T = fe.num_frames(n, p)
+    plan = Plan(ctx, 513, T, 8, max_iter=1, cost_check=False)
+    ds = torch.tensor(s, device="cuda")
+    sp, _w = fe._params(p)
+    lib = _lib.load()
+    lib.snmf_plan_set_v_from_audio_f32(plan._h, C.byref(sp), C.c_void_p(ds.data_ptr()), n, 1); ctx.sync()
+    reps = 10
+    t = time.perf_counter()
+    for _ in range(reps):
+        lib.snmf_plan_set_v_from_audio_f32(plan._h, C.byref(sp), C.c_void_p(ds.data_ptr()), n, 1)
+    ctx.sync(); dt = (time.perf_counter() - t) / reps
+    bytes_alg = n * 4 + 513 * T * 4
+    out = {"config": "front-end: 12 min of 16 kHz audio -> 513 x %d |STFT|^2 + floor in HBM (samples already on device)" % T,
+           "value": T / dt, "unit": "frames/s", "ms": dt * 1e3, "algorithmic_GBps": bytes_alg / dt / 1e9,
+           "note": "includes the per-call scratch malloc/free and window/twiddle upload"}
+    if with_cpu:
+        from oracle import frontend_oracle as fo
+        t = time.perf_counter(); fo.dft_features(s[:16000 * 60].astype(np.float64), p); d2 = time.perf_counter() - t
+        out["cpu_oracle_frames_s"] = fe.num_frames(16000 * 60, p) / d2
+    print(json.dumps(out), flush=True)

@@ -15,7 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libsnmf_hip.so")
 SRC = [os.path.join(_HERE, "csrc", "snmf_api.hip")]
-HDRS = [os.path.join(_HERE, "csrc", "snmf_kernels.h"), os.path.join(_ROOT, "include", "snmf.h")]
+HDRS = [os.path.join(_HERE, "csrc", "snmf_kernels.h"), os.path.join(_HERE, "csrc", "snmf_frontend.h"),
+        os.path.join(_ROOT, "include", "snmf.h")]
 
 # every symbol include/snmf.h declares
 SYMBOLS = [
@@ -31,6 +32,7 @@ SYMBOLS = [
     "snmf_plan_get_w_f64", "snmf_plan_get_w_f32", "snmf_plan_get_h_f64", "snmf_plan_get_h_f32",
     "snmf_plan_get_objective", "snmf_plan_solve_frames_f64", "snmf_plan_solve_frames_f32",
     "snmf_ctx_timing", "snmf_ctx_timing_get", "snmf_plan_describe",
+    "snmf_stft_num_frames", "snmf_stft_features_f32", "snmf_plan_set_v_from_audio_f32", "snmf_mel_features_f32",
 ]
 
 SNMF_OK = 0
@@ -47,6 +49,14 @@ class SnmfParams(C.Structure):
         ("cost_check", C.c_int32), ("floor_v", C.c_int32),
         ("sparsity_kind", C.c_int32), ("sparsity_scalar", C.c_double),
         ("w_update_ind", C.c_void_p), ("h_update_ind", C.c_void_p),
+    ]
+
+
+class SnmfStftParams(C.Structure):
+    _fields_ = [
+        ("framelength", C.c_int32), ("frameshift", C.c_int32), ("fftlength", C.c_int32), ("dcbin", C.c_int32),
+        ("splice", C.c_int32), ("preemph", C.c_double), ("pow", C.c_double), ("nonzerofloor", C.c_double),
+        ("window", C.c_void_p),
     ]
 
 
@@ -136,6 +146,11 @@ def load():
         "snmf_ctx_timing_get": (C.c_int, [vp, C.c_char_p, C.POINTER(dbl), C.POINTER(i64)]),
         "snmf_plan_describe": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
     }
+    SP = C.POINTER(SnmfStftParams)
+    sig["snmf_stft_num_frames"] = (i64, [SP, i64])
+    sig["snmf_stft_features_f32"] = (C.c_int, [vp, SP, vp, i64, C.c_int, vp, i64, C.c_int, C.POINTER(i32)])
+    sig["snmf_plan_set_v_from_audio_f32"] = (C.c_int, [vp, SP, vp, i64, C.c_int])
+    sig["snmf_mel_features_f32"] = (C.c_int, [vp, vp, i32, i32, i32, vp, i64, i32, vp, i64, C.c_int])
     for ty in ("f64", "f32"):
         sig[f"snmf_plan_solve_frames_{ty}"] = (C.c_int, [vp, i32, vp, i64, i32, vp, vp, vp, vp])
     for nm in ("v", "w", "h"):

@@ -4,6 +4,7 @@
 // (lordet01/SE_SNMF_NAT src/sparse_nmf.m:157-292).  No CPU compute fallback exists here: every
 // numeric step is a HIP kernel launch; without a device the entry points fail.
 #include "snmf_kernels.h"
+#include "snmf_frontend.h"
 
 #include <algorithm>
 #include <cmath>
@@ -1190,4 +1191,191 @@ extern "C" int snmf_sparse_nmf_f32(snmf_ctx* ctx, const snmf_params* p, const fl
                                    float* H, const float* sparsity, double* div_out, double* cost_out,
                                    int32_t* n_iter_out) {
     return sparse_nmf_impl<float>(ctx, p, V, ldV, W, H, sparsity, div_out, cost_out, n_iter_out);
+}
+
+// ---- spectrogram front-end ---------------------------------------------------------------------
+extern "C" int64_t snmf_stft_num_frames(const snmf_stft_params* sp, int64_t L) {
+    if (!sp || sp->frameshift <= 0) return 0;
+    // while size_crnt < length(s) - fftlen, size_crnt = 1 + i*shift   (src/stft_fft.m:15,:21,:35)
+    const int64_t lim = L - sp->fftlength - 1;
+    if (lim <= 0) return 0;
+    return (lim + sp->frameshift - 1) / sp->frameshift;
+}
+
+static int validate_stft(const snmf_stft_params* sp) {
+    if (!sp || !sp->window) return fail(SNMF_ERR_INVALID, "stft params / window is NULL");
+    const int N = sp->fftlength;
+    if (N < 64 || N > 4096 || (N & (N - 1))) return fail(SNMF_ERR_UNSUPPORTED, "fftlength must be a power of two in [64,4096]");
+    if (sp->framelength < 1 || sp->framelength > N) return fail(SNMF_ERR_INVALID, "framelength must be in [1, fftlength]");
+    if (sp->frameshift < 1) return fail(SNMF_ERR_INVALID, "frameshift must be positive");
+    if (sp->dcbin < 1)
+        return fail(SNMF_ERR_UNSUPPORTED, "DCbin must be >= 1 (with DCbin = 0 a silent frame becomes an all-zero column, "
+                                          "which run_basis_train.m:61 removes: data-dependent compaction is not implemented)");
+    if (sp->dcbin > N / 2 + 1 || sp->splice < 0) return fail(SNMF_ERR_INVALID, "bad DCbin / Splice");
+    return SNMF_OK;
+}
+
+// features into a device buffer `dst` (column t at dst + t*ld); scratch allocations are freed on return
+static int stft_to_device(snmf_ctx* ctx, const snmf_stft_params* sp, const float* samples, int64_t n_samples,
+                          int samples_on_device, float* dst, int64_t ld, int64_t n_frames) {
+    hipStream_t st = ctx->stream;
+    const int N = sp->fftlength, K = N / 2 + 1, S = sp->splice;
+    float *d_s = nullptr, *d_win = nullptr, *d_tmp = nullptr;
+    float2* d_tw = nullptr;
+    int rc = SNMF_OK;
+    auto cleanup = [&]() {
+        hipStreamSynchronize(st);
+        if (d_s && !samples_on_device) hipFree(d_s);
+        if (d_win) hipFree(d_win);
+        if (d_tw) hipFree(d_tw);
+        if (d_tmp) hipFree(d_tmp);
+    };
+#define FE_TRY(expr)                                                              \
+    do {                                                                          \
+        hipError_t e_ = (expr);                                                   \
+        if (e_ != hipSuccess) {                                                   \
+            rc = fail(SNMF_ERR_NO_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+            cleanup();                                                            \
+            return rc;                                                            \
+        }                                                                         \
+    } while (0)
+    if (samples_on_device) d_s = const_cast<float*>(samples);
+    else {
+        FE_TRY(hipMalloc((void**)&d_s, (size_t)n_samples * 4));
+        FE_TRY(hipMemcpyAsync(d_s, samples, (size_t)n_samples * 4, hipMemcpyHostToDevice, st));
+    }
+    std::vector<float> hw(sp->framelength);
+    for (int i = 0; i < sp->framelength; ++i) hw[i] = (float)sp->window[i];
+    std::vector<float2> htw(N / 2);
+    for (int q = 0; q < N / 2; ++q) {
+        const double ang = -2.0 * M_PI * (double)q / (double)N;
+        htw[q] = make_float2((float)cos(ang), (float)sin(ang));
+    }
+    FE_TRY(hipMalloc((void**)&d_win, hw.size() * 4));
+    FE_TRY(hipMalloc((void**)&d_tw, htw.size() * 8));
+    FE_TRY(hipMemcpyAsync(d_win, hw.data(), hw.size() * 4, hipMemcpyHostToDevice, st));
+    FE_TRY(hipMemcpyAsync(d_tw, htw.data(), htw.size() * 8, hipMemcpyHostToDevice, st));
+    StftArgs a{};
+    a.s = d_s;
+    a.n_samples = n_samples;
+    a.sz = sp->framelength;
+    a.shift = sp->frameshift;
+    a.dcbin = sp->dcbin;
+    a.preemph = (float)sp->preemph;
+    a.win = d_win;
+    a.tw = d_tw;
+    a.powv = (float)sp->pow;
+    a.n_frames = (int)n_frames;
+    if (S == 0) {
+        a.floorv = (float)sp->nonzerofloor;
+        a.out = dst;
+        a.ld = ld;
+    } else {
+        FE_TRY(hipMalloc((void**)&d_tmp, (size_t)K * n_frames * 4));
+        a.floorv = 0.f;
+        a.out = d_tmp;
+        a.ld = K;
+    }
+    dim3 g((unsigned)n_frames), b(256);
+    switch (N) {
+        case 64: hipLaunchKernelGGL(k_stft<6>, g, b, 0, st, a); break;
+        case 128: hipLaunchKernelGGL(k_stft<7>, g, b, 0, st, a); break;
+        case 256: hipLaunchKernelGGL(k_stft<8>, g, b, 0, st, a); break;
+        case 512: hipLaunchKernelGGL(k_stft<9>, g, b, 0, st, a); break;
+        case 1024: hipLaunchKernelGGL(k_stft<10>, g, b, 0, st, a); break;
+        case 2048: hipLaunchKernelGGL(k_stft<11>, g, b, 0, st, a); break;
+        default: hipLaunchKernelGGL(k_stft<12>, g, b, 0, st, a); break;
+    }
+    FE_TRY(hipGetLastError());
+    if (S > 0) {
+        const size_t n = (size_t)(2 * S + 1) * K * n_frames;
+        hipLaunchKernelGGL(k_splice, dim3(grid_for(n)), dim3(256), 0, st, d_tmp, (int64_t)K, K, (int)n_frames, S,
+                           (float)sp->nonzerofloor, dst, ld);
+        FE_TRY(hipGetLastError());
+    }
+#undef FE_TRY
+    cleanup();
+    return SNMF_OK;
+}
+
+extern "C" int snmf_stft_features_f32(snmf_ctx* ctx, const snmf_stft_params* sp, const float* samples,
+                                      int64_t n_samples, int samples_on_device, float* V_out, int64_t ld,
+                                      int out_on_device, int32_t* n_frames_out) {
+    if (!ctx || !samples || !V_out) return fail(SNMF_ERR_INVALID, "NULL argument");
+    SN_TRY(validate_stft(sp));
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int64_t nfr = snmf_stft_num_frames(sp, n_samples);
+    const int64_t F = (int64_t)(2 * sp->splice + 1) * (sp->fftlength / 2 + 1);
+    if (n_frames_out) *n_frames_out = (int32_t)nfr;
+    if (nfr <= 0) return SNMF_OK;
+    if (ld < F) return fail(SNMF_ERR_INVALID, "ld < feature rows %lld", (long long)F);
+    if (out_on_device) return stft_to_device(ctx, sp, samples, n_samples, samples_on_device, V_out, ld, nfr);
+    float* d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_out, (size_t)F * nfr * 4));
+    int rc = stft_to_device(ctx, sp, samples, n_samples, samples_on_device, d_out, F, nfr);
+    if (rc == SNMF_OK) {
+        hipError_t e = hipMemcpy2D(V_out, (size_t)ld * 4, d_out, (size_t)F * 4, (size_t)F * 4, (size_t)nfr,
+                                   hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(SNMF_ERR_NO_DEVICE, "hipMemcpy2D: %s", hipGetErrorString(e));
+    }
+    hipFree(d_out);
+    return rc;
+}
+
+extern "C" int snmf_plan_set_v_from_audio_f32(snmf_plan* pl, const snmf_stft_params* sp, const float* samples,
+                                              int64_t n_samples, int samples_on_device) {
+    PLAN_CHECK(pl);
+    if (!samples) return fail(SNMF_ERR_INVALID, "samples is NULL");
+    SN_TRY(validate_stft(sp));
+    HIP_TRY(hipSetDevice(pl->ctx->device));
+    const int64_t nfr = snmf_stft_num_frames(sp, n_samples);
+    const int64_t F = (int64_t)(2 * sp->splice + 1) * (sp->fftlength / 2 + 1);
+    if (F != pl->p.F || nfr != pl->p.T)
+        return fail(SNMF_ERR_DIM, "audio gives %lld x %lld features, the plan is %d x %d", (long long)F, (long long)nfr,
+                    pl->p.F, pl->p.T);
+    // pad rows/columns of the resident V stay zero; features are >= nonzerofloor^... > 0, the
+    // solver's own floor (src/sparse_nmf.m:169) is applied by clamping the floor value from below
+    HIP_TRY(hipMemsetAsync(pl->V, 0, (size_t)pl->Fp * pl->Tp * 4, pl->ctx->stream));
+    SN_TRY(stft_to_device(pl->ctx, sp, samples, n_samples, samples_on_device, pl->V, pl->Fp, nfr));
+    if (pl->p.floor_v) {
+        // v = max(v, 1e-9) on the real entries (a no-op whenever nonzerofloor >= 1e-9)
+        hipLaunchKernelGGL(k_floor_real, dim3(grid_for((size_t)pl->Fp * pl->p.T)), dim3(256), 0, pl->ctx->stream, pl->V,
+                           pl->Fp, pl->p.F, pl->p.T, kFlr);
+        HIP_TRY(hipGetLastError());
+    }
+    pl->have_v = true;
+    return SNMF_OK;
+}
+
+extern "C" int snmf_mel_features_f32(snmf_ctx* ctx, const float* mel, int32_t M, int32_t n, int32_t K, const float* V,
+                                     int64_t ldv, int32_t T, float* out, int64_t ldo, int on_device) {
+    if (!ctx || !mel || !V || !out) return fail(SNMF_ERR_INVALID, "NULL argument");
+    if (M < 1 || n < 1 || K < 1 || T < 1 || ldv < (int64_t)K * n || ldo < (int64_t)K * M)
+        return fail(SNMF_ERR_INVALID, "bad Mel projection sizes");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    float *d_mel = nullptr, *d_v = nullptr, *d_o = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_mel, (size_t)M * n * 4));
+    HIP_TRY(hipMemcpyAsync(d_mel, mel, (size_t)M * n * 4, hipMemcpyHostToDevice, st));
+    int rc = SNMF_OK;
+    if (on_device) {
+        d_v = const_cast<float*>(V);
+        d_o = out;
+    } else {
+        if (hipMalloc((void**)&d_v, (size_t)ldv * T * 4) != hipSuccess || hipMalloc((void**)&d_o, (size_t)ldo * T * 4) != hipSuccess)
+            rc = fail(SNMF_ERR_NOMEM, "hipMalloc failed");
+        else hipMemcpyAsync(d_v, V, (size_t)ldv * T * 4, hipMemcpyHostToDevice, st);
+    }
+    if (rc == SNMF_OK) {
+        hipLaunchKernelGGL(k_mel, dim3(grid_for((size_t)K * M * T)), dim3(256), 0, st, d_mel, M, n, K, d_v, ldv, T, d_o, ldo);
+        if (hipGetLastError() != hipSuccess) rc = fail(SNMF_ERR_NO_DEVICE, "k_mel launch failed");
+        if (!on_device && rc == SNMF_OK) hipMemcpyAsync(out, d_o, (size_t)ldo * T * 4, hipMemcpyDeviceToHost, st);
+    }
+    hipStreamSynchronize(st);
+    hipFree(d_mel);
+    if (!on_device) {
+        if (d_v) hipFree(d_v);
+        if (d_o) hipFree(d_o);
+    }
+    return rc;
 }

@@ -1,0 +1,118 @@
+"""Spectrogram front-end: oracle checks on CPU, HIP parity on the GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import frontend_oracle as fo
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_stft_oracle_matches_a_direct_dft_and_the_frame_count_rule():
+    rs = np.random.RandomState(0)
+    p = fo.default_params()
+    s = rs.randn(3000) * 1000
+    S = fo.stft_fft(s, p["framelength"], p["frameshift"], p["fftlength"], p["DCbin"], p["win_STFT"], 0.5)
+    assert S.shape == (513, 3000 // 160)
+    nproc = int(np.any(S != 0, axis=0).sum())
+    assert nproc == int(np.ceil((3000 - 1024 - 1) / 160))  # while size_crnt < length(s) - fftlen
+    n = np.arange(1024)
+    for i in (0, 3, nproc - 1):
+        x = s[i * 160:i * 160 + 640].copy()
+        y = x.copy()
+        y[1:] -= 0.5 * x[:-1]
+        y *= p["win_STFT"]
+        for f in (7, 100, 512):
+            X = np.sum(y * np.exp(-2j * np.pi * f * n[:640] / 1024))
+            np.testing.assert_allclose(S[f, i], abs(X), rtol=1e-10)
+        assert np.all(S[:5, i] == 1e-6)
+    assert not S[:, nproc:].any()
+    assert fo.stft_fft(rs.randn(1000), 640, 160, 1024, 5, p["win_STFT"], 0.0).any() == False  # too short
+
+
+def test_frame_splice_and_mel_matrix_oracles():
+    F = np.arange(12.0).reshape(3, 4) + 1
+    S = fo.frame_splice(F, 1)
+    assert S.shape == (9, 4)
+    np.testing.assert_array_equal(S[3:6], F)                       # centre block = the frame itself
+    np.testing.assert_array_equal(S[6:9, :3], F[:, 1:])            # upper block = next frame
+    np.testing.assert_array_equal(S[0:3, 1:], F[:, :3])            # lower block = previous frame
+    assert not S[0:3, 0].any() and not S[6:9, 3].any()             # zero outside the signal
+    np.testing.assert_array_equal(fo.frame_splice(F, 0), F)
+    M = fo.mel_matrix(16000, 64, 1024)
+    assert M.shape == (513, 64) and M.min() >= 0 and np.isclose(M.max(), 1.0)
+    peaks = M.argmax(0)
+    assert np.all(np.diff(peaks) > 0)                              # centres increase with the channel
+    # product-side table is the same function
+    from se_snmf_nat_amd.frontend import mel_matrix
+    np.testing.assert_allclose(mel_matrix(16000, 64, 1024), M, rtol=0, atol=0)
+
+
+def test_oracle_reproduces_frontend_golden():
+    g = dict(np.load(os.path.join(GOLD, "frontend_audio.npz")))
+    p = fo.default_params()
+    V = fo.dft_features(g["samples"].astype(np.float64), p)
+    assert V.shape[1] == int(g["n_frames"]) and V.min() >= 1e-9
+    np.testing.assert_allclose(V[::8, ::4], g["V_sub"], rtol=1e-12)
+    np.testing.assert_allclose(fo.mel_features(V, p)[::4, ::4], g["mel_sub"], rtol=1e-12)
+    V1 = fo.dft_features(g["samples"].astype(np.float64), dict(p, Splice=1, preemph=0.92, pow=1))
+    np.testing.assert_allclose(V1[::16, ::4], g["V1_sub"], rtol=1e-12)
+
+
+# ---------------------------------------------------------------------------------- GPU parity
+# Tolerance: an fp32 radix-2 FFT of 1024 points carries an absolute error of ~eps_f32*log2(N)*||x||
+# per bin, i.e. relative to the LARGEST bin of the frame; powers square it.
+def _close(gpu, ref, colmax):
+    err = np.abs(gpu - ref)
+    assert np.all(err <= 1e-4 * np.abs(ref) + 2e-6 * colmax[None, :]), float((err / (np.abs(ref) + 1e-30)).max())
+
+
+@pytest.mark.gpu
+def test_stft_features_on_device_match_the_oracle(gpu_ctx):
+    from se_snmf_nat_amd import frontend as fe
+    g = dict(np.load(os.path.join(GOLD, "frontend_audio.npz")))
+    s = g["samples"].astype(np.float64)
+    for over in (dict(), dict(Splice=1, preemph=0.92, pow=1), dict(Splice=2, pow=0.7, DCbin=1),
+                 dict(framelength=400, frameshift=100, fftlength=512,
+                      win_STFT=np.hanning(400), DCbin=3)):
+        p = dict(fo.default_params(), **over)
+        ref = fo.dft_features(s, p)
+        out = fe.stft_features(s, p, ctx=gpu_ctx)
+        assert out.shape == ref.shape and fe.num_frames(len(s), p) == ref.shape[1]
+        K = p["fftlength"] // 2 + 1
+        colmax = ref.reshape(-1, K, ref.shape[1]).max(axis=(0, 1)) if p["Splice"] else ref.max(0)
+        colmax = np.maximum(colmax, ref.max() * 1e-3)  # spliced neighbours may dominate a column
+        _close(out.astype(np.float64), ref, colmax)
+    # Mel projection
+    p = fo.default_params()
+    V = fo.dft_features(s, p)
+    mel = fe.mel_features(V, p, ctx=gpu_ctx)
+    np.testing.assert_allclose(mel, fo.mel_features(V.astype(np.float32).astype(np.float64), p), rtol=2e-5)
+    assert fe.num_frames(1000, p) == 0 and fe.stft_features(np.zeros(1000), p, ctx=gpu_ctx).shape == (513, 0)
+
+
+@pytest.mark.gpu
+def test_audio_to_activations_without_v_crossing_pcie(gpu_ctx):
+    """audio -> features in HBM -> H-only solve with the shipped dictionaries, vs the oracle chain
+    (src/bnmf_sep_event_RT_IS16.m:67-78,138-154 shape, batched over a file)."""
+    from oracle.sparse_nmf_oracle import sparse_nmf as oracle_nmf
+    from se_snmf_nat_amd import Plan, frontend as fe
+    g = dict(np.load(os.path.join(GOLD, "frontend_audio.npz")))
+    ref = dict(np.load(os.path.join(GOLD, "ref_data.npz")))
+    s = g["samples"].astype(np.float64)
+    p = fo.default_params()
+    B = ref["B"].astype(np.float64)
+    T = fe.num_frames(len(s), p)
+    H0 = np.random.RandomState(3).random_sample((200, T))
+    plan = Plan(gpu_ctx, 513, T, 200, beta=1.0, max_iter=25, conv_eps=0.0, cost_check=True, sparsity=5.0,
+                w_update_ind=np.zeros(200, bool))
+    fe.set_plan_v_from_audio(plan, s, p)
+    plan.set_w(B); plan.set_h(H0); plan.init(); plan.run()
+    h = plan.get_h()
+    div, cost, n = plan.get_objective()
+    V = fo.dft_features(s, p)
+    wr, hr, orf = oracle_nmf(V, dict(cf="kl", sparsity=5, max_iter=25, init_w=B, init_h=H0, cost_check=1,
+                                     w_update_ind=np.zeros(200, bool)))
+    assert np.linalg.norm(h - hr) / np.linalg.norm(hr) < 1e-4
+    np.testing.assert_allclose(cost[:n], orf["cost"], rtol=2e-5)
