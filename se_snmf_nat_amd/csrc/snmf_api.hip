@@ -364,7 +364,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         if (got >= 2 && (nw == 4 || nw == 8) && (nt == 1 || nt == 2) && (nt == 1 ? lds1 : lds2) <= lds_cap) {
             pl->NWH = nw;
             pl->NT = nt;
-            pl->NLH = (got == 3 && nl == 4 && nw == 8 && nt == 1 && 2 * lds1 - lds_extra <= lds_cap) ? 4 : 0;
+            pl->NLH = (got == 3 && (nl == 4) && nw == 8 && nt == 1 && 2 * lds1 - lds_extra <= lds_cap) ? nl : 0;
         }
     }
     pl->lds_h = std::max<size_t>(pl->NLH ? 2 * lds1 - lds_extra : (pl->NT == 1 ? lds1 : lds2),

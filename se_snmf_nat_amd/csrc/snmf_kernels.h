@@ -281,6 +281,48 @@ __device__ __forceinline__ void stage_in(const float* __restrict__ src, float* d
         }
     }
 }
+// Two tiles (H and V) staged with ALL their loads in flight at once: one HBM round trip for a loader.
+// BA / BB = f32x4 per thread for each array (compile-time bounds; guarded by the real counts).
+template <int NTHREADS, int BA, int BB>
+__device__ __forceinline__ void stage_in2(const float* __restrict__ srcA, float* dstA, int colsA, int rowlenA, int ldA,
+                                          const float* __restrict__ srcB, float* dstB, int colsB, int rowlenB, int ldB,
+                                          int tid) {
+    const int rA = rowlenA / 4, nA = colsA * rA, rB = rowlenB / 4, nB = colsB * rB;
+    if (nA > BA * NTHREADS || nB > BB * NTHREADS) {  // shape too big for one batch: generic path
+        stage_in<NTHREADS>(srcA, dstA, colsA, rowlenA, ldA, tid);
+        stage_in<NTHREADS>(srcB, dstB, colsB, rowlenB, ldB, tid);
+        return;
+    }
+    f32x4 xa[BA], xb[BB];
+#pragma unroll
+    for (int b = 0; b < BA; ++b) {
+        const int i = tid + b * NTHREADS;
+        if (i < nA) xa[b] = *reinterpret_cast<const f32x4*>(srcA + 4 * (size_t)i);
+    }
+#pragma unroll
+    for (int b = 0; b < BB; ++b) {
+        const int i = tid + b * NTHREADS;
+        if (i < nB) xb[b] = *reinterpret_cast<const f32x4*>(srcB + 4 * (size_t)i);
+    }
+    SNMF_PIN();
+#pragma unroll
+    for (int b = 0; b < BA; ++b) {
+        const int i = tid + b * NTHREADS;
+        if (i < nA) {
+            const int t = i / rA, k4 = i - t * rA;
+            *reinterpret_cast<f32x4*>(dstA + t * ldA + 4 * k4) = xa[b];
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < BB; ++b) {
+        const int i = tid + b * NTHREADS;
+        if (i < nB) {
+            const int t = i / rB, k4 = i - t * rB;
+            *reinterpret_cast<f32x4*>(dstB + t * ldB + 4 * k4) = xb[b];
+        }
+    }
+}
+
 template <int NTHREADS>
 __device__ __forceinline__ void stage_out(float* __restrict__ dst, const float* src, int cols, int rowlen, int ld,
                                           int tid) {
@@ -585,9 +627,10 @@ __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(Step
             const int nt = tile + (int)gridDim.x;
             __syncthreads();  // B1
             if (UPD && prev >= 0) stage_out<NLT>(a.Hout + (size_t)prev * Tt * rp, nH, Tt, rp, ldh, lt);
-            if (nt < a.n_tiles) stage_in<NLT>(a.Hin + (size_t)nt * Tt * rp, nH, Tt, rp, ldh, lt);
+            if (nt < a.n_tiles)  // both blocks of tile i+1, one HBM round trip (the ratio image of tile i-1 is dead)
+                stage_in2<NLT, 10, 10>(a.Hin + (size_t)nt * Tt * rp, nH, Tt, rp, ldh, a.V + (size_t)nt * Tt * Fp,
+                                       nH + Tt * ldh, Tt, Fp, ldr, lt);
             __syncthreads();  // B2
-            if (nt < a.n_tiles) stage_in<NLT>(a.V + (size_t)nt * Tt * Fp, nH + Tt * ldh, Tt, Fp, ldr, lt);
             if (UPD && NPASS == 2) {
                 __syncthreads();
                 __syncthreads();
@@ -857,10 +900,9 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
                     }
                 }
             }
-            if (tile + 1 < te) {
-                stage_in<NST>(a.Hin + (size_t)(tile + 1) * 32 * rp, nH, 32, rp, ldh, sid);
-                stage_in<NST>(a.V + (size_t)(tile + 1) * 32 * Fp, nH + 32 * ldh, 32, Fp, Fp, sid);
-            }
+            if (tile + 1 < te)
+                stage_in2<NST, 10, 10>(a.Hin + (size_t)(tile + 1) * 32 * rp, nH, 32, rp, ldh,
+                                       a.V + (size_t)(tile + 1) * 32 * Fp, nH + 32 * ldh, 32, Fp, Fp, sid);
         }
     }
 
