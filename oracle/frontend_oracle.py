@@ -115,3 +115,20 @@ def mel_features(TF_mag, p):
     for k in range(K):
         out[k * p["F_order"]:(k + 1) * p["F_order"], :] = melmat @ TF_mag[k * n:(k + 1) * n, :]  # :76-77
     return out
+
+
+def run_basis_train_signal(s_full, R, p, sample_idx):
+    """run_basis_train.m:58-116 for one event class, cluster_buff = 1, on an assembled signal.
+    sample_idx: 1-based exemplar columns (:81).  Uses the solver oracle for :88,:91."""
+    from oracle.sparse_nmf_oracle import sparse_nmf
+    TF_mag = dft_features(s_full, p)
+    TF_Mel = mel_features(TF_mag, p)
+    idx = np.asarray(sample_idx, dtype=int) - 1
+    q = {k: p[k] for k in ("cf", "beta", "sparsity", "max_iter", "conv_eps", "cost_check") if k in p}
+    q["init_w"] = TF_mag[:, idx]
+    B_DFT, A_DFT, _ = sparse_nmf(TF_mag, q)
+    q["init_w"] = TF_Mel[:, idx]
+    B_Mel, A_Mel, _ = sparse_nmf(TF_Mel, q)
+    B_DFT = B_DFT / np.sqrt((B_DFT ** 2).sum(0)) + 1e-9  # :113-114
+    B_Mel = B_Mel / np.sqrt((B_Mel ** 2).sum(0)) + 1e-9  # :115-116
+    return {"B_DFT_sub": B_DFT, "B_Mel_sub": B_Mel, "A_DFT_sub": A_DFT, "A_Mel_sub": A_Mel}

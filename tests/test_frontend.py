@@ -116,3 +116,27 @@ def test_audio_to_activations_without_v_crossing_pcie(gpu_ctx):
                                      w_update_ind=np.zeros(200, bool)))
     assert np.linalg.norm(h - hr) / np.linalg.norm(hr) < 1e-4
     np.testing.assert_allclose(cost[:n], orf["cost"], rtol=2e-5)
+
+
+@pytest.mark.gpu
+def test_basis_training_caller_end_to_end(gpu_ctx, tmp_path):
+    """run_basis_train.m:58-136 on the GPU (features, Mel, two full-update solves, renormalise, save)
+    against the oracle chain; the saved file has the format of the reference's shipped R_100.mat."""
+    from se_snmf_nat_amd import train
+    g = dict(np.load(os.path.join(GOLD, "frontend_audio.npz")))
+    s = g["samples"].astype(np.float64)
+    p = dict(fo.default_params(), cf="kl", sparsity=5, max_iter=20, conv_eps=0, cost_check=1, cluster_buff=1,
+             train_Exemplar=0)
+    idx = np.random.RandomState(5).choice(114, size=16, replace=False) + 1
+    out = train.run_basis_train_signal(s, 16, p, sample_idx=idx, ctx=gpu_ctx)
+    ref = fo.run_basis_train_signal(s, 16, p, idx)
+    for k in ("B_DFT_sub", "B_Mel_sub", "A_DFT_sub", "A_Mel_sub"):
+        assert out[k].shape == ref[k].shape
+        assert np.linalg.norm(out[k] - ref[k]) / np.linalg.norm(ref[k]) < 2e-4, k
+    assert out["B_DFT_sub"].min() >= 1e-9 and out["B_DFT_sub"].shape == (513, 16) and out["B_Mel_sub"].shape == (64, 16)
+    np.testing.assert_allclose(np.sqrt(((out["B_DFT_sub"] - 1e-9) ** 2).sum(0)), 1.0, atol=1e-6)
+    f = str(tmp_path / "R_16.mat")
+    train.save_basis_mat(f, out)
+    back = train.load_basis_mat(f)
+    assert set(back) == {"B_DFT_sub", "B_Mel_sub", "A_DFT_sub", "A_Mel_sub"}
+    np.testing.assert_array_equal(back["B_DFT_sub"], out["B_DFT_sub"])
