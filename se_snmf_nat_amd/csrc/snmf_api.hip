@@ -416,9 +416,9 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         delete pl;
         return fail(SNMF_ERR_UNSUPPORTED, "r = %d too large for the LDS H tile", r);
     }
-    if (pl->rp > 2 * pl->NWB * 64 && pl->upd_w && pl->bm == BM_KL) {
+    if (pl->rp > 4 * pl->NWB * 64 && pl->upd_w && pl->bm == BM_KL) {
         delete pl;
-        return fail(SNMF_ERR_UNSUPPORTED, "r = %d > %d not supported for KL W updates yet", r, 2 * pl->NWB * 64);
+        return fail(SNMF_ERR_UNSUPPORTED, "r = %d > %d not supported for KL W updates", r, 4 * pl->NWB * 64);
     }
 
     // persistent single-launch path for the online shape (H-only, at most one 32-frame tile)

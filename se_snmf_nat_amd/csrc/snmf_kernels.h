@@ -855,9 +855,9 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     const int chunk = blockIdx.x;
     const bool do_x = a.xr && blockIdx.y == 0 && blockIdx.z == 0;  // extra row: one f-group only
     constexpr int CPW = 32 / NWB;  // columns of the extra-row dot product per wave
-    float gx[8];                   // extra row of the slab: lane <-> k = lane + 64*i
+    float gx[16];                  // extra row of the slab: lane <-> k = lane + 64*i  (rp <= 1024)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) gx[i] = 0.f;
+    for (int i = 0; i < 16; ++i) gx[i] = 0.f;
     if (do_x && WM != 3)
         for (int k = threadIdx.x; k < rp; k += NTHR) wxs[k] = a.wx[k];
     const int phi = blockIdx.y * NWB + w;
@@ -872,11 +872,11 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
 #pragma unroll
     for (int k = 0; k < NK; ++k) G[k] = zero16();
     // row sums of H: kept by the staging threads (loaders, or everybody when NL = 0);
-    // thread <-> k = sid + j*NST (rp <= 2*NST checked on the host)
+    // thread <-> k = sid + j*NST, j < 4 (rp <= 4*NST checked on the host)
     constexpr int NST = NL > 0 ? NL * 64 : NWB * 64;
     const int sid = NL > 0 ? (int)threadIdx.x - NWB * 64 : (int)threadIdx.x;
     const bool do_s = WM == 0 && blockIdx.y == 0 && blockIdx.z == 0;
-    float ssum[2] = {0.f, 0.f};
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f};
     double acc_div = 0.0;
 
     if (is_loader) {
@@ -891,7 +891,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
             __syncthreads();  // tile `tile` is complete in buffer it&1; buffer (it&1)^1 is free
             if (do_s) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < 4; ++j) {
                     const int k = sid + j * NST;
                     if (k < rp) {
                         float sacc = 0.f;
@@ -921,7 +921,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         SNMF_STAMP(1);
         if (NL == 0 && do_s) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < 4; ++j) {
                 const int k = sid + j * NST;
                 if (k < rp) {
                     float sacc = 0.f;
@@ -969,7 +969,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
             }
             if (OBJ) acc_div += (double)dsum;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < 16; ++i) {
                 const int k = lane + 64 * i;
                 if (k < rp) {
                     float g = gx[i];
@@ -1083,7 +1083,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     }
     if (do_s && sid >= 0) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < 4; ++j) {
             const int k = sid + j * NST;
             if (k < rp) a.spart[(size_t)chunk * rp + k] = ssum[j];
         }
@@ -1094,7 +1094,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         float* red = lds;  // [NWB][rp]  (NWB*rp <= 32*ldh)
         if (!is_loader) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < 16; ++i) {
                 const int k = lane + 64 * i;
                 if (k < rp) red[w * rp + k] = gx[i];
             }

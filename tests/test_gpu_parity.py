@@ -88,6 +88,8 @@ CASES = [
     ("kl_r256", 257, 4096, 256, dict(cf="kl", sparsity=5, max_iter=5), None, None),
     ("kl_r512", 130, 700, 512, dict(cf="kl", sparsity=1, max_iter=4), None, None),
     ("kl_r600_honly", 100, 200, 600, dict(cf="kl", sparsity=5, max_iter=5), "none", None),
+    ("kl_r600_full", 97, 200, 600, dict(cf="kl", sparsity=5, max_iter=5), None, None),
+    ("ed_r700_full", 65, 150, 700, dict(cf="ed", sparsity=1, max_iter=4), None, None),
     ("kl_F1025", 1025, 300, 20, dict(cf="kl", sparsity=5, max_iter=5), None, None),
     ("kl_nocheck", 257, 640, 40, dict(cf="kl", sparsity=5, max_iter=20, cost_check=0), None, None),
     ("kl_maxiter1", 65, 100, 8, dict(cf="kl", sparsity=5, max_iter=1, conv_eps=1e-3), None, None),
