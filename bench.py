@@ -166,9 +166,17 @@ def main():
     from se_snmf_nat_amd.dist import ShardedTrainer, shard_bounds
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # SNMF_DIST_BACKEND / SNMF_FORCE_DEVICE exist for single-GPU dry runs of the multi-rank path
+    # (two ranks on one device over gloo); the driver's launch uses RCCL, one rank per GPU.
+    backend = os.environ.get("SNMF_DIST_BACKEND", "nccl")
+    if "SNMF_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["SNMF_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     t0, t1 = shard_bounds(T, world, rank)
     V, W0, H0 = make_problem(F, T, r, t0, t1)
     tr = ShardedTrainer(V.astype(np.float32), W0, H0.astype(np.float32), beta=1.0, sparsity=SPARSITY,
@@ -190,6 +198,8 @@ def main():
     if world > 1:
         dist.all_reduce(dtt, op=dist.ReduceOp.MAX)
     dt = float(dtt.item())
+    div, cost, n_it = tr.plan.get_objective()
+    last_cost = [c for c in cost if c != 0.0]
     if rank == 0:
         ms = dt / K * 1e3
         tot = 2 * flops_half / (ms * 1e-3) / 1e12
@@ -203,6 +213,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "whole iteration (all ranks)", "achieved": tot,
                          "peak": PEAK_F32_MFMA_TFLOPS * world, "unit": "TFLOP/s",
                          "frac": tot / (PEAK_F32_MFMA_TFLOPS * world), "traffic": None},
+            "final_cost": float(last_cost[-1]) if last_cost else None,
         }
         print(json.dumps(out))
     if world > 1:

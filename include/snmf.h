@@ -72,7 +72,10 @@ int snmf_device_count(void); /* number of HIP devices visible, 0 if none (never 
 /* ---- context ---------------------------------------------------------------------------- */
 /* Replaces the implicit gpuArray device state of src/sparse_nmf_GPU.m:161-166. */
 int snmf_ctx_create(snmf_ctx** out, int device);
-/* Use a caller-owned hipStream_t (e.g. torch's current stream); NULL = context's own stream. */
+/* Use a caller-owned hipStream_t; NULL = the context's own (non-blocking) stream.  The legacy
+ * default stream has handle 0 == NULL and therefore cannot be selected: a caller that must order
+ * other work (e.g. an RCCL all-reduce) against the solver passes an explicitly created stream and
+ * issues that work on it (se_snmf_nat_amd/dist.py). */
 int snmf_ctx_set_stream(snmf_ctx* ctx, void* hip_stream);
 int snmf_ctx_sync(snmf_ctx* ctx);
 void snmf_ctx_destroy(snmf_ctx* ctx);

@@ -97,8 +97,13 @@ class ShardedTrainer:
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
         self.ctx = Context(device)
-        if use_torch_stream:
-            self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        # The engine's kernels and the collective must be ordered on ONE stream.  torch's default
+        # stream is handle 0, which snmf_ctx_set_stream reads as "own stream", so the trainer owns
+        # a side stream, hands it to the engine and issues every all-reduce under it (RCCL then
+        # orders its own stream against it with events, as it does for any torch op).
+        self.stream = torch.cuda.Stream(self.device) if use_torch_stream else None
+        if self.stream is not None:
+            self.ctx.set_stream(self.stream.cuda_stream)
         F = w0.shape[0] if not hasattr(w0, "data_ptr") else w0.shape[1]
         r = w0.shape[1] if not hasattr(w0, "data_ptr") else w0.shape[0]
         T = v_local.shape[1] if not hasattr(v_local, "data_ptr") else v_local.shape[0]
@@ -109,6 +114,7 @@ class ShardedTrainer:
         self.plan.set_h(h0_local)
         self.plan.init()
         self.stats = torch.zeros(self.plan.stats_len(), dtype=torch.float64, device=self.device)
+        torch.cuda.current_stream(self.device).synchronize()  # the zero fill ran on torch's current stream
         # H-only solves exchange nothing but the two cost scalars at the tail of the buffer
         w_any = True if w_update_ind is None else bool(np.asarray(w_update_ind).any())
         self._ar_view = self.stats if w_any else self.stats[-2:]
@@ -117,7 +123,16 @@ class ShardedTrainer:
 
     def _all_reduce(self, t):
         if self.world > 1:
-            self.dist.all_reduce(self._ar_view, op=self.dist.ReduceOp.SUM, group=self.group)
+            if self.stream is None:
+                self.ctx.sync()  # engine on its private stream: order by hand
+                self.dist.all_reduce(self._ar_view, op=self.dist.ReduceOp.SUM, group=self.group)
+                self.torch.cuda.current_stream(self.device).synchronize()
+                return
+            with self.torch.cuda.stream(self.stream):
+                if self.dist.get_backend(self.group) != "nccl":
+                    # host-staged backends (gloo dry runs) read the buffer from the host side
+                    self.stream.synchronize()
+                self.dist.all_reduce(self._ar_view, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def run(self, n_iters=None):
         return self.loop.run(n_iters)

@@ -1,0 +1,99 @@
+"""Two ranks of the frame-sharded HIP path (se_snmf_nat_amd/dist.py ShardedTrainer) on ONE GPU.
+
+The driver's multi-GPU bench runs one process per GPU over RCCL; a single-GPU test box cannot do that,
+so this test starts two processes that share device 0 and exchange the statistics buffer over gloo.
+Everything but the transport is the product path: HIP plans on frame shards, one sum-all-reduce of the
+fp64 statistics per iteration, the deterministic W epilogue on every rank
+(src/sparse_nmf.m:186-284 with the frame axis partitioned).  Checked against the fp64 oracle and against
+the unsharded HIP run.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle.sparse_nmf_oracle import sparse_nmf as oracle_nmf, synth_problem
+
+pytestmark = pytest.mark.gpu
+REL_WH = 1e-4
+REL_COST = 1e-5
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case, q):
+    import torch
+    import torch.distributed as dist
+    from se_snmf_nat_amd.dist import ShardedTrainer, shard_bounds
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    V, W0, H0 = synth_problem(case["F"], case["T"], case["r"])
+    t0, t1 = shard_bounds(case["T"], world, rank)
+    w_ind = None if "w_ind" not in case else np.array(case["w_ind"], bool)
+    h_ind = None if "h_ind" not in case else np.array(case["h_ind"], bool)
+    tr = ShardedTrainer(V[:, t0:t1], W0, H0[:, t0:t1], beta=case["beta"], sparsity=case["sparsity"],
+                        max_iter=case["max_iter"], conv_eps=case["conv_eps"], cost_check=True,
+                        w_update_ind=w_ind, h_update_ind=h_ind, device=0)
+    tr.run()
+    tr.sync()
+    w, h, (div, cost, n_iter) = tr.result()
+    q.put((rank, w, h, np.asarray(cost), int(n_iter)))
+    dist.barrier()
+    dist.destroy_process_group()
+    torch.cuda.synchronize()
+
+
+CASES = [
+    dict(F=257, T=2100, r=64, beta=1.0, sparsity=5.0, max_iter=15, conv_eps=0.0),
+    dict(F=257, T=1500, r=40, beta=1.0, sparsity=0.5, max_iter=80, conv_eps=2e-3),           # early stop
+    dict(F=129, T=700, r=24, beta=2.0, sparsity=0.3, max_iter=10, conv_eps=0.0),
+    dict(F=129, T=700, r=24, beta=0.0, sparsity=0.01, max_iter=10, conv_eps=0.0),
+    dict(F=257, T=900, r=32, beta=1.0, sparsity=5.0, max_iter=30, conv_eps=1e-3, w_ind=[0] * 32),  # H-only
+    dict(F=257, T=900, r=32, beta=1.0, sparsity=5.0, max_iter=30, conv_eps=1e-3, h_ind=[0] * 32),  # W-only
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"F{c['F']}-b{c['beta']}-eps{c['conv_eps']}-"
+                         f"{'Honly' if 'w_ind' in c else 'Wonly' if 'h_ind' in c else 'full'}")
+def test_two_ranks_one_gpu_match_oracle_and_unsharded(gpu_ctx, case):
+    import torch.multiprocessing as mp
+    from se_snmf_nat_amd import sparse_nmf
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(rk, world, port, case, q)) for rk in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    V, W0, H0 = synth_problem(case["F"], case["T"], case["r"])
+    cf = {1.0: "kl", 2.0: "ed", 0.0: "is"}[case["beta"]]
+    p = dict(cf=cf, sparsity=case["sparsity"], max_iter=case["max_iter"], conv_eps=case["conv_eps"], init_w=W0,
+             init_h=H0, cost_check=1)
+    if "w_ind" in case:
+        p["w_update_ind"] = np.array(case["w_ind"], bool)
+    if "h_ind" in case:
+        p["h_update_ind"] = np.array(case["h_ind"], bool)
+    wr, hr, orf = oracle_nmf(V, p)
+    w1, h1, o1 = sparse_nmf(V, p, ctx=gpu_ctx)          # unsharded HIP run
+    H = np.concatenate([r_[2] for r_ in res], axis=1)
+    rel = lambda a, b: np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+    assert np.array_equal(res[0][1], res[1][1]), "replicas of W must be bit-identical across ranks"
+    for r_ in res:
+        assert r_[4] == orf["n_iter"] == o1["n_iter"]
+        assert rel(r_[1], wr) < REL_WH
+        np.testing.assert_allclose(r_[3][:len(orf["cost"])], orf["cost"], rtol=REL_COST)
+    assert rel(H, hr) < REL_WH
+    # sharding only reorders fp64 partial sums: the sharded result sits within fp32 rounding of the unsharded one
+    assert rel(res[0][1], w1) < 5e-6 and rel(H, h1) < 5e-6
