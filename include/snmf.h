@@ -212,6 +212,72 @@ int snmf_plan_set_v_from_audio_f32(snmf_plan* plan, const snmf_stft_params* sp, 
 int snmf_mel_features_f32(snmf_ctx* ctx, const float* mel, int32_t M, int32_t n, int32_t K, const float* V,
                           int64_t ldv, int32_t T, float* out, int64_t ldo, int on_device);
 
+/* ---- online separation loop (BASELINE config 3) -------------------
+ * Device-resident replacement of the per-frame function
+ *   [x_hat_i, d_hat_i, x_tilde, g] = bnmf_sep_event_RT_IS16(y, l, g, p)   src/bnmf_sep_event_RT_IS16.m:1
+ * together with its state g (src/init_buff.m:17-42) and the hop queueing / overlap-add / int16 output of
+ * the driver loop src/NTF_sep_event_RT.m:54-135, for the configuration the reference ships
+ * (blk_len_sep = 1, Splice = 0, B_sep_mode = 'DFT', one channel, supervised per-frame solve).
+ * Per frame: STFT -> H-only solve against [B_DFT_x, B_DFT_d] -> reconstructions, block sparsity,
+ * adaptive beta, Wiener / MMSE gain -> noise-reference rings and (when triggered) the W-only
+ * adaptation solve + dictionary re-assembly -> inverse STFT, overlap-add.  Only PCM in, PCM out and a
+ * 32-byte status per frame cross PCIe. */
+typedef struct snmf_online snmf_online;
+
+typedef struct snmf_online_params {
+    /* signal (settings/initial_setting_SNMF_NAT.m:21-37,53,88-92) */
+    int32_t fftlength, framelength, frameshift;
+    int32_t dcbin, dcbin_back;
+    int32_t delay;            /* p.delay: frames before the first hop is written */
+    double preemph, pow, nonzerofloor, overlapscale;
+    /* dictionaries */
+    int32_t R_x, R_d;
+    /* per-frame and adaptation solves (src/sparse_nmf.m parameters) */
+    double beta_div;          /* 1 = 'kl', 2 = 'ed', 0 = 'is' */
+    double sparsity;
+    int32_t max_iter, cost_check;
+    double conv_eps;
+    /* enhancement filter (:221-261) */
+    int32_t enhance_method;   /* 0 = 'Wiener', 1 = 'MMSE' */
+    int32_t init_N_len;
+    double alpha_eta, alpha_d, beta, beta_max;
+    /* block sparsity (src/blk_sparse.m) */
+    int32_t blk_sparse, P_len_k, P_len_l, blk_gap;
+    double alpha_p;
+    /* noise dictionary adaptation (:263-347) */
+    int32_t adapt_train_N, R_a, m_a;
+    double overlap_m_a, Ar_up;
+    int32_t class_outputs;    /* also synthesise the event / noise estimates (x_hat, d_hat) */
+} snmf_online_params;
+
+typedef struct snmf_online_frame {   /* per-frame diagnostics, in frame order */
+    int32_t n_iter;           /* iterations of the frame solve */
+    int32_t trig;             /* adaptation condition :266 */
+    int32_t solved;           /* an adaptation solve ran */
+    int32_t n_up;             /* sum(r_up) */
+    int32_t adapt_iters;      /* iterations of the adaptation solve */
+    float beta, A_x_mag, A_d_mag, Q_control;
+} snmf_online_frame;
+
+/* B_DFT_x: F x R_x, B_DFT_d: F x R_d (column-major, F = fftlength/2+1); H0: r values standing in for
+ * rand(r,1) of src/sparse_nmf.m:133-134 (the same vector every frame, as the reference re-seeds per call);
+ * Ad_blk0: R_a x m_a standing in for rand(R_a, m_a) of src/init_buff.m:39; windows: framelength values. */
+int snmf_online_create(snmf_ctx* ctx, const snmf_online_params* p, const float* B_DFT_x, const float* B_DFT_d,
+                       const float* H0, const float* Ad_blk0, const float* win_stft, const float* win_istft,
+                       snmf_online** out);
+/* Feed n PCM samples (int16-valued floats); every complete hop becomes a frame.  flush != 0 ends the
+ * stream the way the driver does at end of file (delay+1 all-zero frames, src/NTF_sep_event_RT.m:69-76).
+ * Outputs (host, each may be NULL): the denoised signal before rounding, the int16 the driver writes, and
+ * with class_outputs the event / noise estimates; capacity `cap` samples each, *n_out samples written
+ * (at most (n/frameshift + delay + 2) * frameshift). */
+int snmf_online_process_f32(snmf_online* o, const float* pcm, int64_t n, int flush, float* x_tilde_f32,
+                            int16_t* x_tilde_i16, float* x_hat_f32, float* d_hat_f32, int64_t cap, int64_t* n_out);
+/* Current B_DFT_d (what src/NTF_sep_event_RT.m:138-140 saves to B_D_u.mat). */
+int snmf_online_get_basis_f32(snmf_online* o, float* B_DFT_d, int64_t ld);
+/* Diagnostics of the frames processed so far (copies min(cap, n) entries, *n = total frames). */
+int snmf_online_trace(snmf_online* o, snmf_online_frame* out, int64_t cap, int64_t* n);
+void snmf_online_destroy(snmf_online* o);
+
 /* ---- instrumentation (bench.py: HIP-event timing on the engine's own stream) ------------ */
 /* Average device time in milliseconds per launch of the named kernel family over the launches
  * recorded since snmf_ctx_timing(ctx, 1) was switched on.  Families: "hstep", "wstats",

@@ -135,10 +135,11 @@ def sparse_nmf(v, p=None, *, rng=None, gpu_variant=False, mimic_matlab_flops=Fal
     h = h * wn[:, None]
 
     flr = FLR  # :166
-    lam = np.maximum(w @ h, flr)  # :167
+    # max(.,flr) is np.fmax throughout: MATLAB's max skips NaN (max(NaN, flr) = flr)
+    lam = np.fmax(w @ h, flr)  # :167
     last_cost = np.inf  # :168
     if not gpu_variant:
-        v = np.maximum(v, flr)  # :169 (CPU file only)
+        v = np.fmax(v, flr)  # :169 (CPU file only)
 
     div_hist = np.zeros(max_iter)  # :171-173
     cost_hist = np.zeros(max_iter)
@@ -170,20 +171,20 @@ def sparse_nmf(v, p=None, *, rng=None, gpu_variant=False, mimic_matlab_flops=Fal
             wh = w[:, h_ind]
             if beta == 1:
                 dph = np.sum(wh, axis=0)[:, None] + S  # :192
-                dph = np.maximum(dph, flr)  # :193
+                dph = np.fmax(dph, flr)  # :193
                 dmh = wh.T @ (v / lam)  # :194
                 h[h_ind, :] = h[h_ind, :] * dmh / dph  # :195
             elif beta == 2:
                 dph = wh.T @ lam + S  # :197
-                dph = np.maximum(dph, flr)
+                dph = np.fmax(dph, flr)
                 dmh = wh.T @ v  # :199
                 h[h_ind, :] = h[h_ind, :] * dmh / dph
             else:
                 dph = wh.T @ lam ** (beta - 1.0) + S  # :202
-                dph = np.maximum(dph, flr)
+                dph = np.fmax(dph, flr)
                 dmh = wh.T @ (v * lam ** (beta - 2.0))  # :204
                 h[h_ind, :] = h[h_ind, :] * dmh / dph
-            lam = np.maximum(w @ h, flr)  # :207
+            lam = np.fmax(w @ h, flr)  # :207
 
         # ---- W updates :212-244
         if update_w > 0:
@@ -195,7 +196,7 @@ def sparse_nmf(v, p=None, *, rng=None, gpu_variant=False, mimic_matlab_flops=Fal
                     G = (v / lam) @ hw.T
                 s = np.sum(hw, axis=1)[None, :]  # :215
                 dpw = s + np.sum(G * ww, axis=0)[None, :] * ww  # :215-217
-                dpw = np.maximum(dpw, flr)  # :218
+                dpw = np.fmax(dpw, flr)  # :218
                 dmw = G + np.sum(s * ww, axis=0)[None, :] * ww  # :219-221
             elif beta == 2:
                 P = lam @ hw.T  # :224,:228
@@ -204,7 +205,7 @@ def sparse_nmf(v, p=None, *, rng=None, gpu_variant=False, mimic_matlab_flops=Fal
                     P = lam @ hw.T
                     Q = v @ hw.T
                 dpw = P + np.sum(Q * ww, axis=0)[None, :] * ww
-                dpw = np.maximum(dpw, flr)
+                dpw = np.fmax(dpw, flr)
                 dmw = Q + np.sum(P * ww, axis=0)[None, :] * ww
             else:
                 P = lam ** (beta - 1.0) @ hw.T  # :231,:238
@@ -213,11 +214,11 @@ def sparse_nmf(v, p=None, *, rng=None, gpu_variant=False, mimic_matlab_flops=Fal
                     P = lam ** (beta - 1.0) @ hw.T
                     Q = (v * lam ** (beta - 2.0)) @ hw.T
                 dpw = P + np.sum(Q * ww, axis=0)[None, :] * ww
-                dpw = np.maximum(dpw, flr)
+                dpw = np.fmax(dpw, flr)
                 dmw = Q + np.sum(P * ww, axis=0)[None, :] * ww
             w[:, w_ind] = ww * dmw / dpw  # :222,:229,:239
             w = w / np.sqrt(np.sum(w ** 2, axis=0))  # :242 -- ALL columns, H not rescaled
-            lam = np.maximum(w @ h, flr)  # :243
+            lam = np.fmax(w @ h, flr)  # :243
 
         # ---- objective :248-258 (always evaluated)
         div = divergence(v, lam, beta)
@@ -228,7 +229,8 @@ def sparse_nmf(v, p=None, *, rng=None, gpu_variant=False, mimic_matlab_flops=Fal
                 div_hist[it - 1] = div  # :263-264
                 cost_hist[it - 1] = cost
             if it > 1 and conv_eps > 0:  # :273
-                e = abs(cost - last_cost) / last_cost  # :274
+                with np.errstate(divide="ignore", invalid="ignore"):  # MATLAB: x/0 = Inf, 0/0 = NaN (NaN < eps is false)
+                    e = np.float64(abs(cost - last_cost)) / np.float64(last_cost)  # :274
                 if e < conv_eps:  # :275
                     if not gpu_variant:
                         div_hist = div_hist[:it]  # :279-280

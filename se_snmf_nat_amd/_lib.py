@@ -16,7 +16,7 @@ _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libsnmf_hip.so")
 SRC = [os.path.join(_HERE, "csrc", "snmf_api.hip")]
 HDRS = [os.path.join(_HERE, "csrc", "snmf_kernels.h"), os.path.join(_HERE, "csrc", "snmf_frontend.h"),
-        os.path.join(_ROOT, "include", "snmf.h")]
+        os.path.join(_HERE, "csrc", "snmf_online.h"), os.path.join(_ROOT, "include", "snmf.h")]
 
 # every symbol include/snmf.h declares
 SYMBOLS = [
@@ -33,6 +33,8 @@ SYMBOLS = [
     "snmf_plan_get_objective", "snmf_plan_solve_frames_f64", "snmf_plan_solve_frames_f32",
     "snmf_ctx_timing", "snmf_ctx_timing_get", "snmf_plan_describe",
     "snmf_stft_num_frames", "snmf_stft_features_f32", "snmf_plan_set_v_from_audio_f32", "snmf_mel_features_f32",
+    "snmf_online_create", "snmf_online_process_f32", "snmf_online_get_basis_f32", "snmf_online_trace",
+    "snmf_online_destroy",
 ]
 
 SNMF_OK = 0
@@ -57,6 +59,32 @@ class SnmfStftParams(C.Structure):
         ("framelength", C.c_int32), ("frameshift", C.c_int32), ("fftlength", C.c_int32), ("dcbin", C.c_int32),
         ("splice", C.c_int32), ("preemph", C.c_double), ("pow", C.c_double), ("nonzerofloor", C.c_double),
         ("window", C.c_void_p),
+    ]
+
+
+class SnmfOnlineParams(C.Structure):
+    _fields_ = [
+        ("fftlength", C.c_int32), ("framelength", C.c_int32), ("frameshift", C.c_int32),
+        ("dcbin", C.c_int32), ("dcbin_back", C.c_int32), ("delay", C.c_int32),
+        ("preemph", C.c_double), ("pow", C.c_double), ("nonzerofloor", C.c_double), ("overlapscale", C.c_double),
+        ("R_x", C.c_int32), ("R_d", C.c_int32),
+        ("beta_div", C.c_double), ("sparsity", C.c_double), ("max_iter", C.c_int32), ("cost_check", C.c_int32),
+        ("conv_eps", C.c_double),
+        ("enhance_method", C.c_int32), ("init_N_len", C.c_int32),
+        ("alpha_eta", C.c_double), ("alpha_d", C.c_double), ("beta", C.c_double), ("beta_max", C.c_double),
+        ("blk_sparse", C.c_int32), ("P_len_k", C.c_int32), ("P_len_l", C.c_int32), ("blk_gap", C.c_int32),
+        ("alpha_p", C.c_double),
+        ("adapt_train_N", C.c_int32), ("R_a", C.c_int32), ("m_a", C.c_int32),
+        ("overlap_m_a", C.c_double), ("Ar_up", C.c_double),
+        ("class_outputs", C.c_int32),
+    ]
+
+
+class SnmfOnlineFrame(C.Structure):
+    _fields_ = [
+        ("n_iter", C.c_int32), ("trig", C.c_int32), ("solved", C.c_int32), ("n_up", C.c_int32),
+        ("adapt_iters", C.c_int32),
+        ("beta", C.c_float), ("A_x_mag", C.c_float), ("A_d_mag", C.c_float), ("Q_control", C.c_float),
     ]
 
 
@@ -151,6 +179,12 @@ def load():
     sig["snmf_stft_features_f32"] = (C.c_int, [vp, SP, vp, i64, C.c_int, vp, i64, C.c_int, C.POINTER(i32)])
     sig["snmf_plan_set_v_from_audio_f32"] = (C.c_int, [vp, SP, vp, i64, C.c_int])
     sig["snmf_mel_features_f32"] = (C.c_int, [vp, vp, i32, i32, i32, vp, i64, i32, vp, i64, C.c_int])
+    OP = C.POINTER(SnmfOnlineParams)
+    sig["snmf_online_create"] = (C.c_int, [vp, OP, vp, vp, vp, vp, vp, vp, C.POINTER(vp)])
+    sig["snmf_online_process_f32"] = (C.c_int, [vp, vp, i64, C.c_int, vp, vp, vp, vp, i64, C.POINTER(i64)])
+    sig["snmf_online_get_basis_f32"] = (C.c_int, [vp, vp, i64])
+    sig["snmf_online_trace"] = (C.c_int, [vp, vp, i64, C.POINTER(i64)])
+    sig["snmf_online_destroy"] = (None, [vp])
     for ty in ("f64", "f32"):
         sig[f"snmf_plan_solve_frames_{ty}"] = (C.c_int, [vp, i32, vp, i64, i32, vp, vp, vp, vp])
     for nm in ("v", "w", "h"):

@@ -220,7 +220,8 @@ struct snmf_plan {
     int n_mat = 1;
     bool upd_h = true, upd_w = true;
     // device buffers
-    float *V = nullptr, *H[2] = {nullptr, nullptr}, *Wc = nullptr, *Wt4 = nullptr, *Wk4 = nullptr;
+    float *V = nullptr, *H[2] = {nullptr, nullptr}, *Wt4 = nullptr, *Wk4 = nullptr;
+    double* Wc = nullptr;  // fp64 master copy of W (see k_wapply)
     float *dphv = nullptr, *colsum = nullptr, *lamk = nullptr, *S = nullptr, *wx = nullptr;
     float *slabs = nullptr, *spart = nullptr;
     double *part = nullptr, *stats = nullptr, *divh = nullptr, *costh = nullptr, *wn = nullptr;
@@ -465,7 +466,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         return s;
     }
     hipStream_t st = ctx->stream;
-    hipMemsetAsync(pl->Wc, 0, nW * 4, st);
+    hipMemsetAsync(pl->Wc, 0, nW * 8, st);
     hipMemsetAsync(pl->Wt4, 0, nWt * 4, st);
     hipMemsetAsync(pl->Wk4, 0, nWk * 4, st);
     hipMemsetAsync(pl->wx, 0, (size_t)pl->rp * 4, st);
@@ -523,8 +524,8 @@ static int ensure_staging(snmf_plan* pl, size_t bytes) {
 
 static int grid_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 4096); }
 
-template <typename TIn>
-static int pack_in(snmf_plan* pl, const TIn* src, int64_t ld, int rows, int cols, float* dst, int rowsP, int colsP,
+template <typename TIn, typename TDst = float>
+static int pack_in(snmf_plan* pl, const TIn* src, int64_t ld, int rows, int cols, TDst* dst, int rowsP, int colsP,
                    bool do_floor, int is_device) {
     if (!src) return fail(SNMF_ERR_INVALID, "source pointer is NULL");
     if (ld < rows) return fail(SNMF_ERR_INVALID, "leading dimension %lld < rows %d", (long long)ld, rows);
@@ -538,15 +539,15 @@ static int pack_in(snmf_plan* pl, const TIn* src, int64_t ld, int rows, int cols
         dsrc = (const TIn*)pl->staging;
     }
     const size_t n = (size_t)rowsP * colsP;
-    hipLaunchKernelGGL(k_pack<TIn>, dim3(grid_for(n)), dim3(256), 0, st, dsrc, ld, rows, cols, dst, rowsP, colsP, kFlr,
+    hipLaunchKernelGGL((k_pack<TIn, TDst>), dim3(grid_for(n)), dim3(256), 0, st, dsrc, ld, rows, cols, dst, rowsP, colsP, kFlr,
                        do_floor ? 1 : 0);
     HIP_TRY(hipGetLastError());
     if (!is_device) HIP_TRY(hipStreamSynchronize(st));  // staging / host buffer reusable on return
     return SNMF_OK;
 }
 
-template <typename TOut>
-static int unpack_out(snmf_plan* pl, const float* src, int rowsP, int rows, int cols, TOut* dst, int64_t ld,
+template <typename TOut, typename TSrc = float>
+static int unpack_out(snmf_plan* pl, const TSrc* src, int rowsP, int rows, int cols, TOut* dst, int64_t ld,
                       int is_device) {
     if (!dst) return fail(SNMF_ERR_INVALID, "destination pointer is NULL");
     if (ld < rows) return fail(SNMF_ERR_INVALID, "leading dimension %lld < rows %d", (long long)ld, rows);
@@ -554,12 +555,12 @@ static int unpack_out(snmf_plan* pl, const float* src, int rowsP, int rows, int 
     hipStream_t st = pl->ctx->stream;
     const size_t n = (size_t)rows * cols;
     if (is_device) {
-        hipLaunchKernelGGL(k_unpack<TOut>, dim3(grid_for(n)), dim3(256), 0, st, src, rowsP, rows, cols, dst, ld);
+        hipLaunchKernelGGL((k_unpack<TOut, TSrc>), dim3(grid_for(n)), dim3(256), 0, st, src, rowsP, rows, cols, dst, ld);
         HIP_TRY(hipGetLastError());
         return SNMF_OK;
     }
     SN_TRY(ensure_staging(pl, n * sizeof(TOut)));
-    hipLaunchKernelGGL(k_unpack<TOut>, dim3(grid_for(n)), dim3(256), 0, st, src, rowsP, rows, cols,
+    hipLaunchKernelGGL((k_unpack<TOut, TSrc>), dim3(grid_for(n)), dim3(256), 0, st, src, rowsP, rows, cols,
                        (TOut*)pl->staging, (int64_t)rows);
     HIP_TRY(hipGetLastError());
     if (ld == rows) {
@@ -585,7 +586,7 @@ static int set_v(snmf_plan* pl, const T* V, int64_t ld, int dev) {
 template <typename T>
 static int set_w(snmf_plan* pl, const T* W, int64_t ld, int dev) {
     PLAN_CHECK(pl);
-    SN_TRY(pack_in<T>(pl, W, ld, pl->p.F, pl->p.r, pl->Wc, pl->Fp, pl->rp, false, dev));
+    SN_TRY((pack_in<T, double>(pl, W, ld, pl->p.F, pl->p.r, pl->Wc, pl->Fp, pl->rp, false, dev)));
     pl->have_w = true;
     pl->w_dirty = true;
     pl->inited = false;
@@ -624,11 +625,11 @@ extern "C" int snmf_plan_set_sparsity_f32(snmf_plan* pl, const float* S, int d) 
 
 extern "C" int snmf_plan_get_w_f64(snmf_plan* pl, double* W, int64_t ld, int d) {
     PLAN_CHECK(pl);
-    return unpack_out<double>(pl, pl->Wc, pl->Fp, pl->p.F, pl->p.r, W, ld, d);
+    return unpack_out<double, double>(pl, pl->Wc, pl->Fp, pl->p.F, pl->p.r, W, ld, d);
 }
 extern "C" int snmf_plan_get_w_f32(snmf_plan* pl, float* W, int64_t ld, int d) {
     PLAN_CHECK(pl);
-    return unpack_out<float>(pl, pl->Wc, pl->Fp, pl->p.F, pl->p.r, W, ld, d);
+    return unpack_out<float, double>(pl, pl->Wc, pl->Fp, pl->p.F, pl->p.r, W, ld, d);
 }
 
 // ---- launch helpers --------------------------------------------------------------------------
@@ -1378,4 +1379,412 @@ extern "C" int snmf_mel_features_f32(snmf_ctx* ctx, const float* mel, int32_t M,
         if (d_o) hipFree(d_o);
     }
     return rc;
+}
+
+// ---- online separation loop (include/snmf.h: snmf_online_*) -------------------------------------
+// Host side of src/bnmf_sep_event_RT_IS16.m + the frame loop of src/NTF_sep_event_RT.m:54-135.  The
+// host only sequences launches: per frame it reads one 32-byte status (did the adaptation condition
+// fire?) and, when it did, runs the W-only adaptation solve through the engine's ordinary plan.
+#include "snmf_online.h"
+
+struct snmf_online {
+    snmf_ctx* ctx = nullptr;
+    snmf_online_params p{};
+    int F = 0, r = 0, N = 0, nov = 0;
+    snmf_plan* hp = nullptr;  // frame solve: F x 1, rank r, H-only
+    snmf_plan* ap = nullptr;  // adaptation solve: F x m_a, rank R_a, W-only
+    double *B = nullptr, *Bfix = nullptr, *Btmp = nullptr;  // fp64 like the engine's W master copy (k_wapply)
+    float *Bf = nullptr;                                    // fp32 mirror of B for the reconstructions
+    float *H0 = nullptr, *lambda_dav = nullptr, *Xm_tilde = nullptr,
+          *r_blk = nullptr, *ldblk = nullptr, *adblk = nullptr, *Vad = nullptr, *Had = nullptr, *win_s = nullptr,
+          *win_i = nullptr, *syn_tail = nullptr, *syn_tail_x = nullptr, *syn_tail_d = nullptr;
+    float2* tw = nullptr;
+    uint8_t* rup = nullptr;
+    OnlineDev* dev = nullptr;
+    OnlineStatus* status = nullptr;
+    DevState* hst = nullptr;
+    double *hdiv = nullptr, *hcost = nullptr;
+    OnlineStatus* h_status = nullptr;  // pinned
+    // per-call buffers (grown on demand)
+    int cap_frames = 0;
+    float *sig = nullptr, *Ym = nullptr, *Xt = nullptr, *Xh = nullptr, *Dh = nullptr, *syn = nullptr, *outf = nullptr;
+    float2* Yph = nullptr;
+    int16_t* out16 = nullptr;
+    // host state of the driver loop
+    std::vector<float> pending, hist;
+    int64_t l = 0;  // frames processed
+    bool finished = false;
+    std::vector<snmf_online_frame> trace;
+};
+
+static void online_free_call_buffers(snmf_online* o) {
+    void* ptrs[] = {o->sig, o->Ym, o->Xt, o->Xh, o->Dh, o->syn, o->outf, o->Yph, o->out16};
+    for (void* q : ptrs)
+        if (q) hipFree(q);
+    o->sig = o->Ym = o->Xt = o->Xh = o->Dh = o->syn = o->outf = nullptr;
+    o->Yph = nullptr;
+    o->out16 = nullptr;
+    o->cap_frames = 0;
+}
+
+extern "C" void snmf_online_destroy(snmf_online* o) {
+    if (!o) return;
+    hipSetDevice(o->ctx->device);
+    hipStreamSynchronize(o->ctx->stream);
+    if (o->hp) snmf_plan_destroy(o->hp);
+    if (o->ap) snmf_plan_destroy(o->ap);
+    online_free_call_buffers(o);
+    void* ptrs[] = {o->B,   o->Bfix, o->Btmp,  o->H0,    o->lambda_dav, o->Xm_tilde, o->r_blk, o->ldblk, o->adblk,  o->Vad,
+                    o->Had, o->win_s, o->win_i, o->syn_tail, o->tw,       o->rup,      o->dev,   o->status, o->hst,   o->hdiv,
+                    o->hcost, o->syn_tail_x, o->syn_tail_d, o->Bf};
+    for (void* q : ptrs)
+        if (q) hipFree(q);
+    if (o->h_status) hipHostFree(o->h_status);
+    delete o;
+}
+
+static int online_validate(const snmf_online_params* p) {
+    if (!p) return fail(SNMF_ERR_INVALID, "online params is NULL");
+    const int N = p->fftlength;
+    if (N < 64 || N > 4096 || (N & (N - 1))) return fail(SNMF_ERR_UNSUPPORTED, "fftlength must be a power of two in [64,4096]");
+    if (p->framelength < 1 || p->framelength > N || p->frameshift < 1 || p->frameshift > p->framelength)
+        return fail(SNMF_ERR_INVALID, "need 1 <= frameshift <= framelength <= fftlength");
+    const int F = N / 2 + 1;
+    if (p->dcbin < 0 || p->dcbin > F || p->dcbin_back < 0 || p->dcbin_back > F || p->delay < 0)
+        return fail(SNMF_ERR_INVALID, "bad DCbin / DCbin_back / delay");
+    if (p->R_x < 1 || p->R_d < 1) return fail(SNMF_ERR_INVALID, "R_x and R_d must be positive");
+    if (p->max_iter < 1) return fail(SNMF_ERR_INVALID, "max_iter must be positive");
+    if (p->enhance_method != 0 && p->enhance_method != 1) return fail(SNMF_ERR_INVALID, "enhance_method: 0 Wiener, 1 MMSE");
+    if (p->blk_sparse) {
+        if (p->blk_gap < 1 || p->blk_gap % 2 == 0) return fail(SNMF_ERR_INVALID, "blk_gap must be odd (src/blk_sparse.m:4)");
+        if (p->P_len_k < 2 || p->P_len_k % 2 || p->P_len_l < 1) return fail(SNMF_ERR_INVALID, "P_len_k must be even and >= 2, P_len_l >= 1");
+        if (p->P_len_k + p->dcbin > F) return fail(SNMF_ERR_INVALID, "P_len_k + DCbin exceeds the number of bins");
+    }
+    if (p->adapt_train_N) {
+        if (p->R_a < 1 || p->R_a > p->R_d || p->m_a < 1) return fail(SNMF_ERR_INVALID, "need 1 <= R_a <= R_d and m_a >= 1");
+    }
+    return SNMF_OK;
+}
+
+extern "C" int snmf_online_create(snmf_ctx* ctx, const snmf_online_params* p, const float* Bx, const float* Bd, const float* H0,
+                                  const float* Ad0, const float* win_stft, const float* win_istft, snmf_online** out) {
+    if (!ctx || !out || !Bx || !Bd || !H0 || !win_stft || !win_istft) return fail(SNMF_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    SN_TRY(online_validate(p));
+    if (p->adapt_train_N && !Ad0) return fail(SNMF_ERR_INVALID, "Ad_blk0 is required when adapt_train_N is set");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    snmf_online* o = new snmf_online();
+    o->ctx = ctx;
+    o->p = *p;
+    const int N = p->fftlength, F = N / 2 + 1, r = p->R_x + p->R_d, sz = p->framelength, hop = p->frameshift;
+    const int Ra = p->adapt_train_N ? p->R_a : 1, ma = p->adapt_train_N ? p->m_a : 1, Pl = p->blk_sparse ? p->P_len_l : 1;
+    o->F = F;
+    o->r = r;
+    o->N = N;
+    o->nov = (sz + hop - 1) / hop;
+    int s = SNMF_OK;
+    auto A = [&](int v) { if (s == SNMF_OK) s = v; };
+    // the two resident solves
+    snmf_params hp{};
+    hp.F = F; hp.T = 1; hp.r = r; hp.beta = p->beta_div; hp.max_iter = p->max_iter; hp.conv_eps = p->conv_eps;
+    hp.cost_check = p->cost_check; hp.floor_v = 1; hp.sparsity_kind = SNMF_SPARSITY_SCALAR; hp.sparsity_scalar = p->sparsity;
+    std::vector<uint8_t> zeros(std::max(r, Ra), 0), ones(std::max(r, Ra), 1);
+    hp.w_update_ind = zeros.data();  // supervised (:139)
+    hp.h_update_ind = ones.data();   // :148
+    A(snmf_plan_create(ctx, &hp, &o->hp));
+    if (s == SNMF_OK && !o->hp->small_ok) A(fail(SNMF_ERR_UNSUPPORTED, "F + r too large for the persistent frame-solve kernel"));
+    if (p->adapt_train_N) {
+        snmf_params ap = hp;
+        ap.T = ma; ap.r = Ra;
+        ap.w_update_ind = ones.data();   // :330 (the per-solve subset r_up is written on the device)
+        ap.h_update_ind = zeros.data();  // :331
+        A(snmf_plan_create(ctx, &ap, &o->ap));
+    }
+    auto D = [&](auto** ptr, size_t n) { if (s == SNMF_OK) s = dalloc(ptr, n); };
+    D(&o->B, (size_t)F * r); D(&o->Bfix, (size_t)F * p->R_d); D(&o->Btmp, (size_t)F * p->R_d); D(&o->H0, (size_t)r);
+    D(&o->Bf, (size_t)F * r);
+    D(&o->lambda_dav, (size_t)F); D(&o->Xm_tilde, (size_t)F); D(&o->r_blk, (size_t)F * Pl); D(&o->ldblk, (size_t)F * ma);
+    D(&o->adblk, (size_t)Ra * ma); D(&o->Vad, (size_t)F * ma); D(&o->Had, (size_t)Ra * ma); D(&o->win_s, (size_t)sz);
+    D(&o->win_i, (size_t)sz); D(&o->syn_tail, (size_t)std::max(1, o->nov - 1) * sz); D(&o->tw, (size_t)N / 2);
+    if (p->class_outputs) {
+        D(&o->syn_tail_x, (size_t)std::max(1, o->nov - 1) * sz);
+        D(&o->syn_tail_d, (size_t)std::max(1, o->nov - 1) * sz);
+    }
+    D(&o->rup, (size_t)Ra); D(&o->dev, (size_t)1); D(&o->status, (size_t)1); D(&o->hst, (size_t)1);
+    D(&o->hdiv, (size_t)p->max_iter); D(&o->hcost, (size_t)p->max_iter);
+    if (s == SNMF_OK && hipHostMalloc((void**)&o->h_status, sizeof(OnlineStatus)) != hipSuccess) A(fail(SNMF_ERR_NOMEM, "hipHostMalloc"));
+    if (s != SNMF_OK) {
+        snmf_online_destroy(o);
+        return s;
+    }
+    std::vector<float2> htw(N / 2);
+    for (int q = 0; q < N / 2; ++q) {
+        const double ang = -2.0 * M_PI * (double)q / (double)N;
+        htw[q] = make_float2((float)cos(ang), (float)sin(ang));
+    }
+    OnlineDev d0{0, 1, 0, 0};  // update_switch = 1 (src/init_buff.m:42)
+    std::vector<double> hB((size_t)F * r);
+    for (size_t i = 0; i < (size_t)F * p->R_x; ++i) hB[i] = (double)Bx[i];
+    for (size_t i = 0; i < (size_t)F * p->R_d; ++i) hB[(size_t)F * p->R_x + i] = (double)Bd[i];
+    hipMemcpyAsync(o->B, hB.data(), hB.size() * 8, hipMemcpyHostToDevice, st);
+    hipMemcpyAsync(o->Bfix, hB.data() + (size_t)F * p->R_x, (size_t)F * p->R_d * 8, hipMemcpyHostToDevice, st);  // B_Mel_d in DFT mode (:328)
+    hipMemcpyAsync(o->Bf, Bx, (size_t)F * p->R_x * 4, hipMemcpyHostToDevice, st);
+    hipMemcpyAsync(o->Bf + (size_t)F * p->R_x, Bd, (size_t)F * p->R_d * 4, hipMemcpyHostToDevice, st);
+    hipMemcpyAsync(o->H0, H0, (size_t)r * 4, hipMemcpyHostToDevice, st);
+    hipMemcpyAsync(o->win_s, win_stft, (size_t)sz * 4, hipMemcpyHostToDevice, st);
+    hipMemcpyAsync(o->win_i, win_istft, (size_t)sz * 4, hipMemcpyHostToDevice, st);
+    hipMemcpyAsync(o->tw, htw.data(), htw.size() * 8, hipMemcpyHostToDevice, st);
+    hipMemcpyAsync(o->dev, &d0, sizeof d0, hipMemcpyHostToDevice, st);
+    hipMemsetAsync(o->lambda_dav, 0, (size_t)F * 4, st);
+    hipMemsetAsync(o->Xm_tilde, 0, (size_t)F * 4, st);
+    hipMemsetAsync(o->r_blk, 0, (size_t)F * Pl * 4, st);
+    hipMemsetAsync(o->ldblk, 0, (size_t)F * ma * 4, st);
+    hipMemsetAsync(o->adblk, 0, (size_t)Ra * ma * 4, st);
+    hipMemsetAsync(o->syn_tail, 0, (size_t)std::max(1, o->nov - 1) * sz * 4, st);
+    if (p->class_outputs) {
+        hipMemsetAsync(o->syn_tail_x, 0, (size_t)std::max(1, o->nov - 1) * sz * 4, st);
+        hipMemsetAsync(o->syn_tail_d, 0, (size_t)std::max(1, o->nov - 1) * sz * 4, st);
+    }
+    hipMemsetAsync(o->rup, 0, (size_t)Ra, st);
+    if (p->adapt_train_N) hipMemcpyAsync(o->adblk, Ad0, (size_t)Ra * ma * 4, hipMemcpyHostToDevice, st);  // column-major R_a x m_a
+    hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        snmf_online_destroy(o);
+        return fail(SNMF_ERR_NO_DEVICE, "online create: %s", hipGetErrorString(e));
+    }
+    A(set_w<double>(o->hp, o->B, F, 1));
+    if (s != SNMF_OK) {
+        snmf_online_destroy(o);
+        return s;
+    }
+    o->hist.assign((size_t)(sz - hop), 0.f);
+    *out = o;
+    return SNMF_OK;
+}
+
+static int online_reserve(snmf_online* o, int n) {
+    if (n <= o->cap_frames) return SNMF_OK;
+    hipStreamSynchronize(o->ctx->stream);
+    online_free_call_buffers(o);
+    const int cap = std::max(n, 64);
+    const size_t F = o->F, sz = o->p.framelength, hop = o->p.frameshift;
+    SN_TRY(dalloc(&o->sig, (sz - hop) + (size_t)cap * hop));
+    SN_TRY(dalloc(&o->Ym, F * cap));
+    SN_TRY(dalloc(&o->Yph, F * cap));
+    SN_TRY(dalloc(&o->Xt, F * cap));
+    if (o->p.class_outputs) {
+        SN_TRY(dalloc(&o->Xh, F * cap));
+        SN_TRY(dalloc(&o->Dh, F * cap));
+    }
+    SN_TRY(dalloc(&o->syn, (size_t)(cap + o->nov - 1) * sz));
+    SN_TRY(dalloc(&o->outf, (size_t)cap * hop));
+    SN_TRY(dalloc(&o->out16, (size_t)cap * hop));
+    o->cap_frames = cap;
+    return SNMF_OK;
+}
+
+template <typename K>
+static void launch_by_logn(K&& f, int N) {
+    switch (N) {
+        case 64: f(std::integral_constant<int, 6>{}); break;
+        case 128: f(std::integral_constant<int, 7>{}); break;
+        case 256: f(std::integral_constant<int, 8>{}); break;
+        case 512: f(std::integral_constant<int, 9>{}); break;
+        case 1024: f(std::integral_constant<int, 10>{}); break;
+        case 2048: f(std::integral_constant<int, 11>{}); break;
+        default: f(std::integral_constant<int, 12>{}); break;
+    }
+}
+
+// the frame solve (:148-154): V = Ym (device), W resident, H0 the fixed start; leaves A in hp->H[0]
+static int online_solve_frame(snmf_online* o, const float* dV) {
+    snmf_plan* pl = o->hp;
+    hipStream_t st = o->ctx->stream;
+    const size_t nVp = (size_t)pl->Fp * pl->Tp;
+    hipLaunchKernelGGL(k_pack<float>, dim3(grid_for(nVp)), dim3(256), 0, st, dV, (int64_t)o->F, o->F, 1, pl->V, pl->Fp, pl->Tp, kFlr,
+                       pl->p.floor_v ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    pl->have_v = true;
+    if (pl->w_dirty) SN_TRY(launch_wapply(pl, pl->stats, 0, false, true));  // wn, w./wn (:157-159)
+    pl->w_dirty = false;
+    pl->cur = 0;
+    hipLaunchKernelGGL(k_tile_h0<float>, dim3(grid_for((size_t)pl->rp)), dim3(256), 0, st, (const float*)o->H0, pl->wn, o->r, pl->rp, 1,
+                       1, pl->H[0]);  // h .* wn' (:160)
+    HIP_TRY(hipGetLastError());
+    pl->have_h = true;
+    pl->inited = false;
+    HIP_TRY(hipMemsetAsync(o->hst, 0, sizeof(DevState), st));
+    return launch_small(pl, 1, 1, o->hdiv, o->hcost, o->hst);
+}
+
+// :296-336 once the status says the solve is due
+static int online_adapt(snmf_online* o, int32_t* iters) {
+    const snmf_online_params& p = o->p;
+    hipStream_t st = o->ctx->stream;
+    snmf_plan* ap = o->ap;
+    double* Bd = o->B + (size_t)o->F * p.R_x;
+    const size_t n = (size_t)o->F * p.m_a + (size_t)p.R_a * p.m_a + p.R_a;
+    hipLaunchKernelGGL(k_oprep, dim3(grid_for(n)), dim3(256), 0, st, (const float*)o->ldblk, (const float*)o->adblk,
+                       (const uint8_t*)o->rup, (const OnlineDev*)o->dev, o->F, p.R_a, p.m_a, o->Vad, o->Had, ap->w_ind);
+    HIP_TRY(hipGetLastError());
+    SN_TRY(set_v<float>(ap, o->Vad, o->F, 1));         // lambda_d_blk (floored at 1e-9 inside, sparse_nmf.m:169)
+    SN_TRY(set_w<double>(ap, Bd, o->F, 1));            // init_w: first R_a noise columns (:332)
+    SN_TRY(set_h<float>(ap, o->Had, p.R_a, 1));        // init_h (:333)
+    SN_TRY(snmf_plan_init(ap));
+    SN_TRY(snmf_plan_run(ap, p.max_iter, iters));
+    hipLaunchKernelGGL(k_oassemble, dim3(p.R_d), dim3(256), 0, st, (const double*)Bd, (const double*)ap->Wc, ap->Fp, (const double*)o->Bfix,
+                       (const uint8_t*)o->rup, o->F, p.R_a, p.R_d, o->Btmp, o->Bf + (size_t)o->F * p.R_x);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(Bd, o->Btmp, (size_t)o->F * p.R_d * 8, hipMemcpyDeviceToDevice, st));
+    return set_w<double>(o->hp, o->B, o->F, 1);        // next frame's init_w = [B_DFT_x, B_DFT_d] (:140-146)
+}
+
+// n frames whose samples are sig = [history | n hops] (host); appends the hops the driver would write
+static int online_run_frames(snmf_online* o, const std::vector<float>& sig, int n, std::vector<float>* outf,
+                             std::vector<int16_t>* out16, std::vector<float>* xh, std::vector<float>* dh) {
+    const snmf_online_params& p = o->p;
+    const int F = o->F, sz = p.framelength, hop = p.frameshift, nov = o->nov;
+    hipStream_t st = o->ctx->stream;
+    SN_TRY(online_reserve(o, n));
+    HIP_TRY(hipMemcpyAsync(o->sig, sig.data(), sig.size() * 4, hipMemcpyHostToDevice, st));
+    OStftArgs sa{};
+    sa.sig = o->sig; sa.sz = sz; sa.hop = hop; sa.dcbin = p.dcbin; sa.preemph = (float)p.preemph; sa.win = o->win_s; sa.tw = o->tw;
+    sa.powv = (float)p.pow; sa.floorv = (float)p.nonzerofloor; sa.Ym = o->Ym; sa.Yph = o->Yph; sa.ld = F; sa.n_frames = n;
+    launch_by_logn([&](auto L) { hipLaunchKernelGGL(k_ostft<decltype(L)::value>, dim3(n), dim3(256), 0, st, sa); }, o->N);
+    HIP_TRY(hipGetLastError());
+    const size_t lds_post = (size_t)(o->r + 6 * F) * 4;
+    for (int i = 0; i < n; ++i) {
+        const int64_t l = o->l + 1 + i;
+        SN_TRY(online_solve_frame(o, o->Ym + (size_t)i * F));
+        OPostArgs a{};
+        a.A = o->hp->H[0]; a.hst = o->hst; a.B = o->Bf; a.Ym = o->Ym + (size_t)i * F; a.lambda_dav = o->lambda_dav; a.Xm_tilde = o->Xm_tilde;
+        a.r_blk = o->r_blk; a.ldblk = o->ldblk; a.adblk = o->adblk; a.rup = o->rup; a.dev = o->dev; a.status = o->status;
+        a.Xt_out = o->Xt + (size_t)i * F;
+        a.Xh_out = o->Xh ? o->Xh + (size_t)i * F : nullptr;
+        a.Dh_out = o->Dh ? o->Dh + (size_t)i * F : nullptr;
+        a.F = F; a.Rx = p.R_x; a.Rd = p.R_d; a.Ra = p.adapt_train_N ? p.R_a : 1; a.ma = p.adapt_train_N ? p.m_a : 1;
+        a.Pl = p.blk_sparse ? p.P_len_l : 1; a.Pk = p.P_len_k; a.dcbin = p.dcbin; a.gap = p.blk_gap;
+        a.l = (int)std::min<int64_t>(l, 1 << 30);
+        a.blk_sparse = p.blk_sparse; a.adapt = p.adapt_train_N; a.wiener = p.enhance_method == 0; a.init_N_len = p.init_N_len;
+        a.switch_at = (int)std::floor(p.overlap_m_a * p.m_a);
+        a.alpha_p = (float)p.alpha_p; a.alpha_eta = (float)p.alpha_eta; a.alpha_d = (float)p.alpha_d; a.beta0 = (float)p.beta;
+        a.beta_max = (float)p.beta_max; a.Ar_up = (float)p.Ar_up; a.flr = (float)p.nonzerofloor;
+        hipLaunchKernelGGL(k_opost, dim3(1), dim3(1024), lds_post, st, a);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(o->h_status, o->status, sizeof(OnlineStatus), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const OnlineStatus hs = *o->h_status;
+        snmf_online_frame tr{};
+        tr.n_iter = hs.n_iter; tr.trig = hs.trig; tr.n_up = hs.n_up; tr.beta = hs.beta; tr.A_x_mag = hs.A_x_mag; tr.A_d_mag = hs.A_d_mag;
+        tr.Q_control = hs.Q_control;
+        if (hs.do_solve && hs.n_up > 0) {
+            int32_t it = 0;
+            SN_TRY(online_adapt(o, &it));
+            tr.solved = 1;
+            tr.adapt_iters = it;
+        }
+        o->trace.push_back(tr);
+    }
+    // inverse STFT of the n frames behind the nov-1 frames kept from the previous call, overlap-add
+    const int l0 = (int)std::min<int64_t>(o->l + 1, 1 << 30);
+    const int i_first = (int)std::max<int64_t>(0, (int64_t)p.delay + 1 - l0);
+    const int n_out = std::max(0, n - i_first);
+    auto synth = [&](const float* mag, std::vector<float>* of, std::vector<int16_t>* o16, bool keep_tail, float* tail) -> int {
+        if (nov > 1) HIP_TRY(hipMemcpyAsync(o->syn, tail, (size_t)(nov - 1) * sz * 4, hipMemcpyDeviceToDevice, st));
+        OIstftArgs ia{};
+        ia.mag = mag; ia.ph = o->Yph; ia.ld = F; ia.n_frames = n; ia.sz = sz; ia.dcb = p.dcbin_back; ia.powv = (float)p.pow;
+        ia.scale = (float)(p.overlapscale / (double)o->N); ia.preemph = (float)p.preemph; ia.win = o->win_i; ia.tw = o->tw;
+        ia.syn = o->syn + (size_t)(nov - 1) * sz;
+        launch_by_logn([&](auto L) { hipLaunchKernelGGL(k_oistft<decltype(L)::value>, dim3(n), dim3(256), 0, st, ia); }, o->N);
+        HIP_TRY(hipGetLastError());
+        if (n_out > 0) {
+            hipLaunchKernelGGL(k_oola, dim3(grid_for((size_t)n_out * hop)), dim3(256), 0, st, (const float*)o->syn, n, l0, p.delay, sz, hop, nov,
+                               i_first, n_out, o->outf, o16 ? o->out16 : nullptr);
+            HIP_TRY(hipGetLastError());
+            if (of) {
+                const size_t at = of->size();
+                of->resize(at + (size_t)n_out * hop);
+                HIP_TRY(hipMemcpyAsync(of->data() + at, o->outf, (size_t)n_out * hop * 4, hipMemcpyDeviceToHost, st));
+            }
+            if (o16) {
+                const size_t at = o16->size();
+                o16->resize(at + (size_t)n_out * hop);
+                HIP_TRY(hipMemcpyAsync(o16->data() + at, o->out16, (size_t)n_out * hop * 2, hipMemcpyDeviceToHost, st));
+            }
+        }
+        if (keep_tail && nov > 1)
+            HIP_TRY(hipMemcpyAsync(tail, o->syn + (size_t)n * sz, (size_t)(nov - 1) * sz * 4, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return SNMF_OK;
+    };
+    SN_TRY(synth(o->Xt, outf, out16, true, o->syn_tail));
+    if (o->p.class_outputs) {  // x_hat / d_hat of :350-361 (summed over the classes), same synthesis
+        SN_TRY(synth(o->Xh, xh, nullptr, true, o->syn_tail_x));
+        SN_TRY(synth(o->Dh, dh, nullptr, true, o->syn_tail_d));
+    }
+    o->l += n;
+    return SNMF_OK;
+}
+
+extern "C" int snmf_online_process_f32(snmf_online* o, const float* pcm, int64_t n, int flush, float* xt_f32, int16_t* xt_i16,
+                                       float* xh_f32, float* dh_f32, int64_t cap, int64_t* n_out) {
+    if (!o) return fail(SNMF_ERR_INVALID, "online handle is NULL");
+    if (n_out) *n_out = 0;
+    if (n < 0 || (n > 0 && !pcm)) return fail(SNMF_ERR_INVALID, "pcm is NULL");
+    if (o->finished) return fail(SNMF_ERR_STATE, "the stream was flushed; create a new separator");
+    if ((xh_f32 || dh_f32) && !o->p.class_outputs) return fail(SNMF_ERR_STATE, "class outputs were not requested at creation");
+    HIP_TRY(hipSetDevice(o->ctx->device));
+    const int sz = o->p.framelength, hop = o->p.frameshift;
+    o->pending.insert(o->pending.end(), pcm, pcm + n);
+    const int64_t nfr = (int64_t)(o->pending.size() / (size_t)hop);
+    const int64_t tail_frames = flush ? o->p.delay + 1 : 0;
+    const int64_t max_out = (nfr + tail_frames) * hop;
+    if ((xt_f32 || xt_i16 || xh_f32 || dh_f32) && cap < max_out) {
+        o->pending.resize(o->pending.size() - (size_t)n);
+        return fail(SNMF_ERR_INVALID, "output capacity %lld < %lld samples", (long long)cap, (long long)max_out);
+    }
+    std::vector<float> of, ox, od;
+    std::vector<int16_t> o16;
+    const int64_t chunk = 4096;  // frames per device batch
+    int64_t done = 0;
+    while (done < nfr) {
+        const int nb = (int)std::min(chunk, nfr - done);
+        std::vector<float> sig(o->hist);
+        sig.insert(sig.end(), o->pending.begin() + done * hop, o->pending.begin() + (done + nb) * hop);
+        SN_TRY(online_run_frames(o, sig, nb, xt_f32 ? &of : nullptr, xt_i16 ? &o16 : nullptr, xh_f32 ? &ox : nullptr, dh_f32 ? &od : nullptr));
+        o->hist.assign(sig.end() - (sz - hop), sig.end());
+        done += nb;
+    }
+    o->pending.erase(o->pending.begin(), o->pending.begin() + nfr * hop);
+    if (flush) {
+        // a partial hop is dropped and delay+1 all-zero frames follow (src/NTF_sep_event_RT.m:69-76)
+        std::vector<float> sig((size_t)(sz - hop) + (size_t)tail_frames * hop, 0.f);
+        SN_TRY(online_run_frames(o, sig, (int)tail_frames, xt_f32 ? &of : nullptr, xt_i16 ? &o16 : nullptr, xh_f32 ? &ox : nullptr, dh_f32 ? &od : nullptr));
+        o->pending.clear();
+        o->finished = true;
+    }
+    if (xt_f32) std::memcpy(xt_f32, of.data(), of.size() * 4);
+    if (xt_i16) std::memcpy(xt_i16, o16.data(), o16.size() * 2);
+    if (xh_f32) std::memcpy(xh_f32, ox.data(), ox.size() * 4);
+    if (dh_f32) std::memcpy(dh_f32, od.data(), od.size() * 4);
+    if (n_out) *n_out = (int64_t)std::max(std::max(of.size(), o16.size()), std::max(ox.size(), od.size()));
+    return SNMF_OK;
+}
+
+extern "C" int snmf_online_get_basis_f32(snmf_online* o, float* Bd, int64_t ld) {
+    if (!o || !Bd) return fail(SNMF_ERR_INVALID, "NULL argument");
+    if (ld < o->F) return fail(SNMF_ERR_INVALID, "ld < F");
+    HIP_TRY(hipSetDevice(o->ctx->device));
+    HIP_TRY(hipStreamSynchronize(o->ctx->stream));
+    HIP_TRY(hipMemcpy2D(Bd, (size_t)ld * 4, o->Bf + (size_t)o->F * o->p.R_x, (size_t)o->F * 4, (size_t)o->F * 4, (size_t)o->p.R_d,
+                        hipMemcpyDeviceToHost));
+    return SNMF_OK;
+}
+
+extern "C" int snmf_online_trace(snmf_online* o, snmf_online_frame* out, int64_t cap, int64_t* n) {
+    if (!o) return fail(SNMF_ERR_INVALID, "online handle is NULL");
+    if (n) *n = (int64_t)o->trace.size();
+    if (out && cap > 0) std::memcpy(out, o->trace.data(), sizeof(snmf_online_frame) * (size_t)std::min<int64_t>(cap, (int64_t)o->trace.size()));
+    return SNMF_OK;
 }

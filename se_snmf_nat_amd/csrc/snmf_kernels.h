@@ -1272,7 +1272,7 @@ __device__ __forceinline__ bool conv_test(const double* sc, double* divh, double
 
 struct ApplyArgs {
     const double* stats;
-    float* Wc;        // [rp][Fp] master copy, column-major
+    double* Wc;       // [rp][Fp] master copy, column-major, fp64 (see k_wapply)
     float* Wt4;
     float* Wk4;
     float* dphv;
@@ -1293,6 +1293,12 @@ struct ApplyArgs {
 };
 
 // One workgroup (256 threads) per column k of W.  src/sparse_nmf.m:215-244.
+// The master copy of W is fp64 although every contraction runs on fp32 images of it: the update is
+// multiplicative, so an entry that underflows fp32 (rows the data does not excite shrink by orders of
+// magnitude per iteration) would be pinned at exactly 0 for the rest of the solve, while in the
+// reference's doubles it stays positive and comes back as soon as V./Lam is large there -- which the
+// noise-dictionary adaptation (src/bnmf_sep_event_RT_IS16.m:296-336) does all the time.  W is
+// F x r: keeping it in fp64 costs nothing measurable.
 __global__ __launch_bounds__(256) void k_wapply(ApplyArgs a) {
     __shared__ double red[3][256];
     if (a.st->stop) return;
@@ -1307,7 +1313,7 @@ __global__ __launch_bounds__(256) void k_wapply(ApplyArgs a) {
     if (!a.do_update && !a.init_mode) return;
     if (k >= a.r) return;
 
-    float* wc = a.Wc + (size_t)k * a.Fp;
+    double* wc = a.Wc + (size_t)k * a.Fp;
     const bool upd = a.init_mode ? false : (a.w_ind[k] != 0);
     // pass 1: column sums needed by the update
     double cQW = 0.0, cPW = 0.0, cW = 0.0;
@@ -1316,7 +1322,7 @@ __global__ __launch_bounds__(256) void k_wapply(ApplyArgs a) {
         const double* P = (a.n_mat == 2) ? a.stats + nel + (size_t)k * a.Fp : nullptr;
         const double sk = (a.n_mat == 2) ? 0.0 : a.stats[nel * a.n_mat + k];
         for (int f = tid; f < a.F; f += 256) {
-            double wv = (double)wc[f];
+            double wv = wc[f];
             cQW += Q[f] * wv;
             cPW += (P ? P[f] : sk) * wv;
         }
@@ -1336,7 +1342,7 @@ __global__ __launch_bounds__(256) void k_wapply(ApplyArgs a) {
     }
     // updated (un-normalised) entry: dpw = max(P + W.*colsum(Q.*W), flr); dmw = Q + W.*colsum(P.*W)
     auto updated = [&](int f) -> double {
-        double wv = (double)wc[f];
+        double wv = wc[f];
         if (upd) {
             const double Qv = a.stats[(size_t)k * a.Fp + f];
             const double Pv = (a.n_mat == 2) ? a.stats[nel + (size_t)k * a.Fp + f] : a.stats[nel * a.n_mat + k];
@@ -1362,9 +1368,10 @@ __global__ __launch_bounds__(256) void k_wapply(ApplyArgs a) {
     __syncthreads();
     // pass 3: normalise (ALL columns, :242), write the three images, column sum
     for (int f = tid; f < a.F; f += 256) {
-        const float wf = (float)(updated(f) / nrm);
+        const double wd = updated(f) / nrm;
+        const float wf = (float)wd;  // operand images: an entry below fp32 range adds < 1e-38*max(h) to Lam, far under the 1e-9 floor
         cW += (double)wf;
-        wc[f] = wf;
+        wc[f] = wd;
         if (f < a.Fm) {  // Wt4[phi][q][h][f32][e] = W[32phi+f32][8q+4h+e]
             const int phi = f >> 5, f32 = f & 31, q = k >> 3, hh = (k >> 2) & 1, e = k & 3;
             a.Wt4[(((size_t)phi * (a.rp / 8) + q) * 2 + hh) * 128 + f32 * 4 + e] = wf;
@@ -1460,23 +1467,24 @@ __global__ void k_tile_h0(const TIn* __restrict__ H0, const double* __restrict__
 }
 
 // Layout conversion: user column-major (rows x cols, ld) -> padded [colsP][rowsP] fp32, optional floor.
-template <typename TIn>
-__global__ void k_pack(const TIn* __restrict__ src, int64_t ld, int rows, int cols, float* __restrict__ dst, int rowsP,
+// (TDst = double only for the W master copy, which keeps the reference's fp64 range: see k_wapply.)
+template <typename TIn, typename TDst = float>
+__global__ void k_pack(const TIn* __restrict__ src, int64_t ld, int rows, int cols, TDst* __restrict__ dst, int rowsP,
                        int colsP, float floor_val, int do_floor) {
     const size_t n = (size_t)rowsP * colsP;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int rr = (int)(i % rowsP);
         const size_t c = i / rowsP;
-        float v = 0.f;
+        TDst v = (TDst)0;
         if (rr < rows && c < (size_t)cols) {
-            v = (float)src[(size_t)c * ld + rr];
-            if (do_floor) v = fmaxf(v, floor_val);
+            v = (TDst)src[(size_t)c * ld + rr];
+            if (do_floor) v = v > (TDst)floor_val ? v : (TDst)floor_val;
         }
         dst[i] = v;
     }
 }
-template <typename TOut>
-__global__ void k_unpack(const float* __restrict__ src, int rowsP, int rows, int cols, TOut* __restrict__ dst,
+template <typename TOut, typename TSrc = float>
+__global__ void k_unpack(const TSrc* __restrict__ src, int rowsP, int rows, int cols, TOut* __restrict__ dst,
                          int64_t ld) {
     const size_t n = (size_t)rows * cols;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {

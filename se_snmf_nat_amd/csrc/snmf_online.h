@@ -1,0 +1,454 @@
+// snmf_online.h -- the online separation loop around the per-frame solve, kept on the device
+// (BASELINE config 3).  Reference (shipped configuration: blk_len_sep = 1,
+// Splice = 0, B_sep_mode = 'DFT'):
+//   src/bnmf_sep_event_RT_IS16.m:65-81     frame STFT: |Y|^pow with DC bins zeroed + floor, phase
+//   src/bnmf_sep_event_RT_IS16.m:158-202   reconstructions  Xm_hat = B_x*A_x,  Dm_hat = B_d*A_d
+//   src/blk_sparse.m:1-37                  Hoyer block sparsity Q
+//   src/bnmf_sep_event_RT_IS16.m:220-261   adaptive beta, smoothed noise PSD, Wiener / MMSE gain
+//   src/bnmf_sep_event_RT_IS16.m:263-347   noise-reference rings, r_up, dictionary re-assembly
+//   src/synth_ifft_buff.m:1-32             inverse STFT of a frame
+//   src/NTF_sep_event_RT.m:104-124         overlap-add, int16 output
+// Everything here is vector work on F ~ 513 bins per frame: latency-bound, one workgroup per
+// frame for the transforms and ONE workgroup for the sequential post-solve step.  The solves
+// themselves are the engine's kernels (k_hsolve_small for the frame, k_wstats/k_wapply for the
+// adaptation).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace snmf {
+
+struct OnlineStatus {  // written once per frame, read back by the host
+    int trig, do_solve, n_up, n_iter;
+    float beta, A_x_mag, A_d_mag, Q_control;
+};
+
+struct OnlineDev {     // device-resident scalar state of the loop
+    int n_push;        // pushes into the noise-reference rings (lambda_d_blk / Ad_blk)
+    int update_switch; // src/init_buff.m:42
+    int pad0, pad1;
+};
+
+// radix-2 Stockham autosort FFT of N = 2^LOGN points held in LDS; returns the buffer with the result
+template <int LOGN>
+__device__ __forceinline__ float2* fft_lds(float2* x, float2* y, const float2* __restrict__ tw) {
+    constexpr int N = 1 << LOGN;
+    for (int l = N / 2, m = 1; l >= 1; l >>= 1, m <<= 1) {
+        const int tstep = N / (2 * l);
+        for (int idx = threadIdx.x; idx < N / 2; idx += blockDim.x) {
+            const int j = idx / m, k = idx - j * m;
+            const float2 c0 = x[k + j * m];
+            const float2 c1 = x[k + j * m + l * m];
+            const float2 w = tw[j * tstep];
+            const float2 d = make_float2(c0.x - c1.x, c0.y - c1.y);
+            y[k + 2 * j * m] = make_float2(c0.x + c1.x, c0.y + c1.y);
+            y[k + 2 * j * m + m] = make_float2(w.x * d.x - w.y * d.y, w.x * d.y + w.y * d.x);
+        }
+        __syncthreads();
+        float2* t = x;
+        x = y;
+        y = t;
+    }
+    return x;
+}
+
+struct OStftArgs {
+    const float* sig;  // [(sz - hop) history | n_frames * hop new samples]; frame i starts at i*hop
+    int sz, hop, dcbin;
+    float preemph;
+    const float* win;
+    const float2* tw;
+    float powv, floorv;
+    float* Ym;         // column i at Ym + i*ld
+    float2* Yph;       // exp(i*angle(Y)) per bin, same layout
+    int64_t ld;
+    int n_frames;
+};
+
+// src/bnmf_sep_event_RT_IS16.m:65-81
+template <int LOGN>
+__global__ __launch_bounds__(256) void k_ostft(OStftArgs a) {
+    constexpr int N = 1 << LOGN;
+    __shared__ float2 bufA[N];
+    __shared__ float2 bufB[N];
+    const int t = blockIdx.x;
+    if (t >= a.n_frames) return;
+    const float* s = a.sig + (int64_t)t * a.hop;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        float x = 0.f;
+        if (n < a.sz) {
+            const float cur = s[n];
+            const float prev = n > 0 ? s[n - 1] : 0.f;  // filter([1 -preemph],1,y), zero state (:66)
+            x = (cur - a.preemph * prev) * a.win[n];     // :67
+        }
+        bufA[n] = make_float2(x, 0.f);
+    }
+    __syncthreads();
+    const float2* X = fft_lds<LOGN>(bufA, bufB, a.tw);
+    float* om = a.Ym + (int64_t)t * a.ld;
+    float2* op = a.Yph + (int64_t)t * a.ld;
+    for (int f = threadIdx.x; f <= N / 2; f += 256) {
+        const float2 c = X[f];
+        const float mag = sqrtf(c.x * c.x + c.y * c.y);
+        float v;
+        if (a.powv == 2.f) v = mag * mag;
+        else if (a.powv == 1.f) v = mag;
+        else v = powf(mag, a.powv);
+        if (f < a.dcbin) v = 0.f;                        // :74
+        om[f] = v + a.floorv;                            // :77
+        op[f] = mag > 0.f ? make_float2(c.x / mag, c.y / mag) : make_float2(1.f, 0.f);  // angle(0) = 0
+    }
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+// fixed-order block sum, result in every thread; red holds one double per wave
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+    v = wave_sum_d(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+    return s;
+}
+__device__ __forceinline__ float block_max_f(float v, double* red) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = (double)v;
+    __syncthreads();
+    float s = (float)red[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) s = fmaxf(s, (float)red[i]);
+    return s;
+}
+
+struct OPostArgs {
+    const float* A;       // [r] activations of this frame (solver's H buffer, first r of rp)
+    const DevState* hst;  // the frame solve's state (n_iter)
+    const float* B;       // [F x r] column-major, current [B_DFT_x | B_DFT_d]
+    const float* Ym;      // [F]
+    float* lambda_dav;    // [F] state
+    float* Xm_tilde;      // [F] state
+    float* r_blk;         // [Pl][F] ring of SNR_local columns
+    float* ldblk;         // [ma][F] ring  lambda_d_blk
+    float* adblk;         // [ma][Ra] ring Ad_blk
+    uint8_t* rup;         // [Ra]
+    OnlineDev* dev;
+    OnlineStatus* status;
+    float* Xt_out;        // [F] G .* Ym of this frame
+    float* Xh_out;        // [F] Xm_hat_sum (may be NULL)
+    float* Dh_out;        // [F] Dm_hat_sum (may be NULL)
+    int F, Rx, Rd, Ra, ma, Pl, Pk, dcbin, gap;
+    int l;                // 1-based frame index
+    int blk_sparse, adapt, wiener, init_N_len, switch_at;
+    float alpha_p, alpha_eta, alpha_d, beta0, beta_max, Ar_up, flr;
+};
+
+// Everything between the frame solve and the inverse STFT, src/bnmf_sep_event_RT_IS16.m:158-292.
+// One workgroup; dynamic LDS = (r + 6*F) floats.
+__global__ __launch_bounds__(1024) void k_opost(OPostArgs a) {
+    extern __shared__ float sm[];
+    __shared__ double red[16];
+    const int F = a.F, r = a.Rx + a.Rd;
+    float* sA = sm;
+    float* Xs = sA + r;
+    float* Ds = Xs + F;
+    float* Q = Ds + F;
+    float* rs1 = Q + F;
+    float* rs2 = rs1 + F;
+    float* Gs = rs2 + F;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int n_push0 = a.dev->n_push, sw0 = a.dev->update_switch;
+    for (int k = tid; k < r; k += nt) sA[k] = a.A[k];
+    __syncthreads();
+    // A_x_mag, A_d_mag (:228-229)
+    double sx = 0.0, sd = 0.0;
+    for (int k = tid; k < r; k += nt) {
+        if (k < a.Rx) sx += (double)sA[k];
+        else sd += (double)sA[k];
+    }
+    sx = block_sum_d(sx, red);
+    sd = block_sum_d(sd, red);
+    const float A_x_mag = (float)(sx / a.Rx), A_d_mag = (float)(sd / a.Rd);
+    // Xm_hat_sum = B_x*A_x, Dm_hat_sum = B_d*A_d (:158-202; any class partition sums to these)
+    for (int f = tid; f < F; f += nt) {
+        const float* b = a.B + f;
+        float x = 0.f, d = 0.f;
+        for (int k = 0; k < a.Rx; ++k) x = fmaf(b[(size_t)k * F], sA[k], x);
+        b += (size_t)a.Rx * F;
+        for (int k = 0; k < a.Rd; ++k) d = fmaf(b[(size_t)k * F], sA[a.Rx + k], d);
+        Xs[f] = x;
+        Ds[f] = d;
+    }
+    __syncthreads();
+    // ---- src/blk_sparse.m ----
+    if (a.blk_sparse) {
+        float mx = 0.f;
+        for (int f = tid; f < F; f += nt) {
+            const float s = Xs[f] / fmaxf(Ds[f], a.flr);  // :10
+            rs1[f] = s;
+            mx = fmaxf(mx, s);
+        }
+        mx = block_max_f(mx, red);
+        float* col = a.r_blk + (size_t)((a.l - 1) % a.Pl) * F;  // newest column of the ring (:14)
+        for (int f = tid; f < F; f += nt) {
+            col[f] = rs1[f] / mx;                                // :12
+            Q[f] = f < a.dcbin ? 0.f : 0.1f;                     // :16
+        }
+        __syncthreads();
+        if (a.l > a.Pl) {
+            for (int f = tid; f < F; f += nt) {
+                float s1 = 0.f, s2 = 0.f;
+                for (int c = 0; c < a.Pl; ++c) {
+                    const float v = a.r_blk[(size_t)c * F + f];
+                    s1 += v;
+                    s2 = fmaf(v, v, s2);
+                }
+                rs1[f] = s1;
+                rs2[f] = s2;
+            }
+            __syncthreads();
+            const int k2 = a.Pk / 2, gN2 = (a.gap - 1) / 2;
+            const int kfirst = k2 + a.dcbin, klast = F - k2;  // 1-based, :20
+            const int nwin = klast >= kfirst ? (klast - kfirst) / a.gap + 1 : 0;
+            const double sqn = sqrt((double)a.Pl * (double)a.Pk);
+            for (int j = tid; j < nwin; j += nt) {
+                const int k = kfirst + j * a.gap;
+                double l1 = 0.0, l2 = 0.0;
+                for (int row = k - k2; row < k + k2; ++row) {  // 1-based rows k-k2+1 .. k+k2
+                    l1 += (double)rs1[row];
+                    l2 += (double)rs2[row];
+                }
+                Gs[j] = (float)((sqn - l1 / sqrt(l2)) / (sqn - 1.0));  // :26
+            }
+            __syncthreads();
+            if (gN2 >= 1) {
+                // blk_gap >= 3: window k reads Q(k-1), which no other window writes (window k-gap ends at
+                // k-gap+gN2 < k-1), so the recursion of :28 sees the initial value and windows are independent
+                for (int j = tid; j < nwin; j += nt) {
+                    const int k = kfirst + j * a.gap;
+                    const float qprev = (k - 2) < a.dcbin ? 0.f : 0.1f;
+                    const float pv = a.alpha_p * qprev + (1.f - a.alpha_p) * Gs[j];
+                    for (int i = k - gN2 - 1; i <= k + gN2 - 1; ++i) Q[i] = pv;  // :29-30
+                }
+            } else if (tid == 0) {
+                // blk_gap = 1: a genuine first-order recursion along frequency
+                for (int j = 0; j < nwin; ++j) {
+                    const int k = kfirst + j;
+                    Q[k - 1] = a.alpha_p * Q[k - 2] + (1.f - a.alpha_p) * Gs[j];
+                }
+            }
+            __syncthreads();
+            const float qv = Q[a.Pk + a.dcbin - 1];
+            __syncthreads();
+            for (int f = tid; f < a.Pk - 1; f += nt) Q[f] = qv;  // :32
+            __syncthreads();
+        }
+        for (int f = tid; f < a.dcbin; f += nt) Q[f] = 0.f;      // :36
+    } else {
+        for (int f = tid; f < F; f += nt) Q[f] = 1.f;            // :217
+    }
+    __syncthreads();
+    double qs = 0.0;
+    for (int f = tid; f < F; f += nt) qs += (double)Q[f];
+    qs = block_sum_d(qs, red);
+    const float meanQ = (float)(qs / F);
+    // ---- gain (:221-261) ----
+    float beta = (float)(20.0 * log10((double)A_d_mag / (double)A_x_mag)) * a.beta0;  // :230-231
+    if (beta < a.beta0) beta = a.beta0;
+    else if (beta >= a.beta_max) beta = a.beta_max;
+    const bool init = a.l <= a.init_N_len;
+    for (int f = tid; f < F; f += nt) {
+        const float ym = a.Ym[f];
+        float ld = a.l == 1 ? ym : a.lambda_dav[f];                       // :223-225
+        ld = a.alpha_d * ld + (1.f - a.alpha_d) * Ds[f] * beta;           // :241
+        a.lambda_dav[f] = ld;
+        float G;
+        if (a.wiener) {
+            G = Xs[f] / (Xs[f] + Ds[f]);                                  // :245
+        } else {
+            float eta = (a.alpha_eta * a.Xm_tilde[f] + (1.f - a.alpha_eta) * Xs[f] * Q[f]) / fmaxf(ld, a.flr);  // :247
+            eta = fmaxf(0.0031f, eta);                                    // :251
+            G = eta / (eta + 1.f);
+        }
+        G = fminf(G, 1.f);                                                // :254 (min ignores NaN, as MATLAB's)
+        if (init) G = a.flr;                                              // :256-258
+        Gs[f] = G;
+        const float xt = G * ym;                                          // :260
+        a.Xm_tilde[f] = xt;
+        a.Xt_out[f] = xt;
+        if (a.Xh_out) a.Xh_out[f] = Xs[f];
+        if (a.Dh_out) a.Dh_out[f] = Ds[f];
+    }
+    const float A_x_eff = init ? a.flr : A_x_mag;                         // :258
+    const float Q_control = (1.f - meanQ) * a.Ar_up;                      // :264
+    const bool trig = a.adapt && (Q_control * A_d_mag > A_x_eff);         // :266
+    int do_solve = 0, n_up = 0;
+    __syncthreads();
+    if (trig) {
+        const int head = n_push0 % a.ma;  // overwrites the oldest column == shift + append (:282,:285)
+        for (int f = tid; f < F; f += nt) {
+            const float ym = a.Ym[f];
+            const float mref = f < a.dcbin ? a.flr : 1.f - Gs[f];         // :271-272
+            a.ldblk[(size_t)head * F + f] = init ? ym : ym * mref;        // :268-274
+        }
+        for (int k = tid; k < a.Ra; k += nt) a.adblk[(size_t)head * a.Ra + k] = sA[a.Rx + k];
+        __syncthreads();
+        int cnt = 0;
+        for (int k = tid; k < a.Ra; k += nt) {
+            double s = 0.0;
+            for (int c = 0; c < a.ma; ++c) s += (double)a.adblk[(size_t)c * a.Ra + k];
+            const bool up = (double)Q_control * (s / a.ma) > (double)A_x_eff;  // :288
+            a.rup[k] = up ? 1 : 0;
+            cnt += up;
+        }
+        n_up = (int)(block_sum_d((double)cnt, red) + 0.5);
+        do_solve = sw0 == a.switch_at;                                    // :294
+        if (tid == 0) {
+            a.dev->n_push = n_push0 + 1;
+            a.dev->update_switch = do_solve ? 1 : sw0 + 1;                // :343-345
+        }
+    }
+    if (tid == 0) {
+        OnlineStatus s;
+        s.trig = trig;
+        s.do_solve = do_solve;
+        s.n_up = n_up;
+        s.n_iter = a.hst->n_iter;
+        s.beta = beta;
+        s.A_x_mag = A_x_eff;
+        s.A_d_mag = A_d_mag;
+        s.Q_control = Q_control;
+        *a.status = s;
+    }
+}
+
+// Inputs of the adaptation solve (:296-335) in time order: V = lambda_d_blk, H = Ad_blk with the
+// rows not flagged by r_up zeroed (the reference drops those rows/columns; a zero activation row
+// contributes nothing to Lam, G or the cost, so the flagged columns see the same problem), and
+// the engine's W-update mask = r_up.
+__global__ void k_oprep(const float* __restrict__ ldblk, const float* __restrict__ adblk, const uint8_t* __restrict__ rup,
+                        const OnlineDev* dev, int F, int Ra, int ma, float* __restrict__ Vad, float* __restrict__ Had,
+                        uint8_t* __restrict__ w_ind) {
+    const int oldest = dev->n_push % ma;
+    const size_t nv = (size_t)F * ma, nh = (size_t)Ra * ma;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv + nh + Ra; i += (size_t)gridDim.x * blockDim.x) {
+        if (i < nv) {
+            const int c = (int)(i / F), f = (int)(i - (size_t)c * F);
+            Vad[i] = ldblk[(size_t)((oldest + c) % ma) * F + f];
+        } else if (i < nv + nh) {
+            const size_t j = i - nv;
+            const int c = (int)(j / Ra), k = (int)(j - (size_t)c * Ra);
+            Had[j] = rup[k] ? adblk[(size_t)((oldest + c) % ma) * Ra + k] : 0.f;
+        } else {
+            const int k = (int)(i - nv - nh);
+            w_ind[k] = rup[k];
+        }
+    }
+}
+
+// B_DFT_d = [B_d_rem, B_d_tmp, B_d_fix] (:336): kept columns first, then the re-trained ones, then
+// the columns beyond R_a taken from the original dictionary (:328).  One workgroup per column.
+__global__ void k_oassemble(const double* __restrict__ Bd_old, const double* __restrict__ Wc, int Fp,
+                            const double* __restrict__ Bfix, const uint8_t* __restrict__ rup, int F, int Ra, int Rd,
+                            double* __restrict__ Bd_new, float* __restrict__ Bd_f32) {
+    const int j = blockIdx.x;
+    if (j >= Rd) return;
+    const double* src;
+    if (j >= Ra) {
+        src = Bfix + (size_t)j * F;
+    } else {
+        int n_rem = 0;
+        for (int k = 0; k < Ra; ++k) n_rem += rup[k] ? 0 : 1;
+        const bool want_up = j >= n_rem;
+        int need = want_up ? j - n_rem : j, k = 0;
+        for (; k < Ra; ++k) {
+            if ((rup[k] != 0) == want_up) {
+                if (need == 0) break;
+                --need;
+            }
+        }
+        src = want_up ? Wc + (size_t)k * Fp : Bd_old + (size_t)k * F;
+    }
+    for (int f = threadIdx.x; f < F; f += blockDim.x) {
+        const double v = src[f];
+        Bd_new[(size_t)j * F + f] = v;
+        Bd_f32[(size_t)j * F + f] = (float)v;
+    }
+}
+
+struct OIstftArgs {
+    const float* mag;   // column i at mag + i*ld  (magnitude^pow domain)
+    const float2* ph;
+    int64_t ld;
+    int n_frames, sz, dcb;
+    float powv, scale, preemph;  // scale = overlapscale / N
+    const float* win;
+    const float2* tw;
+    float* syn;         // frame i at syn + i*sz
+};
+
+// src/synth_ifft_buff.m:10-28 (+ the overlapscale of src/bnmf_sep_event_RT_IS16.m:363)
+template <int LOGN>
+__global__ __launch_bounds__(256) void k_oistft(OIstftArgs a) {
+    constexpr int N = 1 << LOGN;
+    __shared__ float2 bufA[N];
+    __shared__ float2 bufB[N];
+    const int t = blockIdx.x;
+    if (t >= a.n_frames) return;
+    const float* mg = a.mag + (int64_t)t * a.ld;
+    const float2* ph = a.ph + (int64_t)t * a.ld;
+    // real(ifft(X)) = real(fft(conj(X)))/N with X(N-k) = conj(X(k)) for k = 1..N/2-1 (:16-18)
+    for (int k = threadIdx.x; k < N; k += 256) {
+        const int kk = k <= N / 2 ? k : N - k;
+        float m = kk < a.dcb ? 0.f : mg[kk];                    // :10
+        if (a.powv == 2.f) m = sqrtf(m);                        // :11
+        else if (a.powv != 1.f) m = powf(m, 1.f / a.powv);
+        const float2 p = ph[kk];
+        bufA[k] = make_float2(m * p.x, k <= N / 2 ? -m * p.y : m * p.y);
+    }
+    __syncthreads();
+    float2* X = fft_lds<LOGN>(bufA, bufB, a.tw);
+    float* o = a.syn + (int64_t)t * a.sz;
+    if (a.preemph == 0.f) {
+        for (int n = threadIdx.x; n < a.sz; n += 256) o[n] = X[n].x * a.scale * a.win[n];  // :19-24
+    } else {
+        for (int n = threadIdx.x; n < a.sz; n += 256) X[n].y = X[n].x * a.scale * a.win[n];
+        __syncthreads();
+        if (threadIdx.x == 0) {  // filter(1, [1 -preemph], .) (:26)
+            float acc = 0.f;
+            for (int n = 0; n < a.sz; ++n) {
+                acc = X[n].y + a.preemph * acc;
+                o[n] = acc;
+            }
+        }
+    }
+}
+
+// Overlap-add of src/NTF_sep_event_RT.m:104-124 in closed form: the hop written at frame l is the sum
+// over the frames l-q (q = nov-1 .. 0, oldest first, only frames > delay were ever accumulated) of
+// their samples [q*hop, q*hop + hop).  syn holds nov-1 frames of the previous call, then the new ones.
+__global__ void k_oola(const float* __restrict__ syn, int n_new, int l0, int delay, int sz, int hop, int nov, int i_first,
+                       int n_out, float* __restrict__ outf, int16_t* __restrict__ out16) {
+    const size_t n = (size_t)n_out * hop;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(e / hop), s = (int)(e - (size_t)j * hop);
+        const int i = i_first + j;  // index among the new frames; global frame l = l0 + i
+        float acc = 0.f;
+        for (int q = nov - 1; q >= 0; --q) {
+            const int lq = l0 + i - q, off = q * hop + s;
+            if (lq > delay && lq >= 1 && off < sz) acc += syn[(size_t)(i - q + nov - 1) * sz + off];
+        }
+        if (outf) outf[e] = acc;
+        if (out16) {
+            float rr = copysignf(floorf(fabsf(acc) + 0.5f), acc);  // fwrite(..,'int16'): round half away, saturate
+            rr = fminf(fmaxf(rr, -32768.f), 32767.f);
+            if (!(acc == acc)) rr = 0.f;  // NaN -> 0 as MATLAB's integer conversion
+            out16[e] = (int16_t)rr;
+        }
+    }
+}
+
+}  // namespace snmf
