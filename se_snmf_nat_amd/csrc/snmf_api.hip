@@ -222,6 +222,9 @@ struct snmf_plan {
     // device buffers
     float *V = nullptr, *H[2] = {nullptr, nullptr}, *Wt4 = nullptr, *Wk4 = nullptr;
     double* Wc = nullptr;  // fp64 master copy of W (see k_wapply)
+    float* Wcf = nullptr;  // fp32 rounding of Wc, column-major [rp][Fp] (k_hsolve_frame)
+    int frame_fb = 0, frame_kb = 0;  // register-block geometry of k_hsolve_frame (0: shape not admitted)
+    size_t lds_frame = 0;
     float *dphv = nullptr, *colsum = nullptr, *lamk = nullptr, *S = nullptr, *wx = nullptr;
     float *slabs = nullptr, *spart = nullptr;
     double *part = nullptr, *stats = nullptr, *divh = nullptr, *costh = nullptr, *wn = nullptr;
@@ -294,7 +297,7 @@ extern "C" void snmf_plan_destroy(snmf_plan* pl) {
 #endif
     void* ptrs[] = {pl->V,     pl->H[0],  pl->H[1], pl->Wc,   pl->Wt4,   pl->Wk4,  pl->dphv, pl->colsum, pl->lamk,
                     pl->S,     pl->slabs, pl->spart, pl->part, pl->stats, pl->divh, pl->costh, pl->wn,    pl->st,
-                    pl->w_ind, pl->staging, pl->wx};
+                    pl->w_ind, pl->staging, pl->wx, pl->Wcf};
     for (void* q : ptrs)
         if (q) hipFree(q);
     delete pl;
@@ -428,6 +431,21 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         pl->small_ok = pl->upd_h && !pl->upd_w && need <= lds_cap;   // shape admits the persistent kernel
         pl->small = pl->small_ok && T <= 32 && !getenv("SNMF_NO_SMALL");
         pl->lds_small = need;
+        // one frame per solve: register-resident dictionary (k_hsolve_frame), F <= 64*FB + 1, r <= 8*KB
+        if (pl->small_ok && !getenv("SNMF_NO_FRAME")) {
+            static const int fbs[2] = {4, 8}, kbs[2] = {16, 25};
+            for (int fi = 0; fi < 2 && !pl->frame_fb; ++fi)
+                for (int ki = 0; ki < 2 && !pl->frame_fb; ++ki)
+                    if (F <= 64 * fbs[fi] + 1 && r <= 8 * kbs[ki]) {
+                        pl->frame_fb = fbs[fi];
+                        pl->frame_kb = kbs[ki];
+                    }
+            if (pl->frame_fb) {
+                const int Fm2 = 64 * pl->frame_fb, RB = 8 * pl->frame_kb, nv = pl->bm == BM_KL ? 1 : 2;
+                pl->lds_frame = (size_t)(32 + 4 * RB + 3 * (Fm2 + 4) + 8 * Fm2 + nv * 64 * (RB + 1)) * 4;
+                if (pl->lds_frame > lds_cap) pl->frame_fb = pl->frame_kb = 0;
+            }
+        }
     }
     // allocations
     const size_t nV = (size_t)pl->Fp * pl->Tp, nH = (size_t)pl->rp * pl->Tp, nW = (size_t)pl->Fp * pl->rp;
@@ -438,6 +456,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     A(dalloc(&pl->H[0], nH));
     A(dalloc(&pl->H[1], nH));
     A(dalloc(&pl->Wc, nW));
+    A(dalloc(&pl->Wcf, nW));
     A(dalloc(&pl->Wt4, nWt));
     A(dalloc(&pl->Wk4, nWk));
     A(dalloc(&pl->wx, (size_t)pl->rp));
@@ -467,6 +486,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     }
     hipStream_t st = ctx->stream;
     hipMemsetAsync(pl->Wc, 0, nW * 8, st);
+    hipMemsetAsync(pl->Wcf, 0, nW * 4, st);
     hipMemsetAsync(pl->Wt4, 0, nWt * 4, st);
     hipMemsetAsync(pl->Wk4, 0, nWk * 4, st);
     hipMemsetAsync(pl->wx, 0, (size_t)pl->rp * 4, st);
@@ -477,6 +497,9 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     hipMemsetAsync(pl->stats, 0, ((size_t)pl->n_mat * nW + pl->rp + 2) * 8, st);
     hipMemsetAsync(pl->w_ind, 0, pl->rp, st);
     hipMemcpyAsync(pl->w_ind, pl->h_w_ind.data(), r, hipMemcpyHostToDevice, st);
+    hipMemsetAsync(pl->st, 0, sizeof(DevState), st);  // solve_frames never goes through snmf_plan_init
+    hipMemsetAsync(pl->divh, 0, sizeof(double) * std::max(1, p->max_iter), st);
+    hipMemsetAsync(pl->costh, 0, sizeof(double) * std::max(1, p->max_iter), st);
     {
         std::vector<float> lk(pl->rp, 0.f);
         if (p->sparsity_kind == SNMF_SPARSITY_SCALAR)
@@ -779,6 +802,7 @@ static int launch_wapply(snmf_plan* pl, const double* stats, int check_it, bool 
     ApplyArgs aa{};
     aa.stats = stats;
     aa.Wc = pl->Wc;
+    aa.Wcf = pl->Wcf;
     aa.Wt4 = pl->Wt4;
     aa.Wk4 = pl->Wk4;
     aa.dphv = pl->dphv;
@@ -986,6 +1010,31 @@ static int launch_small(snmf_plan* pl, int n_solves, int tps, double* divh, doub
     };
     ScopedTimer tm(pl->ctx, FAM_HSTEP);
     const bool obj = pl->p.cost_check != 0;
+    if (tps == 1 && pl->frame_fb) {
+        auto launch_f = [&](auto kern) -> int {
+            static std::map<const void*, size_t> attr_set;
+            const void* key = (const void*)kern;
+            if (pl->lds_frame > 64 * 1024 && attr_set[key] < pl->lds_frame) {
+                HIP_TRY(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_frame));
+                attr_set[key] = pl->lds_frame;
+            }
+            hipLaunchKernelGGL(kern, dim3(n_solves), dim3(512), pl->lds_frame, pl->ctx->stream, a, sa, (const float*)pl->Wcf);
+            HIP_TRY(hipGetLastError());
+            return SNMF_OK;
+        };
+        auto by_bm = [&](auto fbc, auto kbc) -> int {
+            constexpr int FB = decltype(fbc)::value, KB = decltype(kbc)::value;
+            if (pl->bm == BM_KL) return obj ? launch_f(k_hsolve_frame<FB, KB, BM_KL, true>) : launch_f(k_hsolve_frame<FB, KB, BM_KL, false>);
+            if (pl->bm == BM_EUC) return obj ? launch_f(k_hsolve_frame<FB, KB, BM_EUC, true>) : launch_f(k_hsolve_frame<FB, KB, BM_EUC, false>);
+            return obj ? launch_f(k_hsolve_frame<FB, KB, BM_GEN, true>) : launch_f(k_hsolve_frame<FB, KB, BM_GEN, false>);
+        };
+        using I4 = std::integral_constant<int, 4>;
+        using I8 = std::integral_constant<int, 8>;
+        using I16 = std::integral_constant<int, 16>;
+        using I25 = std::integral_constant<int, 25>;
+        if (pl->frame_fb == 4) return pl->frame_kb == 16 ? by_bm(I4{}, I16{}) : by_bm(I4{}, I25{});
+        return pl->frame_kb == 16 ? by_bm(I8{}, I16{}) : by_bm(I8{}, I25{});
+    }
     if (pl->bm == BM_KL) return obj ? launch(k_hsolve_small<BM_KL, true>) : launch(k_hsolve_small<BM_KL, false>);
     if (pl->bm == BM_EUC) return obj ? launch(k_hsolve_small<BM_EUC, true>) : launch(k_hsolve_small<BM_EUC, false>);
     return obj ? launch(k_hsolve_small<BM_GEN, true>) : launch(k_hsolve_small<BM_GEN, false>);

@@ -27,6 +27,8 @@
 
 namespace snmf {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -826,6 +828,227 @@ __global__ __launch_bounds__(512, 2) void k_hsolve_small(StepArgs a, SmallArgs s
 }
 
 // ============================================================================================
+// k_hsolve_frame: the same whole-solve-in-one-launch as k_hsolve_small for ONE frame per solve
+// (tps = 1: the real online call, src/bnmf_sep_event_RT_IS16.m:148-154).  A single column wastes
+// 31/32 of every MFMA tile, which made k_hsolve_small matrix-pipe bound on one CU (2 x 1792 MFMAs
+// = 37 us per iteration at 513 x 200).  Here the dictionary lives in REGISTERS for the whole solve
+// and both products are plain fp32 FMAs with no padding:
+//   thread (kb = wave 0..7, fb = lane 0..63) holds the FB x KB block W[FB*fb + i][KB*kb + kk]
+//   P1  lam_part[i] = sum_kk W[i][kk] h[kk]      -> LDS [8][Fm] -> 8-way sum, floor, ratio, div term
+//   P2  d_part[kk]  = sum_i  W[i][kk] ratio[i]   -> LDS [64][8*KB] -> 64-way sum, H update
+// i.e. 2*FB*KB FMAs per thread per iteration and four barriers; W is read from L2 once per
+// solve instead of twice per iteration.  The extra row (F = 64*FB + 1) is a wave-level dot product.
+// Loop semantics, objective recording and the stop test are those of k_hsolve_small.
+// ============================================================================================
+template <int FB, int KB, int BM, bool OBJ>
+__global__ __launch_bounds__(512, 2) void k_hsolve_frame(StepArgs a, SmallArgs sa, const float* __restrict__ Wcf) {
+    constexpr int NTHR = 512, RB = 8 * KB, LDP = RB + 1;  // LDP odd: the 64 row-blocks hit distinct banks
+    constexpr int NV = (BM == BM_KL) ? 1 : 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    {   // this workgroup's frame
+        const size_t c0 = (size_t)blockIdx.x;
+        a.V += c0 * a.Fp;
+        a.Hin += c0 * a.rp;
+        a.Hout += c0 * a.rp;
+        if (a.S) a.S += c0 * a.rp;
+        sa.divh += (size_t)blockIdx.x * sa.max_iter;
+        sa.costh += (size_t)blockIdx.x * sa.max_iter;
+        sa.st += blockIdx.x;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, kb = tid >> 6, fb = lane;
+    const int Fm = 64 * FB;              // rows held in registers (>= F - xr; rows >= F are zero)
+    const int rp = a.rp, F = a.F;
+    const bool xr = F > Fm;              // one extra row, index Fm
+    double* red = reinterpret_cast<double*>(lds);  // [16] objective partial sums
+    float* hs = lds + 32;                // [RB]     activations (k >= r stay zero)
+    float* vs = hs + RB;                 // [Fm + 4] the frame (floored V)
+    float* va = vs + Fm + 4;             // [Fm + 4] ratio (KL) / num vector
+    float* vb = va + Fm + 4;             // [Fm + 4] den vector (beta != 1)
+    float* wxs = vb + Fm + 4;            // [RB]     extra row of W
+    float* sps = wxs + RB;               // [RB]     sparsity weights of this frame
+    float* dps = sps + RB;               // [RB]     KL: max(colsum + S, flr)
+    float* lamp = dps + RB;              // [8][Fm]  P1 partials
+    float* dmp = lamp + 8 * Fm;          // [NV][64][LDP] P2 partials
+
+    // ---- one-time loads -----------------------------------------------------------------------
+    // rows are held in PAIRS (2*i2, 2*i2+1) so that both products map onto v_pk_fma_f32 with the SAME
+    // register pairing (a second pairing would make the compiler keep two copies of the block)
+    static_assert(FB % 2 == 0, "FB must be even");
+    f32x2 wr[FB / 2][KB];
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk) {
+        const int k = kb * KB + kk;
+#pragma unroll
+        for (int i2 = 0; i2 < FB / 2; ++i2) {
+            const int f = fb * FB + 2 * i2;
+            const bool ok = k < rp && f < Fm;
+            wr[i2][kk].x = (ok && f < F) ? Wcf[(size_t)k * a.Fp + f] : 0.f;
+            wr[i2][kk].y = (ok && f + 1 < F) ? Wcf[(size_t)k * a.Fp + f + 1] : 0.f;
+        }
+    }
+    for (int k = tid; k < RB; k += NTHR) {
+        const bool in = k < rp;
+        hs[k] = in ? a.Hin[k] : 0.f;
+        wxs[k] = (in && xr) ? a.wx[k] : 0.f;
+        const float sp = in ? (a.S ? a.S[k] : a.lamk[k]) : 0.f;
+        sps[k] = sp;
+        dps[k] = in ? (a.S ? fmaxf(a.colsum[k] + sp, kFlr) : a.dphv[k]) : 1.f;
+    }
+    for (int f = tid; f < Fm + 4; f += NTHR) {
+        vs[f] = f < F ? a.V[f] : 0.f;
+        va[f] = 0.f;
+        vb[f] = 0.f;
+    }
+    __syncthreads();
+
+    double last_cost = 0.0;
+    int n_rec = 0;
+    bool stopped = false;
+    for (int j = 1; j <= sa.max_iter + 1; ++j) {
+        if (j > sa.max_iter && !(OBJ && sa.max_iter >= 1)) break;
+        const bool upd = j <= sa.max_iter;
+        // ---- P1: Lam = W * h ---------------------------------------------------------------------
+        {
+            f32x2 lp[FB / 2];
+#pragma unroll
+            for (int i2 = 0; i2 < FB / 2; ++i2) lp[i2] = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+                const float hk = hs[kb * KB + kk];  // wave-uniform address: LDS broadcast
+                const f32x2 hk2 = f32x2{hk, hk};
+#pragma unroll
+                for (int i2 = 0; i2 < FB / 2; ++i2) lp[i2] = __builtin_elementwise_fma(wr[i2][kk], hk2, lp[i2]);
+            }
+#pragma unroll
+            for (int i2 = 0; i2 < FB / 2; ++i2)
+                *reinterpret_cast<f32x2*>(lamp + kb * Fm + fb * FB + 2 * i2) = lp[i2];
+        }
+        __syncthreads();
+        float dterm = 0.f;
+        for (int f = tid; f < Fm; f += NTHR) {
+            float s = lamp[f];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) s += lamp[q * Fm + f];
+            const float lam = fmaxf(s, kFlr);
+            const float v = vs[f];
+            const bool real = f < F;
+            if (OBJ) dterm += real ? div_term<BM>(v, lam, a.beta, a.inv_bb1) : 0.f;
+            if (BM == BM_KL) {
+                va[f] = real ? v * fast_rcp(lam) : 0.f;
+            } else {
+                const float den = den_of_lam<BM>(lam, a.beta);
+                float lf = 1.f;  // lam^(beta-2) from den, as hstep_den_to_num
+                if (BM != BM_EUC) lf = (a.beta == 0.f) ? den * den : fast_pow(den, (a.beta - 2.f) / (a.beta - 1.f));
+                vb[f] = real ? den : 0.f;
+                va[f] = real ? v * lf : 0.f;
+            }
+        }
+        if (xr && kb == 0) {  // extra row: wave 0
+            float s = 0.f;
+            for (int k = lane; k < RB; k += 64) s = fmaf(wxs[k], hs[k], s);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+            if (lane == 0) {
+                const float lam = fmaxf(s, kFlr);
+                const float v = vs[Fm];
+                if (OBJ) dterm += div_term<BM>(v, lam, a.beta, a.inv_bb1);
+                if (BM == BM_KL) {
+                    va[Fm] = v * fast_rcp(lam);
+                } else {
+                    const float den = den_of_lam<BM>(lam, a.beta);
+                    float lf = 1.f;
+                    if (BM != BM_EUC) lf = (a.beta == 0.f) ? den * den : fast_pow(den, (a.beta - 2.f) / (a.beta - 1.f));
+                    vb[Fm] = den;
+                    va[Fm] = v * lf;
+                }
+            }
+        }
+        if (OBJ && j > 1) {
+            // cost_{j-1} = div(V, W*H_{j-1}) + sum(S .* H_{j-1}); fixed-order fp64 sums
+            double dv = (double)dterm, sh = 0.0;
+            for (int k = tid; k < RB; k += NTHR) sh += (double)(sps[k] * hs[k]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                dv += __shfl_down(dv, o, 64);
+                sh += __shfl_down(sh, o, 64);
+            }
+            if (lane == 0) {
+                red[kb] = dv;
+                red[8 + kb] = sh;
+            }
+            __syncthreads();
+            double div = 0.0, shs = 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                div += red[q];
+                shs += red[8 + q];
+            }
+            const double cost = div + shs;
+            const int it = j - 1;
+            bool stopnow = false;
+            if (it > 1 && sa.conv_eps > 0.0) stopnow = fabs(cost - last_cost) / last_cost < sa.conv_eps;
+            if (tid == 0) {
+                sa.divh[it - 1] = div;
+                sa.costh[it - 1] = cost;
+            }
+            n_rec = it;
+            last_cost = cost;
+            if (stopnow) {
+                stopped = true;
+                break;
+            }
+        } else {
+            __syncthreads();
+        }
+        if (!upd) break;
+        // ---- P2: W^T * ratio (and W^T * den for beta != 1) -----------------------------------------
+        {
+            f32x2 ra[FB / 2], rb[FB / 2];
+#pragma unroll
+            for (int i2 = 0; i2 < FB / 2; ++i2) {
+                ra[i2] = *reinterpret_cast<const f32x2*>(va + fb * FB + 2 * i2);
+                if (NV == 2) rb[i2] = *reinterpret_cast<const f32x2*>(vb + fb * FB + 2 * i2);
+            }
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+                f32x2 pa = f32x2{0.f, 0.f}, pb = f32x2{0.f, 0.f};
+#pragma unroll
+                for (int i2 = 0; i2 < FB / 2; ++i2) {
+                    pa = __builtin_elementwise_fma(wr[i2][kk], ra[i2], pa);
+                    if (NV == 2) pb = __builtin_elementwise_fma(wr[i2][kk], rb[i2], pb);
+                }
+                dmp[fb * LDP + kb * KB + kk] = pa.x + pa.y;
+                if (NV == 2) dmp[64 * LDP + fb * LDP + kb * KB + kk] = pb.x + pb.y;
+            }
+        }
+        __syncthreads();
+        for (int k = tid; k < RB; k += NTHR) {
+            float sa_ = 0.f, sb_ = 0.f;
+#pragma unroll 8
+            for (int q = 0; q < 64; ++q) {
+                sa_ += dmp[q * LDP + k];
+                if (NV == 2) sb_ += dmp[64 * LDP + q * LDP + k];
+            }
+            if (xr) {
+                sa_ = fmaf(wxs[k], va[Fm], sa_);
+                if (NV == 2) sb_ = fmaf(wxs[k], vb[Fm], sb_);
+            }
+            const float ho = hs[k];
+            float hn;
+            if (BM == BM_KL) hn = ho * sa_ * fast_rcp(dps[k]);                 // H .* dmh ./ dph  (:194-195)
+            else hn = ho * fast_rcp(fmaxf(sb_ + sps[k], kFlr)) * sa_;          // :196-205
+            hs[k] = k < a.rp ? hn : 0.f;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        sa.st->n_iter = n_rec;
+        sa.st->stop = stopped ? 1 : 0;
+    }
+    for (int k = tid; k < rp; k += NTHR) a.Hout[k] = k < RB ? hs[k] : 0.f;
+}
+
+// ============================================================================================
 // k_wstats: the T-reductions of the W half-step, src/sparse_nmf.m:215-239.
 //   WM 0 (KL)      : slab = (V ./ Lam') * H^T        and s = rowsum(H)
 //   WM 1 (P)       : slab = Lam'^(beta-1) * H^T
@@ -1273,6 +1496,7 @@ __device__ __forceinline__ bool conv_test(const double* sc, double* divh, double
 struct ApplyArgs {
     const double* stats;
     double* Wc;       // [rp][Fp] master copy, column-major, fp64 (see k_wapply)
+    float* Wcf;       // [rp][Fp] the same rounded to fp32 (k_hsolve_frame loads its register blocks from it)
     float* Wt4;
     float* Wk4;
     float* dphv;
@@ -1301,7 +1525,7 @@ struct ApplyArgs {
 // F x r: keeping it in fp64 costs nothing measurable.
 __global__ __launch_bounds__(256) void k_wapply(ApplyArgs a) {
     __shared__ double red[3][256];
-    if (a.st->stop) return;
+    if (!a.init_mode && a.st->stop) return;  // normalising a fresh W never depends on an earlier solve's flag
     const int k = blockIdx.x;
     const int tid = threadIdx.x;
     const size_t nel = (size_t)a.rp * a.Fp;
@@ -1372,6 +1596,7 @@ __global__ __launch_bounds__(256) void k_wapply(ApplyArgs a) {
         const float wf = (float)wd;  // operand images: an entry below fp32 range adds < 1e-38*max(h) to Lam, far under the 1e-9 floor
         cW += (double)wf;
         wc[f] = wd;
+        a.Wcf[(size_t)k * a.Fp + f] = wf;
         if (f < a.Fm) {  // Wt4[phi][q][h][f32][e] = W[32phi+f32][8q+4h+e]
             const int phi = f >> 5, f32 = f & 31, q = k >> 3, hh = (k >> 2) & 1, e = k & 3;
             a.Wt4[(((size_t)phi * (a.rp / 8) + q) * 2 + hh) * 128 + f32 * 4 + e] = wf;
