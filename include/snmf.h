@@ -212,6 +212,20 @@ int snmf_plan_set_v_from_audio_f32(snmf_plan* plan, const snmf_stft_params* sp, 
 int snmf_mel_features_f32(snmf_ctx* ctx, const float* mel, int32_t M, int32_t n, int32_t K, const float* V,
                           int64_t ldv, int32_t T, float* out, int64_t ldo, int on_device);
 
+/* ---- missing-data imputation variants --------------------------------
+ * [v_MDI, h, objective] = snmf_mdi(v, Dm, p)     src/snmf_mdi.m:1      (binary observed mask)
+ * [v_MDI, h, objective] = snmf_mdi_Sm(v, Sm, p)  src/snmf_mdi_Sm.m:1   (soft mask in [0,1])
+ * The same solver with a masked start (:175), a re-imputation of v after every iteration (:251-254)
+ * and a gain-matched final imputation (:296-306).  A plan becomes an MDI solve by giving it a mask
+ * (F x T, 1 = observed) before snmf_plan_set_v / snmf_plan_init; the H update must be on
+ * (h_update_ind all true; W-only MDI is not implemented).  The wrappers map p.sparsity_mdi and
+ * p.conv_eps_mdi onto the plan's sparsity / conv_eps. */
+int snmf_plan_set_mask_f64(snmf_plan* plan, const double* M, int64_t ld, int on_device);
+int snmf_plan_set_mask_f32(snmf_plan* plan, const float* M, int64_t ld, int on_device);
+/* v_MDI (:296-306) after snmf_plan_run: F x T, observed entries kept, the rest Nt .* max(w*h, flr). */
+int snmf_plan_get_v_mdi_f64(snmf_plan* plan, double* V, int64_t ld, int on_device);
+int snmf_plan_get_v_mdi_f32(snmf_plan* plan, float* V, int64_t ld, int on_device);
+
 /* ---- online separation loop (BASELINE config 3) -------------------
  * Device-resident replacement of the per-frame function
  *   [x_hat_i, d_hat_i, x_tilde, g] = bnmf_sep_event_RT_IS16(y, l, g, p)   src/bnmf_sep_event_RT_IS16.m:1

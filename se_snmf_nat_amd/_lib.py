@@ -33,6 +33,7 @@ SYMBOLS = [
     "snmf_plan_get_objective", "snmf_plan_solve_frames_f64", "snmf_plan_solve_frames_f32",
     "snmf_ctx_timing", "snmf_ctx_timing_get", "snmf_plan_describe",
     "snmf_stft_num_frames", "snmf_stft_features_f32", "snmf_plan_set_v_from_audio_f32", "snmf_mel_features_f32",
+    "snmf_plan_set_mask_f64", "snmf_plan_set_mask_f32", "snmf_plan_get_v_mdi_f64", "snmf_plan_get_v_mdi_f32",
     "snmf_online_create", "snmf_online_process_f32", "snmf_online_get_basis_f32", "snmf_online_trace",
     "snmf_online_destroy",
 ]
@@ -187,9 +188,11 @@ def load():
     sig["snmf_online_destroy"] = (None, [vp])
     for ty in ("f64", "f32"):
         sig[f"snmf_plan_solve_frames_{ty}"] = (C.c_int, [vp, i32, vp, i64, i32, vp, vp, vp, vp])
-    for nm in ("v", "w", "h"):
+    for nm in ("v", "w", "h", "mask"):
         for ty in ("f64", "f32"):
             sig[f"snmf_plan_set_{nm}_{ty}"] = (C.c_int, [vp, vp, i64, C.c_int])
+    for ty in ("f64", "f32"):
+        sig[f"snmf_plan_get_v_mdi_{ty}"] = (C.c_int, [vp, vp, i64, C.c_int])
     for nm in ("w", "h"):
         for ty in ("f64", "f32"):
             sig[f"snmf_plan_get_{nm}_{ty}"] = (C.c_int, [vp, vp, i64, C.c_int])

@@ -19,7 +19,8 @@ import numpy as np
 from . import _lib
 from ._lib import SnmfError, SnmfParams
 
-__all__ = ["Context", "Plan", "sparse_nmf", "sparse_nmf_GPU", "run_basis_dnmf", "SnmfError", "default_context"]
+__all__ = ["Context", "Plan", "sparse_nmf", "sparse_nmf_GPU", "run_basis_dnmf", "snmf_mdi", "snmf_mdi_Sm", "SnmfError",
+           "default_context"]
 
 
 def _ptr(a):
@@ -304,6 +305,18 @@ class Plan:
     def set_h(self, h):
         self._set("h", h, self.r)
 
+    def set_mask(self, m):
+        """Observed (1) / missing (0) mask, binary or soft: turns the plan into an MDI solve (src/snmf_mdi.m)."""
+        self._set("mask", np.asarray(m, dtype=np.float64) if not hasattr(m, "data_ptr") else m, self.F)
+
+    def get_v_mdi(self, dtype=np.float64):
+        """v_MDI of src/snmf_mdi.m:296-306."""
+        dt = np.dtype(dtype)
+        out = np.empty((self.F, self.T), dtype=dt, order="F")
+        fn = self._lib.snmf_plan_get_v_mdi_f64 if dt == np.float64 else self._lib.snmf_plan_get_v_mdi_f32
+        _lib.check(fn(self._h, _ptr(out), self.F, 0))
+        return out
+
     def init(self):
         _lib.check(self._lib.snmf_plan_init(self._h))
 
@@ -396,3 +409,74 @@ class Plan:
             self.close()
         except Exception:
             pass
+
+
+def _mdi(v, mask, p, *, ctx, dtype, rng):
+    """Shared body of snmf_mdi / snmf_mdi_Sm: src/snmf_mdi.m:71-312 (the two files differ only in how the
+    mask argument is named and complemented; `.*~Dm` equals `.*(1-Sm)` for a 0/1 mask)."""
+    p = dict(p or {})
+    dt = np.dtype(dtype)
+    v = np.asarray(v)
+    mask = np.asarray(mask, dtype=np.float64)
+    if v.ndim != 2 or mask.shape != v.shape:
+        raise SnmfError(3, "v must be 2-D and the mask must have its size")
+    m, n = v.shape
+    max_iter = int(p.get("max_iter", 100))  # :83-85
+    seed = p.get("random_seed", 1)
+    if "sparsity" not in p:  # :87-89 (the default is installed only when p.sparsity is ABSENT)
+        p.setdefault("sparsity_mdi", 0)
+    if "conv_eps" not in p:  # :91-93
+        p.setdefault("conv_eps_mdi", 0)
+    for fld in ("sparsity_mdi", "conv_eps_mdi", "cost_check"):
+        if fld not in p:
+            raise KeyError(f"Reference to non-existent field '{fld}'.")
+    beta = _cf_to_beta(p)
+    if rng is None:
+        rng = np.random.RandomState(int(seed) if seed and seed > 0 else None)  # stand-in for rand('seed',s)
+    if p.get("init_w") is None:  # :116-131
+        if "r" not in p:
+            raise SnmfError(2, "Number of components or initialization must be given")
+        w0 = rng.random_sample((m, int(p["r"])))
+    else:
+        w0 = np.asarray(p["init_w"], dtype=np.float64)
+        if p.get("r") is not None and w0.shape[1] < int(p["r"]):
+            w0 = np.concatenate([w0, rng.random_sample((m, int(p["r"]) - w0.shape[1]))], axis=1)
+    r = w0.shape[1]
+    init_h = p.get("init_h")  # :133-140
+    if init_h is None:
+        h0 = rng.random_sample((r, n))
+    elif isinstance(init_h, str) and init_h == "ones":
+        h0 = np.ones((r, n))
+    else:
+        h0 = np.asarray(init_h, dtype=np.float64)
+        if h0.shape != (r, n):
+            raise SnmfError(3, "init_h must be r x n")
+    w_ind, h_ind = _mask(p, "w_update_ind", r), _mask(p, "h_update_ind", r)
+    plan = Plan(ctx or default_context(), m, n, r, beta=beta, max_iter=max_iter, conv_eps=float(p["conv_eps_mdi"]),
+                cost_check=bool(p["cost_check"]), floor_v=True, sparsity=p["sparsity_mdi"], w_update_ind=w_ind,
+                h_update_ind=h_ind)
+    try:
+        plan.set_mask(mask)
+        plan.set_v(v.astype(dt, copy=False) if v.dtype != dt else v)
+        plan.set_w(w0)
+        plan.set_h(h0)
+        plan.init()
+        n_it = plan.run()
+        v_mdi = plan.get_v_mdi(dtype=dt)
+        h = plan.get_h(dtype=dt)
+        div, cost, nn = plan.get_objective()
+        stopped = plan.stopped()
+    finally:
+        plan.close()
+    k = nn if stopped else max_iter  # :286-287 truncation on convergence only
+    return v_mdi, h, {"div": div[:k], "cost": cost[:k], "n_iter": n_it}
+
+
+def snmf_mdi(v, Dm, p=None, *, ctx=None, dtype=np.float64, rng=None):
+    """[v_MDI, h, objective] = snmf_mdi(v, Dm, p)  -- src/snmf_mdi.m:1 (Dm: 1 = observed, 0 = missing)."""
+    return _mdi(v, np.asarray(Dm) != 0, p, ctx=ctx, dtype=dtype, rng=rng)
+
+
+def snmf_mdi_Sm(v, Sm, p=None, *, ctx=None, dtype=np.float64, rng=None):
+    """[v_MDI, h, objective] = snmf_mdi_Sm(v, Sm, p)  -- src/snmf_mdi_Sm.m:1 (soft mask in [0,1])."""
+    return _mdi(v, Sm, p, ctx=ctx, dtype=dtype, rng=rng)

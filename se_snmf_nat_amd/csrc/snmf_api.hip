@@ -224,6 +224,10 @@ struct snmf_plan {
     double* Wc = nullptr;  // fp64 master copy of W (see k_wapply)
     float* Wcf = nullptr;  // fp32 rounding of Wc, column-major [rp][Fp] (k_hsolve_frame)
     int frame_fb = 0, frame_kb = 0;  // register-block geometry of k_hsolve_frame (0: shape not admitted)
+    float* M = nullptr;    // MDI: observed/missing mask in V's layout (src/snmf_mdi.m); non-null = MDI solve
+    bool mdi_v_fresh = false, mdi_final = false;
+    size_t lds_mdi = 0;
+    int grid_mdi = 1;
     size_t lds_frame = 0;
     float *dphv = nullptr, *colsum = nullptr, *lamk = nullptr, *S = nullptr, *wx = nullptr;
     float *slabs = nullptr, *spart = nullptr;
@@ -297,7 +301,7 @@ extern "C" void snmf_plan_destroy(snmf_plan* pl) {
 #endif
     void* ptrs[] = {pl->V,     pl->H[0],  pl->H[1], pl->Wc,   pl->Wt4,   pl->Wk4,  pl->dphv, pl->colsum, pl->lamk,
                     pl->S,     pl->slabs, pl->spart, pl->part, pl->stats, pl->divh, pl->costh, pl->wn,    pl->st,
-                    pl->w_ind, pl->staging, pl->wx, pl->Wcf};
+                    pl->w_ind, pl->staging, pl->wx, pl->Wcf, pl->M};
     for (void* q : ptrs)
         if (q) hipFree(q);
     delete pl;
@@ -373,6 +377,8 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     }
     pl->lds_h = std::max<size_t>(pl->NLH ? 2 * lds1 - lds_extra : (pl->NT == 1 ? lds1 : lds2),
                                  2 * kMaxNW * 64 * sizeof(double));
+    pl->lds_mdi = std::max<size_t>(lds1, 2 * kMaxNW * 64 * sizeof(double));  // MDI pass: (NW=8, NT=1, NL=0)
+    pl->grid_mdi = std::max(1, std::min(pl->Tp / 32, ctx->n_cu));
     const int n_tiles_h = pl->Tp / (32 * pl->NT);
     // without loaders the NT == 1 kernels are register-bounded for two workgroups per CU
     int wg_per_cu = (pl->lds_h * 2 <= lds_cap && pl->NT == 1 && !pl->NLH) ? 2 : 1;
@@ -604,8 +610,24 @@ static int set_v(snmf_plan* pl, const T* V, int64_t ld, int dev) {
     PLAN_CHECK(pl);
     SN_TRY(pack_in<T>(pl, V, ld, pl->p.F, pl->p.T, pl->V, pl->Fp, pl->Tp, pl->p.floor_v != 0, dev));
     pl->have_v = true;
+    pl->mdi_v_fresh = true;
     return SNMF_OK;
 }
+// MDI: the mask turns the plan into a solve of src/snmf_mdi.m / src/snmf_mdi_Sm.m
+template <typename T>
+static int set_mask(snmf_plan* pl, const T* M, int64_t ld, int dev) {
+    PLAN_CHECK(pl);
+    if (!pl->upd_h) return fail(SNMF_ERR_UNSUPPORTED, "MDI needs the H update (h_update_ind all true); W-only MDI is not implemented");
+    if (!pl->M) {
+        SN_TRY(dalloc(&pl->M, (size_t)pl->Fp * pl->Tp));
+    }
+    SN_TRY(pack_in<T>(pl, M, ld, pl->p.F, pl->p.T, pl->M, pl->Fp, pl->Tp, false, dev));
+    pl->small = false;  // the persistent kernels carry no imputation step
+    pl->inited = false;
+    return SNMF_OK;
+}
+extern "C" int snmf_plan_set_mask_f64(snmf_plan* pl, const double* M, int64_t ld, int dev) { return set_mask<double>(pl, M, ld, dev); }
+extern "C" int snmf_plan_set_mask_f32(snmf_plan* pl, const float* M, int64_t ld, int dev) { return set_mask<float>(pl, M, ld, dev); }
 template <typename T>
 static int set_w(snmf_plan* pl, const T* W, int64_t ld, int dev) {
     PLAN_CHECK(pl);
@@ -723,11 +745,30 @@ static int launch_hstep_g(snmf_plan* pl, const StepArgs& a, bool obj, bool upd) 
     if (pl->bm == BM_EUC) return launch_hstep_nb<NW, NT, NL, BM_EUC>(pl, a, obj, upd);
     return launch_hstep_nb<NW, NT, NL, BM_GEN>(pl, a, obj, upd);
 }
+// MDI pass (src/snmf_mdi.m:251-257 fused into the Lam pass): synchronous-staging geometry, V rewritten in place
+template <int BM>
+static int launch_hstep_mdi_b(snmf_plan* pl, const StepArgs& a, bool obj, bool upd) {
+    dim3 g(pl->grid_mdi), b(8 * 64);
+    hipStream_t st = pl->ctx->stream;
+    if (upd) return obj ? launch_big(k_hstep<8, 1, 0, BM, true, true, true>, g, b, pl->lds_mdi, st, a)
+                        : launch_big(k_hstep<8, 1, 0, BM, false, true, true>, g, b, pl->lds_mdi, st, a);
+    return launch_big(k_hstep<8, 1, 0, BM, true, false, true>, g, b, pl->lds_mdi, st, a);  // imputation (+ objective)
+}
 static int launch_hstep(snmf_plan* pl, bool obj, bool upd) {
     StepArgs a = make_args(pl);
     a.n_tiles = pl->Tp / (32 * pl->NT);
     a.stagger = pl->stagger_h;
     ScopedTimer tm(pl->ctx, FAM_HSTEP);
+    if (pl->M) {
+        a.n_tiles = pl->Tp / 32;
+        a.stagger = 0;
+        a.M = pl->M;
+        a.Vw = pl->V;
+        a.impute = pl->it_done >= 1 ? 1 : 0;  // the first Lam pass precedes any imputation (:175 only)
+        if (pl->bm == BM_KL) return launch_hstep_mdi_b<BM_KL>(pl, a, obj, upd);
+        if (pl->bm == BM_EUC) return launch_hstep_mdi_b<BM_EUC>(pl, a, obj, upd);
+        return launch_hstep_mdi_b<BM_GEN>(pl, a, obj, upd);
+    }
     if (pl->NWH == 8 && pl->NLH == 4) return launch_hstep_g<8, 1, 4>(pl, a, obj, upd);
     if (pl->NWH == 4) return pl->NT == 2 ? launch_hstep_g<4, 2, 0>(pl, a, obj, upd) : launch_hstep_g<4, 1, 0>(pl, a, obj, upd);
     return pl->NT == 2 ? launch_hstep_g<8, 2, 0>(pl, a, obj, upd) : launch_hstep_g<8, 1, 0>(pl, a, obj, upd);
@@ -856,6 +897,16 @@ extern "C" int snmf_plan_init(snmf_plan* pl) {
     if (pl->w_dirty) SN_TRY(launch_wapply(pl, pl->stats, 0, false, true));
     pl->w_dirty = false;
     pl->small_done = false;
+    if (pl->M) {
+        // v = max(v .* M, flr) (src/snmf_mdi.m:175).  V is state in an MDI solve (re-imputed every iteration),
+        // so each solve needs its own snmf_plan_set_v.
+        if (!pl->mdi_v_fresh) return fail(SNMF_ERR_STATE, "MDI: snmf_plan_set_v must precede every snmf_plan_init (V is rewritten by the solve)");
+        hipLaunchKernelGGL(k_mdi_start, dim3(grid_for((size_t)pl->Fp * pl->p.T)), dim3(256), 0, st, pl->V, (const float*)pl->M, pl->Fp,
+                           pl->p.F, pl->p.T, kFlr);
+        HIP_TRY(hipGetLastError());
+        pl->mdi_v_fresh = false;
+        pl->mdi_final = false;
+    }
     // h = h .* wn'
     const size_t nH = (size_t)pl->rp * pl->Tp;
     hipLaunchKernelGGL(k_scale_h, dim3(grid_for(nH)), dim3(256), 0, st, pl->H[pl->cur], pl->wn, pl->rp, pl->p.r, nH);
@@ -1075,6 +1126,12 @@ extern "C" int snmf_plan_run(snmf_plan* pl, int32_t n_iters, int32_t* iters_done
         }
     }
     if (!stopped && pl->it_done >= pl->p.max_iter) SN_TRY(finalize_objective(pl));
+    if (pl->M && !stopped && pl->it_done >= pl->p.max_iter && !pl->mdi_final) {
+        // the re-imputation of the last iteration (src/snmf_mdi.m:251-254) rides on the final objective pass;
+        // without cost_check that pass does not exist, so run the Lam pass for its imputation alone
+        if (!pl->p.cost_check && pl->it_done >= 1) SN_TRY(launch_hstep(pl, true, false));
+        pl->mdi_final = true;
+    }
     if (iters_done) {
         DevState hs{};
         SN_TRY(read_state(pl, &hs));
@@ -1107,6 +1164,32 @@ extern "C" int snmf_plan_get_h_f32(snmf_plan* pl, float* H, int64_t ld, int d) {
     SN_TRY(result_h_index(pl, &idx));
     return unpack_out<float>(pl, pl->H[idx], pl->rp, pl->p.r, pl->p.T, H, ld, d);
 }
+
+// v_MDI of src/snmf_mdi.m:296-306 from the solve's final (W, H, V)
+template <typename T>
+static int get_v_mdi(snmf_plan* pl, T* V, int64_t ld, int dev) {
+    PLAN_CHECK(pl);
+    if (!pl->M) return fail(SNMF_ERR_STATE, "not an MDI plan (snmf_plan_set_mask was not called)");
+    if (!pl->inited || pl->it_done < 1) return fail(SNMF_ERR_STATE, "snmf_plan_run must precede get_v_mdi");
+    HIP_TRY(hipSetDevice(pl->ctx->device));
+    hipStream_t st = pl->ctx->stream;
+    int idx = 0;
+    SN_TRY(result_h_index(pl, &idx));
+    const int F = pl->p.F, Tn = pl->p.T;
+    float* tmp = nullptr;
+    SN_TRY(dalloc(&tmp, (size_t)F * Tn));
+    constexpr int NC = 8;
+    const size_t lds = (size_t)(NC * pl->rp + NC * F + 1) * 4 + 2 * NC * 4 * sizeof(double);
+    hipLaunchKernelGGL(k_mdi_final<NC>, dim3((Tn + NC - 1) / NC), dim3(256), lds, st, (const float*)pl->V, (const float*)pl->M,
+                       (const float*)pl->Wcf, (const float*)pl->H[idx], F, pl->Fp, pl->p.r, pl->rp, Tn, kFlr, tmp);
+    int rc = hipGetLastError() == hipSuccess ? SNMF_OK : fail(SNMF_ERR_NO_DEVICE, "k_mdi_final launch failed");
+    if (rc == SNMF_OK) rc = unpack_out<T, float>(pl, tmp, F, F, Tn, V, ld, dev);
+    hipStreamSynchronize(st);
+    hipFree(tmp);
+    return rc;
+}
+extern "C" int snmf_plan_get_v_mdi_f64(snmf_plan* pl, double* V, int64_t ld, int dev) { return get_v_mdi<double>(pl, V, ld, dev); }
+extern "C" int snmf_plan_get_v_mdi_f32(snmf_plan* pl, float* V, int64_t ld, int dev) { return get_v_mdi<float>(pl, V, ld, dev); }
 
 extern "C" int snmf_plan_get_objective(snmf_plan* pl, double* div_out, double* cost_out, int32_t* n_iter_out) {
     PLAN_CHECK(pl);

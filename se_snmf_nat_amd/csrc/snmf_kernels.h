@@ -128,6 +128,9 @@ struct StepArgs {
     const int* stop;      // device flag: convergence reached -> kernels become no-ops
     unsigned long long* prof;  // -DSNMF_PROF diagnostic builds only: per-wave phase cycle sums
     const float* wx;      // extra-row mode: W[Fm, k]  [rp]
+    const float* M;       // MDI: observed/missing mask in V's layout (1 = observed), src/snmf_mdi.m
+    float* Vw;            // MDI: V, writable (re-imputed in place by the Lam pass)
+    int impute;           // MDI: this pass carries the re-imputation of the previous iteration (:251-254)
     int F, T, Fp, rp, Tp, nf, nk;
     int Fm;               // rows covered by MFMA tiles = 32*nf
     int Fq;               // contraction length of W^T*ratio = Fm + 8*xr
@@ -363,7 +366,9 @@ constexpr int kPF = 20;  // f32x4 a loader thread keeps in flight (covers 32*(rp
 
 // VG: V is read from global memory (persistent small-problem kernel: the LDS V image would be
 // destroyed by the in-place ratio, and V is L2-resident there) instead of the staged LDS image.
-template <int NW, int NT, int BM, bool OBJ, bool VG = false>
+// MDI (src/snmf_mdi.m:251-257): the Lam this pass forms is also the estimate that re-imputes V,
+//   v <- max(v.*M + Lam.*(1-M), flr), written back for the W step, BEFORE the objective and the ratio use it.
+template <int NW, int NT, int BM, bool OBJ, bool VG = false, bool MDI = false>
 __device__ __forceinline__ void hstep_p1_tiles(const StepArgs& a, float* Hs, float* Rs, int t0, int w, int lane,
                                                bool upd, double& acc_div) {
     constexpr int Tt = 32 * NT;
@@ -375,14 +380,16 @@ __device__ __forceinline__ void hstep_p1_tiles(const StepArgs& a, float* Hs, flo
 #pragma unroll
         for (int tau = 0; tau < NT; ++tau) acc[tau] = zero16();
         const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)phi * rp * 32) + lane;
-        f32x4 vfr[NT][4];
-        if (VG) {
+        f32x4 vfr[NT][4], mfr[NT][4];
+        if (VG || MDI) {
 #pragma unroll
             for (int tau = 0; tau < NT; ++tau)
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    vfr[tau][g] = *reinterpret_cast<const f32x4*>(a.V + (size_t)(t0 + tau * 32 + fl) * a.Fp + phi * 32 +
-                                                                  4 * h + 8 * g);
+                for (int g = 0; g < 4; ++g) {
+                    const size_t off = (size_t)(t0 + tau * 32 + fl) * a.Fp + phi * 32 + 4 * h + 8 * g;
+                    vfr[tau][g] = *reinterpret_cast<const f32x4*>(a.V + off);
+                    if (MDI) mfr[tau][g] = *reinterpret_cast<const f32x4*>(a.M + off);
+                }
         }
         contract<NT, false>(acc, wp, Hs + fl * ldh + 4 * h, 32 * ldh, rp / 8);
         // epilogue: lane (t = fl, h), reg -> f = 32*phi + drow(reg,h)
@@ -393,7 +400,16 @@ __device__ __forceinline__ void hstep_p1_tiles(const StepArgs& a, float* Hs, flo
             float* rsp = Rs + (tau * 32 + fl) * ldr + phi * 32 + 4 * h;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 v = VG ? vfr[tau][g] : *reinterpret_cast<const f32x4*>(rsp + 8 * g);  // staged V
+                f32x4 v = (VG || MDI) ? vfr[tau][g] : *reinterpret_cast<const f32x4*>(rsp + 8 * g);  // staged V
+                if (MDI && a.impute) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int f = phi * 32 + 8 * g + 4 * h + j;
+                        const float lam = fmaxf(acc[tau][4 * g + j], kFlr), mk = mfr[tau][g][j];
+                        v[j] = (f < a.F && t < a.T) ? fmaxf(v[j] * mk + lam * (1.f - mk), kFlr) : 0.f;  // pads stay zero
+                    }
+                    *reinterpret_cast<f32x4*>(a.Vw + (size_t)t * a.Fp + phi * 32 + 4 * h + 8 * g) = v;
+                }
                 f32x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -414,7 +430,7 @@ __device__ __forceinline__ void hstep_p1_tiles(const StepArgs& a, float* Hs, flo
 }
 
 // extra row (F = 32*nf + 1): lam_x[t] = sum_k W[Fm,k] H[k,t] on the VALU, 4 columns x 16 lanes at a time
-template <int NW, int NT, int BM, bool OBJ, bool VG = false>
+template <int NW, int NT, int BM, bool OBJ, bool VG = false, bool MDI = false>
 __device__ __forceinline__ void hstep_p1_xrow(const StepArgs& a, float* Hs, float* Rs, const float* wxs, int t0, int w,
                                               int lane, bool upd, double& acc_div) {
     constexpr int Tt = 32 * NT;
@@ -442,8 +458,13 @@ __device__ __forceinline__ void hstep_p1_xrow(const StepArgs& a, float* Hs, floa
             s += __shfl_xor(s, 8);
             if (kl == 0) {
                 const int t = t0 + tl;
-                const float v = VG ? a.V[(size_t)t * a.Fp + a.Fm] : Rs[tl * ldr + a.Fm];  // staged V
+                float v = (VG || MDI) ? a.V[(size_t)t * a.Fp + a.Fm] : Rs[tl * ldr + a.Fm];  // staged V
                 const float lam = fmaxf(s, kFlr);
+                if (MDI && a.impute) {
+                    const float mk = a.M[(size_t)t * a.Fp + a.Fm];
+                    v = t < a.T ? fmaxf(v * mk + lam * (1.f - mk), kFlr) : 0.f;
+                    a.Vw[(size_t)t * a.Fp + a.Fm] = v;
+                }
                 if (OBJ) dsum += (t < a.T) ? div_term<BM>(v, lam, a.beta, a.inv_bb1) : 0.f;
                 if (upd) Rs[tl * ldr + a.Fm] = (BM == BM_KL) ? v * fast_rcp(lam) : den_of_lam<BM>(lam, a.beta);
             }
@@ -455,13 +476,13 @@ __device__ __forceinline__ void hstep_p1_xrow(const StepArgs& a, float* Hs, floa
 // P1 of one wave.  The second half of the waves (the SIMD partners of the first half) run their
 // VALU-only extra-row work FIRST: the two waves of a SIMD then reach their MFMA loops, and later
 // their VALU epilogues, at different times instead of colliding on both.
-template <int NW, int NT, int BM, bool OBJ, bool VG = false>
+template <int NW, int NT, int BM, bool OBJ, bool VG = false, bool MDI = false>
 __device__ __forceinline__ void hstep_p1(const StepArgs& a, float* Hs, float* Rs, const float* wxs, int t0, int w,
                                          int lane, bool upd, double& acc_div) {
     const bool xfirst = a.xr && (w >= NW / 2);
-    if (xfirst) hstep_p1_xrow<NW, NT, BM, OBJ, VG>(a, Hs, Rs, wxs, t0, w, lane, upd, acc_div);
-    hstep_p1_tiles<NW, NT, BM, OBJ, VG>(a, Hs, Rs, t0, w, lane, upd, acc_div);
-    if (a.xr && !xfirst) hstep_p1_xrow<NW, NT, BM, OBJ, VG>(a, Hs, Rs, wxs, t0, w, lane, upd, acc_div);
+    if (xfirst) hstep_p1_xrow<NW, NT, BM, OBJ, VG, MDI>(a, Hs, Rs, wxs, t0, w, lane, upd, acc_div);
+    hstep_p1_tiles<NW, NT, BM, OBJ, VG, MDI>(a, Hs, Rs, t0, w, lane, upd, acc_div);
+    if (a.xr && !xfirst) hstep_p1_xrow<NW, NT, BM, OBJ, VG, MDI>(a, Hs, Rs, wxs, t0, w, lane, upd, acc_div);
 }
 
 // beta != 1: in-place transform of this wave's part of the image, den = lam^(b-1) -> num = V .* lam^(b-2)
@@ -591,8 +612,9 @@ __device__ __forceinline__ void hstep_p2(const StepArgs& a, float* Hs, const flo
 //   B2 | consumers: P2(cur) [+2 barriers for beta != 1]     loaders: regs -> nxt
 // so the only thing the consumers ever wait for is each other.
 // ============================================================================================
-template <int NW, int NT, int NL, int BM, bool OBJ, bool UPD>
+template <int NW, int NT, int NL, int BM, bool OBJ, bool UPD, bool MDI = false>
 __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(StepArgs a) {
+    static_assert(!MDI || NL == 0, "the MDI pass reads and rewrites V in global memory: synchronous staging only");
     constexpr int NTHR = (NW + NL) * 64;
     constexpr int NBUF = NL > 0 ? 2 : 1;
     if (a.stop && *a.stop) return;
@@ -660,7 +682,7 @@ __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(Step
             }
             __syncthreads();  // B1
             SNMF_STAMP(2);
-            hstep_p1<NW, NT, BM, OBJ>(a, Hs, Rs, wxs, t0, w, lane, UPD, acc_div);
+            hstep_p1<NW, NT, BM, OBJ, false, MDI>(a, Hs, Rs, wxs, t0, w, lane, UPD, acc_div);
             SNMF_STAMP(4);
             if (UPD || NL > 0) __syncthreads();  // B2
             SNMF_STAMP(7);
@@ -1716,6 +1738,82 @@ __global__ void k_unpack(const TSrc* __restrict__ src, int rowsP, int rows, int 
         const int rr = (int)(i % rows);
         const size_t c = i / rows;
         dst[c * ld + rr] = (TOut)src[c * rowsP + rr];
+    }
+}
+
+// ---- MDI helpers (src/snmf_mdi.m) ---------------------------------------------------------------
+// v = max(v .* M, flr) on the real entries (:175); pads stay zero
+__global__ void k_mdi_start(float* V, const float* __restrict__ M, int Fp, int F, int T, float flr) {
+    const size_t n = (size_t)Fp * T;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        if ((int)(i % Fp) < F) V[i] = fmaxf(V[i] * M[i], flr);
+}
+
+// v_MDI = max(v.*M + Nt .* max(w*h,flr) .* (1-M), flr),  Nt = sum(v.*M) ./ max(sum(max(w*h,flr).*M), flr)  (:298-306)
+// One 256-thread workgroup per group of NC columns; W from its fp32 column-major copy, h columns in LDS.
+template <int NC>
+__global__ __launch_bounds__(256) void k_mdi_final(const float* __restrict__ V, const float* __restrict__ M,
+                                                   const float* __restrict__ Wcf, const float* __restrict__ H, int F,
+                                                   int Fp, int r, int rp, int T, float flr, float* __restrict__ out) {
+    extern __shared__ float sm[];
+    float* hs = sm;                       // [NC][rp]
+    float* lam = hs + NC * rp;            // [NC][F]
+    double* red = reinterpret_cast<double*>(lam + NC * F + ((NC * F + NC * rp) & 1));  // [2][NC][4 waves]
+    const int t0 = blockIdx.x * NC, tid = threadIdx.x;
+    for (int i = tid; i < NC * rp; i += 256) {
+        const int c = i / rp, k = i - c * rp;
+        hs[i] = (t0 + c < T) ? H[(size_t)(t0 + c) * rp + k] : 0.f;
+    }
+    __syncthreads();
+    double sa[NC], sb[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) sa[c] = sb[c] = 0.0;
+    for (int f = tid; f < F; f += 256) {
+        float acc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = 0.f;
+        for (int k = 0; k < r; ++k) {
+            const float wv = Wcf[(size_t)k * Fp + f];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] = fmaf(wv, hs[c * rp + k], acc[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float l = fmaxf(acc[c], flr);
+            lam[c * F + f] = l;
+            if (t0 + c < T) {
+                const float mk = M[(size_t)(t0 + c) * Fp + f];
+                sa[c] += (double)(V[(size_t)(t0 + c) * Fp + f] * mk);
+                sb[c] += (double)(l * mk);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        double a = sa[c], b = sb[c];
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_down(a, o, 64);
+            b += __shfl_down(b, o, 64);
+        }
+        if ((tid & 63) == 0) {
+            red[(c * 4 + (tid >> 6)) * 2] = a;
+            red[(c * 4 + (tid >> 6)) * 2 + 1] = b;
+        }
+    }
+    __syncthreads();
+    for (int c = 0; c < NC; ++c) {
+        if (t0 + c >= T) break;
+        double a = 0.0, b = 0.0;
+        for (int q = 0; q < 4; ++q) {
+            a += red[(c * 4 + q) * 2];
+            b += red[(c * 4 + q) * 2 + 1];
+        }
+        const float Nt = (float)(a / fmax(b, (double)flr));
+        for (int f = tid; f < F; f += 256) {
+            const size_t i = (size_t)(t0 + c) * Fp + f;
+            const float mk = M[i];
+            out[(size_t)(t0 + c) * F + f] = fmaxf(V[i] * mk + Nt * lam[c * F + f] * (1.f - mk), flr);
+        }
     }
 }
 
