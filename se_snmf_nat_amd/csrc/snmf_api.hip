@@ -448,7 +448,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
                     }
             if (pl->frame_fb) {
                 const int Fm2 = 64 * pl->frame_fb, RB = 8 * pl->frame_kb, nv = pl->bm == BM_KL ? 1 : 2;
-                pl->lds_frame = (size_t)(32 + 4 * RB + 3 * (Fm2 + 4) + 8 * Fm2 + nv * 64 * (RB + 1)) * 4;
+                pl->lds_frame = (size_t)(40 + 4 * RB + 3 * (Fm2 + 4) + 8 * Fm2 + nv * 16 * (RB + 1)) * 4;
                 if (pl->lds_frame > lds_cap) pl->frame_fb = pl->frame_kb = 0;
             }
         }

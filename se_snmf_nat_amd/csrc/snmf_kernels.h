@@ -849,6 +849,33 @@ __global__ __launch_bounds__(512, 2) void k_hsolve_small(StepArgs a, SmallArgs s
     stage_out<NTHR>(a.Hout, Hs, sa.tps, rp, ldh, threadIdx.x);  // only this solve's columns
 }
 
+// ---- cross-lane sums on the DPP path (1 VALU op per step; __shfl_* goes through ds_bpermute) ------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// sum over each aligned group of 4 lanes, result in all 4
+__device__ __forceinline__ float quad_sum_f(float v) {
+    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
+    return v;
+}
+// sum over each row of 16 lanes, result in all 16
+__device__ __forceinline__ float row_sum_f(float v) {
+    v = quad_sum_f(v);
+    v += dpp_f<0x141>(v);  // row_half_mirror
+    v += dpp_f<0x140>(v);  // row_mirror
+    return v;
+}
+// sum over the wave, result wave-uniform
+__device__ __forceinline__ float wave_sum_f(float v) {
+    v = row_sum_f(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)) +
+           __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16)) +
+           __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)) +
+           __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+}
+
 // ============================================================================================
 // k_hsolve_frame: the same whole-solve-in-one-launch as k_hsolve_small for ONE frame per solve
 // (tps = 1: the real online call, src/bnmf_sep_event_RT_IS16.m:148-154).  A single column wastes
@@ -864,7 +891,8 @@ __global__ __launch_bounds__(512, 2) void k_hsolve_small(StepArgs a, SmallArgs s
 // ============================================================================================
 template <int FB, int KB, int BM, bool OBJ>
 __global__ __launch_bounds__(512, 2) void k_hsolve_frame(StepArgs a, SmallArgs sa, const float* __restrict__ Wcf) {
-    constexpr int NTHR = 512, RB = 8 * KB, LDP = RB + 1;  // LDP odd: the 64 row-blocks hit distinct banks
+    constexpr int NTHR = 512, RB = 8 * KB, LDP = RB + 1;  // LDP odd: the partial rows hit distinct banks
+    constexpr int NPR = 16;  // partial rows of the W^T product after the quad pre-reduction
     constexpr int NV = (BM == BM_KL) ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     {   // this workgroup's frame
@@ -882,7 +910,8 @@ __global__ __launch_bounds__(512, 2) void k_hsolve_frame(StepArgs a, SmallArgs s
     const int rp = a.rp, F = a.F;
     const bool xr = F > Fm;              // one extra row, index Fm
     double* red = reinterpret_cast<double*>(lds);  // [16] objective partial sums
-    float* hs = lds + 32;                // [RB]     activations (k >= r stay zero)
+    float* xlam = lds + 32;              // [8]      per-wave partials of the extra row's Lam
+    float* hs = lds + 40;                // [RB]     activations (k >= r stay zero)
     float* vs = hs + RB;                 // [Fm + 4] the frame (floored V)
     float* va = vs + Fm + 4;             // [Fm + 4] ratio (KL) / num vector
     float* vb = va + Fm + 4;             // [Fm + 4] den vector (beta != 1)
@@ -890,7 +919,7 @@ __global__ __launch_bounds__(512, 2) void k_hsolve_frame(StepArgs a, SmallArgs s
     float* sps = wxs + RB;               // [RB]     sparsity weights of this frame
     float* dps = sps + RB;               // [RB]     KL: max(colsum + S, flr)
     float* lamp = dps + RB;              // [8][Fm]  P1 partials
-    float* dmp = lamp + 8 * Fm;          // [NV][64][LDP] P2 partials
+    float* dmp = lamp + 8 * Fm;          // [NV][NPR][LDP] P2 partials
 
     // ---- one-time loads -----------------------------------------------------------------------
     // rows are held in PAIRS (2*i2, 2*i2+1) so that both products map onto v_pk_fma_f32 with the SAME
@@ -944,6 +973,11 @@ __global__ __launch_bounds__(512, 2) void k_hsolve_frame(StepArgs a, SmallArgs s
 #pragma unroll
             for (int i2 = 0; i2 < FB / 2; ++i2)
                 *reinterpret_cast<f32x2*>(lamp + kb * Fm + fb * FB + 2 * i2) = lp[i2];
+            if (xr) {  // extra row: this wave's KB columns of W[Fm,:] * h, lanes 0..KB-1
+                static_assert(KB <= 64, "one lane per column");
+                const float px = wave_sum_f(lane < KB ? wxs[kb * KB + lane] * hs[kb * KB + lane] : 0.f);
+                if (lane == 0) xlam[kb] = px;
+            }
         }
         __syncthreads();
         float dterm = 0.f;
@@ -965,35 +999,27 @@ __global__ __launch_bounds__(512, 2) void k_hsolve_frame(StepArgs a, SmallArgs s
                 va[f] = real ? v * lf : 0.f;
             }
         }
-        if (xr && kb == 0) {  // extra row: wave 0
-            float s = 0.f;
-            for (int k = lane; k < RB; k += 64) s = fmaf(wxs[k], hs[k], s);
+        if (xr && tid == 0) {  // extra row: the 8 per-wave partials were formed in P1
+            float s = xlam[0];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-            if (lane == 0) {
-                const float lam = fmaxf(s, kFlr);
-                const float v = vs[Fm];
-                if (OBJ) dterm += div_term<BM>(v, lam, a.beta, a.inv_bb1);
-                if (BM == BM_KL) {
-                    va[Fm] = v * fast_rcp(lam);
-                } else {
-                    const float den = den_of_lam<BM>(lam, a.beta);
-                    float lf = 1.f;
-                    if (BM != BM_EUC) lf = (a.beta == 0.f) ? den * den : fast_pow(den, (a.beta - 2.f) / (a.beta - 1.f));
-                    vb[Fm] = den;
-                    va[Fm] = v * lf;
-                }
+            for (int q = 1; q < 8; ++q) s += xlam[q];
+            const float lam = fmaxf(s, kFlr);
+            const float v = vs[Fm];
+            if (OBJ) dterm += div_term<BM>(v, lam, a.beta, a.inv_bb1);
+            if (BM == BM_KL) {
+                va[Fm] = v * fast_rcp(lam);
+            } else {
+                const float den = den_of_lam<BM>(lam, a.beta);
+                float lf = 1.f;
+                if (BM != BM_EUC) lf = (a.beta == 0.f) ? den * den : fast_pow(den, (a.beta - 2.f) / (a.beta - 1.f));
+                vb[Fm] = den;
+                va[Fm] = v * lf;
             }
         }
         if (OBJ && j > 1) {
             // cost_{j-1} = div(V, W*H_{j-1}) + sum(S .* H_{j-1}); fixed-order fp64 sums
-            double dv = (double)dterm, sh = 0.0;
-            for (int k = tid; k < RB; k += NTHR) sh += (double)(sps[k] * hs[k]);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                dv += __shfl_down(dv, o, 64);
-                sh += __shfl_down(sh, o, 64);
-            }
+            const float shf = lane < KB ? sps[kb * KB + lane] * hs[kb * KB + lane] : 0.f;  // this wave's columns
+            const double dv = (double)wave_sum_f(dterm), sh = (double)wave_sum_f(shf);  // 64 terms in fp32, then fp64
             if (lane == 0) {
                 red[kb] = dv;
                 red[8 + kb] = sh;
@@ -1039,17 +1065,26 @@ __global__ __launch_bounds__(512, 2) void k_hsolve_frame(StepArgs a, SmallArgs s
                     pa = __builtin_elementwise_fma(wr[i2][kk], ra[i2], pa);
                     if (NV == 2) pb = __builtin_elementwise_fma(wr[i2][kk], rb[i2], pb);
                 }
-                dmp[fb * LDP + kb * KB + kk] = pa.x + pa.y;
-                if (NV == 2) dmp[64 * LDP + fb * LDP + kb * KB + kk] = pb.x + pb.y;
+                // pre-reduce over the 4 row-blocks of a lane quad on the DPP path: 16 partial rows instead of 64
+                const float qa = quad_sum_f(pa.x + pa.y);
+                if ((lane & 3) == 0) dmp[(fb >> 2) * LDP + kb * KB + kk] = qa;
+                if (NV == 2) {
+                    const float qb = quad_sum_f(pb.x + pb.y);
+                    if ((lane & 3) == 0) dmp[NPR * LDP + (fb >> 2) * LDP + kb * KB + kk] = qb;
+                }
             }
         }
         __syncthreads();
-        for (int k = tid; k < RB; k += NTHR) {
+        // Each wave finishes ITS OWN KB columns (lane <-> column): P1, the extra-row partial and the sparsity
+        // sum of the next iteration read exactly those entries of h back, from the same wave, so no workgroup
+        // barrier is needed here (LDS operations of one wave complete in order).
+        if (lane < KB) {
+            const int k = kb * KB + lane;
             float sa_ = 0.f, sb_ = 0.f;
-#pragma unroll 8
-            for (int q = 0; q < 64; ++q) {
+#pragma unroll
+            for (int q = 0; q < NPR; ++q) {
                 sa_ += dmp[q * LDP + k];
-                if (NV == 2) sb_ += dmp[64 * LDP + q * LDP + k];
+                if (NV == 2) sb_ += dmp[NPR * LDP + q * LDP + k];
             }
             if (xr) {
                 sa_ = fmaf(wxs[k], va[Fm], sa_);
@@ -1061,8 +1096,9 @@ __global__ __launch_bounds__(512, 2) void k_hsolve_frame(StepArgs a, SmallArgs s
             else hn = ho * fast_rcp(fmaxf(sb_ + sps[k], kFlr)) * sa_;          // :196-205
             hs[k] = k < a.rp ? hn : 0.f;
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
+    __syncthreads();
     if (tid == 0) {
         sa.st->n_iter = n_rec;
         sa.st->stop = stopped ? 1 : 0;
