@@ -1036,7 +1036,8 @@ static int finalize_objective(snmf_plan* pl) {
 }
 
 // persistent single-launch H-only solves: n_solves independent workgroups of tps <= 32 frames each
-static int launch_small(snmf_plan* pl, int n_solves, int tps, double* divh, double* costh, DevState* st) {
+static int launch_small(snmf_plan* pl, int n_solves, int tps, double* divh, double* costh, DevState* st,
+                        float* recon = nullptr, int recon_rx = 0) {
     StepArgs a = make_args(pl);
     a.Hout = pl->H[pl->cur];  // in place
     a.n_tiles = 1;
@@ -1048,6 +1049,9 @@ static int launch_small(snmf_plan* pl, int n_solves, int tps, double* divh, doub
     sa.costh = costh;
     sa.st = st;
     sa.tps = tps;
+    sa.recon = (tps == 1 && pl->frame_fb) ? recon : nullptr;  // only k_hsolve_frame produces the reconstructions
+    sa.wn = pl->wn;
+    sa.Rx = recon_rx;
     auto launch = [&](auto kern) -> int {
         static std::map<const void*, size_t> attr_set;
         const void* key = (const void*)kern;
@@ -1075,9 +1079,17 @@ static int launch_small(snmf_plan* pl, int n_solves, int tps, double* divh, doub
         };
         auto by_bm = [&](auto fbc, auto kbc) -> int {
             constexpr int FB = decltype(fbc)::value, KB = decltype(kbc)::value;
-            if (pl->bm == BM_KL) return obj ? launch_f(k_hsolve_frame<FB, KB, BM_KL, true>) : launch_f(k_hsolve_frame<FB, KB, BM_KL, false>);
-            if (pl->bm == BM_EUC) return obj ? launch_f(k_hsolve_frame<FB, KB, BM_EUC, true>) : launch_f(k_hsolve_frame<FB, KB, BM_EUC, false>);
-            return obj ? launch_f(k_hsolve_frame<FB, KB, BM_GEN, true>) : launch_f(k_hsolve_frame<FB, KB, BM_GEN, false>);
+            auto by_obj = [&](auto bmc, auto rc) -> int {
+                constexpr int BM = decltype(bmc)::value;
+                constexpr bool RC = decltype(rc)::value;
+                return obj ? launch_f(k_hsolve_frame<FB, KB, BM, true, RC>) : launch_f(k_hsolve_frame<FB, KB, BM, false, RC>);
+            };
+            auto by_rc = [&](auto bmc) -> int {
+                return sa.recon ? by_obj(bmc, std::true_type{}) : by_obj(bmc, std::false_type{});
+            };
+            if (pl->bm == BM_KL) return by_rc(std::integral_constant<int, BM_KL>{});
+            if (pl->bm == BM_EUC) return by_rc(std::integral_constant<int, BM_EUC>{});
+            return by_rc(std::integral_constant<int, BM_GEN>{});
         };
         using I4 = std::integral_constant<int, 4>;
         using I8 = std::integral_constant<int, 8>;
@@ -1525,6 +1537,11 @@ struct snmf_online {
     int F = 0, r = 0, N = 0, nov = 0;
     snmf_plan* hp = nullptr;  // frame solve: F x 1, rank r, H-only
     snmf_plan* ap = nullptr;  // adaptation solve: F x m_a, rank R_a, W-only
+    snmf_plan* hb = nullptr;  // fixed dictionary (no adaptation): the frame solves of a whole batch in one launch
+    DevState* bst = nullptr;
+    double *bdiv = nullptr, *bcost = nullptr;
+    OnlineStatus* bstatus = nullptr;
+    float *recon1 = nullptr, *breco = nullptr;  // B_x*A_x | B_d*A_d from the frame solve: one frame / a batch
     double *B = nullptr, *Bfix = nullptr, *Btmp = nullptr;  // fp64 like the engine's W master copy (k_wapply)
     float *Bf = nullptr;                                    // fp32 mirror of B for the reconstructions
     float *H0 = nullptr, *lambda_dav = nullptr, *Xm_tilde = nullptr,
@@ -1550,7 +1567,15 @@ struct snmf_online {
 };
 
 static void online_free_call_buffers(snmf_online* o) {
-    void* ptrs[] = {o->sig, o->Ym, o->Xt, o->Xh, o->Dh, o->syn, o->outf, o->Yph, o->out16};
+    void* ptrs[] = {o->sig, o->Ym, o->Xt, o->Xh, o->Dh, o->syn, o->outf, o->Yph, o->out16, o->bst, o->bdiv, o->bcost, o->bstatus, o->breco};
+    o->breco = nullptr;
+    if (o->hb) {
+        snmf_plan_destroy(o->hb);
+        o->hb = nullptr;
+    }
+    o->bst = nullptr;
+    o->bdiv = o->bcost = nullptr;
+    o->bstatus = nullptr;
     for (void* q : ptrs)
         if (q) hipFree(q);
     o->sig = o->Ym = o->Xt = o->Xh = o->Dh = o->syn = o->outf = nullptr;
@@ -1568,7 +1593,7 @@ extern "C" void snmf_online_destroy(snmf_online* o) {
     online_free_call_buffers(o);
     void* ptrs[] = {o->B,   o->Bfix, o->Btmp,  o->H0,    o->lambda_dav, o->Xm_tilde, o->r_blk, o->ldblk, o->adblk,  o->Vad,
                     o->Had, o->win_s, o->win_i, o->syn_tail, o->tw,       o->rup,      o->dev,   o->status, o->hst,   o->hdiv,
-                    o->hcost, o->syn_tail_x, o->syn_tail_d, o->Bf};
+                    o->hcost, o->syn_tail_x, o->syn_tail_d, o->Bf, o->recon1};
     for (void* q : ptrs)
         if (q) hipFree(q);
     if (o->h_status) hipHostFree(o->h_status);
@@ -1636,6 +1661,7 @@ extern "C" int snmf_online_create(snmf_ctx* ctx, const snmf_online_params* p, co
     auto D = [&](auto** ptr, size_t n) { if (s == SNMF_OK) s = dalloc(ptr, n); };
     D(&o->B, (size_t)F * r); D(&o->Bfix, (size_t)F * p->R_d); D(&o->Btmp, (size_t)F * p->R_d); D(&o->H0, (size_t)r);
     D(&o->Bf, (size_t)F * r);
+    D(&o->recon1, (size_t)2 * F);
     D(&o->lambda_dav, (size_t)F); D(&o->Xm_tilde, (size_t)F); D(&o->r_blk, (size_t)F * Pl); D(&o->ldblk, (size_t)F * ma);
     D(&o->adblk, (size_t)Ra * ma); D(&o->Vad, (size_t)F * ma); D(&o->Had, (size_t)Ra * ma); D(&o->win_s, (size_t)sz);
     D(&o->win_i, (size_t)sz); D(&o->syn_tail, (size_t)std::max(1, o->nov - 1) * sz); D(&o->tw, (size_t)N / 2);
@@ -1712,6 +1738,20 @@ static int online_reserve(snmf_online* o, int n) {
     SN_TRY(dalloc(&o->syn, (size_t)(cap + o->nov - 1) * sz));
     SN_TRY(dalloc(&o->outf, (size_t)cap * hop));
     SN_TRY(dalloc(&o->out16, (size_t)cap * hop));
+    if (!o->p.adapt_train_N) {
+        snmf_params bp = o->hp->p;
+        bp.T = cap;
+        std::vector<uint8_t> zeros(o->r, 0), ones(o->r, 1);
+        bp.w_update_ind = zeros.data();
+        bp.h_update_ind = ones.data();
+        SN_TRY(snmf_plan_create(o->ctx, &bp, &o->hb));
+        SN_TRY(set_w<double>(o->hb, o->B, o->F, 1));
+        SN_TRY(dalloc(&o->bst, (size_t)cap));
+        SN_TRY(dalloc(&o->bdiv, (size_t)cap * o->p.max_iter));
+        SN_TRY(dalloc(&o->bcost, (size_t)cap * o->p.max_iter));
+        SN_TRY(dalloc(&o->bstatus, (size_t)cap));
+        SN_TRY(dalloc(&o->breco, (size_t)cap * 2 * o->F));
+    }
     o->cap_frames = cap;
     return SNMF_OK;
 }
@@ -1747,7 +1787,7 @@ static int online_solve_frame(snmf_online* o, const float* dV) {
     pl->have_h = true;
     pl->inited = false;
     HIP_TRY(hipMemsetAsync(o->hst, 0, sizeof(DevState), st));
-    return launch_small(pl, 1, 1, o->hdiv, o->hcost, o->hst);
+    return launch_small(pl, 1, 1, o->hdiv, o->hcost, o->hst, o->recon1, o->p.R_x);
 }
 
 // :296-336 once the status says the solve is due
@@ -1786,12 +1826,10 @@ static int online_run_frames(snmf_online* o, const std::vector<float>& sig, int 
     launch_by_logn([&](auto L) { hipLaunchKernelGGL(k_ostft<decltype(L)::value>, dim3(n), dim3(256), 0, st, sa); }, o->N);
     HIP_TRY(hipGetLastError());
     const size_t lds_post = (size_t)(o->r + 6 * F) * 4;
-    for (int i = 0; i < n; ++i) {
-        const int64_t l = o->l + 1 + i;
-        SN_TRY(online_solve_frame(o, o->Ym + (size_t)i * F));
+    auto post_args = [&](int i, int64_t l) {
         OPostArgs a{};
-        a.A = o->hp->H[0]; a.hst = o->hst; a.B = o->Bf; a.Ym = o->Ym + (size_t)i * F; a.lambda_dav = o->lambda_dav; a.Xm_tilde = o->Xm_tilde;
-        a.r_blk = o->r_blk; a.ldblk = o->ldblk; a.adblk = o->adblk; a.rup = o->rup; a.dev = o->dev; a.status = o->status;
+        a.B = o->Bf; a.Ym = o->Ym + (size_t)i * F; a.lambda_dav = o->lambda_dav; a.Xm_tilde = o->Xm_tilde;
+        a.r_blk = o->r_blk; a.ldblk = o->ldblk; a.adblk = o->adblk; a.rup = o->rup; a.dev = o->dev;
         a.Xt_out = o->Xt + (size_t)i * F;
         a.Xh_out = o->Xh ? o->Xh + (size_t)i * F : nullptr;
         a.Dh_out = o->Dh ? o->Dh + (size_t)i * F : nullptr;
@@ -1802,21 +1840,66 @@ static int online_run_frames(snmf_online* o, const std::vector<float>& sig, int 
         a.switch_at = (int)std::floor(p.overlap_m_a * p.m_a);
         a.alpha_p = (float)p.alpha_p; a.alpha_eta = (float)p.alpha_eta; a.alpha_d = (float)p.alpha_d; a.beta0 = (float)p.beta;
         a.beta_max = (float)p.beta_max; a.Ar_up = (float)p.Ar_up; a.flr = (float)p.nonzerofloor;
+        a.n = 1;
+        a.a_stride = 0;
+        return a;
+    };
+    if (!p.adapt_train_N) {
+        // Fixed dictionary: nothing the host decides sits between frames.  All frame solves of the batch run
+        // in ONE launch (one workgroup per frame, W normalised once), then ONE k_opost launch walks the
+        // sequential post-filter recurrences.
+        snmf_plan* pl = o->hb;
+        const size_t nVp = (size_t)pl->Fp * pl->Tp;
+        hipLaunchKernelGGL(k_pack<float>, dim3(grid_for(nVp)), dim3(256), 0, st, (const float*)o->Ym, (int64_t)F, F, n, pl->V, pl->Fp, pl->Tp,
+                           kFlr, pl->p.floor_v ? 1 : 0);
+        HIP_TRY(hipGetLastError());
+        pl->have_v = true;
+        if (pl->w_dirty) SN_TRY(launch_wapply(pl, pl->stats, 0, false, true));
+        pl->w_dirty = false;
+        pl->cur = 0;
+        hipLaunchKernelGGL(k_tile_h0<float>, dim3(grid_for((size_t)n * pl->rp)), dim3(256), 0, st, (const float*)o->H0, pl->wn, o->r, pl->rp,
+                           1, n, pl->H[0]);
+        HIP_TRY(hipGetLastError());
+        pl->have_h = true;
+        pl->inited = false;
+        HIP_TRY(hipMemsetAsync(o->bst, 0, (size_t)n * sizeof(DevState), st));
+        SN_TRY(launch_small(pl, n, 1, o->bdiv, o->bcost, o->bst, o->breco, p.R_x));
+        OPostArgs a = post_args(0, o->l + 1);
+        a.A = pl->H[0]; a.hst = o->bst; a.status = o->bstatus; a.n = n; a.a_stride = pl->rp;
+        a.recon = pl->frame_fb ? o->breco : nullptr;
         hipLaunchKernelGGL(k_opost, dim3(1), dim3(1024), lds_post, st, a);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(o->h_status, o->status, sizeof(OnlineStatus), hipMemcpyDeviceToHost, st));
+        std::vector<OnlineStatus> hst((size_t)n);
+        HIP_TRY(hipMemcpyAsync(hst.data(), o->bstatus, (size_t)n * sizeof(OnlineStatus), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        const OnlineStatus hs = *o->h_status;
-        snmf_online_frame tr{};
-        tr.n_iter = hs.n_iter; tr.trig = hs.trig; tr.n_up = hs.n_up; tr.beta = hs.beta; tr.A_x_mag = hs.A_x_mag; tr.A_d_mag = hs.A_d_mag;
-        tr.Q_control = hs.Q_control;
-        if (hs.do_solve && hs.n_up > 0) {
-            int32_t it = 0;
-            SN_TRY(online_adapt(o, &it));
-            tr.solved = 1;
-            tr.adapt_iters = it;
+        for (const OnlineStatus& hs : hst) {
+            snmf_online_frame tr{};
+            tr.n_iter = hs.n_iter; tr.trig = hs.trig; tr.n_up = hs.n_up; tr.beta = hs.beta; tr.A_x_mag = hs.A_x_mag; tr.A_d_mag = hs.A_d_mag;
+            tr.Q_control = hs.Q_control;
+            o->trace.push_back(tr);
         }
-        o->trace.push_back(tr);
+    } else {
+        for (int i = 0; i < n; ++i) {
+            SN_TRY(online_solve_frame(o, o->Ym + (size_t)i * F));
+            OPostArgs a = post_args(i, o->l + 1 + i);
+            a.A = o->hp->H[0]; a.hst = o->hst; a.status = o->status;
+            a.recon = o->hp->frame_fb ? o->recon1 : nullptr;
+            hipLaunchKernelGGL(k_opost, dim3(1), dim3(1024), lds_post, st, a);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(o->h_status, o->status, sizeof(OnlineStatus), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            const OnlineStatus hs = *o->h_status;
+            snmf_online_frame tr{};
+            tr.n_iter = hs.n_iter; tr.trig = hs.trig; tr.n_up = hs.n_up; tr.beta = hs.beta; tr.A_x_mag = hs.A_x_mag; tr.A_d_mag = hs.A_d_mag;
+            tr.Q_control = hs.Q_control;
+            if (hs.do_solve && hs.n_up > 0) {
+                int32_t it = 0;
+                SN_TRY(online_adapt(o, &it));
+                tr.solved = 1;
+                tr.adapt_iters = it;
+            }
+            o->trace.push_back(tr);
+        }
     }
     // inverse STFT of the n frames behind the nov-1 frames kept from the previous call, overlap-add
     const int l0 = (int)std::min<int64_t>(o->l + 1, 1 << 30);

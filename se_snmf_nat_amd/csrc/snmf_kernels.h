@@ -753,6 +753,12 @@ struct SmallArgs {
     double* costh;  // [gridDim.x][max_iter]
     DevState* st;   // [gridDim.x]
     int tps;        // frames per solve (<= 32); workgroup b solves columns [b*tps, (b+1)*tps)
+    // k_hsolve_frame only: also emit the two reconstructions the online post-filter needs
+    // (src/bnmf_sep_event_RT_IS16.m:158-202), [gridDim.x][2][F]: B(:,1:Rx)*A(1:Rx) and B(:,Rx+1:r)*A(Rx+1:r),
+    // with B = W .* wn' (the un-normalised dictionary) -- the block is already in registers here.
+    float* recon;
+    const double* wn;
+    int Rx;
 };
 
 // One workgroup = one independent solve (gridDim.x solves run concurrently: the batched online
@@ -889,7 +895,7 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 // solve instead of twice per iteration.  The extra row (F = 64*FB + 1) is a wave-level dot product.
 // Loop semantics, objective recording and the stop test are those of k_hsolve_small.
 // ============================================================================================
-template <int FB, int KB, int BM, bool OBJ>
+template <int FB, int KB, int BM, bool OBJ, bool RECON = false>
 __global__ __launch_bounds__(512, 2) void k_hsolve_frame(StepArgs a, SmallArgs sa, const float* __restrict__ Wcf) {
     constexpr int NTHR = 512, RB = 8 * KB, LDP = RB + 1;  // LDP odd: the partial rows hit distinct banks
     constexpr int NPR = 16;  // partial rows of the W^T product after the quad pre-reduction
@@ -1104,6 +1110,53 @@ __global__ __launch_bounds__(512, 2) void k_hsolve_frame(StepArgs a, SmallArgs s
         sa.st->stop = stopped ? 1 : 0;
     }
     for (int k = tid; k < rp; k += NTHR) a.Hout[k] = k < RB ? hs[k] : 0.f;
+    if (RECON) {
+        // Xm_hat_sum = B_x*A_x and Dm_hat_sum = B_d*A_d: two more passes of the P1 shape with h .* wn, the first
+        // over the columns k < Rx, the second over the rest
+        float* out = sa.recon + (size_t)blockIdx.x * 2 * F;
+        __syncthreads();  // H has been copied out: h <- h .* wn in place
+        if (lane < KB) {
+            const int k = kb * KB + lane;
+            hs[k] = k < a.rp ? (float)((double)hs[k] * sa.wn[k]) : 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int part = 0; part < 2; ++part) {
+            f32x2 lp[FB / 2];
+#pragma unroll
+            for (int i2 = 0; i2 < FB / 2; ++i2) lp[i2] = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+                const int k = kb * KB + kk;
+                const float hk = ((k < sa.Rx) == (part == 0)) ? hs[k] : 0.f;
+                const f32x2 hk2 = f32x2{hk, hk};
+#pragma unroll
+                for (int i2 = 0; i2 < FB / 2; ++i2) lp[i2] = __builtin_elementwise_fma(wr[i2][kk], hk2, lp[i2]);
+            }
+#pragma unroll
+            for (int i2 = 0; i2 < FB / 2; ++i2)
+                *reinterpret_cast<f32x2*>(lamp + kb * Fm + fb * FB + 2 * i2) = lp[i2];
+            if (xr) {
+                const int k = kb * KB + lane;
+                const bool mine = lane < KB && (k < sa.Rx) == (part == 0);
+                const float px = wave_sum_f(mine ? wxs[k] * hs[k] : 0.f);
+                if (lane == 0) xlam[kb] = px;
+            }
+            __syncthreads();
+            for (int f = tid; f < Fm && f < F; f += NTHR) {
+                float s = lamp[f];
+#pragma unroll
+                for (int q = 1; q < 8; ++q) s += lamp[q * Fm + f];
+                out[part * F + f] = s;
+            }
+            if (xr && tid == 0) {
+                float s = xlam[0];
+#pragma unroll
+                for (int q = 1; q < 8; ++q) s += xlam[q];
+                out[part * F + Fm] = s;
+            }
+            __syncthreads();
+        }
+    }
 }
 
 // ============================================================================================

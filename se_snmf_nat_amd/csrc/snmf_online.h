@@ -128,6 +128,7 @@ struct OPostArgs {
     const float* A;       // [r] activations of this frame (solver's H buffer, first r of rp)
     const DevState* hst;  // the frame solve's state (n_iter)
     const float* B;       // [F x r] column-major, current [B_DFT_x | B_DFT_d]
+    const float* recon;   // [2][F] per frame: B_x*A_x and B_d*A_d from the frame solve (NULL: computed here from B)
     const float* Ym;      // [F]
     float* lambda_dav;    // [F] state
     float* Xm_tilde;      // [F] state
@@ -144,13 +145,12 @@ struct OPostArgs {
     int l;                // 1-based frame index
     int blk_sparse, adapt, wiener, init_N_len, switch_at;
     float alpha_p, alpha_eta, alpha_d, beta0, beta_max, Ar_up, flr;
+    int n;                // frames handled by this launch, one after the other (> 1 only without adaptation)
+    int a_stride;         // distance between the activation vectors of consecutive frames
 };
 
-// Everything between the frame solve and the inverse STFT, src/bnmf_sep_event_RT_IS16.m:158-292.
-// One workgroup; dynamic LDS = (r + 6*F) floats.
-__global__ __launch_bounds__(1024) void k_opost(OPostArgs a) {
-    extern __shared__ float sm[];
-    __shared__ double red[16];
+// Everything between the frame solve and the inverse STFT, src/bnmf_sep_event_RT_IS16.m:158-292, for one frame.
+__device__ __forceinline__ void opost_frame(const OPostArgs& a, float* sm, double* red) {
     const int F = a.F, r = a.Rx + a.Rd;
     float* sA = sm;
     float* Xs = sA + r;
@@ -173,14 +173,21 @@ __global__ __launch_bounds__(1024) void k_opost(OPostArgs a) {
     sd = block_sum_d(sd, red);
     const float A_x_mag = (float)(sx / a.Rx), A_d_mag = (float)(sd / a.Rd);
     // Xm_hat_sum = B_x*A_x, Dm_hat_sum = B_d*A_d (:158-202; any class partition sums to these)
-    for (int f = tid; f < F; f += nt) {
-        const float* b = a.B + f;
-        float x = 0.f, d = 0.f;
-        for (int k = 0; k < a.Rx; ++k) x = fmaf(b[(size_t)k * F], sA[k], x);
-        b += (size_t)a.Rx * F;
-        for (int k = 0; k < a.Rd; ++k) d = fmaf(b[(size_t)k * F], sA[a.Rx + k], d);
-        Xs[f] = x;
-        Ds[f] = d;
+    if (a.recon) {
+        for (int f = tid; f < F; f += nt) {
+            Xs[f] = a.recon[f];
+            Ds[f] = a.recon[F + f];
+        }
+    } else {
+        for (int f = tid; f < F; f += nt) {
+            const float* b = a.B + f;
+            float x = 0.f, d = 0.f;
+            for (int k = 0; k < a.Rx; ++k) x = fmaf(b[(size_t)k * F], sA[k], x);
+            b += (size_t)a.Rx * F;
+            for (int k = 0; k < a.Rd; ++k) d = fmaf(b[(size_t)k * F], sA[a.Rx + k], d);
+            Xs[f] = x;
+            Ds[f] = d;
+        }
     }
     __syncthreads();
     // ---- src/blk_sparse.m ----
@@ -322,6 +329,29 @@ __global__ __launch_bounds__(1024) void k_opost(OPostArgs a) {
         s.A_d_mag = A_d_mag;
         s.Q_control = Q_control;
         *a.status = s;
+    }
+}
+
+// One workgroup; dynamic LDS = (r + 6*F) floats.  The post-filter recurrences (smoothed noise PSD, the
+// previous frame's G.*Y, the SNR ring) make the frames sequential, but when the dictionary is fixed
+// (no adaptation) nothing the host must decide sits between them: the frame solves of a whole batch run
+// in parallel first and this kernel then walks the batch in ONE launch.
+__global__ __launch_bounds__(1024) void k_opost(OPostArgs a0) {
+    extern __shared__ float sm[];
+    __shared__ double red[16];
+    for (int i = 0; i < a0.n; ++i) {
+        OPostArgs a = a0;
+        a.A += (size_t)i * a0.a_stride;
+        if (a.recon) a.recon += (size_t)i * 2 * a0.F;
+        a.hst += i;
+        a.Ym += (size_t)i * a0.F;
+        a.Xt_out += (size_t)i * a0.F;
+        if (a.Xh_out) a.Xh_out += (size_t)i * a0.F;
+        if (a.Dh_out) a.Dh_out += (size_t)i * a0.F;
+        a.status += i;
+        a.l += i;
+        opost_frame(a, sm, red);
+        __syncthreads();  // state written by this frame (global + LDS scratch) is visible to the next
     }
 }
 
