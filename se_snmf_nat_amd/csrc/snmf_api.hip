@@ -1541,7 +1541,14 @@ struct snmf_online {
     DevState* bst = nullptr;
     double *bdiv = nullptr, *bcost = nullptr;
     OnlineStatus* bstatus = nullptr;
-    float *recon1 = nullptr, *breco = nullptr;  // B_x*A_x | B_d*A_d from the frame solve: one frame / a batch
+    float *recon1 = nullptr, *breco = nullptr;
+    // cooperative single-launch adaptation solve (k_wadapt)
+    bool wadapt = false;
+    int wa_nwg = 0;
+    size_t wa_lds = 0;
+    double *wa_W = nullptr, *wa_p1 = nullptr, *wa_p2 = nullptr, *wa_cost = nullptr;
+    int* wa_nit = nullptr;
+    unsigned* wa_bar = nullptr;  // B_x*A_x | B_d*A_d from the frame solve: one frame / a batch
     double *B = nullptr, *Bfix = nullptr, *Btmp = nullptr;  // fp64 like the engine's W master copy (k_wapply)
     float *Bf = nullptr;                                    // fp32 mirror of B for the reconstructions
     float *H0 = nullptr, *lambda_dav = nullptr, *Xm_tilde = nullptr,
@@ -1593,7 +1600,7 @@ extern "C" void snmf_online_destroy(snmf_online* o) {
     online_free_call_buffers(o);
     void* ptrs[] = {o->B,   o->Bfix, o->Btmp,  o->H0,    o->lambda_dav, o->Xm_tilde, o->r_blk, o->ldblk, o->adblk,  o->Vad,
                     o->Had, o->win_s, o->win_i, o->syn_tail, o->tw,       o->rup,      o->dev,   o->status, o->hst,   o->hdiv,
-                    o->hcost, o->syn_tail_x, o->syn_tail_d, o->Bf, o->recon1};
+                    o->hcost, o->syn_tail_x, o->syn_tail_d, o->Bf, o->recon1, o->wa_W, o->wa_p1, o->wa_p2, o->wa_cost, o->wa_nit, o->wa_bar};
     for (void* q : ptrs)
         if (q) hipFree(q);
     if (o->h_status) hipHostFree(o->h_status);
@@ -1659,6 +1666,22 @@ extern "C" int snmf_online_create(snmf_ctx* ctx, const snmf_online_params* p, co
         A(snmf_plan_create(ctx, &ap, &o->ap));
     }
     auto D = [&](auto** ptr, size_t n) { if (s == SNMF_OK) s = dalloc(ptr, n); };
+    if (p->adapt_train_N && p->beta_div == 1.0 && p->R_a <= kWaRP && !getenv("SNMF_NO_WADAPT")) {
+        int coop = 0;
+        hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, ctx->device);
+        o->wa_nwg = (F + kWaRB - 1) / kWaRB;
+        o->wa_lds = (size_t)(kWaRB * kWaRP + 4 * kWaRP + 8 + 256) * 8 +
+                    (size_t)(2 * kWaRB * kWaRP + kWaRP + 2 * kWaRB * p->m_a + p->R_a * p->m_a + p->m_a * (kWaRP + 1)) * 4;
+        o->wadapt = coop != 0 && o->wa_nwg <= ctx->n_cu && o->wa_nwg <= 2 * kWaQ && o->wa_lds <= 160 * 1024;
+        if (o->wadapt) {
+            D(&o->wa_W, (size_t)p->R_a * F);
+            D(&o->wa_p1, (size_t)o->wa_nwg * (kWaRP + 1));
+            D(&o->wa_p2, (size_t)o->wa_nwg * 2 * kWaRP);
+            D(&o->wa_cost, (size_t)p->max_iter);
+            D(&o->wa_nit, (size_t)1);
+            D(&o->wa_bar, (size_t)1);
+        }
+    }
     D(&o->B, (size_t)F * r); D(&o->Bfix, (size_t)F * p->R_d); D(&o->Btmp, (size_t)F * p->R_d); D(&o->H0, (size_t)r);
     D(&o->Bf, (size_t)F * r);
     D(&o->recon1, (size_t)2 * F);
@@ -1800,6 +1823,33 @@ static int online_adapt(snmf_online* o, int32_t* iters) {
     hipLaunchKernelGGL(k_oprep, dim3(grid_for(n)), dim3(256), 0, st, (const float*)o->ldblk, (const float*)o->adblk,
                        (const uint8_t*)o->rup, (const OnlineDev*)o->dev, o->F, p.R_a, p.m_a, o->Vad, o->Had, ap->w_ind);
     HIP_TRY(hipGetLastError());
+    if (o->wadapt) {
+        // the whole solve in one cooperative launch (k_wadapt)
+        WAdaptArgs wa{};
+        wa.V = o->Vad; wa.H = o->Had; wa.W0 = Bd; wa.w_ind = ap->w_ind; wa.Wout = o->wa_W; wa.part1 = o->wa_p1; wa.part2 = o->wa_p2;
+        wa.costh = o->wa_cost; wa.n_iter_out = o->wa_nit; wa.F = o->F; wa.Ra = p.R_a; wa.ma = p.m_a; wa.max_iter = p.max_iter;
+        wa.cost_check = p.cost_check; wa.sparsity = (float)p.sparsity; wa.flr = kFlr; wa.conv_eps = p.conv_eps;
+        static bool attr_done = false;
+        if (o->wa_lds > 64 * 1024 && !attr_done) {
+            HIP_TRY(hipFuncSetAttribute((const void*)k_wadapt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->wa_lds));
+            attr_done = true;
+        }
+        wa.bar = o->wa_bar;
+        HIP_TRY(hipMemsetAsync(o->wa_bar, 0, 4, st));
+        void* kargs[] = {&wa};
+        HIP_TRY(hipLaunchCooperativeKernel((const void*)k_wadapt, dim3(o->wa_nwg), dim3(256), kargs, (unsigned)o->wa_lds, st));
+        int32_t nit = 0;
+        HIP_TRY(hipMemcpyAsync(&nit, o->wa_nit, 4, hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(k_oassemble, dim3(p.R_d), dim3(256), 0, st, (const double*)Bd, (const double*)o->wa_W, o->F, (const double*)o->Bfix,
+                           (const uint8_t*)o->rup, o->F, p.R_a, p.R_d, o->Btmp, o->Bf + (size_t)o->F * p.R_x);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(Bd, o->Btmp, (size_t)o->F * p.R_d * 8, hipMemcpyDeviceToDevice, st));
+        SN_TRY(set_w<double>(o->hp, o->B, o->F, 1));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (nit < 0) return fail(SNMF_ERR_NO_DEVICE, "adaptation kernel: grid barrier timed out");
+        *iters = nit;
+        return SNMF_OK;
+    }
     SN_TRY(set_v<float>(ap, o->Vad, o->F, 1));         // lambda_d_blk (floored at 1e-9 inside, sparse_nmf.m:169)
     SN_TRY(set_w<double>(ap, Bd, o->F, 1));            // init_w: first R_a noise columns (:332)
     SN_TRY(set_h<float>(ap, o->Had, p.R_a, 1));        // init_h (:333)

@@ -14,6 +14,7 @@
 // adaptation).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_cooperative_groups.h>
 #include <stdint.h>
 
 namespace snmf {
@@ -479,6 +480,259 @@ __global__ void k_oola(const float* __restrict__ syn, int n_new, int l0, int del
             out16[e] = (int16_t)rr;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_wadapt: the whole W-only adaptation solve (src/bnmf_sep_event_RT_IS16.m:330-335 ->
+// src/sparse_nmf.m:157-286 with h_update_ind all false, KL) in ONE cooperative launch.
+// The problem is tiny (513 x 100, rank <= 64) and the generic path costs three launches per
+// iteration (~30 us); here V and H never change, so every workgroup keeps H (both orientations) and its
+// RB = 8 rows of V and W in LDS for the whole solve and an iteration is two small products per row block
+// plus two grid barriers for the column sums (colsum(G.*W), then the column norms).  The convergence
+// test runs identically in every workgroup on the same reduced numbers.  Master copy of W in fp64
+// (see k_wapply).  Grid = ceil(F / 8) workgroups of 256 threads, launched cooperatively.
+// ---------------------------------------------------------------------------------------------
+
+// Cross-workgroup sum of `ncol` (<= 2*RP+1) column quantities, part[q*stride + c], q < nwg, into out[c]
+// (LDS).  After the barrier's acquire these loads come from memory, ~2 us each: every thread issues all of
+// its loads before the first add (4 thread groups x 64 columns, <= kWaQ workgroups per group), then the
+// sums are combined in a fixed order (bit-reproducible).
+constexpr int kWaQ = 40;  // workgroups per thread group: covers nwg <= 80
+__device__ __forceinline__ void cross_sum(const double* __restrict__ part, int stride, int ncol, int nwg, double* scratch /*[2][128]*/,
+                                          double* out /*[128]*/) {
+    const int g = threadIdx.x >> 7, c = threadIdx.x & 127;
+    const int per = (nwg + 1) / 2, q0 = g * per;
+    double v[kWaQ];
+#pragma unroll
+    for (int i = 0; i < kWaQ; ++i) {
+        const int q = q0 + i;
+        v[i] = (i < per && q < nwg && c < ncol) ? part[(size_t)q * stride + c] : 0.0;
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < kWaQ; ++i) s += v[i];
+    scratch[g * 128 + c] = s;
+    __syncthreads();
+    if (threadIdx.x < 128 && threadIdx.x < ncol) out[threadIdx.x] = scratch[c] + scratch[128 + c];
+    __syncthreads();
+}
+
+struct WAdaptArgs {
+    const float* V;        // [ma][F]  lambda_d_blk in time order
+    const float* H;        // [ma][Ra] Ad_blk in time order, rows not in r_up zeroed
+    const double* W0;      // [Ra][F]  init_w (first R_a columns of B_DFT_d)
+    const uint8_t* w_ind;  // [Ra]     r_up
+    double* Wout;          // [Ra][F]  result
+    double* part1;         // [nwg][RP + 1]  colsum(G.*W) partials + divergence partial
+    double* part2;         // [nwg][2][RP]   squared-norm and column-sum partials
+    double* costh;         // [max_iter]
+    int* n_iter_out;
+    unsigned* bar;         // grid-barrier counter, zero at launch
+    int F, Ra, ma, max_iter, cost_check;
+    float sparsity, flr;
+    double conv_eps;
+};
+
+constexpr int kWaRB = 8, kWaRP = 64;
+
+// Grid barrier on a monotonic device counter (zeroed before the launch).  cooperative_groups' grid.sync()
+// measured ~20 us per call here; this is one agent-scope atomic plus a short spin.  The kernel is launched
+// cooperatively, so every workgroup is resident; the spin is bounded all the same so that a lost workgroup
+// ends in wrong numbers (flagged through n_iter_out = -1), never in a hung GPU.
+__device__ __forceinline__ bool grid_bar(unsigned* ctr, unsigned nwg, unsigned& gen) {
+    __shared__ int ok_s;
+    __syncthreads();
+    ++gen;
+    if (threadIdx.x == 0) {
+        __threadfence();  // release this workgroup's global writes at agent scope
+        atomicAdd(ctr, 1u);
+        const unsigned target = gen * nwg;
+        unsigned spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1u << 24))
+            __builtin_amdgcn_s_sleep(1);
+        __threadfence();  // acquire the other workgroups' writes
+        ok_s = spins < (1u << 24);
+    }
+    __syncthreads();
+    return ok_s != 0;
+}
+
+__global__ __launch_bounds__(256) void k_wadapt(WAdaptArgs a) {
+    constexpr int RB = kWaRB, RP = kWaRP;
+    unsigned gen = 0;
+    bool bar_ok = true;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int F = a.F, Ra = a.Ra, ma = a.ma, tid = threadIdx.x, nwg = gridDim.x, wg = blockIdx.x;
+    const int f0 = wg * RB;
+    double* Wd = reinterpret_cast<double*>(sm);          // [RB][RP]
+    double* cq = Wd + RB * RP;                            // [RP] reduced column quantities
+    double* cs = cq + RP;                                 // [RP] colsum(W)
+    double* red = cs + RP;                                // [8]
+    double* scr = red + 8;                                // [2][128] cross_sum scratch
+    double* tmp = scr + 256;                              // [2*RP] reduced quantities of one exchange
+    float* Wf = reinterpret_cast<float*>(tmp + 2 * RP);   // [RB][RP]
+    float* Gs = Wf + RB * RP;                             // [RB][RP]
+    float* sk = Gs + RB * RP;                             // [RP] rowsum(H)
+    float* Vs = sk + RP;                                  // [RB][ma]
+    float* Rs = Vs + RB * ma;                             // [RB][ma]
+    float* Hs = Rs + RB * ma;                             // [Ra][ma]
+    float* HT = Hs + Ra * ma;                             // [ma][RP + 1]
+    const int f = tid >> 5, l32 = tid & 31;               // row of the block, lane within the row's 32 threads
+    const bool row_ok = f0 + f < F;
+
+    // ---- load + src/sparse_nmf.m:157-169 ------------------------------------------------------
+    for (int i = tid; i < RB * RP; i += 256) {
+        const int ff = i / RP, k = i - ff * RP;
+        Wd[i] = (k < Ra && f0 + ff < F) ? a.W0[(size_t)k * F + f0 + ff] : 0.0;
+    }
+    for (int i = tid; i < RB * ma; i += 256) {
+        const int ff = i / ma, t = i - ff * ma;
+        Vs[i] = (f0 + ff < F) ? fmaxf(a.V[(size_t)t * F + f0 + ff], a.flr) : 0.f;   // :169
+    }
+    for (int i = tid; i < Ra * ma; i += 256) {
+        const int t = i / Ra, k = i - t * Ra;
+        Hs[k * ma + t] = a.H[i];
+    }
+    __syncthreads();
+    // wn = sqrt(sum(w.^2)): partial over this block's rows
+    if (tid < RP) {
+        double s = 0.0;
+        for (int ff = 0; ff < RB; ++ff) s += Wd[ff * RP + tid] * Wd[ff * RP + tid];
+        a.part2[(size_t)wg * 2 * RP + tid] = s;
+    }
+    bar_ok &= grid_bar(a.bar, (unsigned)nwg, gen);
+    cross_sum(a.part2, 2 * RP, RP, nwg, scr, tmp);
+    if (tid < RP) cq[tid] = tid < Ra ? sqrt(tmp[tid]) : 1.0;  // wn
+    __syncthreads();
+    for (int i = tid; i < RB * RP; i += 256) {
+        const int k = i % RP;
+        const double w = k < Ra ? Wd[i] / cq[k] : 0.0;   // w = w ./ wn
+        Wd[i] = w;
+        Wf[i] = (float)w;
+    }
+    for (int i = tid; i < Ra * ma; i += 256) {
+        const int k = i / ma;
+        Hs[i] = (float)((double)Hs[i] * cq[k]);          // h = h .* wn'  (:160)
+    }
+    __syncthreads();
+    for (int i = tid; i < ma * (RP + 1); i += 256) {
+        const int t = i / (RP + 1), k = i - t * (RP + 1);
+        HT[i] = k < Ra ? Hs[k * ma + t] : 0.f;
+    }
+    if (tid < RP) {
+        float s = 0.f;
+        if (tid < Ra)
+            for (int t = 0; t < ma; ++t) s += Hs[tid * ma + t];
+        sk[tid] = s;                                     // sum(h,2)
+    }
+    // colsum(w) partial (first use: iteration 1)
+    if (tid < RP) {
+        double s = 0.0;
+        for (int ff = 0; ff < RB; ++ff) s += Wd[ff * RP + tid];
+        a.part2[(size_t)wg * 2 * RP + RP + tid] = s;
+    }
+    bar_ok &= grid_bar(a.bar, (unsigned)nwg, gen);
+    cross_sum(a.part2, 2 * RP, 2 * RP, nwg, scr, tmp);
+    if (tid < RP) cs[tid] = tmp[RP + tid];
+    __syncthreads();
+    double sh_const = 0.0;                               // sum(sum(sparsity .* h)) (:261), constant: H is fixed
+    for (int k = 0; k < Ra; ++k) sh_const += (double)a.sparsity * (double)sk[k];
+
+    double last_cost = 0.0;
+    int n_rec = 0;
+    bool stopped = false;
+    for (int j = 1; j <= a.max_iter + 1; ++j) {
+        if (j > a.max_iter && !a.cost_check) break;
+        // ---- Lam' = max(W*H, flr), ratio, divergence of iterate j-1 ------------------------------
+        float dterm = 0.f;
+        for (int t = l32; t < ma; t += 32) {
+            float acc = 0.f;
+            for (int k = 0; k < Ra; ++k) acc = fmaf(Wf[f * RP + k], Hs[k * ma + t], acc);
+            const float lam = fmaxf(acc, a.flr), v = Vs[f * ma + t];
+            Rs[f * ma + t] = row_ok ? v * fast_rcp(lam) : 0.f;
+            if (row_ok) dterm += div_term<BM_KL>(v, lam, 1.f, 0.f);
+        }
+        __syncthreads();
+        // ---- G = (V./Lam') * H' -----------------------------------------------------------------
+        for (int k = l32; k < RP; k += 32) {
+            float acc = 0.f;
+            if (k < Ra)
+                for (int t = 0; t < ma; ++t) acc = fmaf(Rs[f * ma + t], HT[t * (RP + 1) + k], acc);
+            Gs[f * RP + k] = acc;
+        }
+        const float dw = wave_sum_f(dterm);
+        if ((tid & 63) == 0) red[tid >> 6] = (double)dw;
+        __syncthreads();
+        if (tid < RP) {
+            double s = 0.0;
+            for (int ff = 0; ff < RB; ++ff) s += (double)Gs[ff * RP + tid] * Wd[ff * RP + tid];
+            a.part1[(size_t)wg * (RP + 1) + tid] = s;    // colsum(G .* W) partial (:217)
+        }
+        if (tid == RP) a.part1[(size_t)wg * (RP + 1) + RP] = red[0] + red[1] + red[2] + red[3];
+        bar_ok &= grid_bar(a.bar, (unsigned)nwg, gen);
+        cross_sum(a.part1, RP + 1, RP + 1, nwg, scr, tmp);     // colsum(G .* W) | div
+        if (tid < RP) cq[tid] = tmp[tid];
+        if (tid == RP) red[4] = tmp[RP];
+        __syncthreads();
+        if (a.cost_check && j > 1) {                      // cost of iterate j-1 (:260-284)
+            const double cost = red[4] + sh_const;
+            const int it = j - 1;
+            bool stopnow = false;
+            if (it > 1 && a.conv_eps > 0.0) stopnow = fabs(cost - last_cost) / last_cost < a.conv_eps;
+            if (wg == 0 && tid == 0) a.costh[it - 1] = cost;
+            n_rec = it;
+            last_cost = cost;
+            if (stopnow) {
+                stopped = true;
+                break;
+            }
+        }
+        if (j > a.max_iter) break;
+        // ---- W update (:215-222) on this block's rows, then the norms ------------------------------
+        for (int i = tid; i < RB * RP; i += 256) {
+            const int k = i % RP;
+            double wv = Wd[i];
+            if (k < Ra && a.w_ind[k]) {
+                const double s = (double)sk[k];
+                double dpw = s + wv * cq[k];
+                dpw = dpw > (double)a.flr ? dpw : (double)a.flr;
+                wv = wv * ((double)Gs[i] + wv * (s * cs[k])) / dpw;
+            }
+            Wd[i] = wv;
+        }
+        __syncthreads();
+        if (tid < RP) {
+            double s2 = 0.0, s1 = 0.0;
+            for (int ff = 0; ff < RB; ++ff) {
+                const double w = Wd[ff * RP + tid];
+                s2 += w * w;
+                s1 += w;
+            }
+            a.part2[(size_t)wg * 2 * RP + tid] = s2;
+            a.part2[(size_t)wg * 2 * RP + RP + tid] = s1;
+        }
+        bar_ok &= grid_bar(a.bar, (unsigned)nwg, gen);
+        cross_sum(a.part2, 2 * RP, 2 * RP, nwg, scr, tmp);
+        if (tid < RP) {
+            const double nrm = tid < Ra ? sqrt(tmp[tid]) : 1.0;
+            cq[tid] = nrm;
+            cs[tid] = tmp[RP + tid] / nrm;               // colsum of the normalised W
+        }
+        __syncthreads();
+        for (int i = tid; i < RB * RP; i += 256) {
+            const int k = i % RP;
+            const double w = k < Ra ? Wd[i] / cq[k] : 0.0;   // :242, ALL columns
+            Wd[i] = w;
+            Wf[i] = (float)w;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int i = tid; i < RB * RP; i += 256) {
+        const int ff = i / RP, k = i - ff * RP;
+        if (k < Ra && f0 + ff < F) a.Wout[(size_t)k * F + f0 + ff] = Wd[i];
+    }
+    if (wg == 0 && tid == 0) *a.n_iter_out = !bar_ok ? -1 : (stopped ? n_rec : a.max_iter);
 }
 
 }  // namespace snmf
