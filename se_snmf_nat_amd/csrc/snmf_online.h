@@ -493,6 +493,14 @@ __global__ void k_oola(const float* __restrict__ syn, int n_new, int l0, int del
 // (see k_wapply).  Grid = ceil(F / 8) workgroups of 256 threads, launched cooperatively.
 // ---------------------------------------------------------------------------------------------
 
+// exchange accesses: agent-scope relaxed atomics = sc1 write-through stores / coherent loads (see grid_bar)
+__device__ __forceinline__ void xstore(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double xload(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Cross-workgroup sum of `ncol` (<= 2*RP+1) column quantities, part[q*stride + c], q < nwg, into out[c]
 // (LDS).  After the barrier's acquire these loads come from memory, ~2 us each: every thread issues all of
 // its loads before the first add (4 thread groups x 64 columns, <= kWaQ workgroups per group), then the
@@ -506,7 +514,7 @@ __device__ __forceinline__ void cross_sum(const double* __restrict__ part, int s
 #pragma unroll
     for (int i = 0; i < kWaQ; ++i) {
         const int q = q0 + i;
-        v[i] = (i < per && q < nwg && c < ncol) ? part[(size_t)q * stride + c] : 0.0;
+        v[i] = (i < per && q < nwg && c < ncol) ? xload(part + (size_t)q * stride + c) : 0.0;
     }
     double s = 0.0;
 #pragma unroll
@@ -536,21 +544,23 @@ struct WAdaptArgs {
 constexpr int kWaRB = 8, kWaRP = 64;
 
 // Grid barrier on a monotonic device counter (zeroed before the launch).  cooperative_groups' grid.sync()
-// measured ~20 us per call here; this is one agent-scope atomic plus a short spin.  The kernel is launched
+// measured ~20 us per call here, and an agent-scope release/acquire pair costs a write-back plus an
+// invalidate of the XCD's whole L2 on every workgroup.  Instead, everything the workgroups exchange goes
+// through agent-scope (sc1, write-through / coherent) relaxed atomic stores and loads (xstore / xload):
+// __syncthreads() waits for those stores to be acknowledged by the coherence point, one relaxed agent-scope
+// add publishes the arrival, and the readers' sc1 loads cannot hit a stale line.  The kernel is launched
 // cooperatively, so every workgroup is resident; the spin is bounded all the same so that a lost workgroup
 // ends in wrong numbers (flagged through n_iter_out = -1), never in a hung GPU.
 __device__ __forceinline__ bool grid_bar(unsigned* ctr, unsigned nwg, unsigned& gen) {
     __shared__ int ok_s;
-    __syncthreads();
+    __syncthreads();  // this workgroup's exchange stores have completed
     ++gen;
     if (threadIdx.x == 0) {
-        __threadfence();  // release this workgroup's global writes at agent scope
-        atomicAdd(ctr, 1u);
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = gen * nwg;
         unsigned spins = 0;
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1u << 24))
             __builtin_amdgcn_s_sleep(1);
-        __threadfence();  // acquire the other workgroups' writes
         ok_s = spins < (1u << 24);
     }
     __syncthreads();
@@ -598,7 +608,7 @@ __global__ __launch_bounds__(256) void k_wadapt(WAdaptArgs a) {
     if (tid < RP) {
         double s = 0.0;
         for (int ff = 0; ff < RB; ++ff) s += Wd[ff * RP + tid] * Wd[ff * RP + tid];
-        a.part2[(size_t)wg * 2 * RP + tid] = s;
+        xstore(a.part2 + (size_t)wg * 2 * RP + tid, s);
     }
     bar_ok &= grid_bar(a.bar, (unsigned)nwg, gen);
     cross_sum(a.part2, 2 * RP, RP, nwg, scr, tmp);
@@ -629,7 +639,7 @@ __global__ __launch_bounds__(256) void k_wadapt(WAdaptArgs a) {
     if (tid < RP) {
         double s = 0.0;
         for (int ff = 0; ff < RB; ++ff) s += Wd[ff * RP + tid];
-        a.part2[(size_t)wg * 2 * RP + RP + tid] = s;
+        xstore(a.part2 + (size_t)wg * 2 * RP + RP + tid, s);
     }
     bar_ok &= grid_bar(a.bar, (unsigned)nwg, gen);
     cross_sum(a.part2, 2 * RP, 2 * RP, nwg, scr, tmp);
@@ -666,9 +676,9 @@ __global__ __launch_bounds__(256) void k_wadapt(WAdaptArgs a) {
         if (tid < RP) {
             double s = 0.0;
             for (int ff = 0; ff < RB; ++ff) s += (double)Gs[ff * RP + tid] * Wd[ff * RP + tid];
-            a.part1[(size_t)wg * (RP + 1) + tid] = s;    // colsum(G .* W) partial (:217)
+            xstore(a.part1 + (size_t)wg * (RP + 1) + tid, s);  // colsum(G .* W) partial (:217)
         }
-        if (tid == RP) a.part1[(size_t)wg * (RP + 1) + RP] = red[0] + red[1] + red[2] + red[3];
+        if (tid == RP) xstore(a.part1 + (size_t)wg * (RP + 1) + RP, red[0] + red[1] + red[2] + red[3]);
         bar_ok &= grid_bar(a.bar, (unsigned)nwg, gen);
         cross_sum(a.part1, RP + 1, RP + 1, nwg, scr, tmp);     // colsum(G .* W) | div
         if (tid < RP) cq[tid] = tmp[tid];
@@ -708,8 +718,8 @@ __global__ __launch_bounds__(256) void k_wadapt(WAdaptArgs a) {
                 s2 += w * w;
                 s1 += w;
             }
-            a.part2[(size_t)wg * 2 * RP + tid] = s2;
-            a.part2[(size_t)wg * 2 * RP + RP + tid] = s1;
+            xstore(a.part2 + (size_t)wg * 2 * RP + tid, s2);
+            xstore(a.part2 + (size_t)wg * 2 * RP + RP + tid, s1);
         }
         bar_ok &= grid_bar(a.bar, (unsigned)nwg, gen);
         cross_sum(a.part2, 2 * RP, 2 * RP, nwg, scr, tmp);
