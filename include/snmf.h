@@ -231,7 +231,7 @@ int snmf_plan_get_v_mdi_f32(snmf_plan* plan, float* V, int64_t ld, int on_device
  *   [x_hat_i, d_hat_i, x_tilde, g] = bnmf_sep_event_RT_IS16(y, l, g, p)   src/bnmf_sep_event_RT_IS16.m:1
  * together with its state g (src/init_buff.m:17-42) and the hop queueing / overlap-add / int16 output of
  * the driver loop src/NTF_sep_event_RT.m:54-135, for the configuration the reference ships
- * (blk_len_sep = 1, Splice = 0, B_sep_mode = 'DFT', one channel, supervised per-frame solve).
+ * (blk_len_sep = 1, Splice = 0, B_sep_mode = 'DFT', one channel).
  * Per frame: STFT -> H-only solve against [B_DFT_x, B_DFT_d] -> reconstructions, block sparsity,
  * adaptive beta, Wiener / MMSE gain -> noise-reference rings and (when triggered) the W-only
  * adaptation solve + dictionary re-assembly -> inverse STFT, overlap-add.  Only PCM in, PCM out and a
@@ -262,6 +262,9 @@ typedef struct snmf_online_params {
     int32_t adapt_train_N, R_a, m_a;
     double overlap_m_a, Ar_up;
     int32_t class_outputs;    /* also synthesise the event / noise estimates (x_hat, d_hat) */
+    /* semi-supervised frame solve (:125-139): the frame solve also updates the noise (N) or the event (E)
+     * columns of its private copy of W; only the activations are used afterwards, as in the reference */
+    int32_t basis_update_N, basis_update_E;
 } snmf_online_params;
 
 typedef struct snmf_online_frame {   /* per-frame diagnostics, in frame order */

@@ -79,9 +79,8 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         if (const mxArray* f = mxGetField(p, 0, "B_sep_mode")) mxGetString(f, mode, sizeof mode);
         if (const mxArray* f = mxGetField(p, 0, "ENHANCE_METHOD")) mxGetString(f, meth, sizeof meth);
         if (const mxArray* f = mxGetField(p, 0, "cf")) mxGetString(f, cf, sizeof cf);
-        if (strcmp(mode, "DFT") || fld(p, "Splice", 0) != 0 || fld(p, "blk_len_sep", 1) != 1 || fld(p, "basis_update_N", 0) != 0 ||
-            fld(p, "basis_update_E", 0) != 0)
-            mexErrMsgIdAndTxt("snmf:unsupported", "only B_sep_mode='DFT', Splice=0, blk_len_sep=1, supervised frame solve");
+        if (strcmp(mode, "DFT") || fld(p, "Splice", 0) != 0 || fld(p, "blk_len_sep", 1) != 1)
+            mexErrMsgIdAndTxt("snmf:unsupported", "only B_sep_mode='DFT', Splice=0, blk_len_sep=1");
         snmf_online_params q;
         std::memset(&q, 0, sizeof q);
         q.fftlength = (int32_t)fld(p, "fftlength", 0, true);
@@ -118,6 +117,8 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         q.overlap_m_a = fld(p, "overlap_m_a", 0.01);
         q.Ar_up = fld(p, "Ar_up", 1.0);
         q.class_outputs = 0;
+        q.basis_update_N = fld(p, "basis_update_N", 0) != 0;
+        q.basis_update_E = fld(p, "basis_update_E", 0) != 0;
         const std::vector<float> Bx = to_f32(prhs[1], "B_DFT_x"), Bd = to_f32(prhs[2], "B_DFT_d"), H0 = to_f32(prhs[3], "H0"),
                                  Ad = to_f32(prhs[4], "Ad_blk0");
         const mxArray *ws = mxGetField(p, 0, "win_STFT"), *wi = mxGetField(p, 0, "win_ISTFT");

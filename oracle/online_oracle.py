@@ -141,6 +141,10 @@ def sep_frame(y, l, g, p, H0):
     q = dict(cf=p["cf"], sparsity=p["sparsity"], max_iter=p["max_iter"], conv_eps=p["conv_eps"], cost_check=p["cost_check"],
              init_w=np.concatenate([B_x, B_d], axis=1), init_h=np.asarray(H0, dtype=np.float64).reshape(-1, 1),
              w_update_ind=np.zeros(R_x + R_d, bool), h_update_ind=np.ones(R_x + R_d, bool))
+    if p.get("basis_update_N", 0):  # :125-139 (the third branch, N && E, is unreachable in the reference)
+        q["w_update_ind"] = np.concatenate([np.zeros(R_x, bool), np.ones(R_d, bool)])
+    elif p.get("basis_update_E", 0):
+        q["w_update_ind"] = np.concatenate([np.ones(R_x, bool), np.zeros(R_d, bool)])
     if "beta_div" in p:
         q["beta"] = p["beta_div"]
     _, A, obj = sparse_nmf(Ym[:, None], q)

@@ -77,7 +77,7 @@ class SnmfOnlineParams(C.Structure):
         ("alpha_p", C.c_double),
         ("adapt_train_N", C.c_int32), ("R_a", C.c_int32), ("m_a", C.c_int32),
         ("overlap_m_a", C.c_double), ("Ar_up", C.c_double),
-        ("class_outputs", C.c_int32),
+        ("class_outputs", C.c_int32), ("basis_update_N", C.c_int32), ("basis_update_E", C.c_int32),
     ]
 
 

@@ -1537,6 +1537,7 @@ struct snmf_online {
     int F = 0, r = 0, N = 0, nov = 0;
     snmf_plan* hp = nullptr;  // frame solve: F x 1, rank r, H-only
     snmf_plan* ap = nullptr;  // adaptation solve: F x m_a, rank R_a, W-only
+    snmf_plan* hsemi = nullptr;  // semi-supervised frame solve (basis_update_N / _E): generic path, W reset every frame
     snmf_plan* hb = nullptr;  // fixed dictionary (no adaptation): the frame solves of a whole batch in one launch
     DevState* bst = nullptr;
     double *bdiv = nullptr, *bcost = nullptr;
@@ -1597,6 +1598,7 @@ extern "C" void snmf_online_destroy(snmf_online* o) {
     hipStreamSynchronize(o->ctx->stream);
     if (o->hp) snmf_plan_destroy(o->hp);
     if (o->ap) snmf_plan_destroy(o->ap);
+    if (o->hsemi) snmf_plan_destroy(o->hsemi);
     online_free_call_buffers(o);
     void* ptrs[] = {o->B,   o->Bfix, o->Btmp,  o->H0,    o->lambda_dav, o->Xm_tilde, o->r_blk, o->ldblk, o->adblk,  o->Vad,
                     o->Had, o->win_s, o->win_i, o->syn_tail, o->tw,       o->rup,      o->dev,   o->status, o->hst,   o->hdiv,
@@ -1658,6 +1660,13 @@ extern "C" int snmf_online_create(snmf_ctx* ctx, const snmf_online_params* p, co
     hp.h_update_ind = ones.data();   // :148
     A(snmf_plan_create(ctx, &hp, &o->hp));
     if (s == SNMF_OK && !o->hp->small_ok) A(fail(SNMF_ERR_UNSUPPORTED, "F + r too large for the persistent frame-solve kernel"));
+    if (p->basis_update_N || p->basis_update_E) {
+        snmf_params sp = hp;
+        std::vector<uint8_t> wm(r, 0);
+        for (int k = 0; k < r; ++k) wm[k] = p->basis_update_N ? (k >= p->R_x) : (k < p->R_x);  // :125-131
+        sp.w_update_ind = wm.data();
+        A(snmf_plan_create(ctx, &sp, &o->hsemi));
+    }
     if (p->adapt_train_N) {
         snmf_params ap = hp;
         ap.T = ma; ap.r = Ra;
@@ -1761,7 +1770,7 @@ static int online_reserve(snmf_online* o, int n) {
     SN_TRY(dalloc(&o->syn, (size_t)(cap + o->nov - 1) * sz));
     SN_TRY(dalloc(&o->outf, (size_t)cap * hop));
     SN_TRY(dalloc(&o->out16, (size_t)cap * hop));
-    if (!o->p.adapt_train_N) {
+    if (!o->p.adapt_train_N && !o->hsemi) {
         snmf_params bp = o->hp->p;
         bp.T = cap;
         std::vector<uint8_t> zeros(o->r, 0), ones(o->r, 1);
@@ -1793,9 +1802,27 @@ static void launch_by_logn(K&& f, int N) {
 }
 
 // the frame solve (:148-154): V = Ym (device), W resident, H0 the fixed start; leaves A in hp->H[0]
-static int online_solve_frame(snmf_online* o, const float* dV) {
-    snmf_plan* pl = o->hp;
+static int online_solve_frame(snmf_online* o, const float* dV, const float** A_out, const DevState** st_out, const float** recon_out) {
     hipStream_t st = o->ctx->stream;
+    if (o->hsemi) {
+        // semi-supervised: an ordinary solve with part of W free; init_w = [B_DFT_x, B_DFT_d] again every frame (:140-146)
+        snmf_plan* ps = o->hsemi;
+        SN_TRY(set_v<float>(ps, dV, o->F, 1));
+        SN_TRY(set_w<double>(ps, o->B, o->F, 1));
+        SN_TRY(set_h<float>(ps, o->H0, o->r, 1));
+        SN_TRY(snmf_plan_init(ps));
+        SN_TRY(snmf_plan_run(ps, o->p.max_iter, nullptr));
+        int idx = 0;
+        SN_TRY(result_h_index(ps, &idx));
+        *A_out = ps->H[idx];
+        *st_out = ps->st;
+        *recon_out = nullptr;
+        return SNMF_OK;
+    }
+    snmf_plan* pl = o->hp;
+    *A_out = pl->H[0];
+    *st_out = o->hst;
+    *recon_out = pl->frame_fb ? o->recon1 : nullptr;
     const size_t nVp = (size_t)pl->Fp * pl->Tp;
     hipLaunchKernelGGL(k_pack<float>, dim3(grid_for(nVp)), dim3(256), 0, st, dV, (int64_t)o->F, o->F, 1, pl->V, pl->Fp, pl->Tp, kFlr,
                        pl->p.floor_v ? 1 : 0);
@@ -1894,7 +1921,7 @@ static int online_run_frames(snmf_online* o, const std::vector<float>& sig, int 
         a.a_stride = 0;
         return a;
     };
-    if (!p.adapt_train_N) {
+    if (!p.adapt_train_N && !o->hsemi) {
         // Fixed dictionary: nothing the host decides sits between frames.  All frame solves of the batch run
         // in ONE launch (one workgroup per frame, W normalised once), then ONE k_opost launch walks the
         // sequential post-filter recurrences.
@@ -1930,10 +1957,9 @@ static int online_run_frames(snmf_online* o, const std::vector<float>& sig, int 
         }
     } else {
         for (int i = 0; i < n; ++i) {
-            SN_TRY(online_solve_frame(o, o->Ym + (size_t)i * F));
             OPostArgs a = post_args(i, o->l + 1 + i);
-            a.A = o->hp->H[0]; a.hst = o->hst; a.status = o->status;
-            a.recon = o->hp->frame_fb ? o->recon1 : nullptr;
+            SN_TRY(online_solve_frame(o, o->Ym + (size_t)i * F, &a.A, &a.hst, &a.recon));
+            a.status = o->status;
             hipLaunchKernelGGL(k_opost, dim3(1), dim3(1024), lds_post, st, a);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(o->h_status, o->status, sizeof(OnlineStatus), hipMemcpyDeviceToHost, st));

@@ -11,7 +11,7 @@ gain, the noise-dictionary adaptation, inverse STFT and overlap-add all run in l
 (settings/initial_setting_SNMF_NAT.m); `default_settings()` returns the shipped values.
 
 Scope = the configuration the reference ships: blk_len_sep = 1, Splice = 0, B_sep_mode = 'DFT', one
-channel, supervised per-frame solve (basis_update_N = basis_update_E = 0).  Anything else raises.
+channel (supervised or semi-supervised frame solve).  Anything else raises.
 MATLAB's global-RNG draws (rand(r,1) per frame solve, rand(R_a, m_a) in init_buff) are explicit
 arguments `H0` / `Ad_blk0` (default: numpy RandomState(random_seed) stand-ins).
 """
@@ -60,8 +60,6 @@ class OnlineSeparator:
     def __init__(self, B_DFT_x, B_DFT_d, p, H0=None, Ad_blk0=None, ctx=None, class_outputs=False):
         if p.get("B_sep_mode", "DFT") != "DFT" or p.get("Splice", 0) != 0 or p.get("blk_len_sep", 1) != 1:
             raise NotImplementedError("online path: only B_sep_mode='DFT', Splice=0, blk_len_sep=1 (the shipped settings)")
-        if p.get("basis_update_N", 0) or p.get("basis_update_E", 0):
-            raise NotImplementedError("online path: only the supervised per-frame solve (basis_update_N = basis_update_E = 0)")
         if "cost_check" not in p:
             raise KeyError("Reference to non-existent field 'cost_check'.")  # src/sparse_nmf.m:260
         method = p.get("ENHANCE_METHOD", "MMSE")
@@ -111,6 +109,7 @@ class OnlineSeparator:
         q.adapt_train_N, q.R_a, q.m_a = adapt, R_a, m_a
         q.overlap_m_a, q.Ar_up = float(p.get("overlap_m_a", 0.01)), float(p.get("Ar_up", 1.0))
         q.class_outputs = int(bool(class_outputs))
+        q.basis_update_N, q.basis_update_E = int(bool(p.get("basis_update_N", 0))), int(bool(p.get("basis_update_E", 0)))
         self._q = q
         self.class_outputs = bool(class_outputs)
         self.hop, self.delay = q.frameshift, q.delay

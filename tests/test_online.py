@@ -137,6 +137,8 @@ VARIANTS = [
     dict(cf="ed", sparsity=50.0, adapt_train_N=0),
     dict(blk_gap=1, P_len_l=4, init_N_len=3),
     dict(conv_eps=0.0, max_iter=12),
+    dict(basis_update_N=1, max_iter=30),   # semi-supervised frame solve (:125-127)
+    dict(basis_update_E=1, max_iter=30, adapt_train_N=0),
 ]
 REL_OUT_ED_ADAPT = 2e-3  # see the module docstring
 
@@ -181,8 +183,6 @@ def test_unsupported_modes_and_state_errors(gpu_ctx):
     p = default_settings()
     with pytest.raises(NotImplementedError):
         OnlineSeparator(Bx, Bd, dict(p, B_sep_mode="Mel"), ctx=gpu_ctx)
-    with pytest.raises(NotImplementedError):
-        OnlineSeparator(Bx, Bd, dict(p, basis_update_N=1), ctx=gpu_ctx)
     q = dict(p)
     del q["cost_check"]
     with pytest.raises(KeyError):
