@@ -231,7 +231,7 @@ int snmf_plan_get_v_mdi_f32(snmf_plan* plan, float* V, int64_t ld, int on_device
  *   [x_hat_i, d_hat_i, x_tilde, g] = bnmf_sep_event_RT_IS16(y, l, g, p)   src/bnmf_sep_event_RT_IS16.m:1
  * together with its state g (src/init_buff.m:17-42) and the hop queueing / overlap-add / int16 output of
  * the driver loop src/NTF_sep_event_RT.m:54-135, for the configuration the reference ships
- * (blk_len_sep = 1, Splice = 0, B_sep_mode = 'DFT', one channel).
+ * (blk_len_sep = 1, Splice = 0, one channel; B_sep_mode 'DFT', or 'Mel' through snmf_online_set_mel).
  * Per frame: STFT -> H-only solve against [B_DFT_x, B_DFT_d] -> reconstructions, block sparsity,
  * adaptive beta, Wiener / MMSE gain -> noise-reference rings and (when triggered) the W-only
  * adaptation solve + dictionary re-assembly -> inverse STFT, overlap-add.  Only PCM in, PCM out and a
@@ -282,6 +282,13 @@ typedef struct snmf_online_frame {   /* per-frame diagnostics, in frame order */
 int snmf_online_create(snmf_ctx* ctx, const snmf_online_params* p, const float* B_DFT_x, const float* B_DFT_d,
                        const float* H0, const float* Ad_blk0, const float* win_stft, const float* win_istft,
                        snmf_online** out);
+/* B_sep_mode = 'Mel' (src/bnmf_sep_event_RT_IS16.m:106-120; src/init_buff.m:45-47): call once right after create.
+ * melmat: F_order x F ROW-major (g.melmat = mel_matrix(fs, F_order, fftlength, 1, fs/2)'); B_Mel_x / B_Mel_d:
+ * F_order x R_x / R_d column-major.  mel_conv = p.MelConv (0: Mel activations on the DFT bases). */
+int snmf_online_set_mel(snmf_online* o, int32_t F_order, int32_t mel_conv, const float* melmat, const float* B_Mel_x,
+                        const float* B_Mel_d);
+/* Current B_Mel_d (Mel mode adapts this one; B_DFT_d stays). */
+int snmf_online_get_mel_basis_f32(snmf_online* o, float* B_Mel_d, int64_t ld);
 /* Feed n PCM samples (int16-valued floats); every complete hop becomes a frame.  flush != 0 ends the
  * stream the way the driver does at end of file (delay+1 all-zero frames, src/NTF_sep_event_RT.m:69-76).
  * Outputs (host, each may be NULL): the denoised signal before rounding, the int16 the driver writes, and

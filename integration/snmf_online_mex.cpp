@@ -79,8 +79,8 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         if (const mxArray* f = mxGetField(p, 0, "B_sep_mode")) mxGetString(f, mode, sizeof mode);
         if (const mxArray* f = mxGetField(p, 0, "ENHANCE_METHOD")) mxGetString(f, meth, sizeof meth);
         if (const mxArray* f = mxGetField(p, 0, "cf")) mxGetString(f, cf, sizeof cf);
-        if (strcmp(mode, "DFT") || fld(p, "Splice", 0) != 0 || fld(p, "blk_len_sep", 1) != 1)
-            mexErrMsgIdAndTxt("snmf:unsupported", "only B_sep_mode='DFT', Splice=0, blk_len_sep=1");
+        if ((strcmp(mode, "DFT") && strcmp(mode, "Mel")) || fld(p, "Splice", 0) != 0 || fld(p, "blk_len_sep", 1) != 1)
+            mexErrMsgIdAndTxt("snmf:unsupported", "only Splice=0, blk_len_sep=1, B_sep_mode 'DFT' or 'Mel' (then call 'set_mel')");
         snmf_online_params q;
         std::memset(&q, 0, sizeof q);
         q.fftlength = (int32_t)fld(p, "fftlength", 0, true);
@@ -129,6 +129,18 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
             mexErrMsgIdAndTxt("snmf:create", "%s", snmf_last_error());
         g_handles.push_back(o);
         plhs[0] = mxCreateDoubleScalar((double)g_handles.size());
+    } else if (!strcmp(cmd, "set_mel")) {
+        // snmf_online_mex('set_mel', h, melmat, B_Mel_x, B_Mel_d, MelConv): melmat = g.melmat (F_order x F), init_buff.m:46
+        if (nrhs != 6) mexErrMsgIdAndTxt("snmf:usage", "set_mel: handle, melmat, B_Mel_x, B_Mel_d, MelConv");
+        snmf_online* o = handle_of(prhs[1]);
+        const mwSize n1 = mxGetM(prhs[2]), F = mxGetN(prhs[2]);
+        const double* mm = mxGetDoubles(prhs[2]);
+        std::vector<float> mr((size_t)n1 * F);  // MATLAB is column-major, the C ABI wants the rows contiguous
+        for (mwSize m = 0; m < n1; ++m)
+            for (mwSize f = 0; f < F; ++f) mr[(size_t)m * F + f] = (float)mm[(size_t)f * n1 + m];
+        const std::vector<float> bx = to_f32(prhs[3], "B_Mel_x"), bd = to_f32(prhs[4], "B_Mel_d");
+        if (snmf_online_set_mel(o, (int32_t)n1, mxGetScalar(prhs[5]) != 0, mr.data(), bx.data(), bd.data()) != SNMF_OK)
+            mexErrMsgIdAndTxt("snmf:set_mel", "%s", snmf_last_error());
     } else if (!strcmp(cmd, "process")) {
         if (nrhs != 4) mexErrMsgIdAndTxt("snmf:usage", "process: handle, pcm, flush");
         snmf_online* o = handle_of(prhs[1]);

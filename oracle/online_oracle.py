@@ -16,8 +16,8 @@ fp64 NumPy restatement, each function citing the reference lines it follows:
   src/NTF_sep_event_RT.m:54-135              file-level driver: hop queueing, delay, overlap-add, int16 out
 
 Scope: the configuration the reference ships and runs (settings/initial_setting_SNMF_NAT.m):
-blk_len_sep = 1, Splice = 0, B_sep_mode = 'DFT', one channel.  In that mode the "Mel" dictionary
-slots hold the DFT bases (Do_MultiBatch_IS16_20160324.m:199-200), which is what makes the quirks at
+blk_len_sep = 1, Splice = 0, one channel; B_sep_mode = 'DFT' (shipped) or 'Mel' (with or without MelConv).
+In DFT mode the "Mel" dictionary slots hold the DFT bases (Do_MultiBatch_IS16_20160324.m:199-200), which is what makes the quirks at
 :322-328 (row count n1 and the fixed columns taken from B_Mel_d) well defined; they are restated as
 written.  MATLAB's global-RNG draws (init_buff.m:38-39 rand for Ad_blk, sparse_nmf.m:133-134 rand(r,1)
 for every frame's H0 -- re-seeded identically each frame) are explicit inputs here.
@@ -53,8 +53,9 @@ def default_params():
     )
 
 
-def init_buff(B_DFT_x, B_DFT_d, p, Ad_blk0):
-    """src/init_buff.m:17-42 (DFT mode, m = 1).  Ad_blk0 stands in for rand(R_a, m_a) at :39."""
+def init_buff(B_DFT_x, B_DFT_d, p, Ad_blk0, mel=None):
+    """src/init_buff.m:17-47 (m = 1).  Ad_blk0 stands in for rand(R_a, m_a) at :39.  mel = dict(B_Mel_x, B_Mel_d,
+    melmat) for B_sep_mode = 'Mel' (melmat = mel_matrix(fs, F_order, fftlength, 1, fs/2)', :45-47)."""
     n2 = B_DFT_x.shape[0]
     g = dict(
         Xm_tilde=np.zeros(n2), lambda_dav=np.zeros(n2), lambda_Gy=np.zeros(n2),
@@ -64,6 +65,10 @@ def init_buff(B_DFT_x, B_DFT_d, p, Ad_blk0):
         B_Mel_d=np.array(B_DFT_d, dtype=np.float64),  # DFT mode: Do_MultiBatch_IS16_20160324.m:199-200
     )
     assert g["Ad_blk"].shape == (p["R_a"], p["m_a"])
+    if p.get("B_sep_mode", "DFT") == "Mel":
+        g["B_Mel_x"] = np.array(mel["B_Mel_x"], dtype=np.float64)
+        g["B_Mel_d"] = np.array(mel["B_Mel_d"], dtype=np.float64)
+        g["melmat"] = np.array(mel["melmat"], dtype=np.float64)
     return g
 
 
@@ -137,9 +142,20 @@ def sep_frame(y, l, g, p, H0):
     R_d = B_d.shape[1]
     flr = p["nonzerofloor"]
     Ym, Yp = frame_stft(y, p)
+    mel = p.get("B_sep_mode", "DFT") == "Mel"
+    melconv = mel and bool(p.get("MelConv", 1))
+    if mel:  # :106-120 feature frequency scale conversion + power normalisation matched to Ym
+        melmat = g["melmat"]
+        Ym_Mel = melmat @ Ym
+        vn = np.sqrt(np.sum(Ym_Mel ** 2))
+        tn = np.sqrt(np.sum(Ym ** 2))
+        Ym_Mel = (Ym_Mel / vn + 1e-9) * tn
+        Y_sep, Bs_x, Bs_d = Ym_Mel, g["B_Mel_x"], g["B_Mel_d"]
+    else:
+        Y_sep, Bs_x, Bs_d = Ym, B_x, B_d
     # 1) supervised solve (:124-154)
     q = dict(cf=p["cf"], sparsity=p["sparsity"], max_iter=p["max_iter"], conv_eps=p["conv_eps"], cost_check=p["cost_check"],
-             init_w=np.concatenate([B_x, B_d], axis=1), init_h=np.asarray(H0, dtype=np.float64).reshape(-1, 1),
+             init_w=np.concatenate([Bs_x, Bs_d], axis=1), init_h=np.asarray(H0, dtype=np.float64).reshape(-1, 1),
              w_update_ind=np.zeros(R_x + R_d, bool), h_update_ind=np.ones(R_x + R_d, bool))
     if p.get("basis_update_N", 0):  # :125-139 (the third branch, N && E, is unreachable in the reference)
         q["w_update_ind"] = np.concatenate([np.zeros(R_x, bool), np.ones(R_d, bool)])
@@ -147,11 +163,17 @@ def sep_frame(y, l, g, p, H0):
         q["w_update_ind"] = np.concatenate([np.ones(R_x, bool), np.zeros(R_d, bool)])
     if "beta_div" in p:
         q["beta"] = p["beta_div"]
-    _, A, obj = sparse_nmf(Ym[:, None], q)
+    _, A, obj = sparse_nmf(Y_sep[:, None], q)
     A = A[:, 0]
     # class sums (:158-202): with any class partition the sums are B_x*A_x and B_d*A_d
-    Xs = B_x @ A[:R_x]
-    Ds = B_d @ A[R_x:]
+    if melconv:  # :165-171,:185-192 and :205-211
+        Xs = melmat.T @ (Bs_x @ A[:R_x])
+        Ds = melmat.T @ (Bs_d @ A[R_x:])
+        Ym_Mel_DFT = melmat.T @ Ym_Mel
+    else:  # DFT mode, or coupled dictionaries (Mel activations on the DFT bases)
+        Xs = B_x @ A[:R_x]
+        Ds = B_d @ A[R_x:]
+        Ym_Mel_DFT = Ym
     # block sparsity (:214-218)
     if p["blk_sparse"]:
         Q, g["r_blk"] = blk_sparse(Xs, Ds, g["r_blk"], l, p)
@@ -159,7 +181,7 @@ def sep_frame(y, l, g, p, H0):
         Q = np.ones(n2)
     # 3) gain (:221-261)
     if l == 1:
-        g["lambda_dav"] = Ym.copy()  # :224 (Ym_Mel_DFT == Ym in DFT mode)
+        g["lambda_dav"] = Ym_Mel_DFT.copy()  # :224
     A_d_mag = A[R_x:].sum() / R_d  # :228
     A_x_mag = A[:R_x].sum() / R_x  # :229
     beta = 20 * np.log10(A_d_mag / A_x_mag) * p["beta"]  # :230-231
@@ -198,23 +220,25 @@ def sep_frame(y, l, g, p, H0):
         n_up = int(r_up.sum())
         if g["update_switch"] == int(np.floor(p["overlap_m_a"] * p["m_a"])):  # :294
             Ra = p["R_a"]
-            up = B_d[:, :Ra] * r_up[None, :]
+            Bsrc = g["B_Mel_d"] if mel else B_d  # :298-310 / :322-328
+            Vad = (g["melmat"] @ g["lambda_d_blk"]) if mel else g["lambda_d_blk"]  # :299-303
+            up = Bsrc[:, :Ra] * r_up[None, :]
             up = up[:, np.any(up != 0, axis=0)]  # :324
-            rem = B_d[:, :Ra] * (1 - r_up)[None, :]
+            rem = Bsrc[:, :Ra] * (1 - r_up)[None, :]
             rem = rem[:, np.any(rem != 0, axis=0)]  # :326
-            fix = g["B_Mel_d"][:, Ra:]  # :328
+            fix = g["B_Mel_d"][:, Ra:]  # :309 / :328
             Ad_up = g["Ad_blk"] * r_up[:, None]
             Ad_up = Ad_up[np.any(Ad_up != 0, axis=1), :]  # :292
             if up.shape[1] > 0:
                 qa = dict(cf=p["cf"], sparsity=p["sparsity"], max_iter=p["max_iter"], conv_eps=p["conv_eps"],
                           cost_check=p["cost_check"], init_w=up, init_h=Ad_up,
                           w_update_ind=np.ones(up.shape[1], bool), h_update_ind=np.zeros(up.shape[1], bool))
-                B_tmp, _, oa = sparse_nmf(g["lambda_d_blk"], qa)  # :335
+                B_tmp, _, oa = sparse_nmf(Vad, qa)  # :315 / :335
                 adapt_iters = oa["n_iter"]
-                g["B_DFT_d"] = np.concatenate([rem, B_tmp, fix], axis=1)  # :336
+                g["B_Mel_d" if mel else "B_DFT_d"] = np.concatenate([rem, B_tmp, fix], axis=1)  # :318 / :336
                 solved = True
             else:
-                g["B_DFT_d"] = np.concatenate([rem, fix], axis=1)
+                g["B_Mel_d" if mel else "B_DFT_d"] = np.concatenate([rem, fix], axis=1)
             g["update_switch"] = 1
         else:
             g["update_switch"] += 1
@@ -233,14 +257,14 @@ def _to_int16(x):
     return np.clip(r, -32768, 32767).astype(np.int16)
 
 
-def ntf_sep_event_rt(pcm, B_DFT_x, B_DFT_d, p, H0, Ad_blk0, return_trace=False, class_outputs=False):
+def ntf_sep_event_rt(pcm, B_DFT_x, B_DFT_d, p, H0, Ad_blk0, return_trace=False, class_outputs=False, mel=None):
     """src/NTF_sep_event_RT.m:54-135 for one channel, SNMF algorithm: pcm (int16-valued samples after the
     wav header) -> (denoised int16, float denoised before rounding, final B_DFT_d[, per-frame traces]).
     class_outputs: also overlap-add the event / noise estimates the way :105-119 (commented out in the
     reference) would, appended to the result as (x_hat, d_hat)."""
     pcm = np.asarray(pcm, dtype=np.float64).reshape(-1)
     sz, hop = p["framelength"], p["frameshift"]
-    g = init_buff(B_DFT_x, B_DFT_d, p, Ad_blk0)
+    g = init_buff(B_DFT_x, B_DFT_d, p, Ad_blk0, mel)
     y = np.zeros(sz)
     x_tilde = np.zeros(sz)
     xh_buf, dh_buf = np.zeros(sz), np.zeros(sz)
@@ -274,7 +298,7 @@ def ntf_sep_event_rt(pcm, B_DFT_x, B_DFT_d, p, H0, Ad_blk0, return_trace=False, 
                     dst.append(buf[:hop].copy())
         l += 1
     xf = np.concatenate(out) if out else np.zeros(0)
-    res = (_to_int16(xf), xf, g["B_DFT_d"])
+    res = (_to_int16(xf), xf, g["B_Mel_d"] if p.get("B_sep_mode", "DFT") == "Mel" else g["B_DFT_d"])
     if return_trace:
         res = res + (traces,)
     if class_outputs:

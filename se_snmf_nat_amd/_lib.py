@@ -34,7 +34,7 @@ SYMBOLS = [
     "snmf_ctx_timing", "snmf_ctx_timing_get", "snmf_plan_describe",
     "snmf_stft_num_frames", "snmf_stft_features_f32", "snmf_plan_set_v_from_audio_f32", "snmf_mel_features_f32",
     "snmf_plan_set_mask_f64", "snmf_plan_set_mask_f32", "snmf_plan_get_v_mdi_f64", "snmf_plan_get_v_mdi_f32",
-    "snmf_online_create", "snmf_online_process_f32", "snmf_online_get_basis_f32", "snmf_online_trace",
+    "snmf_online_create", "snmf_online_set_mel", "snmf_online_get_mel_basis_f32", "snmf_online_process_f32", "snmf_online_get_basis_f32", "snmf_online_trace",
     "snmf_online_destroy",
 ]
 
@@ -182,6 +182,8 @@ def load():
     sig["snmf_mel_features_f32"] = (C.c_int, [vp, vp, i32, i32, i32, vp, i64, i32, vp, i64, C.c_int])
     OP = C.POINTER(SnmfOnlineParams)
     sig["snmf_online_create"] = (C.c_int, [vp, OP, vp, vp, vp, vp, vp, vp, C.POINTER(vp)])
+    sig["snmf_online_set_mel"] = (C.c_int, [vp, i32, i32, vp, vp, vp])
+    sig["snmf_online_get_mel_basis_f32"] = (C.c_int, [vp, vp, i64])
     sig["snmf_online_process_f32"] = (C.c_int, [vp, vp, i64, C.c_int, vp, vp, vp, vp, i64, C.POINTER(i64)])
     sig["snmf_online_get_basis_f32"] = (C.c_int, [vp, vp, i64])
     sig["snmf_online_trace"] = (C.c_int, [vp, vp, i64, C.POINTER(i64)])

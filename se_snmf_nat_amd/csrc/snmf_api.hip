@@ -1535,7 +1535,11 @@ struct snmf_online {
     snmf_ctx* ctx = nullptr;
     snmf_online_params p{};
     int F = 0, r = 0, N = 0, nov = 0;
-    snmf_plan* hp = nullptr;  // frame solve: F x 1, rank r, H-only
+    int Fs = 0;               // rows of the solves: F, or F_order in Mel mode
+    int mel = 0, mel_conv = 0, n1 = 0;  // B_sep_mode = 'Mel' (snmf_online_set_mel)
+    float *melmat = nullptr, *Bmf = nullptr, *Ymel = nullptr;
+    double *Bm = nullptr, *Bmtmp = nullptr;  // [n1 x r] Mel dictionaries [B_Mel_x | B_Mel_d], fp64 like B
+    snmf_plan* hp = nullptr;  // frame solve: Fs x 1, rank r, H-only
     snmf_plan* ap = nullptr;  // adaptation solve: F x m_a, rank R_a, W-only
     snmf_plan* hsemi = nullptr;  // semi-supervised frame solve (basis_update_N / _E): generic path, W reset every frame
     snmf_plan* hb = nullptr;  // fixed dictionary (no adaptation): the frame solves of a whole batch in one launch
@@ -1575,7 +1579,8 @@ struct snmf_online {
 };
 
 static void online_free_call_buffers(snmf_online* o) {
-    void* ptrs[] = {o->sig, o->Ym, o->Xt, o->Xh, o->Dh, o->syn, o->outf, o->Yph, o->out16, o->bst, o->bdiv, o->bcost, o->bstatus, o->breco};
+    void* ptrs[] = {o->sig, o->Ym, o->Xt, o->Xh, o->Dh, o->syn, o->outf, o->Yph, o->out16, o->bst, o->bdiv, o->bcost, o->bstatus, o->breco, o->Ymel};
+    o->Ymel = nullptr;
     o->breco = nullptr;
     if (o->hb) {
         snmf_plan_destroy(o->hb);
@@ -1602,7 +1607,7 @@ extern "C" void snmf_online_destroy(snmf_online* o) {
     online_free_call_buffers(o);
     void* ptrs[] = {o->B,   o->Bfix, o->Btmp,  o->H0,    o->lambda_dav, o->Xm_tilde, o->r_blk, o->ldblk, o->adblk,  o->Vad,
                     o->Had, o->win_s, o->win_i, o->syn_tail, o->tw,       o->rup,      o->dev,   o->status, o->hst,   o->hdiv,
-                    o->hcost, o->syn_tail_x, o->syn_tail_d, o->Bf, o->recon1, o->wa_W, o->wa_p1, o->wa_p2, o->wa_cost, o->wa_nit, o->wa_bar};
+                    o->hcost, o->syn_tail_x, o->syn_tail_d, o->Bf, o->recon1, o->wa_W, o->wa_p1, o->wa_p2, o->wa_cost, o->wa_nit, o->wa_bar, o->melmat, o->Bmf, o->Bm, o->Bmtmp};
     for (void* q : ptrs)
         if (q) hipFree(q);
     if (o->h_status) hipHostFree(o->h_status);
@@ -1632,23 +1637,23 @@ static int online_validate(const snmf_online_params* p) {
     return SNMF_OK;
 }
 
-extern "C" int snmf_online_create(snmf_ctx* ctx, const snmf_online_params* p, const float* Bx, const float* Bd, const float* H0,
-                                  const float* Ad0, const float* win_stft, const float* win_istft, snmf_online** out) {
-    if (!ctx || !out || !Bx || !Bd || !H0 || !win_stft || !win_istft) return fail(SNMF_ERR_INVALID, "NULL argument");
-    *out = nullptr;
-    SN_TRY(online_validate(p));
-    if (p->adapt_train_N && !Ad0) return fail(SNMF_ERR_INVALID, "Ad_blk0 is required when adapt_train_N is set");
-    HIP_TRY(hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
-    snmf_online* o = new snmf_online();
-    o->ctx = ctx;
-    o->p = *p;
-    const int N = p->fftlength, F = N / 2 + 1, r = p->R_x + p->R_d, sz = p->framelength, hop = p->frameshift;
-    const int Ra = p->adapt_train_N ? p->R_a : 1, ma = p->adapt_train_N ? p->m_a : 1, Pl = p->blk_sparse ? p->P_len_l : 1;
-    o->F = F;
-    o->r = r;
-    o->N = N;
-    o->nov = (sz + hop - 1) / hop;
+// (re)create the resident solves for o->Fs rows: the frame solve, the optional semi-supervised variant, the
+// adaptation plan and the cooperative adaptation kernel's buffers
+static int online_make_solvers(snmf_online* o) {
+    const snmf_online_params* p = &o->p;
+    snmf_ctx* ctx = o->ctx;
+    const int F = o->Fs, r = o->r;
+    const int Ra = p->adapt_train_N ? p->R_a : 1, ma = p->adapt_train_N ? p->m_a : 1;
+    hipStreamSynchronize(ctx->stream);
+    for (snmf_plan** q : {&o->hp, &o->hsemi, &o->ap}) {
+        if (*q) snmf_plan_destroy(*q);
+        *q = nullptr;
+    }
+    for (void** q : {(void**)&o->wa_W, (void**)&o->wa_p1, (void**)&o->wa_p2, (void**)&o->wa_cost, (void**)&o->wa_nit, (void**)&o->wa_bar}) {
+        if (*q) hipFree(*q);
+        *q = nullptr;
+    }
+    o->wadapt = false;
     int s = SNMF_OK;
     auto A = [&](int v) { if (s == SNMF_OK) s = v; };
     // the two resident solves
@@ -1691,6 +1696,31 @@ extern "C" int snmf_online_create(snmf_ctx* ctx, const snmf_online_params* p, co
             D(&o->wa_bar, (size_t)1);
         }
     }
+    return s;
+}
+
+extern "C" int snmf_online_create(snmf_ctx* ctx, const snmf_online_params* p, const float* Bx, const float* Bd, const float* H0,
+                                  const float* Ad0, const float* win_stft, const float* win_istft, snmf_online** out) {
+    if (!ctx || !out || !Bx || !Bd || !H0 || !win_stft || !win_istft) return fail(SNMF_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    SN_TRY(online_validate(p));
+    if (p->adapt_train_N && !Ad0) return fail(SNMF_ERR_INVALID, "Ad_blk0 is required when adapt_train_N is set");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    snmf_online* o = new snmf_online();
+    o->ctx = ctx;
+    o->p = *p;
+    const int N = p->fftlength, F = N / 2 + 1, r = p->R_x + p->R_d, sz = p->framelength, hop = p->frameshift;
+    const int Ra = p->adapt_train_N ? p->R_a : 1, ma = p->adapt_train_N ? p->m_a : 1, Pl = p->blk_sparse ? p->P_len_l : 1;
+    o->F = F;
+    o->r = r;
+    o->N = N;
+    o->nov = (sz + hop - 1) / hop;
+    int s = SNMF_OK;
+    auto A = [&](int v) { if (s == SNMF_OK) s = v; };
+    o->Fs = F;
+    A(online_make_solvers(o));
+    auto D = [&](auto** ptr, size_t n) { if (s == SNMF_OK) s = dalloc(ptr, n); };
     D(&o->B, (size_t)F * r); D(&o->Bfix, (size_t)F * p->R_d); D(&o->Btmp, (size_t)F * p->R_d); D(&o->H0, (size_t)r);
     D(&o->Bf, (size_t)F * r);
     D(&o->recon1, (size_t)2 * F);
@@ -1753,6 +1783,53 @@ extern "C" int snmf_online_create(snmf_ctx* ctx, const snmf_online_params* p, co
     return SNMF_OK;
 }
 
+// B_sep_mode = 'Mel' (src/bnmf_sep_event_RT_IS16.m:106-120, src/init_buff.m:45-47): the solves run on Mel features
+extern "C" int snmf_online_set_mel(snmf_online* o, int32_t F_order, int32_t mel_conv, const float* melmat, const float* BMx,
+                                   const float* BMd) {
+    if (!o || !melmat || !BMx || !BMd) return fail(SNMF_ERR_INVALID, "NULL argument");
+    if (o->l != 0 || !o->pending.empty()) return fail(SNMF_ERR_STATE, "snmf_online_set_mel must precede the first process call");
+    if (F_order < 2 || F_order > o->F) return fail(SNMF_ERR_INVALID, "F_order must be in [2, fftlength/2+1]");
+    HIP_TRY(hipSetDevice(o->ctx->device));
+    hipStream_t st = o->ctx->stream;
+    const int n1 = F_order, r = o->r, F = o->F, Rx = o->p.R_x, Rd = o->p.R_d;
+    o->mel = 1;
+    o->mel_conv = mel_conv != 0;
+    o->n1 = n1;
+    o->Fs = n1;
+    SN_TRY(online_make_solvers(o));
+    for (void** q : {(void**)&o->melmat, (void**)&o->Bmf, (void**)&o->Bm, (void**)&o->Bmtmp}) {
+        if (*q) hipFree(*q);
+        *q = nullptr;
+    }
+    SN_TRY(dalloc(&o->melmat, (size_t)n1 * F));
+    SN_TRY(dalloc(&o->Bmf, (size_t)n1 * r));
+    SN_TRY(dalloc(&o->Bm, (size_t)n1 * r));
+    SN_TRY(dalloc(&o->Bmtmp, (size_t)n1 * Rd));
+    std::vector<double> hB((size_t)n1 * r);
+    for (size_t i = 0; i < (size_t)n1 * Rx; ++i) hB[i] = (double)BMx[i];
+    for (size_t i = 0; i < (size_t)n1 * Rd; ++i) hB[(size_t)n1 * Rx + i] = (double)BMd[i];
+    HIP_TRY(hipMemcpyAsync(o->Bm, hB.data(), hB.size() * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(o->Bmf, BMx, (size_t)n1 * Rx * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(o->Bmf + (size_t)n1 * Rx, BMd, (size_t)n1 * Rd * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(o->melmat, melmat, (size_t)n1 * F * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    SN_TRY(set_w<double>(o->hp, o->Bm, n1, 1));
+    online_free_call_buffers(o);  // batch buffers depend on the solve geometry
+    return SNMF_OK;
+}
+
+/* Current B_Mel_d (n1 x R_d): what the Mel-mode adaptation updates (src/bnmf_sep_event_RT_IS16.m:318). */
+extern "C" int snmf_online_get_mel_basis_f32(snmf_online* o, float* BMd, int64_t ld) {
+    if (!o || !BMd) return fail(SNMF_ERR_INVALID, "NULL argument");
+    if (!o->mel) return fail(SNMF_ERR_STATE, "not in Mel mode");
+    if (ld < o->n1) return fail(SNMF_ERR_INVALID, "ld < F_order");
+    HIP_TRY(hipSetDevice(o->ctx->device));
+    HIP_TRY(hipStreamSynchronize(o->ctx->stream));
+    HIP_TRY(hipMemcpy2D(BMd, (size_t)ld * 4, o->Bmf + (size_t)o->n1 * o->p.R_x, (size_t)o->n1 * 4, (size_t)o->n1 * 4, (size_t)o->p.R_d,
+                        hipMemcpyDeviceToHost));
+    return SNMF_OK;
+}
+
 static int online_reserve(snmf_online* o, int n) {
     if (n <= o->cap_frames) return SNMF_OK;
     hipStreamSynchronize(o->ctx->stream);
@@ -1762,6 +1839,7 @@ static int online_reserve(snmf_online* o, int n) {
     SN_TRY(dalloc(&o->sig, (sz - hop) + (size_t)cap * hop));
     SN_TRY(dalloc(&o->Ym, F * cap));
     SN_TRY(dalloc(&o->Yph, F * cap));
+    if (o->mel) SN_TRY(dalloc(&o->Ymel, (size_t)o->n1 * cap));
     SN_TRY(dalloc(&o->Xt, F * cap));
     if (o->p.class_outputs) {
         SN_TRY(dalloc(&o->Xh, F * cap));
@@ -1777,12 +1855,12 @@ static int online_reserve(snmf_online* o, int n) {
         bp.w_update_ind = zeros.data();
         bp.h_update_ind = ones.data();
         SN_TRY(snmf_plan_create(o->ctx, &bp, &o->hb));
-        SN_TRY(set_w<double>(o->hb, o->B, o->F, 1));
+        SN_TRY(set_w<double>(o->hb, o->mel ? o->Bm : o->B, o->Fs, 1));
         SN_TRY(dalloc(&o->bst, (size_t)cap));
         SN_TRY(dalloc(&o->bdiv, (size_t)cap * o->p.max_iter));
         SN_TRY(dalloc(&o->bcost, (size_t)cap * o->p.max_iter));
         SN_TRY(dalloc(&o->bstatus, (size_t)cap));
-        SN_TRY(dalloc(&o->breco, (size_t)cap * 2 * o->F));
+        SN_TRY(dalloc(&o->breco, (size_t)cap * 2 * o->Fs));
     }
     o->cap_frames = cap;
     return SNMF_OK;
@@ -1807,8 +1885,8 @@ static int online_solve_frame(snmf_online* o, const float* dV, const float** A_o
     if (o->hsemi) {
         // semi-supervised: an ordinary solve with part of W free; init_w = [B_DFT_x, B_DFT_d] again every frame (:140-146)
         snmf_plan* ps = o->hsemi;
-        SN_TRY(set_v<float>(ps, dV, o->F, 1));
-        SN_TRY(set_w<double>(ps, o->B, o->F, 1));
+        SN_TRY(set_v<float>(ps, dV, o->Fs, 1));
+        SN_TRY(set_w<double>(ps, o->mel ? o->Bm : o->B, o->Fs, 1));
         SN_TRY(set_h<float>(ps, o->H0, o->r, 1));
         SN_TRY(snmf_plan_init(ps));
         SN_TRY(snmf_plan_run(ps, o->p.max_iter, nullptr));
@@ -1822,9 +1900,9 @@ static int online_solve_frame(snmf_online* o, const float* dV, const float** A_o
     snmf_plan* pl = o->hp;
     *A_out = pl->H[0];
     *st_out = o->hst;
-    *recon_out = pl->frame_fb ? o->recon1 : nullptr;
+    *recon_out = (pl->frame_fb && (!o->mel || o->mel_conv)) ? o->recon1 : nullptr;  // Mel without MelConv: B_DFT*A, formed in k_opost
     const size_t nVp = (size_t)pl->Fp * pl->Tp;
-    hipLaunchKernelGGL(k_pack<float>, dim3(grid_for(nVp)), dim3(256), 0, st, dV, (int64_t)o->F, o->F, 1, pl->V, pl->Fp, pl->Tp, kFlr,
+    hipLaunchKernelGGL(k_pack<float>, dim3(grid_for(nVp)), dim3(256), 0, st, dV, (int64_t)o->Fs, o->Fs, 1, pl->V, pl->Fp, pl->Tp, kFlr,
                        pl->p.floor_v ? 1 : 0);
     HIP_TRY(hipGetLastError());
     pl->have_v = true;
@@ -1837,7 +1915,7 @@ static int online_solve_frame(snmf_online* o, const float* dV, const float** A_o
     pl->have_h = true;
     pl->inited = false;
     HIP_TRY(hipMemsetAsync(o->hst, 0, sizeof(DevState), st));
-    return launch_small(pl, 1, 1, o->hdiv, o->hcost, o->hst, o->recon1, o->p.R_x);
+    return launch_small(pl, 1, 1, o->hdiv, o->hcost, o->hst, (o->mel && !o->mel_conv) ? nullptr : o->recon1, o->p.R_x);
 }
 
 // :296-336 once the status says the solve is due
@@ -1845,48 +1923,59 @@ static int online_adapt(snmf_online* o, int32_t* iters) {
     const snmf_online_params& p = o->p;
     hipStream_t st = o->ctx->stream;
     snmf_plan* ap = o->ap;
-    double* Bd = o->B + (size_t)o->F * p.R_x;
-    const size_t n = (size_t)o->F * p.m_a + (size_t)p.R_a * p.m_a + p.R_a;
-    hipLaunchKernelGGL(k_oprep, dim3(grid_for(n)), dim3(256), 0, st, (const float*)o->ldblk, (const float*)o->adblk,
-                       (const uint8_t*)o->rup, (const OnlineDev*)o->dev, o->F, p.R_a, p.m_a, o->Vad, o->Had, ap->w_ind);
+    // DFT mode adapts B_DFT_d on lambda_d_blk (:320-338); Mel mode adapts B_Mel_d on melmat*lambda_d_blk (:298-318)
+    const int Fs = o->Fs;
+    double* Ball = o->mel ? o->Bm : o->B;
+    double* Bd = Ball + (size_t)Fs * p.R_x;
+    double* Btmp = o->mel ? o->Bmtmp : o->Btmp;
+    float* mirror = (o->mel ? o->Bmf : o->Bf) + (size_t)Fs * p.R_x;
+    const double* Bfix = o->mel ? Bd : o->Bfix;  // columns beyond R_a never change; :328 takes them from B_Mel_d
+    if (o->mel) {
+        hipLaunchKernelGGL(k_oprep_mel, dim3(p.m_a), dim3(256), 0, st, (const float*)o->ldblk, (const float*)o->adblk, (const uint8_t*)o->rup,
+                           (const OnlineDev*)o->dev, (const float*)o->melmat, o->F, o->n1, p.R_a, p.m_a, o->Vad, o->Had, ap->w_ind);
+    } else {
+        const size_t n = (size_t)o->F * p.m_a + (size_t)p.R_a * p.m_a + p.R_a;
+        hipLaunchKernelGGL(k_oprep, dim3(grid_for(n)), dim3(256), 0, st, (const float*)o->ldblk, (const float*)o->adblk,
+                           (const uint8_t*)o->rup, (const OnlineDev*)o->dev, o->F, p.R_a, p.m_a, o->Vad, o->Had, ap->w_ind);
+    }
     HIP_TRY(hipGetLastError());
+    const double* Wres = nullptr;
+    int ldw = 0;
     if (o->wadapt) {
         // the whole solve in one cooperative launch (k_wadapt)
         WAdaptArgs wa{};
         wa.V = o->Vad; wa.H = o->Had; wa.W0 = Bd; wa.w_ind = ap->w_ind; wa.Wout = o->wa_W; wa.part1 = o->wa_p1; wa.part2 = o->wa_p2;
-        wa.costh = o->wa_cost; wa.n_iter_out = o->wa_nit; wa.F = o->F; wa.Ra = p.R_a; wa.ma = p.m_a; wa.max_iter = p.max_iter;
+        wa.costh = o->wa_cost; wa.n_iter_out = o->wa_nit; wa.F = Fs; wa.Ra = p.R_a; wa.ma = p.m_a; wa.max_iter = p.max_iter;
         wa.cost_check = p.cost_check; wa.sparsity = (float)p.sparsity; wa.flr = kFlr; wa.conv_eps = p.conv_eps;
-        static bool attr_done = false;
-        if (o->wa_lds > 64 * 1024 && !attr_done) {
+        static size_t attr_lds = 0;
+        if (o->wa_lds > 64 * 1024 && attr_lds < o->wa_lds) {
             HIP_TRY(hipFuncSetAttribute((const void*)k_wadapt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->wa_lds));
-            attr_done = true;
+            attr_lds = o->wa_lds;
         }
         wa.bar = o->wa_bar;
         HIP_TRY(hipMemsetAsync(o->wa_bar, 0, 4, st));
         void* kargs[] = {&wa};
         HIP_TRY(hipLaunchCooperativeKernel((const void*)k_wadapt, dim3(o->wa_nwg), dim3(256), kargs, (unsigned)o->wa_lds, st));
-        int32_t nit = 0;
-        HIP_TRY(hipMemcpyAsync(&nit, o->wa_nit, 4, hipMemcpyDeviceToHost, st));
-        hipLaunchKernelGGL(k_oassemble, dim3(p.R_d), dim3(256), 0, st, (const double*)Bd, (const double*)o->wa_W, o->F, (const double*)o->Bfix,
-                           (const uint8_t*)o->rup, o->F, p.R_a, p.R_d, o->Btmp, o->Bf + (size_t)o->F * p.R_x);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(Bd, o->Btmp, (size_t)o->F * p.R_d * 8, hipMemcpyDeviceToDevice, st));
-        SN_TRY(set_w<double>(o->hp, o->B, o->F, 1));
-        HIP_TRY(hipStreamSynchronize(st));
-        if (nit < 0) return fail(SNMF_ERR_NO_DEVICE, "adaptation kernel: grid barrier timed out");
-        *iters = nit;
-        return SNMF_OK;
+        HIP_TRY(hipMemcpyAsync(iters, o->wa_nit, 4, hipMemcpyDeviceToHost, st));
+        Wres = o->wa_W;
+        ldw = Fs;
+    } else {
+        SN_TRY(set_v<float>(ap, o->Vad, Fs, 1));       // lambda_d_blk[_Mel] (floored at 1e-9 inside, sparse_nmf.m:169)
+        SN_TRY(set_w<double>(ap, Bd, Fs, 1));          // init_w: first R_a noise columns (:332)
+        SN_TRY(set_h<float>(ap, o->Had, p.R_a, 1));    // init_h (:333)
+        SN_TRY(snmf_plan_init(ap));
+        SN_TRY(snmf_plan_run(ap, p.max_iter, iters));
+        Wres = ap->Wc;
+        ldw = ap->Fp;
     }
-    SN_TRY(set_v<float>(ap, o->Vad, o->F, 1));         // lambda_d_blk (floored at 1e-9 inside, sparse_nmf.m:169)
-    SN_TRY(set_w<double>(ap, Bd, o->F, 1));            // init_w: first R_a noise columns (:332)
-    SN_TRY(set_h<float>(ap, o->Had, p.R_a, 1));        // init_h (:333)
-    SN_TRY(snmf_plan_init(ap));
-    SN_TRY(snmf_plan_run(ap, p.max_iter, iters));
-    hipLaunchKernelGGL(k_oassemble, dim3(p.R_d), dim3(256), 0, st, (const double*)Bd, (const double*)ap->Wc, ap->Fp, (const double*)o->Bfix,
-                       (const uint8_t*)o->rup, o->F, p.R_a, p.R_d, o->Btmp, o->Bf + (size_t)o->F * p.R_x);
+    hipLaunchKernelGGL(k_oassemble, dim3(p.R_d), dim3(256), 0, st, (const double*)Bd, Wres, ldw, Bfix, (const uint8_t*)o->rup, Fs, p.R_a,
+                       p.R_d, Btmp, mirror);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(Bd, o->Btmp, (size_t)o->F * p.R_d * 8, hipMemcpyDeviceToDevice, st));
-    return set_w<double>(o->hp, o->B, o->F, 1);        // next frame's init_w = [B_DFT_x, B_DFT_d] (:140-146)
+    HIP_TRY(hipMemcpyAsync(Bd, Btmp, (size_t)Fs * p.R_d * 8, hipMemcpyDeviceToDevice, st));
+    SN_TRY(set_w<double>(o->hp, Ball, Fs, 1));         // next frame's init_w (:140-146)
+    HIP_TRY(hipStreamSynchronize(st));
+    if (*iters < 0) return fail(SNMF_ERR_NO_DEVICE, "adaptation kernel: grid barrier timed out");
+    return SNMF_OK;
 }
 
 // n frames whose samples are sig = [history | n hops] (host); appends the hops the driver would write
@@ -1902,7 +1991,12 @@ static int online_run_frames(snmf_online* o, const std::vector<float>& sig, int 
     sa.powv = (float)p.pow; sa.floorv = (float)p.nonzerofloor; sa.Ym = o->Ym; sa.Yph = o->Yph; sa.ld = F; sa.n_frames = n;
     launch_by_logn([&](auto L) { hipLaunchKernelGGL(k_ostft<decltype(L)::value>, dim3(n), dim3(256), 0, st, sa); }, o->N);
     HIP_TRY(hipGetLastError());
-    const size_t lds_post = (size_t)(o->r + 6 * F) * 4;
+    if (o->mel) {
+        hipLaunchKernelGGL(k_omel_frame, dim3(n), dim3(256), (size_t)(o->n1 + 2) * 4, st, (const float*)o->Ym, (const float*)o->melmat, F, o->n1, n,
+                           o->Ymel);
+        HIP_TRY(hipGetLastError());
+    }
+    const size_t lds_post = (size_t)(o->r + 7 * F + 3 * o->n1) * 4;
     auto post_args = [&](int i, int64_t l) {
         OPostArgs a{};
         a.B = o->Bf; a.Ym = o->Ym + (size_t)i * F; a.lambda_dav = o->lambda_dav; a.Xm_tilde = o->Xm_tilde;
@@ -1919,6 +2013,9 @@ static int online_run_frames(snmf_online* o, const std::vector<float>& sig, int 
         a.beta_max = (float)p.beta_max; a.Ar_up = (float)p.Ar_up; a.flr = (float)p.nonzerofloor;
         a.n = 1;
         a.a_stride = 0;
+        a.mel = o->mel; a.mel_conv = o->mel_conv; a.n1 = o->n1; a.melmat = o->melmat; a.Bmf = o->Bmf;
+        a.Ymel = o->mel ? o->Ymel + (size_t)i * o->n1 : nullptr;
+        a.recon_len = o->Fs;
         return a;
     };
     if (!p.adapt_train_N && !o->hsemi) {
@@ -1927,8 +2024,8 @@ static int online_run_frames(snmf_online* o, const std::vector<float>& sig, int 
         // sequential post-filter recurrences.
         snmf_plan* pl = o->hb;
         const size_t nVp = (size_t)pl->Fp * pl->Tp;
-        hipLaunchKernelGGL(k_pack<float>, dim3(grid_for(nVp)), dim3(256), 0, st, (const float*)o->Ym, (int64_t)F, F, n, pl->V, pl->Fp, pl->Tp,
-                           kFlr, pl->p.floor_v ? 1 : 0);
+        hipLaunchKernelGGL(k_pack<float>, dim3(grid_for(nVp)), dim3(256), 0, st, (const float*)(o->mel ? o->Ymel : o->Ym), (int64_t)o->Fs, o->Fs, n,
+                           pl->V, pl->Fp, pl->Tp, kFlr, pl->p.floor_v ? 1 : 0);
         HIP_TRY(hipGetLastError());
         pl->have_v = true;
         if (pl->w_dirty) SN_TRY(launch_wapply(pl, pl->stats, 0, false, true));
@@ -1940,10 +2037,10 @@ static int online_run_frames(snmf_online* o, const std::vector<float>& sig, int 
         pl->have_h = true;
         pl->inited = false;
         HIP_TRY(hipMemsetAsync(o->bst, 0, (size_t)n * sizeof(DevState), st));
-        SN_TRY(launch_small(pl, n, 1, o->bdiv, o->bcost, o->bst, o->breco, p.R_x));
+        SN_TRY(launch_small(pl, n, 1, o->bdiv, o->bcost, o->bst, (o->mel && !o->mel_conv) ? nullptr : o->breco, p.R_x));
         OPostArgs a = post_args(0, o->l + 1);
         a.A = pl->H[0]; a.hst = o->bst; a.status = o->bstatus; a.n = n; a.a_stride = pl->rp;
-        a.recon = pl->frame_fb ? o->breco : nullptr;
+        a.recon = (pl->frame_fb && (!o->mel || o->mel_conv)) ? o->breco : nullptr;
         hipLaunchKernelGGL(k_opost, dim3(1), dim3(1024), lds_post, st, a);
         HIP_TRY(hipGetLastError());
         std::vector<OnlineStatus> hst((size_t)n);
@@ -1958,7 +2055,7 @@ static int online_run_frames(snmf_online* o, const std::vector<float>& sig, int 
     } else {
         for (int i = 0; i < n; ++i) {
             OPostArgs a = post_args(i, o->l + 1 + i);
-            SN_TRY(online_solve_frame(o, o->Ym + (size_t)i * F, &a.A, &a.hst, &a.recon));
+            SN_TRY(online_solve_frame(o, o->mel ? o->Ymel + (size_t)i * o->n1 : o->Ym + (size_t)i * F, &a.A, &a.hst, &a.recon));
             a.status = o->status;
             hipLaunchKernelGGL(k_opost, dim3(1), dim3(1024), lds_post, st, a);
             HIP_TRY(hipGetLastError());

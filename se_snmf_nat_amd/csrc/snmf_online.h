@@ -146,6 +146,12 @@ struct OPostArgs {
     int l;                // 1-based frame index
     int blk_sparse, adapt, wiener, init_N_len, switch_at;
     float alpha_p, alpha_eta, alpha_d, beta0, beta_max, Ar_up, flr;
+    // B_sep_mode = 'Mel' (:106-120): the solve ran on Mel features
+    const float* melmat;  // [n1][F] row-major (g.melmat)
+    const float* Ymel;    // [n1] this frame's normalised Mel features
+    const float* Bmf;     // [n1 x r] fp32 mirror of [B_Mel_x | B_Mel_d] (reconstruction fallback)
+    int mel, mel_conv, n1;
+    int recon_len;        // rows of one reconstruction in `recon` (F, or n1 with MelConv)
     int n;                // frames handled by this launch, one after the other (> 1 only without adaptation)
     int a_stride;         // distance between the activation vectors of consecutive frames
 };
@@ -174,10 +180,47 @@ __device__ __forceinline__ void opost_frame(const OPostArgs& a, float* sm, doubl
     sd = block_sum_d(sd, red);
     const float A_x_mag = (float)(sx / a.Rx), A_d_mag = (float)(sd / a.Rd);
     // Xm_hat_sum = B_x*A_x, Dm_hat_sum = B_d*A_d (:158-202; any class partition sums to these)
-    if (a.recon) {
+    float* Ymd = Gs + F;  // [F] Ym_Mel_DFT (first frame only), then [3*n1] Mel-domain vectors
+    if (a.mel && a.mel_conv) {
+        // :165-171,:185-192: reconstructions in the Mel domain, mapped back with melmat'; :205-211 Ym_Mel_DFT
+        float* Xm = Ymd + F;
+        float* Dm = Xm + a.n1;
+        float* Ym1 = Dm + a.n1;
+        for (int m = tid; m < a.n1; m += nt) {
+            float x, d;
+            if (a.recon) {
+                x = a.recon[m];
+                d = a.recon[a.recon_len + m];
+            } else {
+                x = 0.f;
+                d = 0.f;
+                const float* b = a.Bmf + m;
+                for (int k = 0; k < a.Rx; ++k) x = fmaf(b[(size_t)k * a.n1], sA[k], x);
+                b += (size_t)a.Rx * a.n1;
+                for (int k = 0; k < a.Rd; ++k) d = fmaf(b[(size_t)k * a.n1], sA[a.Rx + k], d);
+            }
+            Xm[m] = x;
+            Dm[m] = d;
+            Ym1[m] = a.Ymel[m];
+        }
+        __syncthreads();
+        for (int f = tid; f < F; f += nt) {
+            float x = 0.f, d = 0.f, y = 0.f;
+            for (int m = 0; m < a.n1; ++m) {
+                const float mm = a.melmat[(size_t)m * F + f];
+                x = fmaf(mm, Xm[m], x);
+                d = fmaf(mm, Dm[m], d);
+                y = fmaf(mm, Ym1[m], y);
+            }
+            Xs[f] = x;
+            Ds[f] = d;
+            Ymd[f] = y;
+        }
+    } else if (a.recon) {
         for (int f = tid; f < F; f += nt) {
             Xs[f] = a.recon[f];
-            Ds[f] = a.recon[F + f];
+            Ds[f] = a.recon[a.recon_len + f];
+            Ymd[f] = a.Ym[f];
         }
     } else {
         for (int f = tid; f < F; f += nt) {
@@ -188,6 +231,7 @@ __device__ __forceinline__ void opost_frame(const OPostArgs& a, float* sm, doubl
             for (int k = 0; k < a.Rd; ++k) d = fmaf(b[(size_t)k * F], sA[a.Rx + k], d);
             Xs[f] = x;
             Ds[f] = d;
+            Ymd[f] = a.Ym[f];
         }
     }
     __syncthreads();
@@ -270,7 +314,7 @@ __device__ __forceinline__ void opost_frame(const OPostArgs& a, float* sm, doubl
     const bool init = a.l <= a.init_N_len;
     for (int f = tid; f < F; f += nt) {
         const float ym = a.Ym[f];
-        float ld = a.l == 1 ? ym : a.lambda_dav[f];                       // :223-225
+        float ld = a.l == 1 ? Ymd[f] : a.lambda_dav[f];                   // :223-225 (Ym_Mel_DFT)
         ld = a.alpha_d * ld + (1.f - a.alpha_d) * Ds[f] * beta;           // :241
         a.lambda_dav[f] = ld;
         float G;
@@ -333,7 +377,7 @@ __device__ __forceinline__ void opost_frame(const OPostArgs& a, float* sm, doubl
     }
 }
 
-// One workgroup; dynamic LDS = (r + 6*F) floats.  The post-filter recurrences (smoothed noise PSD, the
+// One workgroup; dynamic LDS = (r + 7*F + 3*n1) floats.  The post-filter recurrences (smoothed noise PSD, the
 // previous frame's G.*Y, the SNR ring) make the frames sequential, but when the dictionary is fixed
 // (no adaptation) nothing the host must decide sits between them: the frame solves of a whole batch run
 // in parallel first and this kernel then walks the batch in ONE launch.
@@ -343,7 +387,8 @@ __global__ __launch_bounds__(1024) void k_opost(OPostArgs a0) {
     for (int i = 0; i < a0.n; ++i) {
         OPostArgs a = a0;
         a.A += (size_t)i * a0.a_stride;
-        if (a.recon) a.recon += (size_t)i * 2 * a0.F;
+        if (a.recon) a.recon += (size_t)i * 2 * a0.recon_len;
+        if (a.Ymel) a.Ymel += (size_t)i * a0.n1;
         a.hst += i;
         a.Ym += (size_t)i * a0.F;
         a.Xt_out += (size_t)i * a0.F;
@@ -377,6 +422,58 @@ __global__ void k_oprep(const float* __restrict__ ldblk, const float* __restrict
             const int k = (int)(i - nv - nh);
             w_ind[k] = rup[k];
         }
+    }
+}
+
+// :106-120 for a batch of frames: Ym_Mel = melmat*Ym, normalised to unit norm (+1e-9) and scaled to ||Ym||.
+// One workgroup per frame, one wave per group of outputs.
+__global__ __launch_bounds__(256) void k_omel_frame(const float* __restrict__ Ym, const float* __restrict__ melmat, int F, int n1,
+                                                    int n_frames, float* __restrict__ Ymel) {
+    extern __shared__ float sm[];  // [n1] + 2
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (t >= n_frames) return;
+    const float* y = Ym + (size_t)t * F;
+    float tn2 = 0.f;
+    for (int f = tid; f < F; f += 256) tn2 = fmaf(y[f], y[f], tn2);
+    tn2 = wave_sum_f(tn2);
+    __shared__ float part[4];
+    if (lane == 0) part[w] = tn2;
+    for (int m = w; m < n1; m += 4) {
+        float s = 0.f;
+        for (int f = lane; f < F; f += 64) s = fmaf(melmat[(size_t)m * F + f], y[f], s);
+        s = wave_sum_f(s);
+        if (lane == 0) sm[m] = s;
+    }
+    __syncthreads();
+    const float tn = sqrtf(part[0] + part[1] + part[2] + part[3]);
+    float vn2 = 0.f;
+    for (int m = tid; m < n1; m += 256) vn2 = fmaf(sm[m], sm[m], vn2);
+    vn2 = wave_sum_f(vn2);
+    __syncthreads();
+    if (lane == 0) part[w] = vn2;
+    __syncthreads();
+    const float vn = sqrtf(part[0] + part[1] + part[2] + part[3]);
+    for (int m = tid; m < n1; m += 256) Ymel[(size_t)t * n1 + m] = (sm[m] / vn + 1e-9f) * tn;
+}
+
+// Mel-mode inputs of the adaptation solve (:298-313): lambda_d_blk_Mel = melmat * lambda_d_blk in time order,
+// Ad_blk rows masked by r_up, the update mask.  One workgroup per ring column.
+__global__ __launch_bounds__(256) void k_oprep_mel(const float* __restrict__ ldblk, const float* __restrict__ adblk,
+                                                   const uint8_t* __restrict__ rup, const OnlineDev* dev,
+                                                   const float* __restrict__ melmat, int F, int n1, int Ra, int ma,
+                                                   float* __restrict__ Vad, float* __restrict__ Had, uint8_t* __restrict__ w_ind) {
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int oldest = dev->n_push % ma;
+    const float* col = ldblk + (size_t)((oldest + c) % ma) * F;
+    for (int m = w; m < n1; m += 4) {
+        float s = 0.f;
+        for (int f = lane; f < F; f += 64) s = fmaf(melmat[(size_t)m * F + f], col[f], s);
+        s = wave_sum_f(s);
+        if (lane == 0) Vad[(size_t)c * n1 + m] = s;
+    }
+    for (int k = tid; k < Ra; k += 256) {
+        Had[(size_t)c * Ra + k] = rup[k] ? adblk[(size_t)((oldest + c) % ma) * Ra + k] : 0.f;
+        if (c == 0) w_ind[k] = rup[k];
     }
 }
 

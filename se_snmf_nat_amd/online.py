@@ -10,8 +10,8 @@ gain, the noise-dictionary adaptation, inverse STFT and overlap-add all run in l
 `ntf_sep_event_rt` is the file-level call.  Parameter names are the reference's
 (settings/initial_setting_SNMF_NAT.m); `default_settings()` returns the shipped values.
 
-Scope = the configuration the reference ships: blk_len_sep = 1, Splice = 0, B_sep_mode = 'DFT', one
-channel (supervised or semi-supervised frame solve).  Anything else raises.
+Scope = the configuration the reference ships: blk_len_sep = 1, Splice = 0, one channel; B_sep_mode 'DFT'
+(shipped) or 'Mel' (MelConv 0/1); supervised or semi-supervised frame solve.  Anything else raises.
 MATLAB's global-RNG draws (rand(r,1) per frame solve, rand(R_a, m_a) in init_buff) are explicit
 arguments `H0` / `Ad_blk0` (default: numpy RandomState(random_seed) stand-ins).
 """
@@ -41,7 +41,7 @@ def default_settings():
         fs=fs, framelength=framelength, frameshift=frameshift, fftlength=fftlength, win_STFT=win, win_ISTFT=win.copy(),
         overlapscale=2 * frameshift / framelength, pow=2, preemph=0.0, DCbin=dcbin, DCbin_back=dcbin,
         nonzerofloor=1e-9, Splice=0, blk_len_sep=1, delay=0 + 1 + int(np.floor(0.040 / 0.010 / 2 + 0.5)),
-        B_sep_mode="DFT", basis_update_N=0, basis_update_E=0,
+        B_sep_mode="DFT", MelConv=1, F_order=64, basis_update_N=0, basis_update_E=0,
         adapt_train_N=1, init_N_len=15, R_a=50, m_a=100, overlap_m_a=0.01, Ar_up=1.0,
         blk_sparse=1, P_len_k=60, P_len_l=20, alpha_p=0.4, blk_gap=3,
         ENHANCE_METHOD="MMSE", alpha_eta=0.4, alpha_d=0.6, beta=1.0, beta_max=1000.0,
@@ -57,9 +57,12 @@ def _beta_div(p):
 class OnlineSeparator:
     """State `g` of src/init_buff.m + the per-frame function, resident on the GPU."""
 
-    def __init__(self, B_DFT_x, B_DFT_d, p, H0=None, Ad_blk0=None, ctx=None, class_outputs=False):
-        if p.get("B_sep_mode", "DFT") != "DFT" or p.get("Splice", 0) != 0 or p.get("blk_len_sep", 1) != 1:
-            raise NotImplementedError("online path: only B_sep_mode='DFT', Splice=0, blk_len_sep=1 (the shipped settings)")
+    def __init__(self, B_DFT_x, B_DFT_d, p, H0=None, Ad_blk0=None, ctx=None, class_outputs=False, B_Mel_x=None, B_Mel_d=None):
+        mode = p.get("B_sep_mode", "DFT")
+        if mode not in ("DFT", "Mel") or p.get("Splice", 0) != 0 or p.get("blk_len_sep", 1) != 1:
+            raise NotImplementedError("online path: only Splice=0, blk_len_sep=1 (the shipped settings), B_sep_mode 'DFT' or 'Mel'")
+        if mode == "Mel" and (B_Mel_x is None or B_Mel_d is None):
+            raise ValueError("B_sep_mode='Mel' needs B_Mel_x and B_Mel_d")
         if "cost_check" not in p:
             raise KeyError("Reference to non-existent field 'cost_check'.")  # src/sparse_nmf.m:260
         method = p.get("ENHANCE_METHOD", "MMSE")
@@ -119,6 +122,18 @@ class OnlineSeparator:
                                                 C.byref(h)))
         self._h = h
         self.ctx._plans.add(self)  # destroyed before the context
+        self.mel = mode == "Mel"
+        if self.mel:
+            from .frontend import mel_matrix
+            n1 = int(p.get("F_order", 64))
+            melmat = np.ascontiguousarray(mel_matrix(p["fs"], n1, p["fftlength"], 1.0, p["fs"] / 2).T, dtype=np.float32)  # init_buff.m:46
+            BMx = np.asfortranarray(B_Mel_x, dtype=np.float32)
+            BMd = np.asfortranarray(B_Mel_d, dtype=np.float32)
+            if BMx.shape != (n1, self.R_x) or BMd.shape != (n1, self.R_d):
+                raise ValueError("B_Mel_x / B_Mel_d must be F_order x R_x / R_d")
+            self.n1 = n1
+            _lib.check(self._lib.snmf_online_set_mel(self._h, n1, int(bool(p.get("MelConv", 1))), melmat.ctypes.data, BMx.ctypes.data,
+                                                     BMd.ctypes.data))
 
     def process(self, pcm, flush=False):
         """Feed PCM (int16 or int16-valued floats).  Returns a dict with the hops the driver writes for the
@@ -145,6 +160,12 @@ class OnlineSeparator:
         _lib.check(self._lib.snmf_online_get_basis_f32(self._h, B.ctypes.data, self.F))
         return B.astype(np.float64)
 
+    def mel_basis(self):
+        """Current B_Mel_d (Mel mode: the dictionary the adaptation updates, :318)."""
+        B = np.zeros((self.n1, self.R_d), dtype=np.float32, order="F")
+        _lib.check(self._lib.snmf_online_get_mel_basis_f32(self._h, B.ctypes.data, self.n1))
+        return B.astype(np.float64)
+
     def trace(self):
         """Per-frame diagnostics: list of dicts (n_iter, trig, solved, n_up, adapt_iters, beta, A_x_mag, ...)."""
         n = C.c_int64()
@@ -166,11 +187,11 @@ class OnlineSeparator:
             pass
 
 
-def ntf_sep_event_rt(pcm, B_DFT_x, B_DFT_d, p, H0=None, Ad_blk0=None, ctx=None, chunk=None):
+def ntf_sep_event_rt(pcm, B_DFT_x, B_DFT_d, p, H0=None, Ad_blk0=None, ctx=None, chunk=None, B_Mel_x=None, B_Mel_d=None):
     """src/NTF_sep_event_RT.m for one channel with p.NMF_algorithm = 'SNMF': pcm = the int16 samples after the
     wav header.  Returns (denoised int16, denoised float, final B_DFT_d).  `chunk` (samples per process() call)
     only changes how the stream is fed, not the result."""
-    sep = OnlineSeparator(B_DFT_x, B_DFT_d, p, H0=H0, Ad_blk0=Ad_blk0, ctx=ctx)
+    sep = OnlineSeparator(B_DFT_x, B_DFT_d, p, H0=H0, Ad_blk0=Ad_blk0, ctx=ctx, B_Mel_x=B_Mel_x, B_Mel_d=B_Mel_d)
     try:
         x = np.asarray(pcm).reshape(-1)
         if chunk is None:
@@ -181,6 +202,6 @@ def ntf_sep_event_rt(pcm, B_DFT_x, B_DFT_d, p, H0=None, Ad_blk0=None, ctx=None, 
             parts.append(sep.process(x[:0], flush=True))
             i16 = np.concatenate([q["x_tilde"] for q in parts])
             f32 = np.concatenate([q["x_tilde_f"] for q in parts])
-        return i16.copy(), f32.astype(np.float64), sep.basis()
+        return i16.copy(), f32.astype(np.float64), (sep.mel_basis() if sep.mel else sep.basis())
     finally:
         sep.close()

@@ -181,8 +181,10 @@ def test_unsupported_modes_and_state_errors(gpu_ctx):
     from se_snmf_nat_amd.online import OnlineSeparator, default_settings
     s, Bx, Bd, H0, Ad0 = fixture_inputs(4)
     p = default_settings()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):  # Mel mode needs the Mel dictionaries
         OnlineSeparator(Bx, Bd, dict(p, B_sep_mode="Mel"), ctx=gpu_ctx)
+    with pytest.raises(NotImplementedError):
+        OnlineSeparator(Bx, Bd, dict(p, Splice=1), ctx=gpu_ctx)
     q = dict(p)
     del q["cost_check"]
     with pytest.raises(KeyError):
@@ -245,3 +247,31 @@ def test_device_other_geometries_match_the_oracle(gpu_ctx, geo):
     assert np.abs(out["x_tilde"].astype(int) - o16.astype(int)).max() <= 1
     assert np.linalg.norm(Bn - Bdn) / np.linalg.norm(Bdn) < 1e-3
     assert sum(t["solved"] for t in trd) > 0 or not p["adapt_train_N"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("melconv", [1, 0], ids=["MelConv1", "MelConv0-coupled"])
+def test_device_mel_mode_matches_the_oracle(gpu_ctx, melconv):
+    """B_sep_mode = 'Mel' (src/bnmf_sep_event_RT_IS16.m:106-120,:165-171,:205-211,:298-318): the frame solve and the
+    adaptation run on 64 Mel bands; with MelConv the reconstructions come back through melmat', without it the Mel
+    activations drive the DFT bases (coupled dictionaries)."""
+    from oracle.frontend_oracle import mel_matrix
+    from se_snmf_nat_amd.online import OnlineSeparator, default_settings
+    s, Bx, Bd, H0, Ad0 = fixture_inputs(40)
+    p = dict(default_params(), B_sep_mode="Mel", MelConv=melconv, F_order=64)
+    melmat = mel_matrix(p["fs"], 64, p["fftlength"], 1.0, p["fs"] / 2).T
+    BM = melmat @ np.concatenate([Bx, Bd], axis=1)
+    BM = BM / np.sqrt((BM ** 2).sum(0)) + 1e-9  # the stored form of run_basis_train.m:115-116
+    mel = dict(B_Mel_x=BM[:, :100], B_Mel_d=BM[:, 100:], melmat=melmat)
+    o16, of, BMn, tr = ntf_sep_event_rt(s, Bx, Bd, p, H0, Ad0, return_trace=True, mel=mel)
+    ps = dict(default_settings(), **{k: v for k, v in p.items() if k in default_settings()})
+    sep = OnlineSeparator(Bx, Bd, ps, H0=H0, Ad_blk0=Ad0, ctx=gpu_ctx, B_Mel_x=mel["B_Mel_x"], B_Mel_d=mel["B_Mel_d"])
+    out = sep.process(s, flush=True)
+    trd, Bm, Bdft = sep.trace(), sep.mel_basis(), sep.basis()
+    sep.close()
+    _check_trace(trd, [t["n_iter"] for t in tr], [t["trig"] for t in tr], [t["n_up"] for t in tr], [t["adapt_iters"] for t in tr])
+    assert sum(t["solved"] for t in trd) > 5
+    assert np.linalg.norm(out["x_tilde_f"] - of) / np.linalg.norm(of) < REL_OUT
+    assert np.abs(out["x_tilde"].astype(int) - o16.astype(int)).max() <= 1
+    assert np.linalg.norm(Bm - BMn) / np.linalg.norm(BMn) < 1e-3
+    assert np.array_equal(Bdft.astype(np.float32), Bd.astype(np.float32))  # B_DFT_d is not adapted in Mel mode
