@@ -8,6 +8,7 @@ fp64 NumPy restatements, each citing the reference lines it follows:
   src/mel_matrix.m:16-38        triangular Mel filterbank
   run_basis_train.m:70-78       Mel projection of the (spliced) DFT features
   settings/initial_setting_SNMF_NAT.m:21-37,53,88-90   the shipped parameter values
+  run_basis_DNMF.m:1-57, run_basis_DNMF_Mel.m:1-95     the discriminative re-training callers (waveforms in)
 Only tests/, __graft_entry__.smoke() and bench scripts' CPU legs may import this module.
 """
 from __future__ import annotations
@@ -132,3 +133,19 @@ def run_basis_train_signal(s_full, R, p, sample_idx):
     B_DFT = B_DFT / np.sqrt((B_DFT ** 2).sum(0)) + 1e-9  # :113-114
     B_Mel = B_Mel / np.sqrt((B_Mel ** 2).sum(0)) + 1e-9  # :115-116
     return {"B_DFT_sub": B_DFT, "B_Mel_sub": B_Mel, "A_DFT_sub": A_DFT, "A_Mel_sub": A_Mel}
+
+
+def run_basis_DNMF(x, d, B, p, mel=False):
+    """run_basis_DNMF.m:1-57 / run_basis_DNMF_Mel.m:1-95 (mel=True).  The rand(r,n) of the first solve is the
+    solver oracle's RandomState(p.random_seed) stand-in (the device mirror draws the same)."""
+    from oracle.sparse_nmf_oracle import run_basis_dnmf_solves
+    x = np.asarray(x, dtype=np.float64).reshape(-1)
+    d = np.asarray(d, dtype=np.float64).reshape(-1)
+    n = min(len(x), len(d))
+    x, d = x[:n], d[:n]
+    feats = [dft_features(sig, p) for sig in (x + d, x, d)]
+    if mel:
+        feats = [mel_features(M, p) for M in feats]
+    Y, X, D = feats
+    q = {k: p[k] for k in ("cf", "beta", "sparsity", "max_iter", "conv_eps", "cost_check", "random_seed") if k in p}
+    return run_basis_dnmf_solves(Y, X, D, np.asarray(B, dtype=np.float64), int(p["R_x"]), int(p["R_d"]), q)[0]

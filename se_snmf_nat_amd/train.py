@@ -5,13 +5,15 @@ sparse_nmf solves (api.py); this module only sequences them like the reference d
 
     out = run_basis_train_signal(s_full, R, p)        # B_DFT_sub, B_Mel_sub, A_DFT_sub, A_Mel_sub
     save_basis_mat(path, out)                         # R_<R>.mat with the reference's variable names
+    B_hat = run_basis_DNMF(x, d, B, p)                # run_basis_DNMF.m:1      (waveforms in, like the reference)
+    B_hat = run_basis_DNMF_Mel(x, d, B, p)            # run_basis_DNMF_Mel.m:1
 """
 from __future__ import annotations
 
 import numpy as np
 
 from . import frontend
-from .api import SnmfError, sparse_nmf
+from .api import SnmfError, run_basis_dnmf, sparse_nmf
 
 
 def run_basis_train_signal(s_full, R, p, *, DC_bin=None, sample_idx=None, ctx=None):
@@ -62,3 +64,30 @@ def load_basis_mat(path):
     import scipy.io as sio
     m = sio.loadmat(path)
     return {k: v for k, v in m.items() if not k.startswith("__")}
+
+
+def _dnmf_features(x, d, p, ctx):
+    """run_basis_DNMF.m:3-34: equal lengths, y = x + d (waveform sum), three spectrogram feature sets on the GPU."""
+    x = np.asarray(x, dtype=np.float64).reshape(-1)
+    d = np.asarray(d, dtype=np.float64).reshape(-1)
+    n = min(len(x), len(d))  # :5-9
+    x, d = x[:n], d[:n]
+    y = x + d  # :10
+    return tuple(frontend.stft_features(sig, p, ctx=ctx) for sig in (y, x, d))  # :13-34
+
+
+def run_basis_DNMF(x, d, B, p, *, ctx=None, dtype=np.float32):
+    """B_hat = run_basis_DNMF(x, d, B, p) -- run_basis_DNMF.m:1: clean and noise waveforms, exemplar basis
+    B = [B_x, B_d] (F x (R_x+R_d)); p carries the front-end fields, R_x, R_d and the solver fields."""
+    Y, X, D = _dnmf_features(x, d, p, ctx)
+    B_hat, _ = run_basis_dnmf(Y, X, D, B, int(p["R_x"]), int(p["R_d"]), p, ctx=ctx, dtype=dtype)  # :36-55
+    return B_hat
+
+
+def run_basis_DNMF_Mel(x, d, B, p, *, ctx=None, dtype=np.float32):
+    """B_hat = run_basis_DNMF_Mel(x, d, B, p) -- run_basis_DNMF_Mel.m:1: the same loop on the Mel projections of
+    the three feature sets (:21-69); B is the Mel exemplar basis (F_order*(2*Splice+1) rows)."""
+    Y, X, D = _dnmf_features(x, d, p, ctx)
+    Ym, Xm, Dm = (frontend.mel_features(M, p, ctx=ctx) for M in (Y, X, D))
+    B_hat, _ = run_basis_dnmf(Ym, Xm, Dm, B, int(p["R_x"]), int(p["R_d"]), p, ctx=ctx, dtype=dtype)  # :71-90
+    return B_hat

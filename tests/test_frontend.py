@@ -140,3 +140,23 @@ def test_basis_training_caller_end_to_end(gpu_ctx, tmp_path):
     back = train.load_basis_mat(f)
     assert set(back) == {"B_DFT_sub", "B_Mel_sub", "A_DFT_sub", "A_Mel_sub"}
     np.testing.assert_array_equal(back["B_DFT_sub"], out["B_DFT_sub"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mel", [False, True], ids=["run_basis_DNMF", "run_basis_DNMF_Mel"])
+def test_dnmf_callers_from_waveforms(gpu_ctx, mel):
+    """run_basis_DNMF.m / run_basis_DNMF_Mel.m with the reference's signature (x, d, B, p): equal-length cut,
+    y = x + d, three (Mel) feature sets on the device, the 3-solve loop.  Against the oracle chain."""
+    import oracle.frontend_oracle as fo
+    from se_snmf_nat_amd import train
+    s = np.load(os.path.join(GOLD, "frontend_audio.npz"))["samples"].astype(np.float64)
+    x, d = s[:9000], s[9000:19000][::-1].copy()  # two different signals of unequal length
+    p = dict(fo.default_params(), cf="kl", sparsity=5, max_iter=12, conv_eps=1e-3, cost_check=1, random_seed=1, R_x=10, R_d=12)
+    rs = np.random.RandomState(5)
+    F = 64 if mel else 513
+    B = rs.rand(F, 22) + 0.05
+    ref = fo.run_basis_DNMF(x, d, B, p, mel=mel)
+    dev = (train.run_basis_DNMF_Mel if mel else train.run_basis_DNMF)(x, d, B, p, ctx=gpu_ctx)
+    assert dev.shape == ref.shape == (F, 22)
+    assert np.linalg.norm(dev - ref) / np.linalg.norm(ref) < 1e-4
+    np.testing.assert_allclose(np.sqrt((dev.astype(np.float64) ** 2).sum(0)), 1.0, rtol=1e-5)
