@@ -5,7 +5,7 @@ the basis-training loop of run_basis_DNMF.m) behind the same function signature.
 lives in libsnmf_hip.so (hand-written HIP for gfx950, C ABI in include/snmf.h); this package is
 the host-side mirror of the reference interface.  There is no CPU fallback.
 """
-from .api import (Context, Plan, SnmfError, default_context, run_basis_dnmf, snmf_mdi, snmf_mdi_Sm,  # noqa: F401
+from .api import (Context, Plan, SnmfError, default_context, dnmf_adapt, run_basis_dnmf, snmf_mdi, snmf_mdi_Sm,  # noqa: F401
                   sparse_nmf, sparse_nmf_GPU)
 
 __version__ = "0.1.0"

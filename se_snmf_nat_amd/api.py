@@ -19,7 +19,7 @@ import numpy as np
 from . import _lib
 from ._lib import SnmfError, SnmfParams
 
-__all__ = ["Context", "Plan", "sparse_nmf", "sparse_nmf_GPU", "run_basis_dnmf", "snmf_mdi", "snmf_mdi_Sm", "SnmfError",
+__all__ = ["Context", "Plan", "sparse_nmf", "sparse_nmf_GPU", "run_basis_dnmf", "dnmf_adapt", "snmf_mdi", "snmf_mdi_Sm", "SnmfError",
            "default_context"]
 
 
@@ -245,6 +245,26 @@ def run_basis_dnmf(Y, X, D, B, R_x, R_d, p, *, ctx=None, dtype=np.float64):
     p["init_h"] = A_hat[R_x:R_x + R_d, :]  # :52
     B_hat_d, _, _ = sparse_nmf(D, p, ctx=ctx, dtype=dtype)  # :53
     return np.concatenate([B_hat_x, B_hat_d], axis=1), A_hat  # :55
+
+
+def dnmf_adapt(Y, D, B, p, *, ctx=None, dtype=np.float64):
+    """B_a = DNMF_adapt(Y, D, B, p) -- src/DNMF_adapt.m:1-20: activations of the mixture features Y on the fixed
+    dictionary B = [B_x, B_d] (:4-7), then the noise columns re-trained on the noise features D with those
+    activations fixed (:16-20).  p carries R_x, R_d and the solver fields."""
+    p = dict(p)
+    R_x, R_d = int(p["R_x"]), int(p["R_d"])
+    B = np.asarray(B, dtype=np.float64)
+    p["w_update_ind"] = np.zeros(R_x + R_d, bool)  # :4
+    p["h_update_ind"] = np.ones(R_x + R_d, bool)  # :5
+    p["init_w"] = B  # :6
+    p.pop("init_h", None)
+    _, A_hat, _ = sparse_nmf(Y, p, ctx=ctx, dtype=dtype)  # :7
+    p["w_update_ind"] = np.ones(R_d, bool)  # :16
+    p["h_update_ind"] = np.zeros(R_d, bool)  # :17
+    p["init_w"] = B[:, R_x:R_x + R_d]  # :18
+    p["init_h"] = A_hat[R_x:R_x + R_d, :]  # :19
+    B_a, _, _ = sparse_nmf(D, p, ctx=ctx, dtype=dtype)  # :20
+    return B_a
 
 
 class Plan:

@@ -431,3 +431,17 @@ def test_full_size_c4_dnmf_properties(gpu_ctx):
     assert (B1 >= 0).all() and (A1 >= 0).all() and np.isfinite(A1).all()
     B2, A2 = run_basis_dnmf_sharded(Y, X, D, B, R, R, p, device=0)
     assert rel(B2, B1) < 1e-6 and rel(A2, A1) < 1e-6
+
+
+def test_dnmf_adapt_caller(gpu_ctx):
+    """src/DNMF_adapt.m:1-20 (H-only on Y, then W-only on D for the noise columns) against the same two oracle calls."""
+    from se_snmf_nat_amd import dnmf_adapt
+    V, W0, _ = synth_problem(129, 300, 14)
+    D, _, _ = synth_problem(129, 300, 14, seed_data=5)
+    p = dict(cf="kl", sparsity=1.0, max_iter=25, conv_eps=1e-3, cost_check=1, random_seed=1, R_x=8, R_d=6)
+    B_a = dnmf_adapt(V, D, W0, p, ctx=gpu_ctx)
+    q = dict(p, w_update_ind=np.zeros(14, bool), h_update_ind=np.ones(14, bool), init_w=W0)
+    _, A, _ = oracle_nmf(V, q)
+    q = dict(p, w_update_ind=np.ones(6, bool), h_update_ind=np.zeros(6, bool), init_w=W0[:, 8:], init_h=A[8:, :])
+    ref, _, _ = oracle_nmf(D, q)
+    assert B_a.shape == (129, 6) and rel(B_a, ref) < REL_WH
