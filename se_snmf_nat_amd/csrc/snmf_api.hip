@@ -1955,11 +1955,16 @@ static int online_adapt(snmf_online* o, int32_t* iters) {
         wa.bar = o->wa_bar;
         HIP_TRY(hipMemsetAsync(o->wa_bar, 0, 4, st));
         void* kargs[] = {&wa};
-        HIP_TRY(hipLaunchCooperativeKernel((const void*)k_wadapt, dim3(o->wa_nwg), dim3(256), kargs, (unsigned)o->wa_lds, st));
-        HIP_TRY(hipMemcpyAsync(iters, o->wa_nit, 4, hipMemcpyDeviceToHost, st));
-        Wres = o->wa_W;
-        ldw = Fs;
-    } else {
+        if (hipLaunchCooperativeKernel((const void*)k_wadapt, dim3(o->wa_nwg), dim3(256), kargs, (unsigned)o->wa_lds, st) == hipSuccess) {
+            HIP_TRY(hipMemcpyAsync(iters, o->wa_nit, 4, hipMemcpyDeviceToHost, st));
+            Wres = o->wa_W;
+            ldw = Fs;
+        } else {
+            (void)hipGetLastError();  // cooperative launch refused (e.g. CUs not all available): generic path from now on
+            o->wadapt = false;
+        }
+    }
+    if (!Wres) {
         SN_TRY(set_v<float>(ap, o->Vad, Fs, 1));       // lambda_d_blk[_Mel] (floored at 1e-9 inside, sparse_nmf.m:169)
         SN_TRY(set_w<double>(ap, Bd, Fs, 1));          // init_w: first R_a noise columns (:332)
         SN_TRY(set_h<float>(ap, o->Had, p.R_a, 1));    // init_h (:333)
