@@ -97,3 +97,42 @@ def test_two_ranks_one_gpu_match_oracle_and_unsharded(gpu_ctx, case):
     assert rel(H, hr) < REL_WH
     # sharding only reorders fp64 partial sums: the sharded result sits within fp32 rounding of the unsharded one
     assert rel(res[0][1], w1) < 5e-6 and rel(H, h1) < 5e-6
+
+
+def _rccl_worker(port, q):
+    import torch
+    import torch.distributed as dist
+    from se_snmf_nat_amd.dist import ShardedTrainer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    V, W0, H0 = synth_problem(257, 3000, 64)
+    res = []
+    for force in (False, True):
+        tr = ShardedTrainer(V.astype(np.float32), W0, H0.astype(np.float32), beta=1.0, sparsity=5.0, max_iter=20, conv_eps=0.0,
+                            cost_check=True, device=0)
+        if force:
+            tr.world = 2  # take the RCCL branch: a sum over the one rank of the group is the identity
+        tr.run()
+        tr.sync()
+        w, h, (div, cost, n) = tr.result()
+        res.append((w, h, np.asarray(cost)))
+    q.put(res)
+    dist.destroy_process_group()
+
+
+def test_rccl_all_reduce_call_path_at_world_size_one(gpu_ctx):
+    """The transport the multi-GPU bench uses (RCCL through torch.distributed, issued on the trainer's stream) cannot
+    be run with two ranks on a one-GPU box (RCCL refuses a duplicated device), but the call path can: with a
+    one-rank group the all-reduce is the identity, so forcing the trainer through it must reproduce the bits of the
+    run that skips it."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    (w0, h0, c0), (w1, h1, c1) = q.get(timeout=900)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert np.array_equal(w0, w1) and np.array_equal(h0, h1) and np.array_equal(c0, c1)
