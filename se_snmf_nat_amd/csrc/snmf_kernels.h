@@ -932,15 +932,31 @@ __global__ __launch_bounds__(512, 2) void k_hsolve_frame(StepArgs a, SmallArgs s
     // register pairing (a second pairing would make the compiler keep two copies of the block)
     static_assert(FB % 2 == 0, "FB must be even");
     f32x2 wr[FB / 2][KB];
+    if (Fm <= a.Fp && (a.Fp & 3) == 0 && (FB & 3) == 0) {
+        // whole register rows lie inside the padded column (rows F..Fp-1 of Wcf are zero): 16-byte loads
 #pragma unroll
-    for (int kk = 0; kk < KB; ++kk) {
-        const int k = kb * KB + kk;
+        for (int kk = 0; kk < KB; ++kk) {
+            const int k = kb * KB + kk;
+            const f32x4* src = reinterpret_cast<const f32x4*>(Wcf + (size_t)(k < rp ? k : 0) * a.Fp + fb * FB);
 #pragma unroll
-        for (int i2 = 0; i2 < FB / 2; ++i2) {
-            const int f = fb * FB + 2 * i2;
-            const bool ok = k < rp && f < Fm;
-            wr[i2][kk].x = (ok && f < F) ? Wcf[(size_t)k * a.Fp + f] : 0.f;
-            wr[i2][kk].y = (ok && f + 1 < F) ? Wcf[(size_t)k * a.Fp + f + 1] : 0.f;
+            for (int i4 = 0; i4 < FB / 4; ++i4) {
+                f32x4 v = src[i4];
+                if (k >= rp) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                wr[2 * i4][kk] = f32x2{v[0], v[1]};
+                wr[2 * i4 + 1][kk] = f32x2{v[2], v[3]};
+            }
+        }
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) {
+            const int k = kb * KB + kk;
+#pragma unroll
+            for (int i2 = 0; i2 < FB / 2; ++i2) {
+                const int f = fb * FB + 2 * i2;
+                const bool ok = k < rp && f < Fm;
+                wr[i2][kk].x = (ok && f < F) ? Wcf[(size_t)k * a.Fp + f] : 0.f;
+                wr[i2][kk].y = (ok && f + 1 < F) ? Wcf[(size_t)k * a.Fp + f + 1] : 0.f;
+            }
         }
     }
     for (int k = tid; k < RB; k += NTHR) {
