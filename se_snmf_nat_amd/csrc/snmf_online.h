@@ -648,9 +648,14 @@ constexpr int kWaRB = 8, kWaRP = 64;
 // add publishes the arrival, and the readers' sc1 loads cannot hit a stale line.  The kernel is launched
 // cooperatively, so every workgroup is resident; the spin is bounded all the same so that a lost workgroup
 // ends in wrong numbers (flagged through n_iter_out = -1), never in a hung GPU.
+// (Tried: no barrier at all, every thread re-loading the partial rows until a sentinel value is gone -- "the data
+// is the flag".  Correct, but 256 pollers per workgroup flood the coherent path: 2090 instead of 2790 frames/s.
+// Tried: 16 / 32 rows per workgroup: the exchange does not get cheaper with fewer workgroups, the products do
+// get slower: 2650 / 2400 frames/s.)
 __device__ __forceinline__ bool grid_bar(unsigned* ctr, unsigned nwg, unsigned& gen) {
     __shared__ int ok_s;
-    __syncthreads();  // this workgroup's exchange stores have completed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's exchange stores are acknowledged ...
+    __syncthreads();                                   // ... and so are everybody's in the workgroup
     ++gen;
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
