@@ -217,9 +217,8 @@ int snmf_mel_features_f32(snmf_ctx* ctx, const float* mel, int32_t M, int32_t n,
  * [v_MDI, h, objective] = snmf_mdi_Sm(v, Sm, p)  src/snmf_mdi_Sm.m:1   (soft mask in [0,1])
  * The same solver with a masked start (:175), a re-imputation of v after every iteration (:251-254)
  * and a gain-matched final imputation (:296-306).  A plan becomes an MDI solve by giving it a mask
- * (F x T, 1 = observed) before snmf_plan_set_v / snmf_plan_init; the H update must be on
- * (h_update_ind all true; W-only MDI is not implemented).  The wrappers map p.sparsity_mdi and
- * p.conv_eps_mdi onto the plan's sparsity / conv_eps. */
+ * (F x T, 1 = observed) before snmf_plan_set_v / snmf_plan_init; at least one factor must be updated.
+ * The wrappers map p.sparsity_mdi and p.conv_eps_mdi onto the plan's sparsity / conv_eps. */
 int snmf_plan_set_mask_f64(snmf_plan* plan, const double* M, int64_t ld, int on_device);
 int snmf_plan_set_mask_f32(snmf_plan* plan, const float* M, int64_t ld, int on_device);
 /* v_MDI (:296-306) after snmf_plan_run: F x T, observed entries kept, the rest Nt .* max(w*h, flr). */

@@ -474,7 +474,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         A(dalloc(&pl->slabs, (size_t)pl->n_chunks * pl->n_mat * nW));
         A(dalloc(&pl->spart, (size_t)pl->n_chunks * pl->rp));
     }
-    pl->n_part = std::max(pl->grid_h, pl->n_chunks * pl->n_fg);
+    pl->n_part = std::max(std::max(pl->grid_h, pl->grid_mdi), pl->n_chunks * pl->n_fg);
     pl->n_part = std::max(pl->n_part, 1024);
     A(dalloc(&pl->part, (size_t)2 * pl->n_part));
     A(dalloc(&pl->stats, (size_t)pl->n_mat * nW + pl->rp + 2));
@@ -617,7 +617,7 @@ static int set_v(snmf_plan* pl, const T* V, int64_t ld, int dev) {
 template <typename T>
 static int set_mask(snmf_plan* pl, const T* M, int64_t ld, int dev) {
     PLAN_CHECK(pl);
-    if (!pl->upd_h) return fail(SNMF_ERR_UNSUPPORTED, "MDI needs the H update (h_update_ind all true); W-only MDI is not implemented");
+    if (!pl->upd_h && !pl->upd_w) return fail(SNMF_ERR_UNSUPPORTED, "MDI with neither factor updated is not implemented");
     if (!pl->M) {
         SN_TRY(dalloc(&pl->M, (size_t)pl->Fp * pl->Tp));
     }
@@ -940,8 +940,13 @@ extern "C" int snmf_plan_hstep(snmf_plan* pl) {
     PLAN_CHECK(pl);
     if (!pl->inited) return fail(SNMF_ERR_STATE, "plan not initialised");
     HIP_TRY(hipSetDevice(pl->ctx->device));
-    if (!pl->upd_h) return SNMF_OK;
     const int j = pl->it_done + 1;
+    if (!pl->upd_h) {
+        // W-only MDI: the Lam pass still runs, for the re-imputation of V (src/snmf_mdi.m:251-254) and the objective
+        // of the previous iterate; the W statistics then read the re-imputed V
+        if (pl->M && (pl->it_done >= 1 || want_obj(pl, j))) SN_TRY(launch_hstep(pl, true, false));
+        return SNMF_OK;
+    }
     SN_TRY(launch_hstep(pl, want_obj(pl, j), true));
     pl->cur ^= 1;
     return SNMF_OK;
@@ -956,11 +961,12 @@ extern "C" int snmf_plan_wstats(snmf_plan* pl, double* stats) {
     HIP_TRY(hipSetDevice(pl->ctx->device));
     const int j = pl->it_done + 1;
     const bool obj = want_obj(pl, j);
+    const bool mdi_wonly = pl->M && !pl->upd_h;  // objective partials come from the MDI Lam pass of snmf_plan_hstep
     if (pl->upd_w) {
         // W-only mode: the divergence of iterate j-1 comes from this pass (Lam' = W_{j-1} * H)
-        SN_TRY(launch_wstats(pl, obj && !pl->upd_h));
+        SN_TRY(launch_wstats(pl, obj && !pl->upd_h && !mdi_wonly));
     }
-    const int n_part = pl->upd_h ? pl->grid_h : pl->n_chunks * pl->n_fg;
+    const int n_part = pl->M ? pl->grid_mdi : pl->upd_h ? pl->grid_h : pl->n_chunks * pl->n_fg;
     if (!pl->upd_h && !pl->upd_w && obj) {
         // neither factor is updated: the loop only re-evaluates the objective
         SN_TRY(launch_hstep(pl, true, false));
@@ -993,12 +999,13 @@ extern "C" int snmf_plan_objstats(snmf_plan* pl, double* stats) {
     // sum(S.*H) of the final iterate: the objective-only pass does not visit H's rows, so take it
     // from a dedicated reduction over the current H.
     const int g = 256;
+    const int np = pl->M ? pl->grid_mdi : pl->grid_h;  // workgroups of the Lam pass = objective partials
     hipLaunchKernelGGL(k_sum_sh, dim3(g), dim3(256), 0, pl->ctx->stream, pl->H[pl->cur], pl->S, pl->lamk, pl->rp,
-                       pl->p.r, pl->p.T, pl->part + 2 * (size_t)pl->grid_h);
+                       pl->p.r, pl->p.T, pl->part + 2 * (size_t)np);
     HIP_TRY(hipGetLastError());
-    SN_TRY(launch_reduce(pl, stats, false, true, pl->grid_h, false));
+    SN_TRY(launch_reduce(pl, stats, false, true, np, false));
     const size_t off = (size_t)pl->n_mat * pl->rp * pl->Fp + pl->rp;
-    hipLaunchKernelGGL(k_fold_sh, dim3(1), dim3(64), 0, pl->ctx->stream, pl->part + 2 * (size_t)pl->grid_h, 256,
+    hipLaunchKernelGGL(k_fold_sh, dim3(1), dim3(64), 0, pl->ctx->stream, pl->part + 2 * (size_t)np, 256,
                        stats + off, &pl->st->stop);
     HIP_TRY(hipGetLastError());
     return SNMF_OK;

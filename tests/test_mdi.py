@@ -70,6 +70,8 @@ CASES = [
     dict(cf="is", sparsity_mdi=0.01, conv_eps_mdi=0, max_iter=15),
     dict(cf="kl", sparsity_mdi=0.5, conv_eps_mdi=1e-4, max_iter=60, h_only=True),          # supervised imputation
     dict(cf="kl", sparsity_mdi=0.5, conv_eps_mdi=0, max_iter=12, cost_check=0),
+    dict(cf="kl", sparsity_mdi=0.5, conv_eps_mdi=1e-4, max_iter=40, w_only=True),         # dictionary re-trained on gappy data
+    dict(cf="ed", sparsity_mdi=0.05, conv_eps_mdi=0, max_iter=10, w_only=True, cost_check=0),
     dict(cf="kl", sparsity_mdi=1.0, conv_eps_mdi=0, max_iter=15, F=257, T=1000, r=40),     # extra-row mode, many tiles
 ]
 
@@ -79,12 +81,14 @@ CASES = [
 def test_device_mdi_matches_the_oracle(gpu_ctx, case):
     from se_snmf_nat_amd import snmf_mdi, snmf_mdi_Sm
     c = dict(case)
-    soft, h_only = c.pop("soft", False), c.pop("h_only", False)
+    soft, h_only, w_only = c.pop("soft", False), c.pop("h_only", False), c.pop("w_only", False)
     V, M, W0, H0 = problem(c.pop("F", 65), c.pop("T", 90), c.pop("r", 9), soft=soft)
     p = dict(c, init_w=W0, init_h=H0)
     p.setdefault("cost_check", 1)
     if h_only:
         p["w_update_ind"] = np.zeros(W0.shape[1], bool)
+    if w_only:
+        p["h_update_ind"] = np.zeros(W0.shape[1], bool)
     v_ref, h_ref, o_ref = oracle_mdi(V, M, p)
     v_dev, h_dev, o_dev = (snmf_mdi_Sm if soft else snmf_mdi)(V, M, p, ctx=gpu_ctx)
     rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
@@ -103,8 +107,8 @@ def test_device_mdi_matches_the_oracle(gpu_ctx, case):
 def test_mdi_state_rules(gpu_ctx):
     from se_snmf_nat_amd import Plan, SnmfError
     V, M, W0, H0 = problem(F=33, T=40, r=5)
-    with pytest.raises(SnmfError):  # W-only MDI is not implemented
-        Plan(gpu_ctx, 33, 40, 5, h_update_ind=np.zeros(5, bool)).set_mask(M)
+    with pytest.raises(SnmfError):  # nothing to update: not an imputation problem
+        Plan(gpu_ctx, 33, 40, 5, h_update_ind=np.zeros(5, bool), w_update_ind=np.zeros(5, bool)).set_mask(M)
     pl = Plan(gpu_ctx, 33, 40, 5, max_iter=5, cost_check=True, sparsity=0.1)
     pl.set_mask(M); pl.set_v(V); pl.set_w(W0); pl.set_h(H0); pl.init(); pl.run()
     v1 = pl.get_v_mdi()
