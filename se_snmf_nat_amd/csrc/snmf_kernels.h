@@ -429,6 +429,33 @@ __device__ __forceinline__ void hstep_p1_tiles(const StepArgs& a, float* Hs, flo
     }
 }
 
+// ---- cross-lane sums on the DPP path (1 VALU op per step; __shfl_* goes through ds_bpermute) ------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// sum over each aligned group of 4 lanes, result in all 4
+__device__ __forceinline__ float quad_sum_f(float v) {
+    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
+    return v;
+}
+// sum over each row of 16 lanes, result in all 16
+__device__ __forceinline__ float row_sum_f(float v) {
+    v = quad_sum_f(v);
+    v += dpp_f<0x141>(v);  // row_half_mirror
+    v += dpp_f<0x140>(v);  // row_mirror
+    return v;
+}
+// sum over the wave, result wave-uniform
+__device__ __forceinline__ float wave_sum_f(float v) {
+    v = row_sum_f(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)) +
+           __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16)) +
+           __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)) +
+           __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+}
+
 // extra row (F = 32*nf + 1): lam_x[t] = sum_k W[Fm,k] H[k,t] on the VALU, 4 columns x 16 lanes at a time
 template <int NW, int NT, int BM, bool OBJ, bool VG = false, bool MDI = false>
 __device__ __forceinline__ void hstep_p1_xrow(const StepArgs& a, float* Hs, float* Rs, const float* wxs, int t0, int w,
@@ -451,11 +478,7 @@ __device__ __forceinline__ void hstep_p1_xrow(const StepArgs& a, float* Hs, floa
                 s0 += wv[0] * hv[0] + wv[1] * hv[1];
                 s1 += wv[2] * hv[2] + wv[3] * hv[3];
             }
-            float s = s0 + s1;
-            s += __shfl_xor(s, 1);
-            s += __shfl_xor(s, 2);
-            s += __shfl_xor(s, 4);
-            s += __shfl_xor(s, 8);
+            const float s = row_sum_f(s0 + s1);  // DPP: the same balanced tree as an xor butterfly, no ds_bpermute
             if (kl == 0) {
                 const int t = t0 + tl;
                 float v = (VG || MDI) ? a.V[(size_t)t * a.Fp + a.Fm] : Rs[tl * ldr + a.Fm];  // staged V
@@ -853,33 +876,6 @@ __global__ __launch_bounds__(512, 2) void k_hsolve_small(StepArgs a, SmallArgs s
     }
     __syncthreads();
     stage_out<NTHR>(a.Hout, Hs, sa.tps, rp, ldh, threadIdx.x);  // only this solve's columns
-}
-
-// ---- cross-lane sums on the DPP path (1 VALU op per step; __shfl_* goes through ds_bpermute) ------
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-// sum over each aligned group of 4 lanes, result in all 4
-__device__ __forceinline__ float quad_sum_f(float v) {
-    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
-    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
-    return v;
-}
-// sum over each row of 16 lanes, result in all 16
-__device__ __forceinline__ float row_sum_f(float v) {
-    v = quad_sum_f(v);
-    v += dpp_f<0x141>(v);  // row_half_mirror
-    v += dpp_f<0x140>(v);  // row_mirror
-    return v;
-}
-// sum over the wave, result wave-uniform
-__device__ __forceinline__ float wave_sum_f(float v) {
-    v = row_sum_f(v);
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)) +
-           __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16)) +
-           __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)) +
-           __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
 }
 
 // ============================================================================================
@@ -1300,11 +1296,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
                         s0 += wv[0] * hv[0] + wv[1] * hv[1];
                         s1 += wv[2] * hv[2] + wv[3] * hv[3];
                     }
-                    float s = s0 + s1;
-                    s += __shfl_xor(s, 1);
-                    s += __shfl_xor(s, 2);
-                    s += __shfl_xor(s, 4);
-                    s += __shfl_xor(s, 8);
+                    const float s = row_sum_f(s0 + s1);
                     const float lam = fmaxf(s, kFlr);
                     if (OBJ && kl == 0) dsum += (t < a.T) ? div_term<BM>(v, lam, a.beta, a.inv_bb1) : 0.f;
                     if (WM == 0) rv = v * fast_rcp(lam);
