@@ -295,6 +295,20 @@ extern "C" void snmf_plan_destroy(snmf_plan* pl) {
         const char* const* nm = wlast ? nmw : nmh;
         fprintf(stderr, "[SNMF_PROF] %s phase shares (avg cycles/wave = %.0f):", wlast ? "k_wstats" : "k_hstep", all / nw);
         for (int j = 0; j < 12; ++j) fprintf(stderr, " %s=%.1f%%", nm[j], 100.0 * tot[j] / all);
+        std::vector<unsigned long long> hc((size_t)2 * nw);
+        hipMemcpy(hc.data(), pl->prof + 98304 + (wlast ? (size_t)2 * 4096 : 0), hc.size() * 8, hipMemcpyDeviceToHost);
+        std::vector<double> ghz, span;
+        for (int i = 0; i < nw; ++i)
+            if (hc[2 * i + 1]) {
+                ghz.push_back((double)hc[2 * i] / (double)hc[2 * i + 1] * 0.1);
+                span.push_back((double)hc[2 * i + 1] * 0.01);
+            }
+        if (!ghz.empty()) {
+            std::sort(ghz.begin(), ghz.end());
+            std::sort(span.begin(), span.end());
+            fprintf(stderr, " | in-kernel clock %.3f GHz (median of %zu waves; min %.3f max %.3f), stamped span %.1f us median, %.1f max",
+                    ghz[ghz.size() / 2], ghz.size(), ghz.front(), ghz.back(), span[span.size() / 2], span.back());
+        }
         fprintf(stderr, "\n");
         hipFree(pl->prof);
     }
@@ -484,7 +498,8 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     A(dalloc(&pl->st, (size_t)1));
     A(dalloc(&pl->w_ind, (size_t)pl->rp));
 #ifdef SNMF_PROF
-    A(dalloc(&pl->prof, (size_t)1024 * 8 * 12));
+    A(dalloc(&pl->prof, (size_t)1024 * 8 * 12 + 2 * 8192));  // phase slots, then (cycles, 100 MHz ticks) per wave
+    hipMemset(pl->prof, 0, ((size_t)1024 * 8 * 12 + 2 * 8192) * 8);
 #endif
     if (s != SNMF_OK) {
         snmf_plan_destroy(pl);

@@ -151,13 +151,18 @@ struct StepArgs {
 // scheduler from hoisting the (memory-free) MFMAs above the loads, which has the same effect.
 // Phase stamps (diagnostic build -DSNMF_PROF only; the shipped kernels contain none).
 #ifdef SNMF_PROF
-#define SNMF_STAMP_DECL unsigned long long pf_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long pl_ = __builtin_amdgcn_s_memtime();
+#define SNMF_STAMP_DECL unsigned long long pf_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long pl_ = __builtin_amdgcn_s_memtime(); \
+    const unsigned long long pc0_ = pl_, pr0_ = __builtin_amdgcn_s_memrealtime();
 #define SNMF_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pf_[i] += t_ - pl_; pl_ = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #define SNMF_STAMP_OUT(base, nph) do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < nph; ++i_) (base)[i_] = pf_[i_]; } while (0)
+// in-kernel clock of this wave's stamped span: shader cycles over the 100 MHz real-time counter (slot pair idx behind the phase slots)
+#define SNMF_STAMP_CLK(prof, idx) do { if ((threadIdx.x & 63) == 0) { (prof)[98304 + 2 * (idx)] = __builtin_amdgcn_s_memtime() - pc0_; \
+    (prof)[98304 + 2 * (idx) + 1] = __builtin_amdgcn_s_memrealtime() - pr0_; } } while (0)
 #else
 #define SNMF_STAMP_DECL
 #define SNMF_STAMP(i)
 #define SNMF_STAMP_OUT(base, nph)
+#define SNMF_STAMP_CLK(prof, idx)
 #endif
 
 #define SNMF_PIN()                          \
@@ -729,6 +734,7 @@ __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(Step
         }
         if (NL > 0) __syncthreads();  // matches the loaders' final barrier
         SNMF_STAMP_OUT(a.prof + ((size_t)blockIdx.x * NW + w) * 12, 12);
+        SNMF_STAMP_CLK(a.prof, (size_t)blockIdx.x * NW + w);
     }
 
     if (OBJ) {
@@ -1404,7 +1410,10 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
 #ifdef SNMF_PROF
     if (!is_loader && a.prof) {
         const size_t wv = ((size_t)(blockIdx.x + gridDim.x * blockIdx.y)) * NWB + w;
-        if (wv < 4096) SNMF_STAMP_OUT(a.prof + (4096 + wv) * 12, 12);
+        if (wv < 4096) {
+            SNMF_STAMP_OUT(a.prof + (4096 + wv) * 12, 12);
+            SNMF_STAMP_CLK(a.prof, 4096 + wv);
+        }
     }
 #endif
 
