@@ -369,7 +369,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     // widest tile whose H image + ratio image fit the 160 KiB LDS.  SNMF_HSTEP_CFG=NWxNT overrides.
     const size_t per_col = (size_t)(pl->ldh + pl->ldr) * 4;
     const size_t lds_cap = 160 * 1024;  // gfx950: 160 KiB per CU, one workgroup may take all of it
-    const size_t lds_extra = (size_t)pl->rp * 4;
+    const size_t lds_extra = (size_t)pl->rp * 4 + 16;  // extra row of W + the consumers' arrive counter
     const size_t lds1 = 32 * per_col + lds_extra, lds2 = 64 * per_col + lds_extra;
     if (2 * lds1 - lds_extra <= lds_cap) { pl->NWH = 8; pl->NT = 1; pl->NLH = 4; }  // double-buffered
     else if (lds2 <= lds_cap && pl->Tp / 64 >= ctx->n_cu) { pl->NWH = 8; pl->NT = 2; }

@@ -639,6 +639,11 @@ __device__ __forceinline__ void hstep_p2(const StepArgs& a, float* Hs, const flo
 //   B1 | consumers: P1(cur)            loaders: copy H tile i-1 out of nxt, issue tile i+1 -> regs
 //   B2 | consumers: P2(cur) [+2 barriers for beta != 1]     loaders: regs -> nxt
 // so the only thing the consumers ever wait for is each other.
+// KL update launches (one pass per tile) drop the consumers' half of B1: P1 of tile i touches only buffer cur, so a
+// consumer that has finished P2 of tile i-1 does not have to wait for the others -- it bumps an LDS counter
+// (arrive only) and goes on; the LOADERS wait for the counter before they touch nxt.  One workgroup barrier per
+// tile instead of two, and a wave's epilogue overlaps its neighbours' MFMA loop across the tile boundary.  The
+// loaders' wait is a bounded spin: a lost signal would give wrong numbers (caught by the parity tests), never a hang.
 // ============================================================================================
 template <int NW, int NT, int NL, int BM, bool OBJ, bool UPD, bool MDI = false>
 __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(StepArgs a) {
@@ -662,6 +667,12 @@ __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(Step
         }
     }
     constexpr int NPASS = (BM == BM_KL) ? 1 : 2;
+#ifndef SNMF_HSTEP_SIG
+#define SNMF_HSTEP_SIG 1
+#endif
+    constexpr bool SIG = SNMF_HSTEP_SIG && NL > 0 && UPD && NPASS == 1;
+    unsigned* sig = reinterpret_cast<unsigned*>(wxs + rp);  // consumers' "P2 of the previous tile done" count
+    if (SIG && threadIdx.x == 0) *sig = 0u;
 
     if (NL > 0 && w >= NW) {
         // ================================ loader role =========================================
@@ -677,7 +688,14 @@ __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(Step
         for (; tile < a.n_tiles; tile += gridDim.x, ++it) {
             float* nH = lds + ((it & 1) ^ 1) * bufsz;
             const int nt = tile + (int)gridDim.x;
-            __syncthreads();  // B1
+            if (!SIG || it == 0) {
+                __syncthreads();  // B1
+            } else {
+                const unsigned target = (unsigned)(NW * it);
+                for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target; ++spin)
+                    __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
             if (UPD && prev >= 0) stage_out<NLT>(a.Hout + (size_t)prev * Tt * rp, nH, Tt, rp, ldh, lt);
             if (nt < a.n_tiles)  // both blocks of tile i+1, one HBM round trip (the ratio image of tile i-1 is dead)
                 stage_in2<NLT, 10, 10>(a.Hin + (size_t)nt * Tt * rp, nH, Tt, rp, ldh, a.V + (size_t)nt * Tt * Fp,
@@ -708,7 +726,12 @@ __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(Step
                 stage_in<NTHR>(a.V + (size_t)t0 * Fp, Rs, Tt, Fp, ldr, threadIdx.x);
                 SNMF_STAMP(1);
             }
-            __syncthreads();  // B1
+            if (!SIG || it == 0) {
+                __syncthreads();  // B1
+            } else {  // arrive only: this wave's P2 of the previous tile (its LDS writes included) is complete
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_fetch_add(sig, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             SNMF_STAMP(2);
             hstep_p1<NW, NT, BM, OBJ, false, MDI>(a, Hs, Rs, wxs, t0, w, lane, UPD, acc_div);
             SNMF_STAMP(4);
