@@ -412,9 +412,9 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     {
         const size_t buf = ((size_t)32 * pl->ldhw + (size_t)32 * pl->Fp) * 4;
         // loaders + double buffering when the accumulators allow 2 waves per SIMD and LDS has room
-        pl->NLW = (pl->WPS == 2 && 2 * buf + (size_t)pl->rp * 4 <= lds_cap) ? 4 : 0;
+        pl->NLW = (pl->WPS == 2 && 2 * buf + (size_t)pl->rp * 4 + 16 <= lds_cap) ? 4 : 0;
         if (const char* e = getenv("SNMF_WSTATS_NL")) pl->NLW = (atoi(e) == 4 && pl->NLW == 4) ? 4 : 0;
-        pl->lds_w = std::max<size_t>((pl->NLW ? 2 : 1) * buf + (size_t)pl->rp * 4,
+        pl->lds_w = std::max<size_t>((pl->NLW ? 2 : 1) * buf + (size_t)pl->rp * 4 + 16,  // + ready/done counters
                                      (size_t)(pl->NWB + pl->NLW) * 64 * sizeof(double));
     }
     const int wg_w = pl->NLW ? 1 : pl->WPS;  // workgroups per CU

@@ -1254,16 +1254,40 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     float ssum[4] = {0.f, 0.f, 0.f, 0.f};
     double acc_div = 0.0;
 
+    // NL > 0: no workgroup barrier inside the tile loop.  The consumer waves never exchange data (each owns its rows
+    // of G), so all they need is "tile i is staged" -- an LDS counter the loader waves bump (`ready`, NL per tile) --
+    // and all the loaders need before they refill a buffer is "every consumer is done with tile i-1" (`done`, NWB
+    // per tile).  Waits are bounded spins: a lost signal gives wrong numbers (parity tests), never a hang.
+    unsigned* ready = reinterpret_cast<unsigned*>(wxs + rp);
+    unsigned* done = ready + 1;
+    auto arrive = [&](unsigned* c) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto await = [&](unsigned* c, unsigned target) {
+        for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target; ++spin)
+            __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    if (NL > 0) {
+        if (threadIdx.x == 0) {
+            *ready = 0u;
+            *done = 0u;
+        }
+        __syncthreads();  // counters and wxs are set
+    }
+
     if (is_loader) {
         // ================================ loader role =========================================
         if (tb < te) {
             stage_in<NST>(a.Hin + (size_t)tb * 32 * rp, lds, 32, rp, ldh, sid);
             stage_in<NST>(a.V + (size_t)tb * 32 * Fp, lds + 32 * ldh, 32, Fp, Fp, sid);
+            arrive(ready);
         }
         for (int tile = tb, it = 0; tile < te; ++tile, ++it) {
             const float* cH = lds + (it & 1) * bufsz;
             float* nH = lds + ((it & 1) ^ 1) * bufsz;
-            __syncthreads();  // tile `tile` is complete in buffer it&1; buffer (it&1)^1 is free
+            await(ready, (unsigned)(NL * (it + 1)));  // tile `tile` is complete in buffer it&1 (every loader wave's part)
             if (do_s) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -1275,9 +1299,12 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
                     }
                 }
             }
-            if (tile + 1 < te)
+            if (tile + 1 < te) {
+                await(done, (unsigned)(NWB * it));  // every consumer has finished tile-1, which lives in nH
                 stage_in2<NST, 10, 10>(a.Hin + (size_t)(tile + 1) * 32 * rp, nH, 32, rp, ldh,
                                        a.V + (size_t)(tile + 1) * 32 * Fp, nH + 32 * ldh, 32, Fp, Fp, sid);
+                arrive(ready);
+            }
         }
     }
 
@@ -1291,8 +1318,10 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
             __syncthreads();
             stage_in<NST>(a.Hin + (size_t)t0 * rp, Hs, 32, rp, ldh, sid);
             stage_in<NST>(a.V + (size_t)t0 * Fp, Vs, 32, Fp, Fp, sid);
+            __syncthreads();
+        } else {
+            await(ready, (unsigned)(NL * (it + 1)));
         }
-        __syncthreads();
         SNMF_STAMP(1);
         if (NL == 0 && do_s) {
 #pragma unroll
@@ -1351,7 +1380,10 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
             }
         }
         SNMF_STAMP(2);
-        if (!active) continue;
+        if (!active) {
+            if (NL > 0) arrive(done);
+            continue;
+        }
 
         float R[16];
         if (WM != 3) {
@@ -1428,6 +1460,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         SNMF_KTILE(14, b0, b1)
         SNMF_KTILE(15, b1, b0)
 #undef SNMF_KTILE
+        if (NL > 0) arrive(done);  // this wave's last LDS read of the tile fed the MFMAs above
         SNMF_STAMP(5);
     }
 #ifdef SNMF_PROF
