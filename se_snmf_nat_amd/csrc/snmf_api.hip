@@ -212,6 +212,7 @@ struct snmf_plan {
     int NT = 1, NWH = 8, NLH = 0;  // k_hstep: frame tile = 32*NT, NWH consumer + NLH loader waves
     int NKT = 8, NWB = 4, WPS = 2, NLW = 0;  // k_wstats template geometry (NLW loader waves)
     int n_fg = 1, n_kg = 1, n_chunks = 1;
+    int n_ch1 = 0;  // k_wstats: chunks of row group 1 when the two row groups are split unevenly (else 0)
     int grid_h = 1;
     int ldh = 0, ldr = 0, ldhw = 0;
     int stagger_h = 0, stagger_w = 0;
@@ -419,6 +420,32 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     }
     const int wg_w = pl->NLW ? 1 : pl->WPS;  // workgroups per CU
     pl->n_chunks = std::max(1, std::min(n_tiles_w, ctx->n_cu * wg_w / std::max(1, pl->n_fg * pl->n_kg)));
+    // Two row groups, only group 0 carries the extra row: deal the workgroups out so that both finish together.
+    // Relative cost x of the extra row per tile: ~2.1 k cycles at rp = 256 against 21 k for the two MFMA loops (phase
+    // stamps; a sweep of the split point on C2 has its optimum where this x puts it: 131..135 chunks for group 0,
+    // k_wstats 0.2573 -> 0.2481 ms).  Only for launches without the objective pass (full updates: the objective
+    // rides on k_hstep).
+    pl->n_ch1 = 0;
+    if (pl->xr && pl->n_fg == 2 && pl->n_kg == 1 && pl->NLW && pl->upd_h && pl->upd_w && n_tiles_w >= 4 * pl->n_chunks &&
+        !getenv("SNMF_NO_WSPLIT")) {
+        const int tot = 2 * pl->n_chunks;
+        const double x = (600.0 + 6.0 * pl->rp) / (82.0 * (pl->rp / 2 + 16 * pl->nk));
+        auto cost = [&](int n0) {
+            const int n1 = tot - n0;
+            return std::max(std::ceil((double)n_tiles_w / n0) * (1.0 + x), std::ceil((double)n_tiles_w / n1));
+        };
+        int best = pl->n_chunks;
+        for (int n0 = pl->n_chunks + 1; n0 <= pl->n_chunks + pl->n_chunks / 4; ++n0)
+            if (cost(n0) < cost(best) - 1e-9) best = n0;
+        if (const char* e = getenv("SNMF_WSPLIT")) {  // experiments: chunks of row group 0
+            const int n0 = atoi(e);
+            if (n0 > pl->n_chunks && n0 < tot) best = n0;
+        }
+        if (best != pl->n_chunks) {
+            pl->n_ch1 = tot - best;
+            pl->n_chunks = best;
+        }
+    }
     // start-up stagger (cycles) of the second half of each grid: about half a tile period when two
     // workgroups share a CU.  SNMF_STAGGER=<h>,<w> overrides (0 disables).
     {
@@ -545,9 +572,10 @@ extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
     if (!pl || !buf) return fail(SNMF_ERR_INVALID, "NULL argument");
     snprintf(buf, n,
              "F=%d T=%d r=%d beta=%g | Fm=%d(+%d VALU row) rp=%d Tp=%d | hstep: tile=%d frames, grid=%d x %d thr, lds=%zu B | "
-             "wstats: NK=%d waves=%d+%d grid=(%d chunks,%d fgroups,%d kgroups) lds=%zu B | n_cu=%d",
+             "wstats: NK=%d waves=%d+%d grid=(%d chunks,%d fgroups,%d kgroups; group-1 chunks %d) lds=%zu B | n_cu=%d",
              pl->p.F, pl->p.T, pl->p.r, pl->p.beta, pl->Fm, pl->xr, pl->rp, pl->Tp, 32 * pl->NT, pl->grid_h, (pl->NWH + pl->NLH) * 64,
-             pl->lds_h, pl->NKT, pl->NWB, pl->NLW, pl->n_chunks, pl->n_fg, pl->n_kg, pl->lds_w, pl->ctx->n_cu);
+             pl->lds_h, pl->NKT, pl->NWB, pl->NLW, pl->n_chunks, pl->n_fg, pl->n_kg, pl->n_ch1 ? pl->n_ch1 : pl->n_chunks, pl->lds_w,
+             pl->ctx->n_cu);
     return SNMF_OK;
 }
 
@@ -792,7 +820,10 @@ static int launch_hstep(snmf_plan* pl, bool obj, bool upd) {
 // k_wstats dispatch
 template <int NK, int NWB, int NL, int WPS, int WM, int BM, bool OBJ>
 static int launch_wstats_one(snmf_plan* pl, const StepArgs& a, int mat_index) {
-    dim3 g(pl->n_chunks, pl->n_fg, pl->n_kg), b((NWB + NL) * 64);
+    const bool split = pl->n_ch1 > 0 && !OBJ;  // uneven row-group split: 1-D grid, group 0's chunks first
+    dim3 g(split ? pl->n_chunks + pl->n_ch1 : pl->n_chunks, split ? 1 : pl->n_fg, pl->n_kg), b((NWB + NL) * 64);
+    StepArgs as = a;
+    as.n_ch1 = split ? pl->n_ch1 : 0;
     static std::map<const void*, size_t> attr_set;
     auto kern = k_wstats<NK, NWB, NL, WPS, WM, BM, OBJ>;
     const void* key = (const void*)kern;
@@ -800,7 +831,7 @@ static int launch_wstats_one(snmf_plan* pl, const StepArgs& a, int mat_index) {
         HIP_TRY(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_w));
         attr_set[key] = pl->lds_w;
     }
-    hipLaunchKernelGGL(kern, g, b, pl->lds_w, pl->ctx->stream, a, pl->n_chunks, mat_index, pl->n_mat);
+    hipLaunchKernelGGL(kern, g, b, pl->lds_w, pl->ctx->stream, as, pl->n_chunks, mat_index, pl->n_mat);
     HIP_TRY(hipGetLastError());
     return SNMF_OK;
 }

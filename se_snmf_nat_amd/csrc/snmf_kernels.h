@@ -131,6 +131,7 @@ struct StepArgs {
     const float* M;       // MDI: observed/missing mask in V's layout (1 = observed), src/snmf_mdi.m
     float* Vw;            // MDI: V, writable (re-imputed in place by the Lam pass)
     int impute;           // MDI: this pass carries the re-imputation of the previous iteration (:251-254)
+    int n_ch1;            // k_wstats: > 0 = row group 1 has its own, smaller, number of frame chunks (1-D grid)
     int F, T, Fp, rp, Tp, nf, nk;
     int Fm;               // rows covered by MFMA tiles = 32*nf
     int Fq;               // contraction length of W^T*ratio = Fm + 8*xr
@@ -1227,21 +1228,32 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     const bool is_loader = NL > 0 && w >= NWB;
     const int fl = lane & 31, h = lane >> 5;
     const int rp = a.rp, Fp = a.Fp, ldh = a.ldh;
-    const int chunk = blockIdx.x;
-    const bool do_x = a.xr && blockIdx.y == 0 && blockIdx.z == 0;  // extra row: one f-group only
+    // Row group and frame chunk of this workgroup.  Two row groups of which only group 0 carries the extra row are
+    // not equally expensive per tile (the VALU row costs ~14 % of a tile on the MFMA-issuing waves), so the host may
+    // give them DIFFERENT numbers of frame chunks: a 1-D grid of n_chunks workgroups of group 0 followed by a.n_ch1
+    // of group 1.  The slabs of the chunks group 1 does not have stay zero (set once at plan creation).
+    int chunk = blockIdx.x, by = blockIdx.y, nch = n_chunks;
+    if (a.n_ch1 > 0) {
+        by = chunk >= n_chunks ? 1 : 0;
+        if (by) {
+            chunk -= n_chunks;
+            nch = a.n_ch1;
+        }
+    }
+    const bool do_x = a.xr && by == 0 && blockIdx.z == 0;  // extra row: one f-group only
     constexpr int CPW = 32 / NWB;  // columns of the extra-row dot product per wave
     float gx[16];                  // extra row of the slab: lane <-> k = lane + 64*i  (rp <= 1024)
 #pragma unroll
     for (int i = 0; i < 16; ++i) gx[i] = 0.f;
     if (do_x && WM != 3)
         for (int k = threadIdx.x; k < rp; k += NTHR) wxs[k] = a.wx[k];
-    const int phi = blockIdx.y * NWB + w;
+    const int phi = by * NWB + w;
     const bool active = !is_loader && phi < a.nf;
     const int kap_base = blockIdx.z * NK;  // kappa-group (r > 32*NK: P3 is recomputed per group)
     const bool do_obj = OBJ && blockIdx.z == 0;
     // contiguous, balanced range of 32-frame tiles for this chunk
-    const int tb = (int)(((long long)a.n_tiles * chunk) / n_chunks);
-    const int te = (int)(((long long)a.n_tiles * (chunk + 1)) / n_chunks);
+    const int tb = (int)(((long long)a.n_tiles * chunk) / nch);
+    const int te = (int)(((long long)a.n_tiles * (chunk + 1)) / nch);
 
     f32x16 G[NK];
 #pragma unroll
@@ -1250,7 +1262,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     // thread <-> k = sid + j*NST, j < 4 (rp <= 4*NST checked on the host)
     constexpr int NST = NL > 0 ? NL * 64 : NWB * 64;
     const int sid = NL > 0 ? (int)threadIdx.x - NWB * 64 : (int)threadIdx.x;
-    const bool do_s = WM == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+    const bool do_s = WM == 0 && by == 0 && blockIdx.z == 0;
     float ssum[4] = {0.f, 0.f, 0.f, 0.f};
     double acc_div = 0.0;
 
@@ -1465,7 +1477,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     }
 #ifdef SNMF_PROF
     if (!is_loader && a.prof) {
-        const size_t wv = ((size_t)(blockIdx.x + gridDim.x * blockIdx.y)) * NWB + w;
+        const size_t wv = ((size_t)(blockIdx.x + gridDim.x * blockIdx.y)) * NWB + w;  // 1-D grid in split mode
         if (wv < 4096) {
             SNMF_STAMP_OUT(a.prof + (4096 + wv) * 12, 12);
             SNMF_STAMP_CLK(a.prof, 4096 + wv);
@@ -1525,8 +1537,8 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
             __syncthreads();
         }
         if (threadIdx.x == 0 && blockIdx.z == 0) {
-            a.part[2 * (blockIdx.y * n_chunks + blockIdx.x)] = red[0];
-            a.part[2 * (blockIdx.y * n_chunks + blockIdx.x) + 1] = 0.0;
+            a.part[2 * (by * n_chunks + chunk)] = red[0];
+            a.part[2 * (by * n_chunks + chunk) + 1] = 0.0;
         }
     }
 }
