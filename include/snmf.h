@@ -35,7 +35,8 @@ typedef enum snmf_status {
     SNMF_ERR_NO_DEVICE = 5, /* no HIP device / HIP runtime failure */
     SNMF_ERR_NOMEM = 6,
     SNMF_ERR_STATE = 7,     /* call order violated (e.g. run before set_v) */
-    SNMF_ERR_UNSUPPORTED = 8
+    SNMF_ERR_UNSUPPORTED = 8,
+    SNMF_ERR_INTERNAL = 9   /* a bounded device-side wait gave up (never expected): the results are invalid */
 } snmf_status;
 
 /* sparsity argument forms of src/sparse_nmf.m:150-155 */

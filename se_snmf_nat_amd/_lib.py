@@ -41,7 +41,7 @@ SYMBOLS = [
 SNMF_OK = 0
 STATUS_NAMES = {
     0: "SNMF_OK", 1: "SNMF_ERR_INVALID", 2: "SNMF_ERR_NO_INIT", 3: "SNMF_ERR_DIM", 4: "SNMF_ERR_NO_FIELD",
-    5: "SNMF_ERR_NO_DEVICE", 6: "SNMF_ERR_NOMEM", 7: "SNMF_ERR_STATE", 8: "SNMF_ERR_UNSUPPORTED",
+    5: "SNMF_ERR_NO_DEVICE", 6: "SNMF_ERR_NOMEM", 7: "SNMF_ERR_STATE", 8: "SNMF_ERR_UNSUPPORTED", 9: "SNMF_ERR_INTERNAL",
 }
 
 

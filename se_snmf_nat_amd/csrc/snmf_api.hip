@@ -1070,6 +1070,7 @@ extern "C" int snmf_plan_objapply(snmf_plan* pl, const double* stats) {
 static int read_state(snmf_plan* pl, DevState* hs) {
     HIP_TRY(hipMemcpyAsync(hs, pl->st, sizeof(DevState), hipMemcpyDeviceToHost, pl->ctx->stream));
     HIP_TRY(hipStreamSynchronize(pl->ctx->stream));
+    if (hs->fault) return fail(SNMF_ERR_INTERNAL, "a device-side producer/consumer wait timed out: results are invalid");
     return SNMF_OK;
 }
 

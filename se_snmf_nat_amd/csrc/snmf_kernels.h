@@ -96,8 +96,14 @@ __device__ __forceinline__ float div_term(float v, float lam, float beta, float 
 struct DevState {
     int stop;      // set by the convergence test, src/sparse_nmf.m:275-281
     int n_iter;    // iterations whose objective has been recorded
-    int pad0, pad1;
+    int fault;     // a bounded device-side wait (LDS producer/consumer counters) gave up: results are invalid
+    int pad1;
 };
+// `stop` points at DevState::stop; the fault word sits two ints behind it
+__device__ __forceinline__ void raise_fault(const int* stop) {
+    if (stop) atomicExch(const_cast<int*>(stop) + 2, 1);
+}
+constexpr int kSpinLimit = 1 << 22;  // x >= 64 cycles of s_sleep: ~0.1 s, four orders of magnitude over a tile period
 
 // ------------------------------------------------------------------------------------------
 // Arguments shared by the two big kernels.  Layouts (all fp32, zero padded):
@@ -644,7 +650,7 @@ __device__ __forceinline__ void hstep_p2(const StepArgs& a, float* Hs, const flo
 // consumer that has finished P2 of tile i-1 does not have to wait for the others -- it bumps an LDS counter
 // (arrive only) and goes on; the LOADERS wait for the counter before they touch nxt.  One workgroup barrier per
 // tile instead of two, and a wave's epilogue overlaps its neighbours' MFMA loop across the tile boundary.  The
-// loaders' wait is a bounded spin: a lost signal would give wrong numbers (caught by the parity tests), never a hang.
+// loaders' wait is a bounded spin: a lost signal raises DevState::fault (the host then fails the call), never a hang.
 // ============================================================================================
 template <int NW, int NT, int NL, int BM, bool OBJ, bool UPD, bool MDI = false>
 __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(StepArgs a) {
@@ -693,8 +699,14 @@ __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(Step
                 __syncthreads();  // B1
             } else {
                 const unsigned target = (unsigned)(NW * it);
-                for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target; ++spin)
+                int spin = 0;
+                while (__hip_atomic_load(sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+                    if (++spin > kSpinLimit) {
+                        raise_fault(a.stop);
+                        break;
+                    }
                     __builtin_amdgcn_s_sleep(2);
+                }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
             if (UPD && prev >= 0) stage_out<NLT>(a.Hout + (size_t)prev * Tt * rp, nH, Tt, rp, ldh, lt);
@@ -1269,7 +1281,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     // NL > 0: no workgroup barrier inside the tile loop.  The consumer waves never exchange data (each owns its rows
     // of G), so all they need is "tile i is staged" -- an LDS counter the loader waves bump (`ready`, NL per tile) --
     // and all the loaders need before they refill a buffer is "every consumer is done with tile i-1" (`done`, NWB
-    // per tile).  Waits are bounded spins: a lost signal gives wrong numbers (parity tests), never a hang.
+    // per tile).  Waits are bounded spins: a lost signal raises DevState::fault (the host then fails the call), never a hang.
     unsigned* ready = reinterpret_cast<unsigned*>(wxs + rp);
     unsigned* done = ready + 1;
     auto arrive = [&](unsigned* c) {
@@ -1277,8 +1289,14 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         if (lane == 0) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     auto await = [&](unsigned* c, unsigned target) {
-        for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target; ++spin)
+        int spin = 0;
+        while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+            if (++spin > kSpinLimit) {
+                raise_fault(a.stop);
+                break;
+            }
             __builtin_amdgcn_s_sleep(1);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
     if (NL > 0) {
