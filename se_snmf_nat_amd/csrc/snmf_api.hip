@@ -304,6 +304,26 @@ extern "C" void snmf_plan_destroy(snmf_plan* pl) {
                 ghz.push_back((double)hc[2 * i] / (double)hc[2 * i + 1] * 0.1);
                 span.push_back((double)hc[2 * i + 1] * 0.01);
             }
+        {   // when did the waves start and end, relative to the first start (100 MHz ticks -> us)
+            std::vector<unsigned long long> hs0((size_t)nw);
+            hipMemcpy(hs0.data(), pl->prof + 98304 + 16384 + (wlast ? (size_t)4096 : 0), hs0.size() * 8, hipMemcpyDeviceToHost);
+            std::vector<double> st, en;
+            unsigned long long t0 = ~0ull;
+            for (int i = 0; i < nw; ++i)
+                if (hs0[i]) t0 = std::min(t0, hs0[i]);
+            for (int i = 0; i < nw; ++i)
+                if (hs0[i]) {
+                    st.push_back((double)(hs0[i] - t0) * 0.01);
+                    en.push_back((double)(hs0[i] - t0 + hc[2 * i + 1]) * 0.01);
+                }
+            if (!st.empty()) {
+                std::sort(st.begin(), st.end());
+                std::sort(en.begin(), en.end());
+                auto q = [](const std::vector<double>& v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
+                fprintf(stderr, " | wave start us (10/50/90/100 %%): %.1f %.1f %.1f %.1f; wave end us (0/10/50/90/100 %%): %.1f %.1f %.1f %.1f %.1f",
+                        q(st, .1), q(st, .5), q(st, .9), q(st, 1.), q(en, 0.), q(en, .1), q(en, .5), q(en, .9), q(en, 1.));
+            }
+        }
         if (!ghz.empty()) {
             std::sort(ghz.begin(), ghz.end());
             std::sort(span.begin(), span.end());
@@ -525,8 +545,8 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     A(dalloc(&pl->st, (size_t)1));
     A(dalloc(&pl->w_ind, (size_t)pl->rp));
 #ifdef SNMF_PROF
-    A(dalloc(&pl->prof, (size_t)1024 * 8 * 12 + 2 * 8192));  // phase slots, then (cycles, 100 MHz ticks) per wave
-    hipMemset(pl->prof, 0, ((size_t)1024 * 8 * 12 + 2 * 8192) * 8);
+    A(dalloc(&pl->prof, (size_t)1024 * 8 * 12 + 3 * 8192));  // phase slots, then (cycles, 100 MHz ticks) and start tick per wave
+    hipMemset(pl->prof, 0, ((size_t)1024 * 8 * 12 + 3 * 8192) * 8);
 #endif
     if (s != SNMF_OK) {
         snmf_plan_destroy(pl);

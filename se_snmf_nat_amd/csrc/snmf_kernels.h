@@ -164,7 +164,7 @@ struct StepArgs {
 #define SNMF_STAMP_OUT(base, nph) do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < nph; ++i_) (base)[i_] = pf_[i_]; } while (0)
 // in-kernel clock of this wave's stamped span: shader cycles over the 100 MHz real-time counter (slot pair idx behind the phase slots)
 #define SNMF_STAMP_CLK(prof, idx) do { if ((threadIdx.x & 63) == 0) { (prof)[98304 + 2 * (idx)] = __builtin_amdgcn_s_memtime() - pc0_; \
-    (prof)[98304 + 2 * (idx) + 1] = __builtin_amdgcn_s_memrealtime() - pr0_; } } while (0)
+    (prof)[98304 + 2 * (idx) + 1] = __builtin_amdgcn_s_memrealtime() - pr0_; (prof)[98304 + 16384 + (idx)] = pr0_; } } while (0)
 #else
 #define SNMF_STAMP_DECL
 #define SNMF_STAMP(i)
