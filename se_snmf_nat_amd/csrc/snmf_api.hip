@@ -324,6 +324,18 @@ extern "C" void snmf_plan_destroy(snmf_plan* pl) {
                         q(st, .1), q(st, .5), q(st, .9), q(st, 1.), q(en, 0.), q(en, .1), q(en, .5), q(en, .9), q(en, 1.));
             }
         }
+        if (!wlast) {  // per-tile periods of consumer wave 0: the first workgroup, one from the middle, the last
+            std::vector<unsigned long long> tt((size_t)16384);
+            hipMemcpy(tt.data(), pl->prof + 98304 + 24576, tt.size() * 8, hipMemcpyDeviceToHost);
+            const int wgs[3] = {0, pl->grid_h / 2, pl->grid_h - 1};
+            for (int wi = 0; wi < 3; ++wi) {
+                const int b = wgs[wi];
+                if (b < 0 || b >= 1024) continue;
+                fprintf(stderr, " | wg %d tile periods us:", b);
+                for (int i = 1; i < 16 && tt[(size_t)b * 16 + i]; ++i)
+                    fprintf(stderr, " %.1f", (double)(tt[(size_t)b * 16 + i] - tt[(size_t)b * 16 + i - 1]) * 0.01);
+            }
+        }
         if (!ghz.empty()) {
             std::sort(ghz.begin(), ghz.end());
             std::sort(span.begin(), span.end());
@@ -545,8 +557,8 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     A(dalloc(&pl->st, (size_t)1));
     A(dalloc(&pl->w_ind, (size_t)pl->rp));
 #ifdef SNMF_PROF
-    A(dalloc(&pl->prof, (size_t)1024 * 8 * 12 + 3 * 8192));  // phase slots, then (cycles, 100 MHz ticks) and start tick per wave
-    hipMemset(pl->prof, 0, ((size_t)1024 * 8 * 12 + 3 * 8192) * 8);
+    A(dalloc(&pl->prof, (size_t)1024 * 8 * 12 + 3 * 8192 + 16384));  // phase slots, then (cycles, 100 MHz ticks) and start tick per wave
+    hipMemset(pl->prof, 0, ((size_t)1024 * 8 * 12 + 3 * 8192 + 16384) * 8);
 #endif
     if (s != SNMF_OK) {
         snmf_plan_destroy(pl);

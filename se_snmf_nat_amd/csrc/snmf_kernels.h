@@ -162,6 +162,9 @@ struct StepArgs {
     const unsigned long long pc0_ = pl_, pr0_ = __builtin_amdgcn_s_memrealtime();
 #define SNMF_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); pf_[i] += t_ - pl_; pl_ = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #define SNMF_STAMP_OUT(base, nph) do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < nph; ++i_) (base)[i_] = pf_[i_]; } while (0)
+// start tick (100 MHz) of tile `it` of workgroup `wg`, consumer wave 0, first 16 tiles of the first 1024 workgroups
+#define SNMF_STAMP_TILE(prof, wg, it) do { if (threadIdx.x == 0 && (it) < 16 && (wg) < 1024 && (prof)) \
+    (prof)[98304 + 24576 + (size_t)(wg) * 16 + (it)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 // in-kernel clock of this wave's stamped span: shader cycles over the 100 MHz real-time counter (slot pair idx behind the phase slots)
 #define SNMF_STAMP_CLK(prof, idx) do { if ((threadIdx.x & 63) == 0) { (prof)[98304 + 2 * (idx)] = __builtin_amdgcn_s_memtime() - pc0_; \
     (prof)[98304 + 2 * (idx) + 1] = __builtin_amdgcn_s_memrealtime() - pr0_; (prof)[98304 + 16384 + (idx)] = pr0_; } } while (0)
@@ -170,6 +173,7 @@ struct StepArgs {
 #define SNMF_STAMP(i)
 #define SNMF_STAMP_OUT(base, nph)
 #define SNMF_STAMP_CLK(prof, idx)
+#define SNMF_STAMP_TILE(prof, wg, it)
 #endif
 
 #define SNMF_PIN()                          \
@@ -746,6 +750,7 @@ __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(Step
                 if (lane == 0) __hip_atomic_fetch_add(sig, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             SNMF_STAMP(2);
+            SNMF_STAMP_TILE(a.prof, blockIdx.x, it);
             hstep_p1<NW, NT, BM, OBJ, false, MDI>(a, Hs, Rs, wxs, t0, w, lane, UPD, acc_div);
             SNMF_STAMP(4);
             if (UPD || NL > 0) __syncthreads();  // B2
