@@ -107,7 +107,9 @@ int snmf_sparse_nmf_f32(snmf_ctx* ctx, const snmf_params* p, const float* V, int
 int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan** out);
 void snmf_plan_destroy(snmf_plan* plan);
 
-/* is_device != 0: pointer is device memory on the context's device (fp32/fp64 as named). */
+/* is_device != 0: pointer is device memory on the context's device (fp32/fp64 as named).  The library reads it on
+ * the CONTEXT's stream (snmf_ctx_set_stream): a device buffer produced on another stream must be complete -- or that
+ * stream ordered ahead of the context's with an event -- before the call; the host mirror synchronises the producer. */
 int snmf_plan_set_v_f64(snmf_plan* plan, const double* V, int64_t ld, int is_device);
 int snmf_plan_set_v_f32(snmf_plan* plan, const float* V, int64_t ld, int is_device);
 int snmf_plan_set_w_f64(snmf_plan* plan, const double* W, int64_t ld, int is_device);
@@ -298,7 +300,8 @@ int snmf_online_process_f32(snmf_online* o, const float* pcm, int64_t n, int flu
                             int16_t* x_tilde_i16, float* x_hat_f32, float* d_hat_f32, int64_t cap, int64_t* n_out);
 /* Current B_DFT_d (what src/NTF_sep_event_RT.m:138-140 saves to B_D_u.mat). */
 int snmf_online_get_basis_f32(snmf_online* o, float* B_DFT_d, int64_t ld);
-/* Diagnostics of the frames processed so far (copies min(cap, n) entries, *n = total frames). */
+/* Diagnostics of the most recent frames: the separator keeps a ring of the newest 65536 frames (a real-time stream
+ * runs unbounded); copies the oldest min(cap, *n) of them in order, *n = frames held (= all frames for shorter runs). */
 int snmf_online_trace(snmf_online* o, snmf_online_frame* out, int64_t cap, int64_t* n);
 void snmf_online_destroy(snmf_online* o);
 

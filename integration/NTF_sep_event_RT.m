@@ -18,12 +18,20 @@ fread(fin, 22, 'int16');                               % skip the wav header (:5
 pcm = fread(fin, inf, 'int16');
 fclose(fin);
 
-% the reference's random draws, made here with MATLAB's own generator so that they are the reference's
+% The reference's random draws, made here with MATLAB's own generator and IN THE REFERENCE'S ORDER, so that they are
+% the reference's values:
+%   1. init_buff (src/NTF_sep_event_RT.m:60 -> src/init_buff.m:38-39) draws g.A_d = rand(R_d, m) and then
+%      g.Ad_blk = rand(p.R_a, p.m_a) from the global stream AS THE CALLER LEFT IT -- nothing has re-seeded it yet;
+%   2. only the first sparse_nmf call of the frame loop seeds the legacy generator (src/sparse_nmf.m:112-114) and
+%      draws H0 = rand(r, 1) (:133-134) -- the same vector every frame, because every call re-seeds.
+% g.A_d is never read before it is overwritten (src/bnmf_sep_event_RT_IS16.m:22, :395); it is drawn only to leave
+% the stream where the reference leaves it for Ad_blk.
+A_d0 = rand(size(B_DFT_d,2), p.blk_len_sep);           %#ok<NASGU>  src/init_buff.m:38
+Ad_blk0 = rand(p.R_a, p.m_a);                          % src/init_buff.m:39
 if p.random_seed > 0
     rand('seed', p.random_seed);                       %#ok<RAND>  src/sparse_nmf.m:112-114
 end
-H0 = rand(size(B_DFT_x,2) + size(B_DFT_d,2), 1);      % src/sparse_nmf.m:133-134 (same vector every frame)
-Ad_blk0 = rand(p.R_a, p.m_a);                          % src/init_buff.m:39
+H0 = rand(size(B_DFT_x,2) + size(B_DFT_d,2), 1);      % src/sparse_nmf.m:133-134
 
 h = snmf_online_mex('create', B_DFT_x, B_DFT_d, H0, Ad_blk0, p);
 x = snmf_online_mex('process', h, pcm, 1);             % every hop + the delay+1 end-of-file frames (:67-76)

@@ -1,9 +1,13 @@
 """CPU oracle for the sparse-NMF multiplicative-update path.  TEST INFRASTRUCTURE ONLY.
 
-PARITY UNPINNED: the reference (lordet01/SE_SNMF_NAT) is 100 % MATLAB, ships no tests,
-no golden vectors and no known-answer fixtures for this path, and neither MATLAB nor Octave
-exists in the build container or on the GPU box, so the reference itself cannot be run.  This
-file is a line-by-line fp64 NumPy restatement of ``src/sparse_nmf.m`` (every block below cites
+PARITY: SOFT PIN.  The reference (lordet01/SE_SNMF_NAT) is 100 % MATLAB, ships no tests, no golden vectors and no
+known-answer fixtures for this path, and neither MATLAB nor Octave exists in the build container or on the GPU box, so
+the reference itself cannot be run.  What the reference DOES hold are two recordings its own code processed
+(wav/*_out_v3.9_18.wav); tests/test_refwav.py runs the whole online chain -- which calls this solver once per frame
+(H-only, KL) and once per adaptation (W-only, KL) -- over the matching inputs and reproduces MATLAB's output to
+corr 0.997 / 21.8 dB and 0.996 / 20.7 dB (a soft pin: MATLAB's legacy rand stream is not
+recoverable).  Bit-level / 1e-4 parity of a single call, the full-update mode and beta != 1 remain UNPINNED against
+MATLAB.  This file is a line-by-line fp64 NumPy restatement of ``src/sparse_nmf.m`` (every block below cites
 the lines it follows); it is cross-checked by (i) an independently written loop-form restatement
 (``oracle/sparse_nmf_loops.py``), (ii) scikit-learn's ``_beta_divergence`` for the four divergence
 formulas, (iii) the algorithm's invariants (monotone cost, unit-norm W, fixed point) and (iv) the

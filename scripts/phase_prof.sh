@@ -1,7 +1,16 @@
 #!/bin/bash
-# diagnostic: run bench with the -DSNMF_PROF build of the library (phase shares on stderr)
-cp se_snmf_nat_amd/libsnmf_hip.so /tmp/libsnmf_hip.so.bak
-cp scripts/prof_build/libsnmf_hip_prof.bin se_snmf_nat_amd/libsnmf_hip.so
+# diagnostic: run bench with the -DSNMF_PROF build of the library (phase shares on stderr).
+# The diagnostic build lives at its OWN path (scripts/prof_build/libsnmf_hip_prof.so, git-ignored, built here when
+# missing) and is selected with SNMF_LIB_PATH; the product library se_snmf_nat_amd/libsnmf_hip.so is never touched.
+set -e
+cd "$(dirname "$0")/.."
+PROF=scripts/prof_build/libsnmf_hip_prof.so
+if [ ! -f "$PROF" ] || [ se_snmf_nat_amd/csrc/snmf_kernels.h -nt "$PROF" ] || [ se_snmf_nat_amd/csrc/snmf_api.hip -nt "$PROF" ]; then
+    mkdir -p scripts/prof_build
+    /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -Wno-unused-value -DSNMF_PROF \
+        -Iinclude -Ise_snmf_nat_amd/csrc -o "$PROF" se_snmf_nat_amd/csrc/snmf_api.hip
+fi
+export SNMF_LIB_PATH="$PWD/$PROF"
 run() { echo "== $*"; env "$@" python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | grep -E "SNMF_PROF|kernel_ms" | python -c "
 import sys,json
 for l in sys.stdin:
@@ -11,4 +20,3 @@ for l in sys.stdin:
 run SNMF_X=1
 run SNMF_PROF_W=1
 run SNMF_PROF_W=1 SNMF_WSTATS_NL=0
-cp /tmp/libsnmf_hip.so.bak se_snmf_nat_amd/libsnmf_hip.so

@@ -141,12 +141,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("SNMF_LIB_PATH") or LIB_PATH  # SNMF_LIB_PATH: a diagnostic build (scripts/phase_prof.sh)
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  The engine has no CPU fallback.")
     _preload_torch_hip_runtime()
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     PP = C.POINTER(SnmfParams)
     sig = {

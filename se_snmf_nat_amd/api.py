@@ -305,6 +305,10 @@ class Plan:
             if a.dim() != 2 or not a.is_contiguous() or a.shape[1] != rows:
                 raise SnmfError(1, f"device tensor for {name} must be contiguous with shape (cols, {rows}) "
                                    "(= column-major rows x cols)")
+            # The tensor was produced on torch's CURRENT stream; the engine packs it on its own stream, and nothing
+            # orders the two.  set_* is not a hot path, so wait for the producer here (an input still being written
+            # by e.g. `.cuda().T.contiguous()` would otherwise be packed half-finished, silently).
+            torch.cuda.current_stream(a.device).synchronize()
             fn = getattr(self._lib, f"snmf_plan_set_{name}_{ty}")
             _lib.check(fn(self._h, C.c_void_p(a.data_ptr()), rows, 1))
             return

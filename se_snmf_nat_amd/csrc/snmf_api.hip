@@ -11,7 +11,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -210,6 +212,7 @@ struct snmf_plan {
     int Fp = 0, rp = 0, Tp = 0, nf = 0, nk = 0;
     int Fm = 0, Fq = 0, xr = 0;
     int NT = 1, NWH = 8, NLH = 0;  // k_hstep: frame tile = 32*NT, NWH consumer + NLH loader waves
+    bool hstep_rp = true;          // KL update launches of the (8, 1, 4) geometry use the role pipeline k_hstep_rp (SNMF_HSTEP_RP=0: k_hstep)
     int NKT = 8, NWB = 4, WPS = 2, NLW = 0;  // k_wstats template geometry (NLW loader waves)
     int n_fg = 1, n_kg = 1, n_chunks = 1;
     int n_ch1 = 0;  // k_wstats: chunks of row group 1 when the two row groups are split unevenly (else 0)
@@ -422,6 +425,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
             pl->NLH = (got == 3 && (nl == 4) && nw == 8 && nt == 1 && 2 * lds1 - lds_extra <= lds_cap) ? nl : 0;
         }
     }
+    if (const char* e = getenv("SNMF_HSTEP_RP")) pl->hstep_rp = atoi(e) != 0;
     pl->lds_h = std::max<size_t>(pl->NLH ? 2 * lds1 - lds_extra : (pl->NT == 1 ? lds1 : lds2),
                                  2 * kMaxNW * 64 * sizeof(double));
     pl->lds_mdi = std::max<size_t>(lds1, 2 * kMaxNW * 64 * sizeof(double));  // MDI pass: (NW=8, NT=1, NL=0)
@@ -790,15 +794,27 @@ static StepArgs make_args(snmf_plan* pl) {
     return a;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: the cache of "already raised to"
+// is keyed by (device, kernel) and guarded, so that a second context on another device, or two host threads, cannot
+// skip a call they need (launches with more than 64 KiB of LDS would fail) or race on the map.
+static int ensure_dyn_lds(int device, const void* kern, size_t lds) {
+    if (lds <= 64 * 1024) return SNMF_OK;
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> raised;
+    std::lock_guard<std::mutex> lk(mu);
+    size_t& cur = raised[{device, kern}];
+    if (cur < lds) {
+        HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        cur = lds;
+    }
+    return SNMF_OK;
+}
+
 template <typename K>
 static int launch_big(K kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, StepArgs a) {
-    static std::map<const void*, size_t> attr_set;
-    const void* key = (const void*)kern;
-    auto it = attr_set.find(key);
-    if (lds > 64 * 1024 && (it == attr_set.end() || it->second < lds)) {
-        HIP_TRY(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[key] = lds;
-    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));  // every caller has set the plan's device
+    SN_TRY(ensure_dyn_lds(dev, (const void*)kern, lds));
     hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     HIP_TRY(hipGetLastError());
     return SNMF_OK;
@@ -844,7 +860,14 @@ static int launch_hstep(snmf_plan* pl, bool obj, bool upd) {
         if (pl->bm == BM_EUC) return launch_hstep_mdi_b<BM_EUC>(pl, a, obj, upd);
         return launch_hstep_mdi_b<BM_GEN>(pl, a, obj, upd);
     }
-    if (pl->NWH == 8 && pl->NLH == 4) return launch_hstep_g<8, 1, 4>(pl, a, obj, upd);
+    if (pl->NWH == 8 && pl->NLH == 4) {
+        if (pl->hstep_rp && pl->bm == BM_KL && upd) {  // KL update launches: the role pipeline (k_hstep_rp)
+            dim3 g(pl->grid_h), b(768);
+            return obj ? launch_big(k_hstep_rp<true>, g, b, pl->lds_h, pl->ctx->stream, a)
+                       : launch_big(k_hstep_rp<false>, g, b, pl->lds_h, pl->ctx->stream, a);
+        }
+        return launch_hstep_g<8, 1, 4>(pl, a, obj, upd);
+    }
     if (pl->NWH == 4) return pl->NT == 2 ? launch_hstep_g<4, 2, 0>(pl, a, obj, upd) : launch_hstep_g<4, 1, 0>(pl, a, obj, upd);
     return pl->NT == 2 ? launch_hstep_g<8, 2, 0>(pl, a, obj, upd) : launch_hstep_g<8, 1, 0>(pl, a, obj, upd);
 }
@@ -856,13 +879,8 @@ static int launch_wstats_one(snmf_plan* pl, const StepArgs& a, int mat_index) {
     dim3 g(split ? pl->n_chunks + pl->n_ch1 : pl->n_chunks, split ? 1 : pl->n_fg, pl->n_kg), b((NWB + NL) * 64);
     StepArgs as = a;
     as.n_ch1 = split ? pl->n_ch1 : 0;
-    static std::map<const void*, size_t> attr_set;
     auto kern = k_wstats<NK, NWB, NL, WPS, WM, BM, OBJ>;
-    const void* key = (const void*)kern;
-    if (pl->lds_w > 64 * 1024 && attr_set[key] < pl->lds_w) {
-        HIP_TRY(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_w));
-        attr_set[key] = pl->lds_w;
-    }
+    SN_TRY(ensure_dyn_lds(pl->ctx->device, (const void*)kern, pl->lds_w));
     hipLaunchKernelGGL(kern, g, b, pl->lds_w, pl->ctx->stream, as, pl->n_chunks, mat_index, pl->n_mat);
     HIP_TRY(hipGetLastError());
     return SNMF_OK;
@@ -1139,12 +1157,7 @@ static int launch_small(snmf_plan* pl, int n_solves, int tps, double* divh, doub
     sa.wn = pl->wn;
     sa.Rx = recon_rx;
     auto launch = [&](auto kern) -> int {
-        static std::map<const void*, size_t> attr_set;
-        const void* key = (const void*)kern;
-        if (pl->lds_small > 64 * 1024 && attr_set[key] < pl->lds_small) {
-            HIP_TRY(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_small));
-            attr_set[key] = pl->lds_small;
-        }
+        SN_TRY(ensure_dyn_lds(pl->ctx->device, (const void*)kern, pl->lds_small));
         hipLaunchKernelGGL(kern, dim3(n_solves), dim3(512), pl->lds_small, pl->ctx->stream, a, sa);
         HIP_TRY(hipGetLastError());
         return SNMF_OK;
@@ -1153,12 +1166,7 @@ static int launch_small(snmf_plan* pl, int n_solves, int tps, double* divh, doub
     const bool obj = pl->p.cost_check != 0;
     if (tps == 1 && pl->frame_fb) {
         auto launch_f = [&](auto kern) -> int {
-            static std::map<const void*, size_t> attr_set;
-            const void* key = (const void*)kern;
-            if (pl->lds_frame > 64 * 1024 && attr_set[key] < pl->lds_frame) {
-                HIP_TRY(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_frame));
-                attr_set[key] = pl->lds_frame;
-            }
+            SN_TRY(ensure_dyn_lds(pl->ctx->device, (const void*)kern, pl->lds_frame));
             hipLaunchKernelGGL(kern, dim3(n_solves), dim3(512), pl->lds_frame, pl->ctx->stream, a, sa, (const float*)pl->Wcf);
             HIP_TRY(hipGetLastError());
             return SNMF_OK;
@@ -1617,6 +1625,7 @@ extern "C" int snmf_mel_features_f32(snmf_ctx* ctx, const float* mel, int32_t M,
 // fire?) and, when it did, runs the W-only adaptation solve through the engine's ordinary plan.
 #include "snmf_online.h"
 
+constexpr size_t kTraceCap = 1u << 16;  // diagnostics ring: the newest 65536 frames (~11 min at 100 frames/s)
 struct snmf_online {
     snmf_ctx* ctx = nullptr;
     snmf_online_params p{};
@@ -1661,7 +1670,8 @@ struct snmf_online {
     std::vector<float> pending, hist;
     int64_t l = 0;  // frames processed
     bool finished = false;
-    std::vector<snmf_online_frame> trace;
+    bool failed = false;  // a device batch failed midway: frame counter, history and rings are no longer consistent
+    std::deque<snmf_online_frame> trace;  // bounded: the newest kTraceCap frames (a real-time stream runs for days)
 };
 
 static void online_free_call_buffers(snmf_online* o) {
@@ -2033,16 +2043,16 @@ static int online_adapt(snmf_online* o, int32_t* iters) {
         wa.V = o->Vad; wa.H = o->Had; wa.W0 = Bd; wa.w_ind = ap->w_ind; wa.Wout = o->wa_W; wa.part1 = o->wa_p1; wa.part2 = o->wa_p2;
         wa.costh = o->wa_cost; wa.n_iter_out = o->wa_nit; wa.F = Fs; wa.Ra = p.R_a; wa.ma = p.m_a; wa.max_iter = p.max_iter;
         wa.cost_check = p.cost_check; wa.sparsity = (float)p.sparsity; wa.flr = kFlr; wa.conv_eps = p.conv_eps;
-        static size_t attr_lds = 0;
-        if (o->wa_lds > 64 * 1024 && attr_lds < o->wa_lds) {
-            HIP_TRY(hipFuncSetAttribute((const void*)k_wadapt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)o->wa_lds));
-            attr_lds = o->wa_lds;
-        }
+        SN_TRY(ensure_dyn_lds(o->ctx->device, (const void*)k_wadapt, o->wa_lds));
         wa.bar = o->wa_bar;
         HIP_TRY(hipMemsetAsync(o->wa_bar, 0, 4, st));
         void* kargs[] = {&wa};
         if (hipLaunchCooperativeKernel((const void*)k_wadapt, dim3(o->wa_nwg), dim3(256), kargs, (unsigned)o->wa_lds, st) == hipSuccess) {
             HIP_TRY(hipMemcpyAsync(iters, o->wa_nit, 4, hipMemcpyDeviceToHost, st));
+            // the solve's verdict is read BEFORE its W is merged into the dictionary: a timed-out grid barrier leaves
+            // wa_W invalid, and B_d, its fp32 mirror and the frame-solve plan must not see it
+            HIP_TRY(hipStreamSynchronize(st));
+            if (*iters < 0) return fail(SNMF_ERR_INTERNAL, "adaptation kernel: grid barrier timed out (dictionary left untouched)");
             Wres = o->wa_W;
             ldw = Fs;
         } else {
@@ -2064,9 +2074,7 @@ static int online_adapt(snmf_online* o, int32_t* iters) {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(Bd, Btmp, (size_t)Fs * p.R_d * 8, hipMemcpyDeviceToDevice, st));
     SN_TRY(set_w<double>(o->hp, Ball, Fs, 1));         // next frame's init_w (:140-146)
-    HIP_TRY(hipStreamSynchronize(st));
-    if (*iters < 0) return fail(SNMF_ERR_NO_DEVICE, "adaptation kernel: grid barrier timed out");
-    return SNMF_OK;
+    return SNMF_OK;  // `iters` is already on the host (both paths synchronised when they read it)
 }
 
 // n frames whose samples are sig = [history | n hops] (host); appends the hops the driver would write
@@ -2142,6 +2150,7 @@ static int online_run_frames(snmf_online* o, const std::vector<float>& sig, int 
             tr.n_iter = hs.n_iter; tr.trig = hs.trig; tr.n_up = hs.n_up; tr.beta = hs.beta; tr.A_x_mag = hs.A_x_mag; tr.A_d_mag = hs.A_d_mag;
             tr.Q_control = hs.Q_control;
             o->trace.push_back(tr);
+            if (o->trace.size() > kTraceCap) o->trace.pop_front();
         }
     } else {
         for (int i = 0; i < n; ++i) {
@@ -2163,6 +2172,7 @@ static int online_run_frames(snmf_online* o, const std::vector<float>& sig, int 
                 tr.adapt_iters = it;
             }
             o->trace.push_back(tr);
+            if (o->trace.size() > kTraceCap) o->trace.pop_front();
         }
     }
     // inverse STFT of the n frames behind the nov-1 frames kept from the previous call, overlap-add
@@ -2212,6 +2222,7 @@ extern "C" int snmf_online_process_f32(snmf_online* o, const float* pcm, int64_t
     if (n_out) *n_out = 0;
     if (n < 0 || (n > 0 && !pcm)) return fail(SNMF_ERR_INVALID, "pcm is NULL");
     if (o->finished) return fail(SNMF_ERR_STATE, "the stream was flushed; create a new separator");
+    if (o->failed) return fail(SNMF_ERR_STATE, "an earlier call failed midway through a batch; the separator state is not reusable, create a new one");
     if ((xh_f32 || dh_f32) && !o->p.class_outputs) return fail(SNMF_ERR_STATE, "class outputs were not requested at creation");
     HIP_TRY(hipSetDevice(o->ctx->device));
     const int sz = o->p.framelength, hop = o->p.frameshift;
@@ -2231,7 +2242,10 @@ extern "C" int snmf_online_process_f32(snmf_online* o, const float* pcm, int64_t
         const int nb = (int)std::min(chunk, nfr - done);
         std::vector<float> sig(o->hist);
         sig.insert(sig.end(), o->pending.begin() + done * hop, o->pending.begin() + (done + nb) * hop);
-        SN_TRY(online_run_frames(o, sig, nb, xt_f32 ? &of : nullptr, xt_i16 ? &o16 : nullptr, xh_f32 ? &ox : nullptr, dh_f32 ? &od : nullptr));
+        if (int rc = online_run_frames(o, sig, nb, xt_f32 ? &of : nullptr, xt_i16 ? &o16 : nullptr, xh_f32 ? &ox : nullptr, dh_f32 ? &od : nullptr)) {
+            o->failed = true;  // frames of this call were consumed and the device state advanced: never retry on it
+            return rc;
+        }
         o->hist.assign(sig.end() - (sz - hop), sig.end());
         done += nb;
     }
@@ -2239,7 +2253,10 @@ extern "C" int snmf_online_process_f32(snmf_online* o, const float* pcm, int64_t
     if (flush) {
         // a partial hop is dropped and delay+1 all-zero frames follow (src/NTF_sep_event_RT.m:69-76)
         std::vector<float> sig((size_t)(sz - hop) + (size_t)tail_frames * hop, 0.f);
-        SN_TRY(online_run_frames(o, sig, (int)tail_frames, xt_f32 ? &of : nullptr, xt_i16 ? &o16 : nullptr, xh_f32 ? &ox : nullptr, dh_f32 ? &od : nullptr));
+        if (int rc = online_run_frames(o, sig, (int)tail_frames, xt_f32 ? &of : nullptr, xt_i16 ? &o16 : nullptr, xh_f32 ? &ox : nullptr, dh_f32 ? &od : nullptr)) {
+            o->failed = true;
+            return rc;
+        }
         o->pending.clear();
         o->finished = true;
     }
@@ -2264,6 +2281,6 @@ extern "C" int snmf_online_get_basis_f32(snmf_online* o, float* Bd, int64_t ld) 
 extern "C" int snmf_online_trace(snmf_online* o, snmf_online_frame* out, int64_t cap, int64_t* n) {
     if (!o) return fail(SNMF_ERR_INVALID, "online handle is NULL");
     if (n) *n = (int64_t)o->trace.size();
-    if (out && cap > 0) std::memcpy(out, o->trace.data(), sizeof(snmf_online_frame) * (size_t)std::min<int64_t>(cap, (int64_t)o->trace.size()));
+    if (out && cap > 0) std::copy_n(o->trace.begin(), (size_t)std::min<int64_t>(cap, (int64_t)o->trace.size()), out);
     return SNMF_OK;
 }

@@ -807,6 +807,335 @@ __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(Step
 }
 
 // ============================================================================================
+// k_hstep_rp: the KL H half-step as a ROLE PIPELINE (round 2).  Same arithmetic as k_hstep<8,1,4,BM_KL,OBJ,true>,
+// different schedule.  In k_hstep all eight consumer waves run P1 of a tile, meet at a barrier, then all run P2: the
+// VALU epilogues of the two waves of a SIMD coincide and the matrix pipe idles through them and through the barrier
+// (48.9 k cycles per tile where the pipe needs 33.3 k, round-1 phase stamps).  Here the consumer waves are split by
+// ROLE, one wave of each role per SIMD:
+//     A team (waves 0-3) : P1 of tile i+1   Lam = W*H -> ratio image (in place over the staged V), + the extra row
+//     B team (waves 4-7) : P2 of tile i     W^T*ratio -> H update in LDS
+//     loaders (waves 8-11): copy the updated H tile i out, bring tile i+2 into the buffer that tile i leaves
+// so that on every SIMD one wave's epilogue, wait or reload always has the OTHER role's MFMA loop running beside it,
+// on a different tile.  No workgroup barrier inside the tile loop: three monotonic LDS counters order the roles
+//     ready  (+NL per tile, loaders)  "tile j is staged"              A waits
+//     p1done (+4  per tile, A team)   "the ratio image of j is whole" B waits
+//     p2done (+4  per tile, B team)   "H_j is updated, its ratio dead" loaders wait
+// (dependencies run strictly forward in the tile index, so the waits cannot form a cycle; every wait is a bounded spin
+// that raises DevState::fault instead of hanging).  Each wave owns TWO 32-row (A) / 32-column (B) output tiles whose
+// MFMA chains share every LDS fragment: one ds_read_b128 feeds 8 MFMAs instead of 4, and two independent accumulator
+// chains alternate in the pipe.  The loaders fetch tile i+2 into REGISTERS before they wait for p2done(i), so the
+// reload that sits between P2(i) and P1(i+2) is an LDS write, not an HBM round trip.
+// Fences are LDS-only ("local"): LDS operations of a wave complete in order, and a workgroup-wide release that also
+// drained vmcnt would make the loaders wait for their H stores to be acknowledged by HBM.
+// ============================================================================================
+__device__ __forceinline__ void rp_arrive(unsigned* c, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    if (lane == 0) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void rp_await(unsigned* c, unsigned target, const int* stop) {
+    int spin = 0;
+    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+        if (++spin > kSpinLimit) {
+            raise_fault(stop);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// acc[i] += sum_q Wfrag_i(q) (x) Sfrag(q), i < NA: NA output tiles that share the LDS operand stream.
+//   wp[i]: this lane's f32x4 of W operand image i, consecutive k-blocks 64 f32x4 apart;  sp: this lane's LDS row.
+// Two named stages (A, B), each one k-block = 4*NA MFMAs; stage X+1's loads are issued before stage X's MFMAs.
+// An odd block count needs no tail code: the clamped prefetch of the last round already holds block nq-1.
+template <int NA>
+__device__ __forceinline__ void contract_shared(f32x16 (&acc)[NA], const f32x4* const (&wp)[NA], const float* sp, int nq) {
+    f32x4 wA[NA], wB[NA], sA, sB;
+    const int last = nq - 1;
+    auto ld = [&](f32x4 (&w)[NA], f32x4& sf, int q) {
+        const int qq = q < last ? q : last;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) w[i] = wp[i][(size_t)qq * 64];
+        sf = *reinterpret_cast<const f32x4*>(sp + 8 * qq);
+    };
+    auto mm = [&](const f32x4 (&w)[NA], const f32x4& sf) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < NA; ++i) acc[i] = mfma32(w[i][e], sf[e], acc[i]);
+    };
+    ld(wA, sA, 0);
+    int q = 0;
+    for (; q + 1 < nq; q += 2) {
+        ld(wB, sB, q + 1);
+        SNMF_PIN();
+        mm(wA, sA);
+        ld(wA, sA, q + 2);
+        SNMF_PIN();
+        mm(wB, sB);
+    }
+    if (q < nq) mm(wA, sA);
+}
+
+// P1 epilogue of one 32-row tile: Lam -> ratio in place over the staged V (+ the divergence terms of the previous iterate)
+template <bool OBJ>
+__device__ __forceinline__ void rp_p1_epilogue(const StepArgs& a, const f32x16& acc, float* Rs, int phi, int t0, int lane,
+                                               float& dsum) {
+    const int fl = lane & 31, h = lane >> 5;
+    const int t = t0 + fl;
+    float* rsp = Rs + fl * a.ldr + phi * 32 + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(rsp + 8 * g);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lam = fmaxf(acc[4 * g + j], kFlr);
+            if (OBJ) {
+                const int f = phi * 32 + 8 * g + 4 * h + j;
+                const float d = div_term<BM_KL>(v[j], lam, a.beta, a.inv_bb1);
+                dsum += (f < a.F && t < a.T) ? d : 0.f;
+            }
+            o[j] = v[j] * fast_rcp(lam);
+        }
+        *reinterpret_cast<f32x4*>(rsp + 8 * g) = o;
+    }
+}
+
+// P2 epilogue of one 32-column tile of W^T*ratio: H <- H .* dmh ./ dph in LDS (src/sparse_nmf.m:192-195).
+// dpf / spf: max(colsum(W)+lambda, flr) and lambda of this lane's 16 columns (scalar / r-vector sparsity), loaded by
+// the caller BEFORE the MFMA loop; with a full r x T sparsity matrix they are formed here from S.
+template <bool OBJ>
+__device__ __forceinline__ void rp_p2_epilogue(const StepArgs& a, const f32x16& acc, float* Hs, int kap, int t0, int lane,
+                                               const f32x4 (&dpf)[4], float& shsum) {
+    const int fl = lane & 31, h = lane >> 5;
+    const int t = t0 + fl;
+    float* hsp = Hs + fl * a.ldh + kap * 32 + 4 * h;
+    f32x4 spv[4];  // lambda of this lane's 16 columns: only the objective needs it, so it is fetched here (L2) and used last
+    if (OBJ || a.S) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int k0 = kap * 32 + 8 * g + 4 * h;
+            spv[g] = a.S ? *reinterpret_cast<const f32x4*>(a.S + (size_t)t * a.rp + k0)
+                         : *reinterpret_cast<const f32x4*>(a.lamk + k0);
+        }
+    }
+    f32x4 hov[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int k0 = kap * 32 + 8 * g + 4 * h;
+        hov[g] = *reinterpret_cast<f32x4*>(hsp + 8 * g);
+        f32x4 dp;
+        if (a.S) {
+            const f32x4 cs = *reinterpret_cast<const f32x4*>(a.colsum + k0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dp[j] = fmaxf(cs[j] + spv[g][j], kFlr);
+        } else {
+            dp = dpf[g];
+        }
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = hov[g][j] * acc[4 * g + j] * fast_rcp(dp[j]);
+        *reinterpret_cast<f32x4*>(hsp + 8 * g) = o;
+    }
+    if (OBJ) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) shsum += spv[g][j] * hov[g][j];
+    }
+}
+__device__ __forceinline__ void rp_p2_consts(const StepArgs& a, int kap, int lane, f32x4 (&dpf)[4]) {
+    const int h = lane >> 5;
+    if (!a.S) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dpf[g] = *reinterpret_cast<const f32x4*>(a.dphv + kap * 32 + 8 * g + 4 * h);
+    }
+}
+
+template <bool OBJ>
+__global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
+    constexpr int NA = 4, NB = 4, NL = 4, NTHR = (NA + NB + NL) * 64, NLT = NL * 64, Tt = 32;
+    constexpr int PA = 10, PB = 10;  // f32x4 per loader thread of the H / V block held in registers (as stage_in2)
+    if (a.stop && *a.stop) return;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int rp = a.rp, Fp = a.Fp, ldh = a.ldh, ldr = a.ldr;
+    const int bufsz = Tt * (ldh + ldr);  // floats per buffer: Hs [Tt][ldh] then Rs [Tt][ldr]
+    float* wxs = lds + 2 * bufsz;        // [rp] extra row of W
+    unsigned* cnt = reinterpret_cast<unsigned*>(wxs + rp);
+    unsigned *ready = cnt, *p1done = cnt + 1, *p2done = cnt + 2;
+    double acc_div = 0.0, acc_sh = 0.0;
+    if (a.xr) {
+        for (int k = threadIdx.x; k < rp; k += NTHR) wxs[k] = a.wx[k];
+        // the 7 unused cells of the extra 8-deep k-block stay zero for the whole kernel
+        for (int i = threadIdx.x; i < 2 * Tt * 8; i += NTHR) {
+            const int bsel = i / (Tt * 8), ii = i - bsel * Tt * 8;
+            lds[bsel * bufsz + Tt * ldh + (ii >> 3) * ldr + a.Fm + (ii & 7)] = 0.f;
+        }
+    }
+    if (threadIdx.x < 3) cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    const int nmy = blockIdx.x < (unsigned)a.n_tiles ? (a.n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    auto tile_of = [&](int j) { return (int)blockIdx.x + j * (int)gridDim.x; };
+
+    if (w >= NA + NB) {
+        // ================================ loaders ===================================================
+        const int lt = threadIdx.x - (NA + NB) * 64;
+        const int rA = rp / 4, nA = Tt * rA, rB = Fp / 4, nB = Tt * rB;
+        const bool fits = nA <= PA * NLT && nB <= PB * NLT;
+        // floor(i / d) = umulhi(i, ceil(2^32 / d)) for 0 <= i < 2^16 (i < 20 * 256 here), d >= 1
+        const unsigned invA = (unsigned)((0x100000000ull + (unsigned)rA - 1) / (unsigned)rA);
+        const unsigned invB = (unsigned)((0x100000000ull + (unsigned)rB - 1) / (unsigned)rB);
+        for (int j = 0; j < 2 && j < nmy; ++j) {
+            float* bH = lds + j * bufsz;
+            stage_in2<NLT, PA, PB>(a.Hin + (size_t)tile_of(j) * Tt * rp, bH, Tt, rp, ldh, a.V + (size_t)tile_of(j) * Tt * Fp,
+                                   bH + Tt * ldh, Tt, Fp, ldr, lt);
+            rp_arrive(ready, lane);
+        }
+        for (int j = 0; j < nmy; ++j) {
+            float* bH = lds + (j & 1) * bufsz;
+            const bool more = j + 2 < nmy;
+            // tile j+2 -> registers while tile j is still being worked on
+            f32x4 xa[PA], xb[PB];
+            if (more && fits) {
+                const float* srcA = a.Hin + (size_t)tile_of(j + 2) * Tt * rp;
+                const float* srcB = a.V + (size_t)tile_of(j + 2) * Tt * Fp;
+#pragma unroll
+                for (int b = 0; b < PA; ++b) {
+                    const int i = lt + b * NLT;
+                    if (i < nA) xa[b] = *reinterpret_cast<const f32x4*>(srcA + 4 * (size_t)i);
+                }
+#pragma unroll
+                for (int b = 0; b < PB; ++b) {
+                    const int i = lt + b * NLT;
+                    if (i < nB) xb[b] = *reinterpret_cast<const f32x4*>(srcB + 4 * (size_t)i);
+                }
+            }
+            SNMF_PIN();
+            rp_await(p2done, (unsigned)(NB * (j + 1)), a.stop);
+            stage_out<NLT>(a.Hout + (size_t)tile_of(j) * Tt * rp, bH, Tt, rp, ldh, lt);
+            if (more) {
+                if (fits) {
+                    // row of cell i = i / r4 through a reciprocal multiply on an index the compiler cannot see through:
+                    // hoisted out of the tile loop, the 2 x 20 cell addresses cost more VGPRs than the role has (spills)
+#pragma unroll
+                    for (int b = 0; b < PA; ++b) {
+                        int i = lt + b * NLT;
+                        asm volatile("" : "+v"(i));
+                        if (i < nA) {
+                            const int t = (int)__umulhi((unsigned)i, invA), k4 = i - t * rA;
+                            *reinterpret_cast<f32x4*>(bH + t * ldh + 4 * k4) = xa[b];
+                        }
+                    }
+#pragma unroll
+                    for (int b = 0; b < PB; ++b) {
+                        int i = lt + b * NLT;
+                        asm volatile("" : "+v"(i));
+                        if (i < nB) {
+                            const int t = (int)__umulhi((unsigned)i, invB), k4 = i - t * rB;
+                            *reinterpret_cast<f32x4*>(bH + Tt * ldh + t * ldr + 4 * k4) = xb[b];
+                        }
+                    }
+                } else {
+                    stage_in<NLT>(a.Hin + (size_t)tile_of(j + 2) * Tt * rp, bH, Tt, rp, ldh, lt);
+                    stage_in<NLT>(a.V + (size_t)tile_of(j + 2) * Tt * Fp, bH + Tt * ldh, Tt, Fp, ldr, lt);
+                }
+                rp_arrive(ready, lane);
+            }
+        }
+    } else if (w < NA) {
+        // ================================ A team: P1 ================================================
+        for (int j = 0; j < nmy; ++j) {
+            const int t0 = tile_of(j) * Tt;
+            float* Hs = lds + (j & 1) * bufsz;
+            float* Rs = Hs + Tt * ldh;
+            rp_await(ready, (unsigned)(NL * (j + 1)), a.stop);
+            const int fl = lane & 31, h = lane >> 5;
+            const float* sp = Hs + fl * ldh + 4 * h;
+            float dsum = 0.f;
+            for (int phi = w; phi < a.nf; phi += 2 * NA) {
+                if (phi + NA < a.nf) {
+                    f32x16 acc[2] = {zero16(), zero16()};
+                    const f32x4* const wp[2] = {reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)phi * rp * 32) + lane,
+                                                reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)(phi + NA) * rp * 32) + lane};
+                    contract_shared<2>(acc, wp, sp, rp / 8);
+                    rp_p1_epilogue<OBJ>(a, acc[0], Rs, phi, t0, lane, dsum);
+                    rp_p1_epilogue<OBJ>(a, acc[1], Rs, phi + NA, t0, lane, dsum);
+                } else {
+                    f32x16 acc[1] = {zero16()};
+                    const f32x4* const wp[1] = {reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)phi * rp * 32) + lane};
+                    contract_shared<1>(acc, wp, sp, rp / 8);
+                    rp_p1_epilogue<OBJ>(a, acc[0], Rs, phi, t0, lane, dsum);
+                }
+            }
+            if (OBJ) acc_div += (double)dsum;
+            hstep_p1_xrow<NA, 1, BM_KL, OBJ>(a, Hs, Rs, wxs, t0, w, lane, true, acc_div);
+            rp_arrive(p1done, lane);
+        }
+    } else {
+        // ================================ B team: P2 ================================================
+        const int wb = w - NA;
+        for (int j = 0; j < nmy; ++j) {
+            const int t0 = tile_of(j) * Tt;
+            float* Hs = lds + (j & 1) * bufsz;
+            const float* Rs = Hs + Tt * ldh;
+            rp_await(p1done, (unsigned)(NA * (j + 1)), a.stop);
+            const int fl = lane & 31, h = lane >> 5;
+            const float* sp = Rs + fl * ldr + 4 * h;
+            float shsum = 0.f;
+            for (int kap = wb; kap < a.nk; kap += 2 * NB) {
+                if (kap + NB < a.nk) {
+                    f32x16 acc[2] = {zero16(), zero16()};
+                    const f32x4* const wp[2] = {reinterpret_cast<const f32x4*>(a.Wk4 + (size_t)kap * a.Fq * 32) + lane,
+                                                reinterpret_cast<const f32x4*>(a.Wk4 + (size_t)(kap + NB) * a.Fq * 32) + lane};
+                    f32x4 dp0[4], dp1[4];
+                    rp_p2_consts(a, kap, lane, dp0);
+                    rp_p2_consts(a, kap + NB, lane, dp1);
+                    contract_shared<2>(acc, wp, sp, a.Fq / 8);
+                    rp_p2_epilogue<OBJ>(a, acc[0], Hs, kap, t0, lane, dp0, shsum);
+                    rp_p2_epilogue<OBJ>(a, acc[1], Hs, kap + NB, t0, lane, dp1, shsum);
+                } else {
+                    f32x16 acc[1] = {zero16()};
+                    const f32x4* const wp[1] = {reinterpret_cast<const f32x4*>(a.Wk4 + (size_t)kap * a.Fq * 32) + lane};
+                    f32x4 dp0[4];
+                    rp_p2_consts(a, kap, lane, dp0);
+                    contract_shared<1>(acc, wp, sp, a.Fq / 8);
+                    rp_p2_epilogue<OBJ>(a, acc[0], Hs, kap, t0, lane, dp0, shsum);
+                }
+            }
+            if (OBJ) acc_sh += (double)shsum;
+            rp_arrive(p2done, lane);
+        }
+    }
+
+    if (OBJ) {
+        // deterministic workgroup reduction of the two fp64 partial sums (as k_hstep)
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(lds);  // [2][NTHR]
+        red[threadIdx.x] = acc_div;
+        red[NTHR + threadIdx.x] = acc_sh;
+        __syncthreads();
+        if ((int)threadIdx.x + 512 < NTHR) {
+            red[threadIdx.x] += red[threadIdx.x + 512];
+            red[NTHR + threadIdx.x] += red[NTHR + threadIdx.x + 512];
+        }
+        __syncthreads();
+        for (int s = 256; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) {
+                red[threadIdx.x] += red[threadIdx.x + s];
+                red[NTHR + threadIdx.x] += red[NTHR + threadIdx.x + s];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            a.part[2 * blockIdx.x] = red[0];
+            a.part[2 * blockIdx.x + 1] = red[NTHR];
+        }
+    }
+}
+
+// ============================================================================================
 // k_hsolve_small: the WHOLE H-only solve of src/sparse_nmf.m:186-286 for T <= 32 frames in ONE
 // launch by ONE workgroup: the online separation call (src/bnmf_sep_event_RT_IS16.m:138-154,
 // T = 1, W = [B_x, B_d] fixed) is latency-bound -- ~27 iterations of two GEMV-sized products --

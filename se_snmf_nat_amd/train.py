@@ -25,6 +25,10 @@ def run_basis_train_signal(s_full, R, p, *, DC_bin=None, sample_idx=None, ctx=No
     cluster_buff = int(p.get("cluster_buff", 1))
     if cluster_buff > 1:
         raise SnmfError(8, "cluster_buff > 1 (k-means rank reduction, run_basis_train.m:118-129) is not implemented")
+    if p.get("domain_DD", 0):
+        # run_basis_train.m:64-67 replaces the features by TF_DD(TF_mag, p); that transform is not part of this path
+        # (the shipped settings leave domain_DD = 0), and silently training on the wrong features would be worse
+        raise SnmfError(8, "domain_DD != 0 (TF_DD feature transform, run_basis_train.m:64-67) is not implemented")
     fp = dict(p)
     if DC_bin is not None:
         fp["DCbin"] = int(DC_bin)

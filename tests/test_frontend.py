@@ -44,9 +44,28 @@ def test_frame_splice_and_mel_matrix_oracles():
     assert M.shape == (513, 64) and M.min() >= 0 and np.isclose(M.max(), 1.0)
     peaks = M.argmax(0)
     assert np.all(np.diff(peaks) > 0)                              # centres increase with the channel
-    # product-side table is the same function
+    # Entries worked out BY HAND from src/mel_matrix.m:16-38 for (fs, NbCh, Nfft) = (16000, 64, 1024) -- the product-side
+    # table and the oracle's are near-identical restatements, so comparing them with each other would pin nothing:
+    #   LowMel = 2595*log10(1+64/700) = 98.60, NyqMel = 2595*log10(1+8000/700) = 2840.02
+    #   channel 1 : fCen = 64 Hz     -> StartBin = round(4.096)+1 = 5;  StartBin(2) = round(5.960)+1 = 7 -> LowLen = 3;
+    #               EndMel -> 123.39 Hz -> EndBin = round(7.897)+1 = 9 -> TotLen = 5, HiLen = 3
+    #               rows 5..7 = (1:3)/3, rows 7..9 = (3:-1:1)/3
+    #   channel 32: StartBin = 112 (1737.40 Hz), StartBin(33) = 118 -> LowLen = 7; EndBin = 124 -> HiLen = 7
+    #   channel 64: StartBin = 473 (7372.61 Hz), EndBin(63) = 493 -> LowLen = 21; EndBin = 513 -> TotLen = 41, HiLen = 21
     from se_snmf_nat_amd.frontend import mel_matrix
-    np.testing.assert_allclose(mel_matrix(16000, 64, 1024), M, rtol=0, atol=0)
+    for name, tab in (("oracle", M), ("product", mel_matrix(16000, 64, 1024))):
+        def col(k):  # 1-based channel -> (first bin, last bin, weights), 1-based bins like the reference
+            nz = np.nonzero(tab[:, k - 1])[0]
+            return nz[0] + 1, nz[-1] + 1, tab[nz[0]:nz[-1] + 1, k - 1]
+        b0, b1, wts = col(1)
+        assert (b0, b1) == (5, 9), name
+        np.testing.assert_allclose(wts, [1 / 3, 2 / 3, 1, 2 / 3, 1 / 3], rtol=1e-15, err_msg=name)
+        b0, b1, wts = col(32)
+        assert (b0, b1) == (112, 124), name
+        np.testing.assert_allclose(wts, np.r_[np.arange(1, 8), np.arange(6, 0, -1)] / 7, rtol=1e-15, err_msg=name)
+        b0, b1, wts = col(64)
+        assert (b0, b1) == (473, 513), name
+        np.testing.assert_allclose(wts, np.r_[np.arange(1, 22), np.arange(20, 0, -1)] / 21, rtol=1e-15, err_msg=name)
 
 
 def test_oracle_reproduces_frontend_golden():

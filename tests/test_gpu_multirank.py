@@ -136,3 +136,28 @@ def test_rccl_all_reduce_call_path_at_world_size_one(gpu_ctx):
     p.join(timeout=120)
     assert p.exitcode == 0
     assert np.array_equal(w0, w1) and np.array_equal(h0, h1) and np.array_equal(c0, c1)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` with no launcher around it (no WORLD_SIZE) must start the N ranks itself and print
+    ONE line with n_gpus = N (it used to solve the whole problem on one GPU and report n_gpus 1).  The
+    parent never touches HIP; the two children share this box's one GPU over gloo (SNMF_DIST_BACKEND /
+    SNMF_FORCE_DEVICE are the single-GPU dry-run switches of bench.py) -- on an 8-GPU node the same code path runs one
+    rank per GPU over RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SNMF_DIST_BACKEND="gloo", SNMF_FORCE_DEVICE="0")
+    pr = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                         "--T", "6400", "--r", "64", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE,
+                        stderr=subprocess.PIPE, text=True, timeout=900)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, pr.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2 and d["value"] > 0
+    assert d["scaling"] == "strong" and "frames/2" in d["config"]["parallelism"]
+    assert len(d["roofline"]["kernel_ms_per_rank"]) == 2 and all(k["hstep"] > 0 for k in d["roofline"]["kernel_ms_per_rank"])
+    assert d["final_cost"] and d["final_cost"] > 0

@@ -222,6 +222,32 @@ def test_full_size_c2_properties(gpu_ctx):
     assert rel(hpart, hf[:, t0:t1]) < 1e-6
 
 
+def test_full_size_c2_against_the_oracle_golden(gpu_ctx):
+    """BASELINE C2 at FULL size (257 x 100000, r = 256, KL, sparsity 5) against the fp64 oracle: the committed golden
+    tests/golden/c2_full_257x100000_r256.npz (tests/golden/make_golden_c2.py, ~12 min of oracle time, run once) holds
+    W and the head / tail frames of H after 12 iterations and the cost of every iterate on exactly the inputs bench.py
+    times (bench.make_problem, V and H0 rounded to fp32).  Tolerances: W, H within 1e-4 relative (north_star), every
+    cost within 1e-6 relative (src/sparse_nmf.m:248-264)."""
+    from bench import F_, R_, SPARSITY, T_, make_problem
+    from se_snmf_nat_amd import Plan
+    g = np.load(os.path.join(GOLD, "c2_full_257x100000_r256.npz"))
+    assert (int(g["F"]), int(g["T"]), int(g["r"])) == (F_, T_, R_)
+    V, W0, H0 = make_problem(F_, T_, R_)
+    plan = Plan(gpu_ctx, F_, T_, R_, beta=1.0, max_iter=12, conv_eps=0.0, cost_check=True, sparsity=SPARSITY)
+    plan.set_v(V.astype(np.float32)); plan.set_w(W0); plan.set_h(H0.astype(np.float32)); plan.init()
+    assert plan.run() == 12
+    w, h = plan.get_w(), plan.get_h()
+    div, cost, n = plan.get_objective()
+    plan.close()
+    assert n == 12
+    np.testing.assert_allclose(cost[:12], g["cost"][:12], rtol=1e-6)
+    np.testing.assert_allclose(div[:12], g["div"][:12], rtol=1e-6)
+    ew, eh0, eh1 = rel(w, g["W12"]), rel(h[:, :64], g["H12_head"]), rel(h[:, -64:], g["H12_tail"])
+    print(f"C2 full size vs oracle: relW={ew:.2e} relH(head)={eh0:.2e} relH(tail)={eh1:.2e} "
+          f"relcost={abs(cost[11] - g['cost'][11]) / g['cost'][11]:.2e}")
+    assert ew < REL_WH and eh0 < REL_WH and eh1 < REL_WH
+
+
 def test_plan_step_api_equals_run(gpu_ctx):
     """hstep / wstats / wapply with a device statistics buffer (the multi-GPU path at world size 1,
     driven by se_snmf_nat_amd.dist.ShardedTrainer over torch) gives the same bits as plan.run."""
