@@ -117,7 +117,7 @@ def self_launch(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
            "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--F", str(args.F), "--T", str(args.T), "--r", str(args.r)]
+           "--dim-F", str(args.F), "--dim-T", str(args.T), "--dim-r", str(args.r)]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
     pr = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
@@ -137,9 +137,10 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--F", type=int, default=F_)
-    ap.add_argument("--T", type=int, default=T_)
-    ap.add_argument("--r", type=int, default=R_)
+    # --dim-*: the spellings self_launch() passes on (torch.distributed.run's own parser prefix-matches a bare --r)
+    ap.add_argument("--F", "--dim-F", dest="F", type=int, default=F_)
+    ap.add_argument("--T", "--dim-T", dest="T", type=int, default=T_)
+    ap.add_argument("--r", "--dim-r", dest="r", type=int, default=R_)
     args = ap.parse_args()
     F, T, r = args.F, args.T, args.r
     K, W = args.steps, args.warmup

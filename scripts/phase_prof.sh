@@ -11,12 +11,14 @@ if [ ! -f "$PROF" ] || [ se_snmf_nat_amd/csrc/snmf_kernels.h -nt "$PROF" ] || [ 
         -Iinclude -Ise_snmf_nat_amd/csrc -o "$PROF" se_snmf_nat_amd/csrc/snmf_api.hip
 fi
 export SNMF_LIB_PATH="$PWD/$PROF"
-run() { echo "== $*"; env "$@" python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | grep -E "SNMF_PROF|kernel_ms" | python -c "
+run() { echo "== $*"; env "$@" python bench.py --steps 200 --warmup 2 --no-cpu-baseline 2>&1 | grep -E "SNMF_PROF|kernel_ms" | python -c "
 import sys,json
+last=''
 for l in sys.stdin:
     if l.startswith('[SNMF'): last=l
     elif l.startswith('{'): d=json.loads(l); print(last.strip()); print({k:round(v,4) for k,v in d['roofline']['kernel_ms'].items()})
 "; }
-run SNMF_X=1
+if [ $# -gt 0 ]; then for v in "$@"; do run $v; done; exit 0; fi
+run SNMF_HSTEP_RP=1
+run SNMF_HSTEP_RP=0
 run SNMF_PROF_W=1
-run SNMF_PROF_W=1 SNMF_WSTATS_NL=0

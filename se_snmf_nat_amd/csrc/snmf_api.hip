@@ -405,7 +405,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     // widest tile whose H image + ratio image fit the 160 KiB LDS.  SNMF_HSTEP_CFG=NWxNT overrides.
     const size_t per_col = (size_t)(pl->ldh + pl->ldr) * 4;
     const size_t lds_cap = 160 * 1024;  // gfx950: 160 KiB per CU, one workgroup may take all of it
-    const size_t lds_extra = (size_t)pl->rp * 4 + 16;  // extra row of W + the consumers' arrive counter
+    const size_t lds_extra = (size_t)pl->rp * 4 + 16;  // extra row of W + the roles' LDS counters
     const size_t lds1 = 32 * per_col + lds_extra, lds2 = 64 * per_col + lds_extra;
     if (2 * lds1 - lds_extra <= lds_cap) { pl->NWH = 8; pl->NT = 1; pl->NLH = 4; }  // double-buffered
     else if (lds2 <= lds_cap && pl->Tp / 64 >= ctx->n_cu) { pl->NWH = 8; pl->NT = 2; }
@@ -606,10 +606,12 @@ extern "C" int64_t snmf_plan_stats_len(const snmf_plan* pl) {
 
 extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
     if (!pl || !buf) return fail(SNMF_ERR_INVALID, "NULL argument");
+    const bool kl_pipe = pl->NWH == 8 && pl->NLH == 4 && pl->bm == BM_KL && pl->upd_h && !pl->M && pl->hstep_rp;
     snprintf(buf, n,
-             "F=%d T=%d r=%d beta=%g | Fm=%d(+%d VALU row) rp=%d Tp=%d | hstep: tile=%d frames, grid=%d x %d thr, lds=%zu B | "
+             "F=%d T=%d r=%d beta=%g | Fm=%d(+%d VALU row) rp=%d Tp=%d | hstep: %s, tile=%d frames, grid=%d x %d thr, lds=%zu B | "
              "wstats: NK=%d waves=%d+%d grid=(%d chunks,%d fgroups,%d kgroups; group-1 chunks %d) lds=%zu B | n_cu=%d",
-             pl->p.F, pl->p.T, pl->p.r, pl->p.beta, pl->Fm, pl->xr, pl->rp, pl->Tp, 32 * pl->NT, pl->grid_h, (pl->NWH + pl->NLH) * 64,
+             pl->p.F, pl->p.T, pl->p.r, pl->p.beta, pl->Fm, pl->xr, pl->rp, pl->Tp,
+             kl_pipe ? "k_hstep_rp (4 P1 + 4 P2 + 4 loader waves)" : "k_hstep", 32 * pl->NT, pl->grid_h, (pl->NWH + pl->NLH) * 64,
              pl->lds_h, pl->NKT, pl->NWB, pl->NLW, pl->n_chunks, pl->n_fg, pl->n_kg, pl->n_ch1 ? pl->n_ch1 : pl->n_chunks, pl->lds_w,
              pl->ctx->n_cu);
     return SNMF_OK;
@@ -911,7 +913,7 @@ static int launch_wstats(snmf_plan* pl, bool obj) {
     return launch_wstats_geo<16, 4, 0, 1>(pl, a, obj);
 }
 
-static int launch_reduce(snmf_plan* pl, double* stats, bool do_mats, bool do_obj, int n_part, bool sh_const) {
+static ReduceArgs make_reduce_args(snmf_plan* pl, double* stats, bool do_mats, bool do_obj, int n_part, bool sh_const) {
     ReduceArgs ra{};
     ra.slabs = pl->slabs;
     ra.spart = pl->spart;
@@ -927,6 +929,10 @@ static int launch_reduce(snmf_plan* pl, double* stats, bool do_mats, bool do_obj
     ra.do_obj = do_obj;
     ra.sh_const = pl->sh_const;
     ra.use_sh_const = sh_const;
+    return ra;
+}
+static int launch_reduce(snmf_plan* pl, double* stats, bool do_mats, bool do_obj, int n_part, bool sh_const) {
+    const ReduceArgs ra = make_reduce_args(pl, stats, do_mats, do_obj, n_part, sh_const);
     const size_t tot = do_mats ? ((size_t)pl->n_mat * pl->rp * pl->Fp) / 4 : 1;
     ScopedTimer tm(pl->ctx, FAM_REDUCE);
     hipLaunchKernelGGL(k_reduce, dim3((int)std::max<size_t>(1, std::min<size_t>((tot + 31) / 32, 4096))), dim3(256),
@@ -935,7 +941,7 @@ static int launch_reduce(snmf_plan* pl, double* stats, bool do_mats, bool do_obj
     return SNMF_OK;
 }
 
-static int launch_wapply(snmf_plan* pl, const double* stats, int check_it, bool do_update, bool init_mode) {
+static ApplyArgs make_apply_args(snmf_plan* pl, const double* stats, int check_it, bool do_update, bool init_mode) {
     ApplyArgs aa{};
     aa.stats = stats;
     aa.Wc = pl->Wc;
@@ -963,8 +969,33 @@ static int launch_wapply(snmf_plan* pl, const double* stats, int check_it, bool 
     aa.init_mode = init_mode;
     aa.conv_eps = pl->p.conv_eps;
     aa.wn = pl->wn;
+    return aa;
+}
+static int launch_wapply(snmf_plan* pl, const double* stats, int check_it, bool do_update, bool init_mode) {
+    const ApplyArgs aa = make_apply_args(pl, stats, check_it, do_update, init_mode);
     ScopedTimer tm(pl->ctx, FAM_WAPPLY);
     hipLaunchKernelGGL(k_wapply, dim3(pl->p.r), dim3(256), 0, pl->ctx->stream, aa);
+    HIP_TRY(hipGetLastError());
+    return SNMF_OK;
+}
+
+// k_reduce + k_wapply in one launch (single-rank solves): positions per thread NP = ceil(Fp/4 / 32)
+static int wfused_np(const snmf_plan* pl) { return (pl->Fp / 4 + 31) / 32; }
+static int launch_wfused(snmf_plan* pl, bool do_obj, int n_part, bool sh_const, int check_it) {
+    const ReduceArgs ra = make_reduce_args(pl, pl->stats, true, do_obj, n_part, sh_const);
+    const ApplyArgs aa = make_apply_args(pl, pl->stats, check_it, true, false);
+    const size_t lds = (size_t)pl->n_mat * pl->Fp * sizeof(double);
+    ScopedTimer tm(pl->ctx, FAM_WAPPLY);
+    dim3 g(pl->p.r), b(256);
+    hipStream_t st = pl->ctx->stream;
+    switch (wfused_np(pl)) {
+        case 1: hipLaunchKernelGGL(k_wfused<1>, g, b, lds, st, ra, aa); break;
+        case 2: hipLaunchKernelGGL(k_wfused<2>, g, b, lds, st, ra, aa); break;
+        case 3: hipLaunchKernelGGL(k_wfused<3>, g, b, lds, st, ra, aa); break;
+        case 4: hipLaunchKernelGGL(k_wfused<4>, g, b, lds, st, ra, aa); break;
+        case 5: hipLaunchKernelGGL(k_wfused<5>, g, b, lds, st, ra, aa); break;
+        default: return fail(SNMF_ERR_INTERNAL, "k_wfused: F too large (caller must use the two-launch path)");
+    }
     HIP_TRY(hipGetLastError());
     return SNMF_OK;
 }
@@ -1031,6 +1062,10 @@ extern "C" int snmf_plan_init(snmf_plan* pl) {
 // Iteration j (1-based) = hstep(j) -> wstats(j) -> [reduce] -> wapply(j).  The objective of
 // iterate j-1 is produced by the first pass of iteration j that forms Lam = W_{j-1} * H_{j-1}.
 static bool want_obj(const snmf_plan* pl, int j) { return pl->p.cost_check && j > 1; }
+// objective partials written by an H-UPDATE launch of k_hstep* (= its grid; the objective-only launches use grid_h)
+static int hupd_parts(const snmf_plan* pl) {
+    return pl->M ? pl->grid_mdi : pl->grid_h;
+}
 
 extern "C" int snmf_plan_hstep(snmf_plan* pl) {
     PLAN_CHECK(pl);
@@ -1062,7 +1097,7 @@ extern "C" int snmf_plan_wstats(snmf_plan* pl, double* stats) {
         // W-only mode: the divergence of iterate j-1 comes from this pass (Lam' = W_{j-1} * H)
         SN_TRY(launch_wstats(pl, obj && !pl->upd_h && !mdi_wonly));
     }
-    const int n_part = pl->M ? pl->grid_mdi : pl->upd_h ? pl->grid_h : pl->n_chunks * pl->n_fg;
+    const int n_part = pl->upd_h ? hupd_parts(pl) : pl->M ? pl->grid_mdi : pl->n_chunks * pl->n_fg;
     if (!pl->upd_h && !pl->upd_w && obj) {
         // neither factor is updated: the loop only re-evaluates the objective
         SN_TRY(launch_hstep(pl, true, false));
@@ -1217,10 +1252,25 @@ extern "C" int snmf_plan_run(snmf_plan* pl, int32_t n_iters, int32_t* iters_done
     const bool can_stop = pl->p.cost_check && pl->p.conv_eps > 0.0;
     int since_poll = 0;
     bool stopped = false;
+    // single-rank solve: nothing is exchanged between the slab reduction and the W epilogue, so they can be ONE launch
+    // (k_wfused).  Measured on C2 it is not faster than the pair (22.8 us against 11.6 + 10.0: one workgroup per column
+    // is too little parallelism for the 35 MB of slabs), so it stays opt-in: SNMF_WFUSED=1.
+    const char* wf_env = getenv("SNMF_WFUSED");
+    const bool fused = pl->upd_w && wfused_np(pl) <= 5 && wf_env && atoi(wf_env) != 0;
     while (pl->it_done < target) {
         SN_TRY(snmf_plan_hstep(pl));
-        SN_TRY(snmf_plan_wstats(pl, pl->stats));
-        SN_TRY(snmf_plan_wapply(pl, pl->stats));
+        if (fused) {
+            const int j = pl->it_done + 1;
+            const bool obj = want_obj(pl, j);
+            const bool mdi_wonly = pl->M && !pl->upd_h;  // objective partials come from the MDI Lam pass of snmf_plan_hstep
+            SN_TRY(launch_wstats(pl, obj && !pl->upd_h && !mdi_wonly));
+            const int n_part = pl->upd_h ? hupd_parts(pl) : pl->M ? pl->grid_mdi : pl->n_chunks * pl->n_fg;
+            SN_TRY(launch_wfused(pl, obj, n_part, !pl->upd_h, obj ? j - 1 : 0));
+            pl->it_done = j;
+        } else {
+            SN_TRY(snmf_plan_wstats(pl, pl->stats));
+            SN_TRY(snmf_plan_wapply(pl, pl->stats));
+        }
         if (can_stop && ++since_poll >= 4) {
             since_poll = 0;
             DevState hs{};

@@ -203,11 +203,21 @@ __device__ __forceinline__ void mfma_block(f32x16 (&acc)[NT], const f32x4& w, co
 // The loop is unrolled by two SB-block stages held in NAMED registers (A, B): rotating buffers with
 // register copies would make the copy wait for the load it has just issued.  Stage X+1's loads are
 // issued before stage X's 4*SB*NT MFMAs (256*SB*NT cycles alone), which is what hides the L2 latency.
-template <int NT, bool SWAP, int SB>
+// DUAL: the two k-blocks of a stage feed two INDEPENDENT accumulator chains (summed at the end).  A single chain of
+// dependent v_mfma_f32_32x32x2_f32 issues every ~82 cycles when the wave is alone on its SIMD (k_wstats' P3: 128 MFMAs
+// in 10.5 k cycles, round-1 phase stamps) against ~68 for independent accumulators (P4): the pipe waits for the
+// previous result.  Changes the fp32 summation order (even / odd k-blocks), deterministically.
+template <int NT, bool SWAP, int SB, bool DUAL = false>
 __device__ __forceinline__ void contract_sb(f32x16 (&acc)[NT], const f32x4* __restrict__ wp, const float* sp,
                                             int sstride, int nq) {
+    static_assert(!DUAL || SB == 2, "DUAL pairs the two blocks of a stage");
     f32x4 wA[SB], wB[SB];
     f32x4 sA[SB][NT], sB[SB][NT];
+    f32x16 acc2[NT];
+    if (DUAL) {
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau) acc2[tau] = zero16();
+    }
     const int last = nq - 1;
     auto ldstage = [&](f32x4 (&w)[SB], f32x4 (&sf)[SB][NT], int q0) {
 #pragma unroll
@@ -220,8 +230,23 @@ __device__ __forceinline__ void contract_sb(f32x16 (&acc)[NT], const f32x4* __re
         }
     };
     auto mmstage = [&](const f32x4 (&w)[SB], const f32x4 (&sf)[SB][NT]) {
+        if (DUAL) {
 #pragma unroll
-        for (int j = 0; j < SB; ++j) mfma_block<NT, SWAP>(acc, w[j], sf[j]);
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int tau = 0; tau < NT; ++tau) {
+                    if (SWAP) {
+                        acc[tau] = mfma32(sf[0][tau][e], w[0][e], acc[tau]);
+                        acc2[tau] = mfma32(sf[1][tau][e], w[1][e], acc2[tau]);
+                    } else {
+                        acc[tau] = mfma32(w[0][e], sf[0][tau][e], acc[tau]);
+                        acc2[tau] = mfma32(w[1][e], sf[1][tau][e], acc2[tau]);
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < SB; ++j) mfma_block<NT, SWAP>(acc, w[j], sf[j]);
+        }
     };
     const int nmain = nq - nq % (2 * SB);
     int q = 0;
@@ -253,6 +278,12 @@ __device__ __forceinline__ void contract_sb(f32x16 (&acc)[NT], const f32x4* __re
 #pragma unroll
             for (int tau = 0; tau < NT; ++tau) s0[tau] = s1[tau];
         }
+    }
+    if (DUAL) {
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[tau][i] += acc2[tau][i];
     }
 }
 template <int NT, bool SWAP>
@@ -848,15 +879,23 @@ __device__ __forceinline__ void rp_await(unsigned* c, unsigned target, const int
 //   wp[i]: this lane's f32x4 of W operand image i, consecutive k-blocks 64 f32x4 apart;  sp: this lane's LDS row.
 // Two named stages (A, B), each one k-block = 4*NA MFMAs; stage X+1's loads are issued before stage X's MFMAs.
 // An odd block count needs no tail code: the clamped prefetch of the last round already holds block nq-1.
+// (-DSNMF_PROF diagnostic builds only: wmask / smask re-use operand fragments -- wrong results, same MFMAs -- to
+// measure what the L2 and LDS operand streams cost; StepArgs::stagger_shift carries the selector.)
 template <int NA>
-__device__ __forceinline__ void contract_shared(f32x16 (&acc)[NA], const f32x4* const (&wp)[NA], const float* sp, int nq) {
+__device__ __forceinline__ void contract_shared(f32x16 (&acc)[NA], const f32x4* const (&wp)[NA], const float* sp, int nq,
+                                                int wmask = -1, int smask = -1) {
     f32x4 wA[NA], wB[NA], sA, sB;
     const int last = nq - 1;
     auto ld = [&](f32x4 (&w)[NA], f32x4& sf, int q) {
         const int qq = q < last ? q : last;
+#ifdef SNMF_PROF
+        const int qw = qq & wmask, qs = qq & smask;
+#else
+        const int qw = qq, qs = qq;
+#endif
 #pragma unroll
-        for (int i = 0; i < NA; ++i) w[i] = wp[i][(size_t)qq * 64];
-        sf = *reinterpret_cast<const f32x4*>(sp + 8 * qq);
+        for (int i = 0; i < NA; ++i) w[i] = wp[i][(size_t)qw * 64];
+        sf = *reinterpret_cast<const f32x4*>(sp + 8 * qs);
     };
     auto mm = [&](const f32x4 (&w)[NA], const f32x4& sf) {
 #pragma unroll
@@ -976,9 +1015,25 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
     }
     if (threadIdx.x < 3) cnt[threadIdx.x] = 0u;
     __syncthreads();
+    // diagnostic operand-reuse experiment (SNMF_PROF builds): 1 = W fragments of even k-blocks only, 2 = W block 0 only,
+    // 3 = LDS fragments of even k-blocks only, 4 = LDS block 0 only, 5 = both streams block 0 only
+    const int xsel = a.stagger_shift;
+    const int xw = (xsel == 1) ? ~1 : (xsel == 2 || xsel == 5) ? 0 : -1, xs = (xsel == 3) ? ~1 : (xsel == 4 || xsel == 5) ? 0 : -1;
     const int nmy = blockIdx.x < (unsigned)a.n_tiles ? (a.n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     auto tile_of = [&](int j) { return (int)blockIdx.x + j * (int)gridDim.x; };
 
+    // Wave priorities (experiments, SNMF_STAGGER=<n>,0; measured on C2, none helps: 5 and 2 cost 3 %, 3 and 4 change
+    // nothing): 0 = none (default), 5 = loaders 3 / A 2, 2 = loaders 3 / B 2, 3 = A 2 only, 4 = A 3 / loaders 2.
+    {
+        const int role = w >= NA + NB ? 2 : (w < NA ? 0 : 1);
+        switch (a.stagger) {
+            case 5: if (role == 2) __builtin_amdgcn_s_setprio(3); else if (role == 0) __builtin_amdgcn_s_setprio(2); break;
+            case 2: if (role == 2) __builtin_amdgcn_s_setprio(3); else if (role == 1) __builtin_amdgcn_s_setprio(2); break;
+            case 3: if (role == 0) __builtin_amdgcn_s_setprio(2); break;
+            case 4: if (role == 0) __builtin_amdgcn_s_setprio(3); else if (role == 2) __builtin_amdgcn_s_setprio(2); break;
+            default: break;
+        }
+    }
     if (w >= NA + NB) {
         // ================================ loaders ===================================================
         const int lt = threadIdx.x - (NA + NB) * 64;
@@ -996,61 +1051,80 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
         for (int j = 0; j < nmy; ++j) {
             float* bH = lds + (j & 1) * bufsz;
             const bool more = j + 2 < nmy;
-            // tile j+2 -> registers while tile j is still being worked on
+            // tile j+2 -> registers while tile j is still being worked on.  Every access below is UNCONDITIONAL: a slot past
+            // the end of a block falls back onto the thread's OWN first cell (the same 16 bytes read and written again, by
+            // the same thread, so program order keeps "copy out, then overwrite" intact -- a cell owned by another thread
+            // could already hold the next tile), so the loader is straight-line code and the compiler's s_waitcnt
+            // bookkeeping stays exact.  With predicated
+            // accesses it fell back to vmcnt(0) in front of the first LDS write of the prefetched registers, i.e. it also
+            // waited for the H stores issued just before to be acknowledged by HBM: 7 us of every 21 us tile period in
+            // which neither team had a tile to work on (phase stamps of the diagnostic build).
+            // Row of cell i = i / r4 through a reciprocal multiply on an index the compiler cannot see through: hoisted out
+            // of the tile loop, the cell addresses cost more VGPRs than the role has (spills).
             f32x4 xa[PA], xb[PB];
+            auto cell = [&](int b, int n) {
+                int l = lt;
+                asm volatile("" : "+v"(l));  // opaque: keeps the clamped indices from being hoisted out of the tile loop
+                const int i = l + b * NLT;
+                return i < n ? i : l;        // l < n: a block has at least 32 * 32 / 4 = 256 cells
+            };
             if (more && fits) {
                 const float* srcA = a.Hin + (size_t)tile_of(j + 2) * Tt * rp;
                 const float* srcB = a.V + (size_t)tile_of(j + 2) * Tt * Fp;
 #pragma unroll
-                for (int b = 0; b < PA; ++b) {
-                    const int i = lt + b * NLT;
-                    if (i < nA) xa[b] = *reinterpret_cast<const f32x4*>(srcA + 4 * (size_t)i);
-                }
+                for (int b = 0; b < PA; ++b) xa[b] = *reinterpret_cast<const f32x4*>(srcA + 4 * (size_t)cell(b, nA));
 #pragma unroll
-                for (int b = 0; b < PB; ++b) {
-                    const int i = lt + b * NLT;
-                    if (i < nB) xb[b] = *reinterpret_cast<const f32x4*>(srcB + 4 * (size_t)i);
-                }
+                for (int b = 0; b < PB; ++b) xb[b] = *reinterpret_cast<const f32x4*>(srcB + 4 * (size_t)cell(b, nB));
             }
             SNMF_PIN();
             rp_await(p2done, (unsigned)(NB * (j + 1)), a.stop);
-            stage_out<NLT>(a.Hout + (size_t)tile_of(j) * Tt * rp, bH, Tt, rp, ldh, lt);
-            if (more) {
-                if (fits) {
-                    // row of cell i = i / r4 through a reciprocal multiply on an index the compiler cannot see through:
-                    // hoisted out of the tile loop, the 2 x 20 cell addresses cost more VGPRs than the role has (spills)
-#pragma unroll
-                    for (int b = 0; b < PA; ++b) {
-                        int i = lt + b * NLT;
-                        asm volatile("" : "+v"(i));
-                        if (i < nA) {
-                            const int t = (int)__umulhi((unsigned)i, invA), k4 = i - t * rA;
-                            *reinterpret_cast<f32x4*>(bH + t * ldh + 4 * k4) = xa[b];
-                        }
-                    }
-#pragma unroll
-                    for (int b = 0; b < PB; ++b) {
-                        int i = lt + b * NLT;
-                        asm volatile("" : "+v"(i));
-                        if (i < nB) {
-                            const int t = (int)__umulhi((unsigned)i, invB), k4 = i - t * rB;
-                            *reinterpret_cast<f32x4*>(bH + Tt * ldh + t * ldr + 4 * k4) = xb[b];
-                        }
-                    }
-                } else {
+            float* const dstH = a.Hout + (size_t)tile_of(j) * Tt * rp;
+            if (!fits) {  // shape too big for the register path: plain copy-out, then a plain (latency-exposed) refill
+                stage_out<NLT>(dstH, bH, Tt, rp, ldh, lt);
+                if (more) {
                     stage_in<NLT>(a.Hin + (size_t)tile_of(j + 2) * Tt * rp, bH, Tt, rp, ldh, lt);
                     stage_in<NLT>(a.V + (size_t)tile_of(j + 2) * Tt * Fp, bH + Tt * ldh, Tt, Fp, ldr, lt);
+                    rp_arrive(ready, lane);
+                }
+                continue;
+            }
+            // the updated H tile leaves (LDS -> registers -> HBM; the stores are only ISSUED here) ...
+#pragma unroll
+            for (int b = 0; b < PA; ++b) {
+                const int i = cell(b, nA);
+                const int t = (int)__umulhi((unsigned)i, invA), k4 = i - t * rA;
+                const f32x4 ho = *reinterpret_cast<const f32x4*>(bH + t * ldh + 4 * k4);
+                *reinterpret_cast<f32x4*>(dstH + 4 * (size_t)i) = ho;
+            }
+            // ... and the prefetched tile takes its place (its loads completed long ago; the wait in front of the first
+            // write is for "all but the newest PA stores")
+            if (more) {
+#pragma unroll
+                for (int b = 0; b < PA; ++b) {
+                    const int i = cell(b, nA);
+                    const int t = (int)__umulhi((unsigned)i, invA), k4 = i - t * rA;
+                    *reinterpret_cast<f32x4*>(bH + t * ldh + 4 * k4) = xa[b];
+                }
+#pragma unroll
+                for (int b = 0; b < PB; ++b) {
+                    const int i = cell(b, nB);
+                    const int t = (int)__umulhi((unsigned)i, invB), k4 = i - t * rB;
+                    *reinterpret_cast<f32x4*>(bH + Tt * ldh + t * ldr + 4 * k4) = xb[b];
                 }
                 rp_arrive(ready, lane);
             }
         }
     } else if (w < NA) {
         // ================================ A team: P1 ================================================
+        SNMF_STAMP_DECL
         for (int j = 0; j < nmy; ++j) {
             const int t0 = tile_of(j) * Tt;
             float* Hs = lds + (j & 1) * bufsz;
             float* Rs = Hs + Tt * ldh;
+            SNMF_STAMP(11);
             rp_await(ready, (unsigned)(NL * (j + 1)), a.stop);
+            SNMF_STAMP(0);
+            SNMF_STAMP_TILE(a.prof, blockIdx.x, j);
             const int fl = lane & 31, h = lane >> 5;
             const float* sp = Hs + fl * ldh + 4 * h;
             float dsum = 0.f;
@@ -1059,28 +1133,36 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     f32x16 acc[2] = {zero16(), zero16()};
                     const f32x4* const wp[2] = {reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)phi * rp * 32) + lane,
                                                 reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)(phi + NA) * rp * 32) + lane};
-                    contract_shared<2>(acc, wp, sp, rp / 8);
+                    contract_shared<2>(acc, wp, sp, rp / 8, xw, xs);
+                    SNMF_STAMP(4);
                     rp_p1_epilogue<OBJ>(a, acc[0], Rs, phi, t0, lane, dsum);
                     rp_p1_epilogue<OBJ>(a, acc[1], Rs, phi + NA, t0, lane, dsum);
+                    SNMF_STAMP(5);
                 } else {
                     f32x16 acc[1] = {zero16()};
                     const f32x4* const wp[1] = {reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)phi * rp * 32) + lane};
-                    contract_shared<1>(acc, wp, sp, rp / 8);
+                    contract_shared<1>(acc, wp, sp, rp / 8, xw, xs);
                     rp_p1_epilogue<OBJ>(a, acc[0], Rs, phi, t0, lane, dsum);
                 }
             }
             if (OBJ) acc_div += (double)dsum;
             hstep_p1_xrow<NA, 1, BM_KL, OBJ>(a, Hs, Rs, wxs, t0, w, lane, true, acc_div);
+            SNMF_STAMP(6);
             rp_arrive(p1done, lane);
         }
+        SNMF_STAMP_OUT(a.prof + ((size_t)blockIdx.x * (NA + NB) + w) * 12, 12);
+        SNMF_STAMP_CLK(a.prof, (size_t)blockIdx.x * (NA + NB) + w);
     } else {
         // ================================ B team: P2 ================================================
         const int wb = w - NA;
+        SNMF_STAMP_DECL
         for (int j = 0; j < nmy; ++j) {
             const int t0 = tile_of(j) * Tt;
             float* Hs = lds + (j & 1) * bufsz;
             const float* Rs = Hs + Tt * ldh;
+            SNMF_STAMP(11);
             rp_await(p1done, (unsigned)(NA * (j + 1)), a.stop);
+            SNMF_STAMP(7);
             const int fl = lane & 31, h = lane >> 5;
             const float* sp = Rs + fl * ldr + 4 * h;
             float shsum = 0.f;
@@ -1092,21 +1174,25 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     f32x4 dp0[4], dp1[4];
                     rp_p2_consts(a, kap, lane, dp0);
                     rp_p2_consts(a, kap + NB, lane, dp1);
-                    contract_shared<2>(acc, wp, sp, a.Fq / 8);
+                    contract_shared<2>(acc, wp, sp, a.Fq / 8, xw, xs);
+                    SNMF_STAMP(9);
                     rp_p2_epilogue<OBJ>(a, acc[0], Hs, kap, t0, lane, dp0, shsum);
                     rp_p2_epilogue<OBJ>(a, acc[1], Hs, kap + NB, t0, lane, dp1, shsum);
+                    SNMF_STAMP(10);
                 } else {
                     f32x16 acc[1] = {zero16()};
                     const f32x4* const wp[1] = {reinterpret_cast<const f32x4*>(a.Wk4 + (size_t)kap * a.Fq * 32) + lane};
                     f32x4 dp0[4];
                     rp_p2_consts(a, kap, lane, dp0);
-                    contract_shared<1>(acc, wp, sp, a.Fq / 8);
+                    contract_shared<1>(acc, wp, sp, a.Fq / 8, xw, xs);
                     rp_p2_epilogue<OBJ>(a, acc[0], Hs, kap, t0, lane, dp0, shsum);
                 }
             }
             if (OBJ) acc_sh += (double)shsum;
             rp_arrive(p2done, lane);
         }
+        SNMF_STAMP_OUT(a.prof + ((size_t)blockIdx.x * (NA + NB) + w) * 12, 12);
+        SNMF_STAMP_CLK(a.prof, (size_t)blockIdx.x * (NA + NB) + w);
     }
 
     if (OBJ) {
@@ -1754,7 +1840,10 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
             // ---- P3: Lam'^T[t, f] = sum_k H[k,t] W[f,k]  (A = H from LDS, B = W from L2) -----
             f32x16 acc1[1] = {zero16()};
             const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)phi * rp * 32) + lane;
-            contract<1, true>(acc1, wp, Hs + fl * ldh + 4 * h, 0, rp / 8);
+#ifndef SNMF_WSTATS_DUAL
+#define SNMF_WSTATS_DUAL 0  // measured on C2: 0.2488 ms with the two chains against 0.2475 without -- the dependent chain is not what P3 waits for
+#endif
+            contract_sb<1, true, 2, SNMF_WSTATS_DUAL != 0>(acc1, wp, Hs + fl * ldh + 4 * h, 0, rp / 8);
             SNMF_STAMP(3);
             const f32x16 acc = acc1[0];
             // lane (f = fl, h), reg -> t = t0 + drow(reg,h)
@@ -2071,28 +2160,15 @@ struct ApplyArgs {
 // reference's doubles it stays positive and comes back as soon as V./Lam is large there -- which the
 // noise-dictionary adaptation (src/bnmf_sep_event_RT_IS16.m:296-336) does all the time.  W is
 // F x r: keeping it in fp64 costs nothing measurable.
-__global__ __launch_bounds__(256) void k_wapply(ApplyArgs a) {
-    __shared__ double red[3][256];
-    if (!a.init_mode && a.st->stop) return;  // normalising a fresh W never depends on an earlier solve's flag
-    const int k = blockIdx.x;
-    const int tid = threadIdx.x;
-    const size_t nel = (size_t)a.rp * a.Fp;
-    if (a.check_it > 0) {
-        const double* sc = a.stats + nel * a.n_mat + a.rp;
-        bool stopnow = conv_test(sc, a.divh, a.costh, a.st, a.check_it, a.conv_eps, k == 0 && tid == 0);
-        if (stopnow) return;
-    }
-    if (!a.do_update && !a.init_mode) return;
-    if (k >= a.r) return;
-
+// Q / P: this column of the reduced statistics (global memory in k_wapply, LDS in k_wfused); P == nullptr: KL, the
+// "P" of every row is the row sum sk of H.
+__device__ __forceinline__ void wapply_column(const ApplyArgs& a, int k, int tid, const double* Q, const double* P,
+                                              double sk, double (&red)[3][256]) {
     double* wc = a.Wc + (size_t)k * a.Fp;
     const bool upd = a.init_mode ? false : (a.w_ind[k] != 0);
     // pass 1: column sums needed by the update
     double cQW = 0.0, cPW = 0.0, cW = 0.0;
     if (upd) {
-        const double* Q = a.stats + (size_t)k * a.Fp;
-        const double* P = (a.n_mat == 2) ? a.stats + nel + (size_t)k * a.Fp : nullptr;
-        const double sk = (a.n_mat == 2) ? 0.0 : a.stats[nel * a.n_mat + k];
         for (int f = tid; f < a.F; f += 256) {
             double wv = wc[f];
             cQW += Q[f] * wv;
@@ -2116,8 +2192,8 @@ __global__ __launch_bounds__(256) void k_wapply(ApplyArgs a) {
     auto updated = [&](int f) -> double {
         double wv = wc[f];
         if (upd) {
-            const double Qv = a.stats[(size_t)k * a.Fp + f];
-            const double Pv = (a.n_mat == 2) ? a.stats[nel + (size_t)k * a.Fp + f] : a.stats[nel * a.n_mat + k];
+            const double Qv = Q[f];
+            const double Pv = P ? P[f] : sk;
             double dpw = Pv + wv * cQW;
             dpw = dpw > 1e-9 ? dpw : 1e-9;
             wv = wv * (Qv + wv * cPW) / dpw;
@@ -2168,6 +2244,144 @@ __global__ __launch_bounds__(256) void k_wapply(ApplyArgs a) {
         a.dphv[k] = fmaxf(cs + a.lamk[k], kFlr);
         if (a.init_mode) a.wn[k] = nrm;
     }
+}
+
+__global__ __launch_bounds__(256) void k_wapply(ApplyArgs a) {
+    __shared__ double red[3][256];
+    if (!a.init_mode && a.st->stop) return;  // normalising a fresh W never depends on an earlier solve's flag
+    const int k = blockIdx.x;
+    const int tid = threadIdx.x;
+    const size_t nel = (size_t)a.rp * a.Fp;
+    if (a.check_it > 0) {
+        const double* sc = a.stats + nel * a.n_mat + a.rp;
+        bool stopnow = conv_test(sc, a.divh, a.costh, a.st, a.check_it, a.conv_eps, k == 0 && tid == 0);
+        if (stopnow) return;
+    }
+    if (!a.do_update && !a.init_mode) return;
+    if (k >= a.r) return;
+    const double* Q = a.stats + (size_t)k * a.Fp;
+    const double* P = (a.n_mat == 2) ? a.stats + nel + (size_t)k * a.Fp : nullptr;
+    const double sk = (a.n_mat == 2 || a.init_mode) ? 0.0 : a.stats[nel * a.n_mat + k];
+    wapply_column(a, k, tid, Q, P, sk, red);
+}
+
+// ============================================================================================
+// k_wfused = k_reduce + k_wapply in ONE launch (single-rank solves: nothing has to be exchanged between the two).
+// The workgroup of column k sums ITS column of the split-T slabs (and its row sum of H, and the objective partials) in
+// exactly the order k_reduce uses -- eight groups of consecutive chunks, ascending inside a group, then the eight
+// group sums in group order, all in fp64 -- so W comes out bit-identical to the two-launch path (the multi-rank step
+// API, where the reduced statistics cross the all-reduce), and applies the epilogue from LDS.  One launch, one pass
+// over the slabs, no fp64 statistics round trip through HBM.
+// NP = f32x4 positions per thread (ceil(Fp/4 / 32)); all NP positions of a chunk batch are in flight together.
+// ============================================================================================
+template <int NP>
+__global__ __launch_bounds__(256) void k_wfused(ReduceArgs ra, ApplyArgs a) {
+    __shared__ double red[3][256];
+    __shared__ double part[8][NP][32][4];
+    extern __shared__ __attribute__((aligned(16))) double cols[];  // [n_mat][Fp4*4] reduced column(s)
+    if (a.st->stop) return;
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const int e = tid & 31, g = tid >> 5;
+    // objective partials -> (div, sum S.*H), folded by EVERY workgroup in k_reduce's order (strided, then a tree)
+    double sc[2] = {0.0, 0.0};
+    if (a.check_it > 0) {
+        double d = 0.0, h = 0.0;
+        if (ra.do_obj) {
+            for (int c = tid; c < ra.n_part; c += 256) {
+                d += ra.part[2 * c];
+                h += ra.part[2 * c + 1];
+            }
+        }
+        red[0][tid] = d;
+        red[1][tid] = h;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) {
+                red[0][tid] += red[0][tid + st];
+                red[1][tid] += red[1][tid + st];
+            }
+            __syncthreads();
+        }
+        sc[0] = ra.do_obj ? red[0][0] : 0.0;
+        sc[1] = ra.do_obj ? (ra.use_sh_const ? ra.sh_const : red[1][0]) : 0.0;
+        __syncthreads();
+        if (conv_test(sc, a.divh, a.costh, a.st, a.check_it, a.conv_eps, k == 0 && tid == 0)) return;
+    }
+    if (!a.do_update) return;
+    if (k >= a.r) return;
+    const int Fp4 = a.Fp / 4;
+    const size_t nel = (size_t)a.rp * a.Fp, cstride = nel * ra.n_mat;
+    const int cb = (int)(((long long)ra.n_chunks * g) / 8), ce = (int)(((long long)ra.n_chunks * (g + 1)) / 8);
+    for (int m = 0; m < ra.n_mat; ++m) {
+        const float* base = ra.slabs + (size_t)m * nel + (size_t)k * a.Fp;
+        double s[NP][4];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) s[p][0] = s[p][1] = s[p][2] = s[p][3] = 0.0;
+        constexpr int CB = NP <= 3 ? 8 : 4;  // chunks per batch: CB * NP f32x4 in flight
+        int c = cb;
+        for (; c + CB <= ce; c += CB) {
+            f32x4 x[CB][NP];
+#pragma unroll
+            for (int j = 0; j < CB; ++j)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const int f4 = p * 32 + e;
+                    x[j][p] = f4 < Fp4 ? *reinterpret_cast<const f32x4*>(base + (size_t)(c + j) * cstride + 4 * f4)
+                                       : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+            for (int j = 0; j < CB; ++j)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    s[p][0] += (double)x[j][p][0];
+                    s[p][1] += (double)x[j][p][1];
+                    s[p][2] += (double)x[j][p][2];
+                    s[p][3] += (double)x[j][p][3];
+                }
+        }
+        for (; c < ce; ++c) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int f4 = p * 32 + e;
+                if (f4 < Fp4) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(base + (size_t)c * cstride + 4 * f4);
+                    s[p][0] += (double)x[0];
+                    s[p][1] += (double)x[1];
+                    s[p][2] += (double)x[2];
+                    s[p][3] += (double)x[3];
+                }
+            }
+        }
+        __syncthreads();  // part[] of the previous matrix has been read
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[g][p][e][j] = s[p][j];
+        __syncthreads();
+        for (int i = tid; i < NP * 128; i += 256) {
+            const int p = i >> 7, ee = (i >> 2) & 31, j = i & 3;
+            double t = 0.0;
+#pragma unroll
+            for (int gg = 0; gg < 8; ++gg) t += part[gg][p][ee][j];
+            const int f = 4 * (p * 32 + ee) + j;
+            if (f < a.Fp) cols[(size_t)m * a.Fp + f] = t;
+        }
+    }
+    // row sum of H for this column (KL; zero otherwise), same two-level order as k_reduce
+    double sk = 0.0;
+    if (ra.n_mat == 1) {
+        double sp = 0.0;
+        if (e == 0)
+            for (int c = cb; c < ce; ++c) sp += (double)ra.spart[(size_t)c * a.rp + k];
+        __syncthreads();
+        if (e == 0) part[g][0][0][0] = sp;
+        __syncthreads();
+#pragma unroll
+        for (int gg = 0; gg < 8; ++gg) sk += part[gg][0][0][0];
+    }
+    __syncthreads();
+    // M0 = Q (or G), M1 = P: as in the statistics buffer
+    wapply_column(a, k, tid, cols, ra.n_mat == 2 ? cols + a.Fp : nullptr, sk, red);
 }
 
 // Convergence check alone (H-only mode and the final objective pass): one thread.
