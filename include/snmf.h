@@ -305,6 +305,50 @@ int snmf_online_get_basis_f32(snmf_online* o, float* B_DFT_d, int64_t ld);
 int snmf_online_trace(snmf_online* o, snmf_online_frame* out, int64_t cap, int64_t* n);
 void snmf_online_destroy(snmf_online* o);
 
+/* ---- multi-GPU solves: one process, several devices ------------------------------------- */
+/* The reference's host is ONE MATLAB interpreter (run_basis_train.m:88, run_basis_DNMF.m:40,47,53 call sparse_nmf from
+ * a single thread), so the MEX shim cannot bring a process-per-GPU launcher with it: this is the entry that puts the
+ * multi-GPU path behind the same call.  The frame axis is sharded over `n_dev` ranks (columns are independent given
+ * W, src/sparse_nmf.m:189-208), rank g on devices[g] (a device may appear more than once: the ranks then share it --
+ * single-GPU testing); W is replicated.  Per iteration ONE exchange of the fp64 statistics
+ *     [ G or Q | P (beta != 1) | rowsum(H) | div | sum(S.*H) ]        (src/sparse_nmf.m:215-239, :248-261)
+ * as a one-shot all-reduce over peer-mapped memory: every rank stores its buffer into its slot on every peer, every
+ * rank sums the slots in rank order, so the W replicas and the stop decision (:272-284) are bit-identical everywhere.
+ * H-only solves exchange only the two cost scalars.  Call order as for a plan: create -> set_v / set_w / set_h
+ * [/ set_sparsity] -> init -> run -> get_*.  Matrices are HOST buffers of the WHOLE problem (V: F x T, H: r x T,
+ * column-major); params->T is the total frame count.
+ *   col_begin: n_dev + 1 ascending column offsets (col_begin[0] = 0, col_begin[n_dev] = T), or NULL = balanced. */
+typedef struct snmf_multi snmf_multi;
+int snmf_multi_create(const int32_t* devices, int32_t n_dev, const snmf_params* params, const int64_t* col_begin,
+                      snmf_multi** out);
+void snmf_multi_destroy(snmf_multi* m);
+int snmf_multi_set_v_f64(snmf_multi* m, const double* V, int64_t ld);
+int snmf_multi_set_v_f32(snmf_multi* m, const float* V, int64_t ld);
+int snmf_multi_set_w_f64(snmf_multi* m, const double* W, int64_t ld);
+int snmf_multi_set_w_f32(snmf_multi* m, const float* W, int64_t ld);
+int snmf_multi_set_h_f64(snmf_multi* m, const double* H, int64_t ld);
+int snmf_multi_set_h_f32(snmf_multi* m, const float* H, int64_t ld);
+/* r doubles (RVEC) or r x T, leading dimension r (FULL) */
+int snmf_multi_set_sparsity_f64(snmf_multi* m, const double* S);
+int snmf_multi_set_sparsity_f32(snmf_multi* m, const float* S);
+int snmf_multi_init(snmf_multi* m);
+/* as snmf_plan_run; one host thread per rank issues that rank's launches, the ranks meet only in the exchange */
+int snmf_multi_run(snmf_multi* m, int32_t n_iters, int32_t* iters_done);
+int snmf_multi_get_w_f64(snmf_multi* m, double* W, int64_t ld);
+int snmf_multi_get_w_f32(snmf_multi* m, float* W, int64_t ld);
+/* the replica of W held by one rank (the replicas are bit-identical by construction; tests check it) */
+int snmf_multi_get_w_rank_f64(snmf_multi* m, int32_t rank, double* W, int64_t ld);
+int snmf_multi_get_h_f64(snmf_multi* m, double* H, int64_t ld);
+int snmf_multi_get_h_f32(snmf_multi* m, float* H, int64_t ld);
+int snmf_multi_get_objective(snmf_multi* m, double* div_out, double* cost_out, int32_t* n_iter_out);
+/* One-shot drop-in with a device list: snmf_sparse_nmf_f64 / _f32 sharded over `n_dev` ranks. */
+int snmf_sparse_nmf_multi_f64(const int32_t* devices, int32_t n_dev, const snmf_params* p, const double* V, int64_t ldV,
+                              double* W, double* H, const double* sparsity, double* div_out, double* cost_out,
+                              int32_t* n_iter_out);
+int snmf_sparse_nmf_multi_f32(const int32_t* devices, int32_t n_dev, const snmf_params* p, const float* V, int64_t ldV,
+                              float* W, float* H, const float* sparsity, double* div_out, double* cost_out,
+                              int32_t* n_iter_out);
+
 /* ---- instrumentation (bench.py: HIP-event timing on the engine's own stream) ------------ */
 /* Average device time in milliseconds per launch of the named kernel family over the launches
  * recorded since snmf_ctx_timing(ctx, 1) was switched on.  Families: "hstep", "wstats",

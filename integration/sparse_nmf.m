@@ -53,6 +53,11 @@ gpu_variant = isfield(p, 'snmf_gpu_variant') && p.snmf_gpu_variant;
 opts = struct('beta', p.beta, 'max_iter', p.max_iter, 'conv_eps', p.conv_eps, ...
               'w_update_ind', logical(p.w_update_ind(:)), 'h_update_ind', logical(p.h_update_ind(:)), ...
               'floor_v', double(~gpu_variant), 'device', 0);
+if isfield(p, 'snmf_devices') && ~isempty(p.snmf_devices)
+    % p.snmf_devices = 0:7 -- the same call with the frames sharded over these GPUs (one MATLAB process, the C ABI's
+    % snmf_sparse_nmf_multi_f64): how run_basis_DNMF.m:40,47,53 / run_basis_train.m:88 reach the 8-GPU path unchanged
+    opts.devices = double(p.snmf_devices(:)');
+end
 if gpu_variant
     opts.cost_check = 1;
 else

@@ -2,9 +2,10 @@
 //
 // This is the binding a maintainer of lordet01/SE_SNMF_NAT adds to make src/sparse_nmf.m /
 // src/sparse_nmf_GPU.m run on an MI355X.  It is written against the documented MEX C API
-// (mex.h / matrix.h).  MATLAB is not available in the build container or on the GPU box, so this
-// file is NOT compiled by __graft_entry__.build(); the same C ABI is exercised by the Python
-// ctypes binding (se_snmf_nat_amd/_lib.py), which is what the tests drive.
+// (mex.h / matrix.h).  MATLAB is not available in the build container or on the GPU box, so
+// __graft_entry__.build() only SYNTAX-CHECKS this file against a stub of those prototypes
+// (integration/mex_stub/mex.h); the same C ABI is exercised by the Python ctypes binding
+// (se_snmf_nat_amd/_lib.py), which is what the tests drive.
 //
 // Build (on a machine with MATLAB + ROCm):
 //     mex -R2018a -I<repo>/include integration/sparse_nmf_mex.cpp -L<repo>/se_snmf_nat_amd -lsnmf_hip
@@ -17,7 +18,9 @@
 //   h0       r x T double          init_h                     (:133-140)
 //   sparsity scalar | r x 1 | r x T double                    (:150-155)
 //   opts     struct: beta, max_iter, conv_eps, cost_check, floor_v (0 for the _GPU variant),
-//            w_update_ind (r x 1 logical), h_update_ind (r x 1 logical), device (0-based)
+//            w_update_ind (r x 1 logical), h_update_ind (r x 1 logical), device (0-based),
+//            devices (vector of 0-based device ordinals, optional): the frames are sharded over these GPUs inside
+//            this one MATLAB process (snmf_sparse_nmf_multi_f64: one exchange of the W statistics per iteration)
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -118,8 +121,21 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     mxArray* divv = mxCreateDoubleMatrix(1, p.max_iter > 0 ? p.max_iter : 1, mxREAL);
     mxArray* costv = mxCreateDoubleMatrix(1, p.max_iter > 0 ? p.max_iter : 1, mxREAL);
     int32_t n_iter = 0;
-    const int st = snmf_sparse_nmf_f64(g_ctx, &p, mxGetDoubles(v), (int64_t)F, mxGetDoubles(plhs[0]),
-                                       mxGetDoubles(hout), sparsity, mxGetDoubles(divv), mxGetDoubles(costv), &n_iter);
+    // opts.devices = [0 1 ... 7]: the same call over several GPUs (run_basis_DNMF.m:40,47,53 / run_basis_train.m:88 at scale)
+    std::vector<int32_t> devices;
+    if (const mxArray* dv = mxGetField(opts, 0, "devices")) {
+        if (!mxIsEmpty(dv)) {
+            if (!mxIsDouble(dv)) mexErrMsgIdAndTxt("snmf:type", "opts.devices must be a double vector of device ordinals");
+            const double* d = mxGetDoubles(dv);
+            for (size_t i = 0; i < mxGetNumberOfElements(dv); ++i) devices.push_back((int32_t)d[i]);
+        }
+    }
+    const int st = devices.empty()
+        ? snmf_sparse_nmf_f64(g_ctx, &p, mxGetDoubles(v), (int64_t)F, mxGetDoubles(plhs[0]), mxGetDoubles(hout), sparsity,
+                              mxGetDoubles(divv), mxGetDoubles(costv), &n_iter)
+        : snmf_sparse_nmf_multi_f64(devices.data(), (int32_t)devices.size(), &p, mxGetDoubles(v), (int64_t)F,
+                                    mxGetDoubles(plhs[0]), mxGetDoubles(hout), sparsity, mxGetDoubles(divv),
+                                    mxGetDoubles(costv), &n_iter);
     if (st != SNMF_OK) {
         mxDestroyArray(hout);
         mxDestroyArray(divv);

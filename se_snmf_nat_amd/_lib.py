@@ -36,6 +36,11 @@ SYMBOLS = [
     "snmf_plan_set_mask_f64", "snmf_plan_set_mask_f32", "snmf_plan_get_v_mdi_f64", "snmf_plan_get_v_mdi_f32",
     "snmf_online_create", "snmf_online_set_mel", "snmf_online_get_mel_basis_f32", "snmf_online_process_f32", "snmf_online_get_basis_f32", "snmf_online_trace",
     "snmf_online_destroy",
+    "snmf_multi_create", "snmf_multi_destroy", "snmf_multi_set_v_f64", "snmf_multi_set_v_f32", "snmf_multi_set_w_f64",
+    "snmf_multi_set_w_f32", "snmf_multi_set_h_f64", "snmf_multi_set_h_f32", "snmf_multi_set_sparsity_f64",
+    "snmf_multi_set_sparsity_f32", "snmf_multi_init", "snmf_multi_run", "snmf_multi_get_w_f64", "snmf_multi_get_w_f32",
+    "snmf_multi_get_w_rank_f64", "snmf_multi_get_h_f64", "snmf_multi_get_h_f32", "snmf_multi_get_objective",
+    "snmf_sparse_nmf_multi_f64", "snmf_sparse_nmf_multi_f32",
 ]
 
 SNMF_OK = 0
@@ -201,6 +206,20 @@ def load():
             sig[f"snmf_plan_get_{nm}_{ty}"] = (C.c_int, [vp, vp, i64, C.c_int])
     for ty in ("f64", "f32"):
         sig[f"snmf_plan_set_sparsity_{ty}"] = (C.c_int, [vp, vp, C.c_int])
+    sig["snmf_multi_create"] = (C.c_int, [vp, i32, PP, vp, C.POINTER(vp)])
+    sig["snmf_multi_destroy"] = (None, [vp])
+    for nm in ("v", "w", "h"):
+        for ty in ("f64", "f32"):
+            sig[f"snmf_multi_set_{nm}_{ty}"] = (C.c_int, [vp, vp, i64])
+    for ty in ("f64", "f32"):
+        sig[f"snmf_multi_set_sparsity_{ty}"] = (C.c_int, [vp, vp])
+        sig[f"snmf_multi_get_w_{ty}"] = (C.c_int, [vp, vp, i64])
+        sig[f"snmf_multi_get_h_{ty}"] = (C.c_int, [vp, vp, i64])
+        sig[f"snmf_sparse_nmf_multi_{ty}"] = (C.c_int, [vp, i32, PP, vp, i64, vp, vp, vp, vp, vp, C.POINTER(i32)])
+    sig["snmf_multi_init"] = (C.c_int, [vp])
+    sig["snmf_multi_run"] = (C.c_int, [vp, i32, C.POINTER(i32)])
+    sig["snmf_multi_get_w_rank_f64"] = (C.c_int, [vp, i32, vp, i64])
+    sig["snmf_multi_get_objective"] = (C.c_int, [vp, vp, vp, C.POINTER(i32)])
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
         fn.restype = res

@@ -126,7 +126,7 @@ def _sparsity_form(sparsity, r, n, dtype):
     return 2, 0.0, np.asfortranarray(sp)
 
 
-def _solve(v, p, *, gpu_variant, ctx, dtype, rng):
+def _solve(v, p, *, gpu_variant, ctx, dtype, rng, devices=None):
     p = dict(p or {})
     dt = np.dtype(dtype)
     if dt not in (np.dtype(np.float64), np.dtype(np.float32)):
@@ -190,10 +190,19 @@ def _solve(v, p, *, gpu_variant, ctx, dtype, rng):
     cost = np.zeros(max(max_iter, 1))
     n_iter = C.c_int32(0)
     lib = _lib.load()
-    ctx = ctx or default_context()
-    fn = lib.snmf_sparse_nmf_f64 if dt == np.float64 else lib.snmf_sparse_nmf_f32
-    _lib.check(fn(ctx._h, C.byref(sp), _ptr(vv), vv.strides[1] // dt.itemsize if n > 1 else m, _ptr(W), _ptr(H),
-                  _ptr(sarr) if sarr is not None else None, _ptr(div), _ptr(cost), C.byref(n_iter)))
+    ldv = vv.strides[1] // dt.itemsize if n > 1 else m
+    if devices is not None:
+        # the same call over several GPUs: frames sharded over len(devices) ranks, one-shot exchange of the W statistics
+        # per iteration (include/snmf.h: snmf_sparse_nmf_multi_*; the MEX shim's opts.devices)
+        devs = np.ascontiguousarray(np.asarray(devices, dtype=np.int32).reshape(-1))
+        fn = lib.snmf_sparse_nmf_multi_f64 if dt == np.float64 else lib.snmf_sparse_nmf_multi_f32
+        _lib.check(fn(_ptr(devs), int(devs.size), C.byref(sp), _ptr(vv), ldv, _ptr(W), _ptr(H),
+                      _ptr(sarr) if sarr is not None else None, _ptr(div), _ptr(cost), C.byref(n_iter)))
+    else:
+        ctx = ctx or default_context()
+        fn = lib.snmf_sparse_nmf_f64 if dt == np.float64 else lib.snmf_sparse_nmf_f32
+        _lib.check(fn(ctx._h, C.byref(sp), _ptr(vv), ldv, _ptr(W), _ptr(H),
+                      _ptr(sarr) if sarr is not None else None, _ptr(div), _ptr(cost), C.byref(n_iter)))
     ni = n_iter.value
     if gpu_variant:
         # sparse_nmf_GPU.m:263-264 never fills the vectors: zeros(1, max_iter) are returned
@@ -208,12 +217,14 @@ def _solve(v, p, *, gpu_variant, ctx, dtype, rng):
     return W, H, objective
 
 
-def sparse_nmf(v, p=None, *, ctx=None, dtype=np.float64, rng=None):
+def sparse_nmf(v, p=None, *, ctx=None, dtype=np.float64, rng=None, devices=None):
     """[w, h, objective] = sparse_nmf(v, p) -- drop-in for src/sparse_nmf.m on the MI355X.
 
     `dtype` selects the host-buffer type handed over the C ABI (the device arithmetic is fp32
-    MFMA + fp64 objective either way)."""
-    return _solve(v, p, gpu_variant=False, ctx=ctx, dtype=dtype, rng=rng)
+    MFMA + fp64 objective either way).  `devices`: list of device ordinals -> the frame axis is sharded over
+    that many ranks inside this one process (snmf_sparse_nmf_multi_*), same results up to the fp64 summation order
+    of the W statistics."""
+    return _solve(v, p, gpu_variant=False, ctx=ctx, dtype=dtype, rng=rng, devices=devices)
 
 
 def sparse_nmf_GPU(v, p=None, *, ctx=None, dtype=np.float64, rng=None):
@@ -222,28 +233,29 @@ def sparse_nmf_GPU(v, p=None, *, ctx=None, dtype=np.float64, rng=None):
     return _solve(v, p, gpu_variant=True, ctx=ctx, dtype=dtype, rng=rng)
 
 
-def run_basis_dnmf(Y, X, D, B, R_x, R_d, p, *, ctx=None, dtype=np.float64):
+def run_basis_dnmf(Y, X, D, B, R_x, R_d, p, *, ctx=None, dtype=np.float64, devices=None):
     """The 3-solve discriminative re-training loop of run_basis_DNMF.m:36-55 on formed features.
 
     Y, X, D are the F x T features of mixture / clean / noise (run_basis_DNMF.m:13-34); B is the
-    F x (R_x+R_d) exemplar basis.  Returns (B_hat, A_hat)."""
+    F x (R_x+R_d) exemplar basis.  Returns (B_hat, A_hat).  `devices`: shard the frames of all three solves over
+    these GPUs inside this process (BASELINE config 4 behind the reference's own call)."""
     p = dict(p)
     B = np.asarray(B, dtype=np.float64)
     p["w_update_ind"] = np.zeros(R_x + R_d, bool)  # :37
     p["h_update_ind"] = np.ones(R_x + R_d, bool)  # :38
     p["init_w"] = B  # :39
     p.pop("init_h", None)
-    _, A_hat, _ = sparse_nmf(Y, p, ctx=ctx, dtype=dtype)  # :40
+    _, A_hat, _ = sparse_nmf(Y, p, ctx=ctx, dtype=dtype, devices=devices)  # :40
     p["w_update_ind"] = np.ones(R_x, bool)  # :43
     p["h_update_ind"] = np.zeros(R_x, bool)  # :44
     p["init_w"] = B[:, :R_x]  # :45
     p["init_h"] = A_hat[:R_x, :]  # :46
-    B_hat_x, _, _ = sparse_nmf(X, p, ctx=ctx, dtype=dtype)  # :47
+    B_hat_x, _, _ = sparse_nmf(X, p, ctx=ctx, dtype=dtype, devices=devices)  # :47
     p["w_update_ind"] = np.ones(R_d, bool)  # :49
     p["h_update_ind"] = np.zeros(R_d, bool)  # :50
     p["init_w"] = B[:, R_x:R_x + R_d]  # :51
     p["init_h"] = A_hat[R_x:R_x + R_d, :]  # :52
-    B_hat_d, _, _ = sparse_nmf(D, p, ctx=ctx, dtype=dtype)  # :53
+    B_hat_d, _, _ = sparse_nmf(D, p, ctx=ctx, dtype=dtype, devices=devices)  # :53
     return np.concatenate([B_hat_x, B_hat_d], axis=1), A_hat  # :55
 
 

@@ -2334,3 +2334,6 @@ extern "C" int snmf_online_trace(snmf_online* o, snmf_online_frame* out, int64_t
     if (out && cap > 0) std::copy_n(o->trace.begin(), (size_t)std::min<int64_t>(cap, (int64_t)o->trace.size()), out);
     return SNMF_OK;
 }
+
+// ---- multi-GPU entry behind the C ABI (one process, several devices) --------------------------------------------
+#include "snmf_multi.h"

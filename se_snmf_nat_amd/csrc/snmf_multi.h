@@ -1,0 +1,435 @@
+// snmf_multi.h -- multi-GPU solves behind the C ABI (include/snmf.h: snmf_multi_*), included by snmf_api.hip.
+//
+// One PROCESS, several devices: the reference's host is a single MATLAB interpreter (run_basis_DNMF.m:36-55 calls
+// sparse_nmf from one thread), so the MEX shim cannot bring a process-per-GPU launcher with it; this is the entry that
+// puts the 8-GPU path behind "the same function signature" (SURVEY.md section 8b(1), 8e).  The process-per-GPU path over
+// RCCL stays in se_snmf_nat_amd/dist.py (bench.py --gpus N).
+//
+// Frames are independent given W (src/sparse_nmf.m:189-208): rank g owns the contiguous column block
+// [col[g], col[g+1]) of V and H on device devices[g] as an ordinary snmf_plan; W is replicated.  One host thread per
+// rank issues that rank's launches.  Per iteration there is ONE exchange, the ONE-SHOT all-reduce SURVEY.md section 5 / 8e
+// asks for instead of a ring (the message is ~0.5 MB: latency, not bytes, is the enemy on the fully connected xGMI
+// mesh):
+//     k_push_stats  every rank writes its fp64 statistics into slot g of EVERY rank's gather buffer (peer stores)
+//     event record / cross-stream event waits (no host synchronisation of the device work)
+//     k_sum_ranks   every rank adds the n slots of its own gather buffer in rank order
+// so all ranks hold bit-identical sums, run the identical deterministic W epilogue and take identical stop decisions.
+// Gather buffers and events are double-buffered by iteration parity: rank g can only push iteration j+2 after it has
+// seen every peer's push of j+1, which each peer issued after its own sum of iteration j.
+// H-only solves exchange just the two cost scalars at the tail of the buffer.
+#pragma once
+
+#include <atomic>
+#include <thread>
+
+namespace snmf {
+
+struct PushArgs {
+    const double* src;
+    double* dst[16];
+    size_t len;
+    int n;
+};
+__global__ __launch_bounds__(256) void k_push_stats(PushArgs a) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.len; i += (size_t)gridDim.x * 256) {
+        const double v = a.src[i];
+        for (int q = 0; q < a.n; ++q) a.dst[q][i] = v;
+    }
+}
+// out[i] = slot_0[i] + slot_1[i] + ... in rank order (identical on every rank)
+__global__ __launch_bounds__(256) void k_sum_ranks(const double* __restrict__ slots, int n, size_t len, double* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (size_t)gridDim.x * 256) {
+        double s = slots[i];
+        for (int q = 1; q < n; ++q) s += slots[(size_t)q * len + i];
+        out[i] = s;
+    }
+}
+
+}  // namespace snmf
+
+struct snmf_multi {
+    int n = 0;
+    snmf_params p{};
+    std::vector<int> dev;
+    std::vector<int64_t> col;         // n + 1 column offsets
+    std::vector<snmf_ctx*> ctx;
+    std::vector<snmf_plan*> plan;
+    std::vector<double*> stats;       // [n] device statistics buffer of each rank
+    std::vector<double*> slots;       // [n] gather buffers: [2 parities][n ranks][xlen]
+    std::vector<hipEvent_t> ev[2];    // ev[parity][rank]: "rank has pushed"
+    std::vector<uint8_t> w_ind, h_ind;
+    size_t len = 0, xoff = 0, xlen = 0;  // statistics length; the exchanged part [xoff, xoff + xlen)
+    bool upd_w = true, can_stop = false;
+    int it = 0;                       // iterations issued
+    int par = 0;                      // parity of the next exchange
+    bool inited = false, finalized = false, stopped = false;
+    // host barrier of the rank threads (sense reversing)
+    std::atomic<int> bar_count{0};
+    std::atomic<int> bar_gen{0};
+    std::atomic<int> failed_at{0x7fffffff};  // number of the first barrier some rank entered as failed
+    std::vector<int> rc;
+    std::vector<std::string> err;
+};
+
+// Host barrier of the rank threads that also AGREES on failure: a rank publishes "I have failed" only on its way INTO
+// barrier number `seq` (as the smallest such number), and everybody reads the word only on the way OUT, comparing it
+// with the number of the barrier just passed -- so a fast rank that fails and publishes at barrier seq+1 cannot make a
+// slow rank, still reading after barrier seq, leave the loop one barrier early (it would never arrive at seq+1).
+// Returns true when every rank was healthy up to this barrier.
+static bool multi_barrier(snmf_multi* m, int seq, bool i_failed) {
+    if (i_failed) {
+        int cur = m->failed_at.load(std::memory_order_relaxed);
+        while (seq < cur && !m->failed_at.compare_exchange_weak(cur, seq, std::memory_order_relaxed)) {}
+    }
+    const int gen = m->bar_gen.load(std::memory_order_acquire);
+    if (m->bar_count.fetch_add(1, std::memory_order_acq_rel) == m->n - 1) {
+        m->bar_count.store(0, std::memory_order_relaxed);
+        m->bar_gen.store(gen + 1, std::memory_order_release);
+    } else {
+        while (m->bar_gen.load(std::memory_order_acquire) == gen) std::this_thread::yield();
+    }
+    return m->failed_at.load(std::memory_order_acquire) > seq;
+}
+
+extern "C" void snmf_multi_destroy(snmf_multi* m) {
+    if (!m) return;
+    for (int g = 0; g < (int)m->plan.size(); ++g) {
+        if (g < (int)m->ctx.size() && m->ctx[g]) {
+            hipSetDevice(m->dev[g]);
+            hipStreamSynchronize(m->ctx[g]->stream);
+        }
+    }
+    for (int g = 0; g < (int)m->plan.size(); ++g) {
+        hipSetDevice(m->dev[g]);
+        for (int q = 0; q < 2; ++q)
+            if (g < (int)m->ev[q].size() && m->ev[q][g]) hipEventDestroy(m->ev[q][g]);
+        if (g < (int)m->stats.size() && m->stats[g]) hipFree(m->stats[g]);
+        if (g < (int)m->slots.size() && m->slots[g]) hipFree(m->slots[g]);
+        if (m->plan[g]) snmf_plan_destroy(m->plan[g]);
+    }
+    for (snmf_ctx* c : m->ctx)
+        if (c) snmf_ctx_destroy(c);
+    delete m;
+}
+
+extern "C" int snmf_multi_create(const int32_t* devices, int32_t n_dev, const snmf_params* p, const int64_t* col_begin,
+                                 snmf_multi** out) {
+    if (!devices || !p || !out) return fail(SNMF_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (n_dev < 1 || n_dev > 16) return fail(SNMF_ERR_INVALID, "n_dev = %d outside [1, 16]", n_dev);
+    SN_TRY(validate_params(p));
+    if (p->T < n_dev) return fail(SNMF_ERR_INVALID, "fewer frames (%d) than ranks (%d)", p->T, n_dev);
+    snmf_multi* m = new snmf_multi();
+    m->n = n_dev;
+    m->p = *p;
+    m->dev.assign(devices, devices + n_dev);
+    m->col.resize(n_dev + 1);
+    for (int g = 0; g <= n_dev; ++g) m->col[g] = col_begin ? col_begin[g] : ((int64_t)p->T * g) / n_dev;  // balanced, contiguous
+    if (m->col[0] != 0 || m->col[n_dev] != p->T) {
+        delete m;
+        return fail(SNMF_ERR_INVALID, "column ranges must start at 0 and end at T");
+    }
+    for (int g = 0; g < n_dev; ++g)
+        if (m->col[g + 1] <= m->col[g]) {
+            delete m;
+            return fail(SNMF_ERR_INVALID, "rank %d owns no frames", g);
+        }
+    if (p->w_update_ind) m->w_ind.assign(p->w_update_ind, p->w_update_ind + p->r);
+    if (p->h_update_ind) m->h_ind.assign(p->h_update_ind, p->h_update_ind + p->r);
+    m->p.w_update_ind = m->w_ind.empty() ? nullptr : m->w_ind.data();
+    m->p.h_update_ind = m->h_ind.empty() ? nullptr : m->h_ind.data();
+    m->ctx.assign(n_dev, nullptr);
+    m->plan.assign(n_dev, nullptr);
+    m->stats.assign(n_dev, nullptr);
+    m->slots.assign(n_dev, nullptr);
+    m->ev[0].assign(n_dev, nullptr);
+    m->ev[1].assign(n_dev, nullptr);
+    m->rc.assign(n_dev, SNMF_OK);
+    m->err.assign(n_dev, std::string());
+    int s = SNMF_OK;
+    for (int g = 0; g < n_dev && s == SNMF_OK; ++g) {
+        s = snmf_ctx_create(&m->ctx[g], m->dev[g]);
+        if (s != SNMF_OK) break;
+        snmf_params pg = m->p;
+        pg.T = (int32_t)(m->col[g + 1] - m->col[g]);
+        s = snmf_plan_create(m->ctx[g], &pg, &m->plan[g]);
+    }
+    if (s == SNMF_OK) {
+        m->upd_w = m->plan[0]->upd_w;
+        m->can_stop = p->cost_check && p->conv_eps > 0.0;
+        m->len = (size_t)snmf_plan_stats_len(m->plan[0]);
+        m->xoff = m->upd_w ? 0 : m->len - 2;  // H-only solves exchange nothing but (div, sum S.*H)
+        m->xlen = m->len - m->xoff;
+    }
+    for (int g = 0; g < n_dev && s == SNMF_OK; ++g) {
+        if (hipSetDevice(m->dev[g]) != hipSuccess) s = fail(SNMF_ERR_NO_DEVICE, "hipSetDevice(%d)", m->dev[g]);
+        if (s == SNMF_OK) s = dalloc(&m->stats[g], m->len);
+        if (s == SNMF_OK) s = dalloc(&m->slots[g], (size_t)2 * n_dev * m->xlen);
+        if (s == SNMF_OK) {
+            hipMemset(m->stats[g], 0, m->len * sizeof(double));
+            for (int q = 0; q < 2 && s == SNMF_OK; ++q)
+                if (hipEventCreateWithFlags(&m->ev[q][g], hipEventDisableTiming) != hipSuccess)
+                    s = fail(SNMF_ERR_NO_DEVICE, "hipEventCreate failed on device %d", m->dev[g]);
+        }
+        // peer stores into every other device's gather buffer
+        for (int q = 0; q < n_dev && s == SNMF_OK; ++q) {
+            if (m->dev[q] == m->dev[g]) continue;
+            int can = 0;
+            hipDeviceCanAccessPeer(&can, m->dev[g], m->dev[q]);
+            if (!can) {
+                s = fail(SNMF_ERR_UNSUPPORTED, "device %d cannot access device %d as a peer", m->dev[g], m->dev[q]);
+                break;
+            }
+            const hipError_t e = hipDeviceEnablePeerAccess(m->dev[q], 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                s = fail(SNMF_ERR_NO_DEVICE, "hipDeviceEnablePeerAccess(%d -> %d): %s", m->dev[g], m->dev[q], hipGetErrorString(e));
+            (void)hipGetLastError();
+        }
+    }
+    if (s != SNMF_OK) {
+        const std::string keep = g_err;
+        snmf_multi_destroy(m);
+        g_err = keep;
+        return s;
+    }
+    *out = m;
+    return SNMF_OK;
+}
+
+#define MULTI_CHECK(m) \
+    if (!(m)) return fail(SNMF_ERR_INVALID, "multi handle is NULL")
+
+template <typename T>
+static int multi_set_cols(snmf_multi* m, const T* A, int64_t ld, int which) {
+    MULTI_CHECK(m);
+    if (!A) return fail(SNMF_ERR_INVALID, "NULL matrix");
+    for (int g = 0; g < m->n; ++g) {
+        const T* Ag = A + (size_t)m->col[g] * ld;
+        SN_TRY(which == 0 ? set_v<T>(m->plan[g], Ag, ld, 0) : set_h<T>(m->plan[g], Ag, ld, 0));
+    }
+    m->inited = false;
+    return SNMF_OK;
+}
+extern "C" int snmf_multi_set_v_f64(snmf_multi* m, const double* V, int64_t ld) { return multi_set_cols(m, V, ld, 0); }
+extern "C" int snmf_multi_set_v_f32(snmf_multi* m, const float* V, int64_t ld) { return multi_set_cols(m, V, ld, 0); }
+extern "C" int snmf_multi_set_h_f64(snmf_multi* m, const double* H, int64_t ld) { return multi_set_cols(m, H, ld, 1); }
+extern "C" int snmf_multi_set_h_f32(snmf_multi* m, const float* H, int64_t ld) { return multi_set_cols(m, H, ld, 1); }
+template <typename T>
+static int multi_set_w(snmf_multi* m, const T* W, int64_t ld) {
+    MULTI_CHECK(m);
+    if (!W) return fail(SNMF_ERR_INVALID, "NULL matrix");
+    for (int g = 0; g < m->n; ++g) SN_TRY(set_w<T>(m->plan[g], W, ld, 0));
+    m->inited = false;
+    return SNMF_OK;
+}
+extern "C" int snmf_multi_set_w_f64(snmf_multi* m, const double* W, int64_t ld) { return multi_set_w(m, W, ld); }
+extern "C" int snmf_multi_set_w_f32(snmf_multi* m, const float* W, int64_t ld) { return multi_set_w(m, W, ld); }
+template <typename T>
+static int multi_set_s(snmf_multi* m, const T* S) {
+    MULTI_CHECK(m);
+    if (!S) return fail(SNMF_ERR_INVALID, "NULL sparsity");
+    for (int g = 0; g < m->n; ++g) {
+        const T* Sg = m->p.sparsity_kind == SNMF_SPARSITY_FULL ? S + (size_t)m->col[g] * m->p.r : S;  // r x T, ld = r
+        SN_TRY(set_s<T>(m->plan[g], Sg, 0));
+    }
+    m->inited = false;
+    return SNMF_OK;
+}
+extern "C" int snmf_multi_set_sparsity_f64(snmf_multi* m, const double* S) { return multi_set_s(m, S); }
+extern "C" int snmf_multi_set_sparsity_f32(snmf_multi* m, const float* S) { return multi_set_s(m, S); }
+
+extern "C" int snmf_multi_init(snmf_multi* m) {
+    MULTI_CHECK(m);
+    for (int g = 0; g < m->n; ++g) SN_TRY(snmf_plan_init(m->plan[g]));
+    for (int g = 0; g < m->n; ++g) SN_TRY(snmf_ctx_sync(m->ctx[g]));
+    m->it = 0;
+    m->par = 0;
+    m->inited = true;
+    m->finalized = false;
+    m->stopped = false;
+    return SNMF_OK;
+}
+
+// One exchange on rank g (device work only; the host barrier makes sure every peer has ISSUED its event record before
+// anybody waits on it, and that nobody re-records an event a peer has not yet waited on).  `rc` is the rank's status so
+// far: a failed rank still takes part in the barrier.  Returns false when the ranks agreed to stop (some rank failed).
+static bool multi_exchange(snmf_multi* m, int g, int par, int& seq, int& rc, std::string& err) {
+    hipStream_t st = m->ctx[g]->stream;
+    auto note = [&](int s) {
+        if (rc == SNMF_OK && s != SNMF_OK) {
+            rc = s;
+            err = g_err;
+        }
+    };
+    const int grid = (int)std::max<size_t>(1, std::min<size_t>((m->xlen + 255) / 256, 512));
+    if (m->n > 1 && rc == SNMF_OK) {
+        PushArgs pa{};
+        pa.src = m->stats[g] + m->xoff;
+        pa.len = m->xlen;
+        pa.n = m->n;
+        for (int q = 0; q < m->n; ++q) pa.dst[q] = m->slots[q] + ((size_t)par * m->n + g) * m->xlen;
+        hipLaunchKernelGGL(k_push_stats, dim3(grid), dim3(256), 0, st, pa);
+        if (hipGetLastError() != hipSuccess) note(fail(SNMF_ERR_NO_DEVICE, "k_push_stats launch failed"));
+        else if (hipEventRecord(m->ev[par][g], st) != hipSuccess) note(fail(SNMF_ERR_NO_DEVICE, "hipEventRecord failed"));
+    }
+    if (!multi_barrier(m, seq++, rc != SNMF_OK)) return false;  // every rank has recorded -- or somebody failed: all leave
+    if (m->n > 1) {
+        for (int q = 0; q < m->n; ++q)
+            if (q != g && hipStreamWaitEvent(st, m->ev[par][q], 0) != hipSuccess) note(fail(SNMF_ERR_NO_DEVICE, "hipStreamWaitEvent failed"));
+        if (rc == SNMF_OK) {
+            hipLaunchKernelGGL(k_sum_ranks, dim3(grid), dim3(256), 0, st, (const double*)(m->slots[g] + (size_t)par * m->n * m->xlen),
+                               m->n, m->xlen, m->stats[g] + m->xoff);
+            if (hipGetLastError() != hipSuccess) note(fail(SNMF_ERR_NO_DEVICE, "k_sum_ranks launch failed"));
+        }
+    }
+    return true;
+}
+
+// the loop of rank g: iterations [it0, target), then (optionally) the objective of the last iterate
+static void multi_rank_loop(snmf_multi* m, int g, int it0, int target, bool finalize, int* stopped_out) {
+    int rc = SNMF_OK, seq = 0;
+    std::string err;
+    auto step = [&](int st) {
+        if (rc == SNMF_OK && st != SNMF_OK) {
+            rc = st;
+            err = g_err;
+        }
+    };
+    step(hipSetDevice(m->dev[g]) == hipSuccess ? SNMF_OK : fail(SNMF_ERR_NO_DEVICE, "hipSetDevice(%d) failed", m->dev[g]));
+    int par = m->par, since = 0, stopped = 0;
+    bool all_ok = true;
+    for (int it = it0; it < target && all_ok; ++it) {
+        if (rc == SNMF_OK) step(snmf_plan_hstep(m->plan[g]));
+        if (rc == SNMF_OK) step(snmf_plan_wstats(m->plan[g], m->stats[g]));
+        all_ok = multi_exchange(m, g, par, seq, rc, err);
+        if (!all_ok) break;
+        par ^= 1;
+        if (rc == SNMF_OK) step(snmf_plan_wapply(m->plan[g], m->stats[g]));
+        if (m->can_stop && ++since >= 4) {  // same poll schedule and (bit-identical statistics) same answer on every rank
+            since = 0;
+            int32_t sflag = 0;
+            if (rc == SNMF_OK) step(snmf_plan_stopped(m->plan[g], &sflag));
+            all_ok = multi_barrier(m, seq++, rc != SNMF_OK);
+            if (all_ok && sflag) {
+                stopped = 1;
+                break;
+            }
+        }
+    }
+    if (all_ok) all_ok = multi_barrier(m, seq++, rc != SNMF_OK);  // agree on the state the loop was left in
+    if (all_ok && finalize && !stopped) {
+        if (rc == SNMF_OK) step(snmf_plan_objstats(m->plan[g], m->stats[g]));
+        all_ok = multi_exchange(m, g, par, seq, rc, err);
+        if (all_ok) {
+            par ^= 1;
+            if (rc == SNMF_OK) step(snmf_plan_objapply(m->plan[g], m->stats[g]));
+        }
+    }
+    if (rc == SNMF_OK) step(snmf_ctx_sync(m->ctx[g]));
+    m->rc[g] = rc;
+    m->err[g] = err;
+    if (g == 0) {
+        m->par = par;
+        *stopped_out = stopped;
+    }
+}
+
+extern "C" int snmf_multi_run(snmf_multi* m, int32_t n_iters, int32_t* iters_done) {
+    MULTI_CHECK(m);
+    if (!m->inited) return fail(SNMF_ERR_STATE, "snmf_multi_init must precede snmf_multi_run");
+    const int target = std::min(m->p.max_iter, m->it + std::max(0, n_iters));
+    const bool finalize = target >= m->p.max_iter && m->p.cost_check && !m->finalized && target > 0;
+    int stopped = 0;
+    if (!m->stopped && (m->it < target || finalize)) {
+        m->failed_at.store(0x7fffffff);
+        m->bar_count.store(0);
+        std::vector<std::thread> th;
+        for (int g = 1; g < m->n; ++g) th.emplace_back(multi_rank_loop, m, g, m->it, target, finalize, &stopped);
+        multi_rank_loop(m, 0, m->it, target, finalize, &stopped);
+        for (auto& t : th) t.join();
+        for (int g = 0; g < m->n; ++g)
+            if (m->rc[g] != SNMF_OK) return fail(m->rc[g], "rank %d (device %d): %s", g, m->dev[g], m->err[g].c_str());
+        if (m->failed_at.load() != 0x7fffffff) return fail(SNMF_ERR_INTERNAL, "a rank failed");
+        m->it = m->plan[0]->it_done;
+        if (stopped) m->stopped = true;
+        else if (finalize) m->finalized = true;
+    }
+    if (iters_done) {
+        int32_t n_it = 0;
+        SN_TRY(snmf_plan_get_objective(m->plan[0], nullptr, nullptr, &n_it));
+        *iters_done = n_it;
+    }
+    return SNMF_OK;
+}
+
+extern "C" int snmf_multi_get_w_f64(snmf_multi* m, double* W, int64_t ld) {
+    MULTI_CHECK(m);
+    return snmf_plan_get_w_f64(m->plan[0], W, ld, 0);
+}
+extern "C" int snmf_multi_get_w_f32(snmf_multi* m, float* W, int64_t ld) {
+    MULTI_CHECK(m);
+    return snmf_plan_get_w_f32(m->plan[0], W, ld, 0);
+}
+// the W replica of one rank (tests: replicas must be bit-identical)
+extern "C" int snmf_multi_get_w_rank_f64(snmf_multi* m, int32_t rank, double* W, int64_t ld) {
+    MULTI_CHECK(m);
+    if (rank < 0 || rank >= m->n) return fail(SNMF_ERR_INVALID, "rank out of range");
+    return snmf_plan_get_w_f64(m->plan[rank], W, ld, 0);
+}
+extern "C" int snmf_multi_get_h_f64(snmf_multi* m, double* H, int64_t ld) {
+    MULTI_CHECK(m);
+    for (int g = 0; g < m->n; ++g) SN_TRY(snmf_plan_get_h_f64(m->plan[g], H + (size_t)m->col[g] * ld, ld, 0));
+    return SNMF_OK;
+}
+extern "C" int snmf_multi_get_h_f32(snmf_multi* m, float* H, int64_t ld) {
+    MULTI_CHECK(m);
+    for (int g = 0; g < m->n; ++g) SN_TRY(snmf_plan_get_h_f32(m->plan[g], H + (size_t)m->col[g] * ld, ld, 0));
+    return SNMF_OK;
+}
+extern "C" int snmf_multi_get_objective(snmf_multi* m, double* div_out, double* cost_out, int32_t* n_iter_out) {
+    MULTI_CHECK(m);
+    return snmf_plan_get_objective(m->plan[0], div_out, cost_out, n_iter_out);
+}
+
+template <typename T>
+static int sparse_nmf_multi_impl(const int32_t* devices, int32_t n_dev, const snmf_params* p, const T* V, int64_t ldV, T* W,
+                                 T* H, const T* sparsity, double* div_out, double* cost_out, int32_t* n_iter_out) {
+    if (!V || !W || !H) return fail(SNMF_ERR_INVALID, "V, W and H must be non-NULL");
+    snmf_multi* m = nullptr;
+    SN_TRY(snmf_multi_create(devices, n_dev, p, nullptr, &m));
+    int s = SNMF_OK;
+    auto step = [&](int st) { if (s == SNMF_OK) s = st; };
+    step(multi_set_cols<T>(m, V, ldV, 0));
+    step(multi_set_w<T>(m, W, p->F));
+    step(multi_set_cols<T>(m, H, p->r, 1));
+    if (p->sparsity_kind != SNMF_SPARSITY_SCALAR) {
+        if (!sparsity) step(fail(SNMF_ERR_INVALID, "sparsity array required for this sparsity_kind"));
+        else step(multi_set_s<T>(m, sparsity));
+    }
+    step(snmf_multi_init(m));
+    if (s == SNMF_OK) step(snmf_multi_run(m, p->max_iter, nullptr));
+    if (s == SNMF_OK) {
+        if (sizeof(T) == 8) {
+            step(snmf_multi_get_w_f64(m, (double*)W, p->F));
+            step(snmf_multi_get_h_f64(m, (double*)H, p->r));
+        } else {
+            step(snmf_multi_get_w_f32(m, (float*)W, p->F));
+            step(snmf_multi_get_h_f32(m, (float*)H, p->r));
+        }
+    }
+    if (s == SNMF_OK) step(snmf_multi_get_objective(m, div_out, cost_out, n_iter_out));
+    const std::string keep = g_err;
+    snmf_multi_destroy(m);
+    g_err = keep;
+    return s;
+}
+extern "C" int snmf_sparse_nmf_multi_f64(const int32_t* devices, int32_t n_dev, const snmf_params* p, const double* V, int64_t ldV,
+                                         double* W, double* H, const double* sparsity, double* div_out, double* cost_out,
+                                         int32_t* n_iter_out) {
+    return sparse_nmf_multi_impl<double>(devices, n_dev, p, V, ldV, W, H, sparsity, div_out, cost_out, n_iter_out);
+}
+extern "C" int snmf_sparse_nmf_multi_f32(const int32_t* devices, int32_t n_dev, const snmf_params* p, const float* V, int64_t ldV,
+                                         float* W, float* H, const float* sparsity, double* div_out, double* cost_out,
+                                         int32_t* n_iter_out) {
+    return sparse_nmf_multi_impl<float>(devices, n_dev, p, V, ldV, W, H, sparsity, div_out, cost_out, n_iter_out);
+}
