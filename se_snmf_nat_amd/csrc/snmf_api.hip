@@ -212,6 +212,7 @@ struct snmf_plan {
     int Fp = 0, rp = 0, Tp = 0, nf = 0, nk = 0;
     int Fm = 0, Fq = 0, xr = 0;
     int NT = 1, NWH = 8, NLH = 0;  // k_hstep: frame tile = 32*NT, NWH consumer + NLH loader waves
+    int TTH = 32, TTW = 32;        // frames per tile of k_hstep (NT == 1) / k_wstats; 16 = narrow tiles (images too big for 32 frames)
     bool hstep_rp = true;          // KL update launches of the (8, 1, 4) geometry use the role pipeline k_hstep_rp (SNMF_HSTEP_RP=0: k_hstep)
     int NKT = 8, NWB = 4, WPS = 2, NLW = 0;  // k_wstats template geometry (NLW loader waves)
     int n_fg = 1, n_kg = 1, n_chunks = 1;
@@ -410,10 +411,14 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     if (2 * lds1 - lds_extra <= lds_cap) { pl->NWH = 8; pl->NT = 1; pl->NLH = 4; }  // double-buffered
     else if (lds2 <= lds_cap && pl->Tp / 64 >= ctx->n_cu) { pl->NWH = 8; pl->NT = 2; }
     else if (lds1 <= lds_cap) { pl->NWH = 8; pl->NT = 1; }
-    else {
+    else if (16 * per_col + lds_extra <= lds_cap) {
+        // the H image + ratio image of 32 frames do not fit (F + r > 1272, e.g. the reference's exemplar setting
+        // R_x = R_d = 500 at F = 513, settings/bak_IS16_results/initial_setting_Exemplar.m:47-48): 16-frame tiles
+        pl->NWH = 8; pl->NT = 1; pl->TTH = 16;
+    } else {
         delete pl;
         return fail(SNMF_ERR_UNSUPPORTED, "F + r = %d too large for the %zu-byte LDS tile (limit F+r <= %zu)", F + r,
-                    lds_cap, lds_cap / 128 - 8);
+                    lds_cap, lds_cap / 64 - 16);
     }
     if (const char* e = getenv("SNMF_HSTEP_CFG")) {
         int nw = 0, nt = 0;
@@ -426,11 +431,11 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         }
     }
     if (const char* e = getenv("SNMF_HSTEP_RP")) pl->hstep_rp = atoi(e) != 0;
-    pl->lds_h = std::max<size_t>(pl->NLH ? 2 * lds1 - lds_extra : (pl->NT == 1 ? lds1 : lds2),
+    pl->lds_h = std::max<size_t>(pl->NLH ? 2 * lds1 - lds_extra : (pl->NT == 1 ? (size_t)pl->TTH * per_col + lds_extra : lds2),
                                  2 * kMaxNW * 64 * sizeof(double));
     pl->lds_mdi = std::max<size_t>(lds1, 2 * kMaxNW * 64 * sizeof(double));  // MDI pass: (NW=8, NT=1, NL=0)
     pl->grid_mdi = std::max(1, std::min(pl->Tp / 32, ctx->n_cu));
-    const int n_tiles_h = pl->Tp / (32 * pl->NT);
+    const int n_tiles_h = pl->Tp / (pl->TTH * pl->NT);
     // without loaders the NT == 1 kernels are register-bounded for two workgroups per CU
     int wg_per_cu = (pl->lds_h * 2 <= lds_cap && pl->NT == 1 && !pl->NLH) ? 2 : 1;
     if (const char* e = getenv("SNMF_WGPCU")) wg_per_cu = std::max(1, std::min(wg_per_cu, atoi(e)));  // experiments
@@ -443,11 +448,13 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     pl->NWB = 4;
     pl->n_kg = (pl->nk + pl->NKT - 1) / pl->NKT;
     pl->n_fg = (pl->nf + pl->NWB - 1) / pl->NWB;
-    const int n_tiles_w = pl->Tp / 32;
     // H image of k_wstats: rows padded to whole NKT-tile groups (branch-free P4, see the kernel)
     pl->ldhw = std::max(pl->rp, 32 * pl->NKT * pl->n_kg) + 4;
+    if (((size_t)32 * pl->ldhw + (size_t)32 * pl->Fp) * 4 + (size_t)pl->rp * 4 + 16 > lds_cap && pl->NKT == 16)
+        pl->TTW = 16;  // large r: 16-frame tiles (the 32-frame H + V images do not fit the LDS)
+    const int n_tiles_w = pl->Tp / pl->TTW;
     {
-        const size_t buf = ((size_t)32 * pl->ldhw + (size_t)32 * pl->Fp) * 4;
+        const size_t buf = ((size_t)pl->TTW * pl->ldhw + (size_t)pl->TTW * pl->Fp) * 4;
         // loaders + double buffering when the accumulators allow 2 waves per SIMD and LDS has room
         pl->NLW = (pl->WPS == 2 && 2 * buf + (size_t)pl->rp * 4 + 16 <= lds_cap) ? 4 : 0;
         if (const char* e = getenv("SNMF_WSTATS_NL")) pl->NLW = (atoi(e) == 4 && pl->NLW == 4) ? 4 : 0;
@@ -503,9 +510,11 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         delete pl;
         return fail(SNMF_ERR_UNSUPPORTED, "r = %d too large for the LDS H tile", r);
     }
-    if (pl->rp > 4 * pl->NWB * 64 && pl->upd_w && pl->bm == BM_KL) {
+    if (pl->rp > 4 * pl->NWB * 64 && pl->upd_w && (pl->bm == BM_KL || pl->xr)) {
+        // k_wstats keeps the row sums of H (KL) and the extra row of the slab (F = 32n+1) in per-thread registers: 1024 columns
         delete pl;
-        return fail(SNMF_ERR_UNSUPPORTED, "r = %d > %d not supported for KL W updates", r, 4 * pl->NWB * 64);
+        return fail(SNMF_ERR_UNSUPPORTED, "r = %d > %d not supported for W updates with %s", r, 4 * pl->NWB * 64,
+                    pl->bm == BM_KL ? "the KL divergence" : "F = 32n+1 rows");
     }
 
     // persistent single-launch path for the online shape (H-only, at most one 32-frame tile)
@@ -611,7 +620,7 @@ extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
              "F=%d T=%d r=%d beta=%g | Fm=%d(+%d VALU row) rp=%d Tp=%d | hstep: %s, tile=%d frames, grid=%d x %d thr, lds=%zu B | "
              "wstats: NK=%d waves=%d+%d grid=(%d chunks,%d fgroups,%d kgroups; group-1 chunks %d) lds=%zu B | n_cu=%d",
              pl->p.F, pl->p.T, pl->p.r, pl->p.beta, pl->Fm, pl->xr, pl->rp, pl->Tp,
-             kl_pipe ? "k_hstep_rp (4 P1 + 4 P2 + 4 loader waves)" : "k_hstep", 32 * pl->NT, pl->grid_h, (pl->NWH + pl->NLH) * 64,
+             kl_pipe ? "k_hstep_rp (4 P1 + 4 P2 + 4 loader waves)" : "k_hstep", pl->TTH * pl->NT, pl->grid_h, (pl->NWH + pl->NLH) * 64,
              pl->lds_h, pl->NKT, pl->NWB, pl->NLW, pl->n_chunks, pl->n_fg, pl->n_kg, pl->n_ch1 ? pl->n_ch1 : pl->n_chunks, pl->lds_w,
              pl->ctx->n_cu);
     return SNMF_OK;
@@ -699,6 +708,8 @@ template <typename T>
 static int set_mask(snmf_plan* pl, const T* M, int64_t ld, int dev) {
     PLAN_CHECK(pl);
     if (!pl->upd_h && !pl->upd_w) return fail(SNMF_ERR_UNSUPPORTED, "MDI with neither factor updated is not implemented");
+    if (pl->TTH != 32 || pl->TTW != 32)
+        return fail(SNMF_ERR_UNSUPPORTED, "MDI needs the 32-frame tile images in LDS: F + r = %d is too large", pl->p.F + pl->p.r);
     if (!pl->M) {
         SN_TRY(dalloc(&pl->M, (size_t)pl->Fp * pl->Tp));
     }
@@ -823,20 +834,20 @@ static int launch_big(K kern, dim3 grid, dim3 block, size_t lds, hipStream_t st,
 }
 
 // k_hstep dispatch over (NW, NT, NL, BM, OBJ, UPD)
-template <int NW, int NT, int NL, int BM>
+template <int NW, int NT, int NL, int BM, int TT>
 static int launch_hstep_nb(snmf_plan* pl, const StepArgs& a, bool obj, bool upd) {
     dim3 g(pl->grid_h), b((NW + NL) * 64);
     hipStream_t st = pl->ctx->stream;
-    if (obj && upd) return launch_big(k_hstep<NW, NT, NL, BM, true, true>, g, b, pl->lds_h, st, a);
-    if (!obj && upd) return launch_big(k_hstep<NW, NT, NL, BM, false, true>, g, b, pl->lds_h, st, a);
-    if (obj && !upd) return launch_big(k_hstep<NW, NT, NL, BM, true, false>, g, b, pl->lds_h, st, a);
+    if (obj && upd) return launch_big(k_hstep<NW, NT, NL, BM, true, true, false, TT>, g, b, pl->lds_h, st, a);
+    if (!obj && upd) return launch_big(k_hstep<NW, NT, NL, BM, false, true, false, TT>, g, b, pl->lds_h, st, a);
+    if (obj && !upd) return launch_big(k_hstep<NW, NT, NL, BM, true, false, false, TT>, g, b, pl->lds_h, st, a);
     return SNMF_OK;
 }
-template <int NW, int NT, int NL>
+template <int NW, int NT, int NL, int TT = 32>
 static int launch_hstep_g(snmf_plan* pl, const StepArgs& a, bool obj, bool upd) {
-    if (pl->bm == BM_KL) return launch_hstep_nb<NW, NT, NL, BM_KL>(pl, a, obj, upd);
-    if (pl->bm == BM_EUC) return launch_hstep_nb<NW, NT, NL, BM_EUC>(pl, a, obj, upd);
-    return launch_hstep_nb<NW, NT, NL, BM_GEN>(pl, a, obj, upd);
+    if (pl->bm == BM_KL) return launch_hstep_nb<NW, NT, NL, BM_KL, TT>(pl, a, obj, upd);
+    if (pl->bm == BM_EUC) return launch_hstep_nb<NW, NT, NL, BM_EUC, TT>(pl, a, obj, upd);
+    return launch_hstep_nb<NW, NT, NL, BM_GEN, TT>(pl, a, obj, upd);
 }
 // MDI pass (src/snmf_mdi.m:251-257 fused into the Lam pass): synchronous-staging geometry, V rewritten in place
 template <int BM>
@@ -849,7 +860,7 @@ static int launch_hstep_mdi_b(snmf_plan* pl, const StepArgs& a, bool obj, bool u
 }
 static int launch_hstep(snmf_plan* pl, bool obj, bool upd) {
     StepArgs a = make_args(pl);
-    a.n_tiles = pl->Tp / (32 * pl->NT);
+    a.n_tiles = pl->Tp / (pl->TTH * pl->NT);
     a.stagger = pl->stagger_h;
     ScopedTimer tm(pl->ctx, FAM_HSTEP);
     if (pl->M) {
@@ -871,45 +882,47 @@ static int launch_hstep(snmf_plan* pl, bool obj, bool upd) {
         return launch_hstep_g<8, 1, 4>(pl, a, obj, upd);
     }
     if (pl->NWH == 4) return pl->NT == 2 ? launch_hstep_g<4, 2, 0>(pl, a, obj, upd) : launch_hstep_g<4, 1, 0>(pl, a, obj, upd);
+    if (pl->TTH == 16) return launch_hstep_g<8, 1, 0, 16>(pl, a, obj, upd);
     return pl->NT == 2 ? launch_hstep_g<8, 2, 0>(pl, a, obj, upd) : launch_hstep_g<8, 1, 0>(pl, a, obj, upd);
 }
 
 // k_wstats dispatch
-template <int NK, int NWB, int NL, int WPS, int WM, int BM, bool OBJ>
+template <int NK, int NWB, int NL, int WPS, int WM, int BM, bool OBJ, int TT = 32>
 static int launch_wstats_one(snmf_plan* pl, const StepArgs& a, int mat_index) {
     const bool split = pl->n_ch1 > 0 && !OBJ;  // uneven row-group split: 1-D grid, group 0's chunks first
     dim3 g(split ? pl->n_chunks + pl->n_ch1 : pl->n_chunks, split ? 1 : pl->n_fg, pl->n_kg), b((NWB + NL) * 64);
     StepArgs as = a;
     as.n_ch1 = split ? pl->n_ch1 : 0;
-    auto kern = k_wstats<NK, NWB, NL, WPS, WM, BM, OBJ>;
+    auto kern = k_wstats<NK, NWB, NL, WPS, WM, BM, OBJ, TT>;
     SN_TRY(ensure_dyn_lds(pl->ctx->device, (const void*)kern, pl->lds_w));
     hipLaunchKernelGGL(kern, g, b, pl->lds_w, pl->ctx->stream, as, pl->n_chunks, mat_index, pl->n_mat);
     HIP_TRY(hipGetLastError());
     return SNMF_OK;
 }
-template <int NK, int NWB, int NL, int WPS>
+template <int NK, int NWB, int NL, int WPS, int TT = 32>
 static int launch_wstats_geo(snmf_plan* pl, const StepArgs& a, bool obj) {
     if (pl->bm == BM_KL) {
-        return obj ? launch_wstats_one<NK, NWB, NL, WPS, 0, BM_KL, true>(pl, a, 0)
-                   : launch_wstats_one<NK, NWB, NL, WPS, 0, BM_KL, false>(pl, a, 0);
+        return obj ? launch_wstats_one<NK, NWB, NL, WPS, 0, BM_KL, true, TT>(pl, a, 0)
+                   : launch_wstats_one<NK, NWB, NL, WPS, 0, BM_KL, false, TT>(pl, a, 0);
     }
     if (pl->bm == BM_EUC) {
-        SN_TRY(obj ? (launch_wstats_one<NK, NWB, NL, WPS, 1, BM_EUC, true>(pl, a, 1))
-                   : (launch_wstats_one<NK, NWB, NL, WPS, 1, BM_EUC, false>(pl, a, 1)));
-        return launch_wstats_one<NK, NWB, NL, WPS, 3, BM_EUC, false>(pl, a, 0);
+        SN_TRY(obj ? (launch_wstats_one<NK, NWB, NL, WPS, 1, BM_EUC, true, TT>(pl, a, 1))
+                   : (launch_wstats_one<NK, NWB, NL, WPS, 1, BM_EUC, false, TT>(pl, a, 1)));
+        return launch_wstats_one<NK, NWB, NL, WPS, 3, BM_EUC, false, TT>(pl, a, 0);
     }
-    SN_TRY(obj ? (launch_wstats_one<NK, NWB, NL, WPS, 1, BM_GEN, true>(pl, a, 1))
-               : (launch_wstats_one<NK, NWB, NL, WPS, 1, BM_GEN, false>(pl, a, 1)));
-    return launch_wstats_one<NK, NWB, NL, WPS, 2, BM_GEN, false>(pl, a, 0);
+    SN_TRY(obj ? (launch_wstats_one<NK, NWB, NL, WPS, 1, BM_GEN, true, TT>(pl, a, 1))
+               : (launch_wstats_one<NK, NWB, NL, WPS, 1, BM_GEN, false, TT>(pl, a, 1)));
+    return launch_wstats_one<NK, NWB, NL, WPS, 2, BM_GEN, false, TT>(pl, a, 0);
 }
 static int launch_wstats(snmf_plan* pl, bool obj) {
     StepArgs a = make_args(pl);
-    a.n_tiles = pl->Tp / 32;
+    a.n_tiles = pl->Tp / pl->TTW;
     a.ldh = pl->ldhw;
     a.stagger = pl->stagger_w;
     ScopedTimer tm(pl->ctx, FAM_WSTATS);
     if (pl->NKT == 4) return pl->NLW ? launch_wstats_geo<4, 4, 4, 2>(pl, a, obj) : launch_wstats_geo<4, 4, 0, 2>(pl, a, obj);
     if (pl->NKT == 8) return pl->NLW ? launch_wstats_geo<8, 4, 4, 2>(pl, a, obj) : launch_wstats_geo<8, 4, 0, 2>(pl, a, obj);
+    if (pl->TTW == 16) return launch_wstats_geo<16, 4, 0, 1, 16>(pl, a, obj);
     return launch_wstats_geo<16, 4, 0, 1>(pl, a, obj);
 }
 

@@ -415,11 +415,17 @@ constexpr int kPF = 20;  // f32x4 a loader thread keeps in flight (covers 32*(rp
 // destroyed by the in-place ratio, and V is L2-resident there) instead of the staged LDS image.
 // MDI (src/snmf_mdi.m:251-257): the Lam this pass forms is also the estimate that re-imputes V,
 //   v <- max(v.*M + Lam.*(1-M), flr), written back for the W step, BEFORE the objective and the ratio use it.
-template <int NW, int NT, int BM, bool OBJ, bool VG = false, bool MDI = false>
+// TT < 32 (NT == 1 only): NARROW tiles of TT frames for shapes whose 32-frame images do not fit the LDS (F + r > 1272).
+// The MFMAs still span 32 columns; lanes fl >= TT feed them a duplicate of frame fl & (TT-1) and take no part in any
+// epilogue, so (32-TT)/32 of the matrix work of this fallback path is wasted and nothing else changes.
+template <int NW, int NT, int BM, bool OBJ, bool VG = false, bool MDI = false, int TT = 32>
 __device__ __forceinline__ void hstep_p1_tiles(const StepArgs& a, float* Hs, float* Rs, int t0, int w, int lane,
                                                bool upd, double& acc_div) {
-    constexpr int Tt = 32 * NT;
+    constexpr int Tt = NT == 1 ? TT : 32 * NT;
+    static_assert(TT == 32 || (NT == 1 && (TT == 16 || TT == 8)), "narrow tiles: one sub-tile of 16 or 8 frames");
     const int fl = lane & 31, h = lane >> 5;
+    const int flt = fl & (Tt < 32 ? Tt - 1 : 31);  // LDS / global row this lane addresses
+    const bool fvalid = Tt >= 32 || fl < Tt;
     const int rp = a.rp, ldh = a.ldh, ldr = a.ldr;
     // ---- P1: Lam[phi] = W[phi,:] * H[:, tile]  -> ratio / den image (in place over the staged V)
     for (int phi = w; phi < a.nf; phi += NW) {
@@ -433,16 +439,17 @@ __device__ __forceinline__ void hstep_p1_tiles(const StepArgs& a, float* Hs, flo
             for (int tau = 0; tau < NT; ++tau)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const size_t off = (size_t)(t0 + tau * 32 + fl) * a.Fp + phi * 32 + 4 * h + 8 * g;
+                    const size_t off = (size_t)(t0 + tau * 32 + flt) * a.Fp + phi * 32 + 4 * h + 8 * g;
                     vfr[tau][g] = *reinterpret_cast<const f32x4*>(a.V + off);
                     if (MDI) mfr[tau][g] = *reinterpret_cast<const f32x4*>(a.M + off);
                 }
         }
-        contract<NT, false>(acc, wp, Hs + fl * ldh + 4 * h, 32 * ldh, rp / 8);
+        contract<NT, false>(acc, wp, Hs + flt * ldh + 4 * h, 32 * ldh, rp / 8);
         // epilogue: lane (t = fl, h), reg -> f = 32*phi + drow(reg,h)
         float dsum = 0.f;
 #pragma unroll
         for (int tau = 0; tau < NT; ++tau) {
+            if (!fvalid) break;
             const int t = t0 + tau * 32 + fl;
             float* rsp = Rs + (tau * 32 + fl) * ldr + phi * 32 + 4 * h;
 #pragma unroll
@@ -504,14 +511,15 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 }
 
 // extra row (F = 32*nf + 1): lam_x[t] = sum_k W[Fm,k] H[k,t] on the VALU, 4 columns x 16 lanes at a time
-template <int NW, int NT, int BM, bool OBJ, bool VG = false, bool MDI = false>
+template <int NW, int NT, int BM, bool OBJ, bool VG = false, bool MDI = false, int TT = 32>
 __device__ __forceinline__ void hstep_p1_xrow(const StepArgs& a, float* Hs, float* Rs, const float* wxs, int t0, int w,
                                               int lane, bool upd, double& acc_div) {
-    constexpr int Tt = 32 * NT;
+    constexpr int Tt = NT == 1 ? TT : 32 * NT;
     const int rp = a.rp, ldh = a.ldh, ldr = a.ldr;
-    if (a.xr) {
+    // narrow tiles: fewer than 4 frames per wave -> the first Tt/4 waves take 4 frames each
+    constexpr int CPW = Tt >= 4 * NW ? Tt / NW : 4;
+    if (a.xr && w * CPW < Tt) {
         // extra row: lam_x[t] = sum_k W[Fm,k] H[k,t]; 4 columns x 16 lanes at a time
-        constexpr int CPW = Tt / NW;
         float dsum = 0.f;
 #pragma unroll
         for (int c0 = 0; c0 < CPW; c0 += 4) {
@@ -546,24 +554,25 @@ __device__ __forceinline__ void hstep_p1_xrow(const StepArgs& a, float* Hs, floa
 // P1 of one wave.  The second half of the waves (the SIMD partners of the first half) run their
 // VALU-only extra-row work FIRST: the two waves of a SIMD then reach their MFMA loops, and later
 // their VALU epilogues, at different times instead of colliding on both.
-template <int NW, int NT, int BM, bool OBJ, bool VG = false, bool MDI = false>
+template <int NW, int NT, int BM, bool OBJ, bool VG = false, bool MDI = false, int TT = 32>
 __device__ __forceinline__ void hstep_p1(const StepArgs& a, float* Hs, float* Rs, const float* wxs, int t0, int w,
                                          int lane, bool upd, double& acc_div) {
     const bool xfirst = a.xr && (w >= NW / 2);
-    if (xfirst) hstep_p1_xrow<NW, NT, BM, OBJ, VG, MDI>(a, Hs, Rs, wxs, t0, w, lane, upd, acc_div);
-    hstep_p1_tiles<NW, NT, BM, OBJ, VG, MDI>(a, Hs, Rs, t0, w, lane, upd, acc_div);
-    if (a.xr && !xfirst) hstep_p1_xrow<NW, NT, BM, OBJ, VG, MDI>(a, Hs, Rs, wxs, t0, w, lane, upd, acc_div);
+    if (xfirst) hstep_p1_xrow<NW, NT, BM, OBJ, VG, MDI, TT>(a, Hs, Rs, wxs, t0, w, lane, upd, acc_div);
+    hstep_p1_tiles<NW, NT, BM, OBJ, VG, MDI, TT>(a, Hs, Rs, t0, w, lane, upd, acc_div);
+    if (a.xr && !xfirst) hstep_p1_xrow<NW, NT, BM, OBJ, VG, MDI, TT>(a, Hs, Rs, wxs, t0, w, lane, upd, acc_div);
 }
 
 // beta != 1: in-place transform of this wave's part of the image, den = lam^(b-1) -> num = V .* lam^(b-2)
-template <int NW, int NT, int BM>
+template <int NW, int NT, int BM, int TT = 32>
 __device__ __forceinline__ void hstep_den_to_num(const StepArgs& a, float* Rs, int t0, int w, int lane) {
-    constexpr int Tt = 32 * NT;
+    constexpr int Tt = NT == 1 ? TT : 32 * NT;
     const int fl = lane & 31, h = lane >> 5;
     const int Fp = a.Fp, ldr = a.ldr;
     for (int phi = w; phi < a.nf; phi += NW) {
 #pragma unroll
         for (int tau = 0; tau < NT; ++tau) {
+            if (Tt < 32 && fl >= Tt) break;  // narrow tiles: lanes past the tile own no frame
             const int t = t0 + tau * 32 + fl;
             const float* vp = a.V + (size_t)t * Fp + phi * 32 + 4 * h;
             float* rsp = Rs + (tau * 32 + fl) * ldr + phi * 32 + 4 * h;
@@ -585,8 +594,8 @@ __device__ __forceinline__ void hstep_den_to_num(const StepArgs& a, float* Rs, i
             }
         }
     }
-    if (a.xr) {
-        constexpr int CPW = Tt / NW;
+    constexpr int CPW = Tt >= 4 * NW ? Tt / NW : 4;
+    if (a.xr && w * CPW < Tt) {
         if ((lane & 15) == 0) {
 #pragma unroll
             for (int c0 = 0; c0 < CPW; c0 += 4) {
@@ -604,10 +613,13 @@ __device__ __forceinline__ void hstep_den_to_num(const StepArgs& a, float* Rs, i
 
 // ---- P2: contraction over f with W^T.  KL: dmh = W^T*ratio; H <- H .* dmh ./ dphv.
 // beta != 1, pass 0: dph = W^T*den + S; Hs <- H ./ max(dph, flr);   pass 1: dmh = W^T*num; H <- Hs .* dmh
-template <int NW, int NT, int BM, bool OBJ>
+template <int NW, int NT, int BM, bool OBJ, int TT = 32>
 __device__ __forceinline__ void hstep_p2(const StepArgs& a, float* Hs, const float* Rs, int t0, int w, int lane,
                                          int pass, double& acc_sh) {
+    constexpr int Tt = NT == 1 ? TT : 32 * NT;
     const int fl = lane & 31, h = lane >> 5;
+    const int flt = fl & (Tt < 32 ? Tt - 1 : 31);
+    const bool fvalid = Tt >= 32 || fl < Tt;
     const int rp = a.rp, ldh = a.ldh, ldr = a.ldr;
     for (int kap = w; kap < a.nk; kap += NW) {
         f32x16 acc[NT];
@@ -624,11 +636,12 @@ __device__ __forceinline__ void hstep_p2(const StepArgs& a, float* Hs, const flo
                 if (OBJ || BM != BM_KL) spf[g] = *reinterpret_cast<const f32x4*>(a.lamk + k0);
             }
         }
-        contract<NT, false>(acc, wp, Rs + fl * ldr + 4 * h, 32 * ldr, a.Fq / 8);
+        contract<NT, false>(acc, wp, Rs + flt * ldr + 4 * h, 32 * ldr, a.Fq / 8);
         // epilogue: lane (t = fl, h), reg -> k = 32*kap + drow(reg,h)
         float shsum = 0.f;
 #pragma unroll
         for (int tau = 0; tau < NT; ++tau) {
+            if (!fvalid) break;
             const int t = t0 + tau * 32 + fl;
             float* hsp = Hs + (tau * 32 + fl) * ldh + kap * 32 + 4 * h;
 #pragma unroll
@@ -687,14 +700,15 @@ __device__ __forceinline__ void hstep_p2(const StepArgs& a, float* Hs, const flo
 // tile instead of two, and a wave's epilogue overlaps its neighbours' MFMA loop across the tile boundary.  The
 // loaders' wait is a bounded spin: a lost signal raises DevState::fault (the host then fails the call), never a hang.
 // ============================================================================================
-template <int NW, int NT, int NL, int BM, bool OBJ, bool UPD, bool MDI = false>
+template <int NW, int NT, int NL, int BM, bool OBJ, bool UPD, bool MDI = false, int TT = 32>
 __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(StepArgs a) {
     static_assert(!MDI || NL == 0, "the MDI pass reads and rewrites V in global memory: synchronous staging only");
+    static_assert(TT == 32 || (NL == 0 && NT == 1 && !MDI), "narrow tiles: synchronous staging, one sub-tile");
     constexpr int NTHR = (NW + NL) * 64;
     constexpr int NBUF = NL > 0 ? 2 : 1;
     if (a.stop && *a.stop) return;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int Tt = 32 * NT;
+    constexpr int Tt = NT == 1 ? TT : 32 * NT;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int rp = a.rp, Fp = a.Fp, ldh = a.ldh, ldr = a.ldr;
     const int bufsz = Tt * (ldh + ldr);  // floats per buffer: Hs [Tt][ldh] then Rs [Tt][ldr]
@@ -782,19 +796,19 @@ __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(Step
             }
             SNMF_STAMP(2);
             SNMF_STAMP_TILE(a.prof, blockIdx.x, it);
-            hstep_p1<NW, NT, BM, OBJ, false, MDI>(a, Hs, Rs, wxs, t0, w, lane, UPD, acc_div);
+            hstep_p1<NW, NT, BM, OBJ, false, MDI, TT>(a, Hs, Rs, wxs, t0, w, lane, UPD, acc_div);
             SNMF_STAMP(4);
             if (UPD || NL > 0) __syncthreads();  // B2
             SNMF_STAMP(7);
             if (UPD) {
-                hstep_p2<NW, NT, BM, OBJ>(a, Hs, Rs, t0, w, lane, 0, acc_sh);
+                hstep_p2<NW, NT, BM, OBJ, TT>(a, Hs, Rs, t0, w, lane, 0, acc_sh);
                 SNMF_STAMP(9);
                 if (NPASS == 2) {
                     __syncthreads();  // every wave finished reading the den image
-                    hstep_den_to_num<NW, NT, BM>(a, Rs, t0, w, lane);
+                    hstep_den_to_num<NW, NT, BM, TT>(a, Rs, t0, w, lane);
                     __syncthreads();
                     double dummy = 0.0;
-                    hstep_p2<NW, NT, BM, false>(a, Hs, Rs, t0, w, lane, 1, dummy);
+                    hstep_p2<NW, NT, BM, false, TT>(a, Hs, Rs, t0, w, lane, 1, dummy);
                 }
                 if (NL == 0) {
                     __syncthreads();  // the updated H tile leaves through one coalesced copy
@@ -1647,14 +1661,17 @@ __global__ __launch_bounds__(512, 2) void k_hsolve_frame(StepArgs a, SmallArgs s
 // while the NWB consumer waves -- ONE per SIMD, so nothing contends for the matrix pipe -- run
 // P3/P4 on tile i; one barrier per tile.  NL = 0: consumers stage synchronously (two workgroups per
 // CU when the accumulators leave room).
-template <int NK, int NWB, int NL, int WPS, int WM, int BM, bool OBJ>
+// TT = frames per tile (32; 16 = narrow tiles for shapes whose 32-frame H image does not fit the LDS: lanes / rows past
+// the tile carry duplicates that are masked out of the ratio, P4 contracts over TT frames only, P3 wastes half its MFMAs).
+template <int NK, int NWB, int NL, int WPS, int WM, int BM, bool OBJ, int TT = 32>
 __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int n_chunks, int mat_index,
                                                                  int n_mat) {
+    static_assert(TT == 32 || (TT == 16 && NL == 0), "narrow tiles: 16 frames, synchronous staging");
     constexpr int NTHR = (NWB + NL) * 64;
     constexpr int NBUF = NL > 0 ? 2 : 1;
     if (a.stop && *a.stop) return;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int bufsz = 32 * (a.ldh + a.Fp);  // floats per buffer: Hs [32][ldh] then Vs [32][Fp]
+    const int bufsz = TT * (a.ldh + a.Fp);  // floats per buffer: Hs [TT][ldh] then Vs [TT][Fp]
     float* wxs = lds + NBUF * bufsz;        // [rp] extra row of W
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const bool is_loader = NL > 0 && w >= NWB;
@@ -1673,7 +1690,8 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         }
     }
     const bool do_x = a.xr && by == 0 && blockIdx.z == 0;  // extra row: one f-group only
-    constexpr int CPW = 32 / NWB;  // columns of the extra-row dot product per wave
+    constexpr int CPW = TT / NWB;  // columns of the extra-row dot product per wave
+    static_assert(CPW % 4 == 0, "the extra row takes 4 frames x 16 lanes at a time");
     float gx[16];                  // extra row of the slab: lane <-> k = lane + 64*i  (rp <= 1024)
 #pragma unroll
     for (int i = 0; i < 16; ++i) gx[i] = 0.f;
@@ -1730,8 +1748,8 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     if (is_loader) {
         // ================================ loader role =========================================
         if (tb < te) {
-            stage_in<NST>(a.Hin + (size_t)tb * 32 * rp, lds, 32, rp, ldh, sid);
-            stage_in<NST>(a.V + (size_t)tb * 32 * Fp, lds + 32 * ldh, 32, Fp, Fp, sid);
+            stage_in<NST>(a.Hin + (size_t)tb * TT * rp, lds, TT, rp, ldh, sid);
+            stage_in<NST>(a.V + (size_t)tb * TT * Fp, lds + TT * ldh, TT, Fp, Fp, sid);
             arrive(ready);
         }
         for (int tile = tb, it = 0; tile < te; ++tile, ++it) {
@@ -1744,15 +1762,15 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
                     const int k = sid + j * NST;
                     if (k < rp) {
                         float sacc = 0.f;
-                        for (int t = 0; t < 32; ++t) sacc += cH[t * ldh + k];
+                        for (int t = 0; t < TT; ++t) sacc += cH[t * ldh + k];
                         ssum[j] += sacc;
                     }
                 }
             }
             if (tile + 1 < te) {
                 await(done, (unsigned)(NWB * it));  // every consumer has finished tile-1, which lives in nH
-                stage_in2<NST, 10, 10>(a.Hin + (size_t)(tile + 1) * 32 * rp, nH, 32, rp, ldh,
-                                       a.V + (size_t)(tile + 1) * 32 * Fp, nH + 32 * ldh, 32, Fp, Fp, sid);
+                stage_in2<NST, 10, 10>(a.Hin + (size_t)(tile + 1) * TT * rp, nH, TT, rp, ldh,
+                                       a.V + (size_t)(tile + 1) * TT * Fp, nH + TT * ldh, TT, Fp, Fp, sid);
                 arrive(ready);
             }
         }
@@ -1760,14 +1778,14 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
 
     SNMF_STAMP_DECL
     for (int tile = tb, it = 0; tile < te && !is_loader; ++tile, ++it) {
-        const int t0 = tile * 32;
+        const int t0 = tile * TT;
         SNMF_STAMP(0);
         float* Hs = lds + (NL > 0 ? (it & 1) * bufsz : 0);  // [32][ldh]
-        float* Vs = Hs + 32 * ldh;                            // [32][Fp]  (no HBM access in the MFMA loops)
+        float* Vs = Hs + TT * ldh;                            // [TT][Fp]  (no HBM access in the MFMA loops)
         if (NL == 0) {
             __syncthreads();
-            stage_in<NST>(a.Hin + (size_t)t0 * rp, Hs, 32, rp, ldh, sid);
-            stage_in<NST>(a.V + (size_t)t0 * Fp, Vs, 32, Fp, Fp, sid);
+            stage_in<NST>(a.Hin + (size_t)t0 * rp, Hs, TT, rp, ldh, sid);
+            stage_in<NST>(a.V + (size_t)t0 * Fp, Vs, TT, Fp, Fp, sid);
             __syncthreads();
         } else {
             await(ready, (unsigned)(NL * (it + 1)));
@@ -1779,7 +1797,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
                 const int k = sid + j * NST;
                 if (k < rp) {
                     float sacc = 0.f;
-                    for (int t = 0; t < 32; ++t) sacc += Hs[t * ldh + k];
+                    for (int t = 0; t < TT; ++t) sacc += Hs[t * ldh + k];
                     ssum[j] += sacc;
                 }
             }
@@ -1843,7 +1861,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
 #ifndef SNMF_WSTATS_DUAL
 #define SNMF_WSTATS_DUAL 0  // measured on C2: 0.2488 ms with the two chains against 0.2475 without -- the dependent chain is not what P3 waits for
 #endif
-            contract_sb<1, true, 2, SNMF_WSTATS_DUAL != 0>(acc1, wp, Hs + fl * ldh + 4 * h, 0, rp / 8);
+            contract_sb<1, true, 2, SNMF_WSTATS_DUAL != 0>(acc1, wp, Hs + (fl & (TT - 1)) * ldh + 4 * h, 0, rp / 8);
             SNMF_STAMP(3);
             const f32x16 acc = acc1[0];
             // lane (f = fl, h), reg -> t = t0 + drow(reg,h)
@@ -1851,6 +1869,10 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
             float dsum = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
+                if (TT < 32 && i >= TT / 2) {  // rows drow(i,h) >= TT: duplicates of the narrow tile
+                    R[i] = 0.f;
+                    continue;
+                }
                 const int t = t0 + drow(i, h);
                 const float v = Vs[drow(i, h) * Fp + f];
                 float lam = fmaxf(acc[i], kFlr);
@@ -1868,7 +1890,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         } else {
             const int f = phi * 32 + fl;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) R[i] = Vs[drow(i, h) * Fp + f];
+            for (int i = 0; i < 16; ++i) R[i] = (TT < 32 && i >= TT / 2) ? 0.f : Vs[drow(i, h) * Fp + f];
         }
         // ---- P4: G[phi, kap] += ratio[f, t] * H[k, t]  (A = ratio registers, B = H from LDS)
         // B fragments (one ds_read_b32 per MFMA) are fetched a whole kappa-tile (16 reads) ahead.
@@ -1885,7 +1907,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         float b0[16], b1[16];
         auto ldb = [&](float (&b)[16], int kap) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) b[i] = hrow[i][kap * 32];
+            for (int i = 0; i < TT / 2; ++i) b[i] = hrow[i][kap * 32];
         };
         // two named buffers alternate (a register copy would have to wait for the load it follows);
         // the tile index is a compile-time constant so that G[] is never indexed dynamically
@@ -1893,7 +1915,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     if constexpr ((KP) < NK) {                                                    \
         if constexpr ((KP) + 1 < NK) ldb(NXT, (KP) + 1);                          \
         SNMF_PIN();                                                               \
-        _Pragma("unroll") for (int i = 0; i < 16; ++i) G[KP] = mfma32(R[i], CUR[i], G[KP]); \
+        _Pragma("unroll") for (int i = 0; i < TT / 2; ++i) G[KP] = mfma32(R[i], CUR[i], G[KP]); \
     }
         ldb(b0, 0);
         SNMF_KTILE(0, b0, b1)

@@ -103,6 +103,13 @@ CASES = [
     ("b05_full", 257, 640, 40, dict(cf="beta", beta=0.5, sparsity=1, max_iter=20), None, None),
     ("b15_r300", 129, 300, 300, dict(cf="beta", beta=1.5, sparsity=1, max_iter=10), None, None),
     ("b3_full", 65, 200, 16, dict(cf="beta", beta=3.0, sparsity=1, max_iter=10), None, None),
+    # F + r > 1272: the 32-frame LDS images do not fit -> 16-frame tiles (the reference's exemplar setting R_x = R_d = 500
+    # at F = 513, settings/bak_IS16_results/initial_setting_Exemplar.m:47-48; src/bnmf_sep_event_RT_IS16.m:138-154)
+    ("kl_r1000_honly", 513, 64, 1000, dict(cf="kl", sparsity=5, max_iter=8, conv_eps=1e-3), "none", None),
+    ("kl_r1000_full", 513, 300, 1000, dict(cf="kl", sparsity=5, max_iter=4), None, None),
+    ("kl_r1000_wonly", 513, 200, 1000, dict(cf="kl", sparsity=5, max_iter=4), None, "none"),
+    ("ed_r1000_full", 513, 200, 1000, dict(cf="ed", sparsity=1, max_iter=3), None, None),
+    ("b05_r800_513", 513, 150, 800, dict(cf="beta", beta=0.5, sparsity=1, max_iter=3), None, None),
 ]
 
 
@@ -471,3 +478,17 @@ def test_dnmf_adapt_caller(gpu_ctx):
     q = dict(p, w_update_ind=np.ones(6, bool), h_update_ind=np.zeros(6, bool), init_w=W0[:, 8:], init_h=A[8:, :])
     ref, _, _ = oracle_nmf(D, q)
     assert B_a.shape == (129, 6) and rel(B_a, ref) < REL_WH
+
+
+def test_shape_limits_are_reported(gpu_ctx):
+    """What the engine cannot hold in LDS / registers is refused with SNMF_ERR_UNSUPPORTED and a message, never run
+    wrongly: F + r beyond the 16-frame tile images (~2540), and W updates with r > 1024 under KL or with F = 32n+1 rows
+    (src/sparse_nmf.m itself has no such limit; DESIGN.md section 7 lists them)."""
+    from se_snmf_nat_amd import Plan, SnmfError
+    with pytest.raises(SnmfError) as e:
+        Plan(gpu_ctx, 513, 64, 2100, beta=1.0, max_iter=2, cost_check=True)
+    assert e.value.status == 8 and "too large" in e.value.message
+    with pytest.raises(SnmfError) as e:
+        Plan(gpu_ctx, 512, 64, 1100, beta=1.0, max_iter=2, cost_check=True)
+    assert e.value.status == 8 and "W updates" in e.value.message
+    Plan(gpu_ctx, 512, 64, 1100, beta=1.0, max_iter=2, cost_check=True, w_update_ind=np.zeros(1100, bool)).close()  # H-only is fine
