@@ -1823,7 +1823,8 @@ static int online_make_solvers(snmf_online* o) {
     hp.w_update_ind = zeros.data();  // supervised (:139)
     hp.h_update_ind = ones.data();   // :148
     A(snmf_plan_create(ctx, &hp, &o->hp));
-    if (s == SNMF_OK && !o->hp->small_ok) A(fail(SNMF_ERR_UNSUPPORTED, "F + r too large for the persistent frame-solve kernel"));
+    // !small_ok (F + r too large for the persistent single-launch kernels, e.g. the exemplar setting R_x = R_d = 500 of
+    // settings/bak_IS16_results/initial_setting_Exemplar.m:47-48): the frame solve runs through the ordinary plan loop
     if (p->basis_update_N || p->basis_update_E) {
         snmf_params sp = hp;
         std::vector<uint8_t> wm(r, 0);
@@ -2007,7 +2008,7 @@ static int online_reserve(snmf_online* o, int n) {
     SN_TRY(dalloc(&o->syn, (size_t)(cap + o->nov - 1) * sz));
     SN_TRY(dalloc(&o->outf, (size_t)cap * hop));
     SN_TRY(dalloc(&o->out16, (size_t)cap * hop));
-    if (!o->p.adapt_train_N && !o->hsemi) {
+    if (!o->p.adapt_train_N && !o->hsemi && o->hp->small_ok) {
         snmf_params bp = o->hp->p;
         bp.T = cap;
         std::vector<uint8_t> zeros(o->r, 0), ones(o->r, 1);
@@ -2057,6 +2058,19 @@ static int online_solve_frame(snmf_online* o, const float* dV, const float** A_o
         return SNMF_OK;
     }
     snmf_plan* pl = o->hp;
+    if (!pl->small_ok) {
+        // large rank: the ordinary plan loop (16-frame tiles), one solve per frame; reconstructions are formed in k_opost
+        SN_TRY(set_v<float>(pl, dV, o->Fs, 1));
+        SN_TRY(set_h<float>(pl, o->H0, o->r, 1));
+        SN_TRY(snmf_plan_init(pl));  // W and its norms are reused unless the adaptation has replaced the dictionary
+        SN_TRY(snmf_plan_run(pl, o->p.max_iter, nullptr));
+        int idx = 0;
+        SN_TRY(result_h_index(pl, &idx));
+        *A_out = pl->H[idx];
+        *st_out = pl->st;
+        *recon_out = nullptr;
+        return SNMF_OK;
+    }
     *A_out = pl->H[0];
     *st_out = o->hst;
     *recon_out = (pl->frame_fb && (!o->mel || o->mel_conv)) ? o->recon1 : nullptr;  // Mel without MelConv: B_DFT*A, formed in k_opost
@@ -2180,7 +2194,7 @@ static int online_run_frames(snmf_online* o, const std::vector<float>& sig, int 
         a.recon_len = o->Fs;
         return a;
     };
-    if (!p.adapt_train_N && !o->hsemi) {
+    if (!p.adapt_train_N && !o->hsemi && o->hb) {
         // Fixed dictionary: nothing the host decides sits between frames.  All frame solves of the batch run
         // in ONE launch (one workgroup per frame, W normalised once), then ONE k_opost launch walks the
         // sequential post-filter recurrences.

@@ -215,6 +215,10 @@ GEOMETRIES = [
     (256, 160, 80, 16, 16, dict(R_a=8, m_a=9, P_len_k=16, P_len_l=3, init_N_len=6, DCbin=1, DCbin_back=1, ENHANCE_METHOD="Wiener",
                                  overlap_m_a=0.25, delay=2)),
     (1024, 640, 160, 50, 70, dict(R_a=50, m_a=30, overlap_m_a=0.05, Ar_up=2.0, beta=2.0, alpha_d=0.8, alpha_eta=0.7, sparsity=1.0)),
+    # the reference's exemplar setting R_x = R_d = 500 (settings/bak_IS16_results/initial_setting_Exemplar.m:47-48): r = 1000
+    # does not fit the persistent frame-solve kernels; the frame solve runs through the plan loop on 16-frame tiles
+    (1024, 640, 160, 500, 500, dict()),
+    (1024, 640, 160, 500, 500, dict(adapt_train_N=0)),
 ]
 
 
