@@ -22,16 +22,20 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
-    F, T, r, K, W = 257, 100_000, 256, 200, 20
+    F, T, r, K, W = 257, 100_000, 256, 200, 300  # W: enough load (>= 30 ms) for the chip to reach its steady clock at every shard size
     base = {}
     for n in (1, 2, 4, 8):
         Tn = T // n
         V, W0, H0 = make_problem(F, T, r, 0, Tn)
         ctx = Context(0)
-        plan = Plan(ctx, F, Tn, r, beta=1.0, max_iter=W + K + 1, conv_eps=0.0, cost_check=True, sparsity=SPARSITY)
+        plan = Plan(ctx, F, Tn, r, beta=1.0, max_iter=W + K + 21, conv_eps=0.0, cost_check=True, sparsity=SPARSITY)
         plan.set_v(V.astype(np.float32)); plan.set_w(W0); plan.set_h(H0.astype(np.float32)); plan.init()
         plan.run_async(W); ctx.sync()
         t = time.perf_counter(); plan.run_async(K); ctx.sync(); a = (time.perf_counter() - t) / K * 1e3
+        ctx.timing(True); plan.run_async(20); ctx.sync()
+        fam = {f: round(ctx.timing_get(f)[0] * 1e3, 1) for f in ("hstep", "wstats", "reduce", "wapply")}
+        ctx.timing(False)
+        geo = plan.describe()
         plan.close()
         tr = ShardedTrainer(V.astype(np.float32), W0, H0.astype(np.float32), beta=1.0, sparsity=SPARSITY, max_iter=W + K + 1,
                             conv_eps=0.0, cost_check=True, device=0)
@@ -40,7 +44,9 @@ def main():
         t = time.perf_counter(); tr.run(K); th = time.perf_counter() - t; tr.sync(); b = (time.perf_counter() - t) / K * 1e3
         base.setdefault("a", a); base.setdefault("b", b)
         print(f"N={n}: shard {F}x{Tn}  C loop {a:.4f} ms/it (bound {base['a'] / a:.2f}x)   sharded loop + RCCL call {b:.4f} ms/it "
-              f"(bound {base['b'] / b:.2f}x; host issue {th / K * 1e3:.4f} ms/it)", flush=True)
+              f"(bound {base['b'] / b:.2f}x; host issue {th / K * 1e3:.4f} ms/it)  kernels us {fam}", flush=True)
+        if n == 8:
+            print("   ", geo)
     dist.destroy_process_group()
 
 

@@ -801,6 +801,8 @@ static StepArgs make_args(snmf_plan* pl) {
     a.nk = pl->nk;
     a.ldh = pl->ldh;
     a.ldr = pl->ldr;
+    a.lam_is_u = pl->p.sparsity_kind == SNMF_SPARSITY_SCALAR ? 1 : 0;
+    a.lam_u = (float)pl->p.sparsity_scalar;
     a.beta = (float)pl->p.beta;
     const double bb1 = pl->p.beta * (pl->p.beta - 1.0);
     a.inv_bb1 = bb1 != 0.0 ? (float)(1.0 / bb1) : 0.f;

@@ -146,6 +146,8 @@ struct StepArgs {
     int ldh, ldr;         // LDS leading dimensions (floats)
     int stagger;          // cycles by which half of the workgroups start late (0 = off)
     int stagger_shift;    // which half: bit `shift` of the linear block id (-1: upper half of the grid)
+    int lam_is_u;         // scalar sparsity: every real row has the same lambda (pad rows of H are zero anyway)
+    float lam_u;          // ... that lambda
     float beta, inv_bb1;
 };
 
@@ -930,34 +932,49 @@ __device__ __forceinline__ void contract_shared(f32x16 (&acc)[NA], const f32x4* 
     if (q < nq) mm(wA, sA);
 }
 
-// P1 epilogue of one 32-row tile: Lam -> ratio in place over the staged V (+ the divergence terms of the previous iterate)
-template <bool OBJ>
-__device__ __forceinline__ void rp_p1_epilogue(const StepArgs& a, const f32x16& acc, float* Rs, int phi, int t0, int lane,
-                                               float& dsum) {
+// P1 epilogue of one 32-row tile: Lam -> ratio in place over the staged V (+ the divergence terms of the previous iterate).
+// VALU work is not free beside another wave's MFMAs (phase stamps: the tile period is the MFMA time PLUS the epilogue
+// time of both waves of a SIMD, whatever the schedule), so the per-element bounds masks of the objective are only
+// evaluated for the tiles that need them: a wave-uniform test picks the unmasked loop for interior tiles.
+template <bool OBJ, bool MASKED>
+__device__ __forceinline__ void rp_p1_epilogue_t(const StepArgs& a, const f32x16& acc, float* Rs, int phi, int t0, int lane,
+                                                 float& dsum) {
     const int fl = lane & 31, h = lane >> 5;
     const int t = t0 + fl;
     float* rsp = Rs + fl * a.ldr + phi * 32 + 4 * h;
+    f32x4 v[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) v[g] = *reinterpret_cast<const f32x4*>(rsp + 8 * g);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(rsp + 8 * g);
         f32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float lam = fmaxf(acc[4 * g + j], kFlr);
             if (OBJ) {
-                const int f = phi * 32 + 8 * g + 4 * h + j;
-                const float d = div_term<BM_KL>(v[j], lam, a.beta, a.inv_bb1);
-                dsum += (f < a.F && t < a.T) ? d : 0.f;
+                const float d = div_term<BM_KL>(v[g][j], lam, a.beta, a.inv_bb1);
+                if (MASKED) {
+                    const int f = phi * 32 + 8 * g + 4 * h + j;
+                    dsum += (f < a.F && t < a.T) ? d : 0.f;
+                } else {
+                    dsum += d;
+                }
             }
-            o[j] = v[j] * fast_rcp(lam);
+            o[j] = v[g][j] * fast_rcp(lam);
         }
         *reinterpret_cast<f32x4*>(rsp + 8 * g) = o;
     }
 }
+template <bool OBJ>
+__device__ __forceinline__ void rp_p1_epilogue(const StepArgs& a, const f32x16& acc, float* Rs, int phi, int t0, int lane,
+                                               float& dsum) {
+    if (!OBJ || (phi * 32 + 32 <= a.F && t0 + 32 <= a.T)) rp_p1_epilogue_t<OBJ, false>(a, acc, Rs, phi, t0, lane, dsum);
+    else rp_p1_epilogue_t<OBJ, true>(a, acc, Rs, phi, t0, lane, dsum);
+}
 
 // P2 epilogue of one 32-column tile of W^T*ratio: H <- H .* dmh ./ dph in LDS (src/sparse_nmf.m:192-195).
-// dpf / spf: max(colsum(W)+lambda, flr) and lambda of this lane's 16 columns (scalar / r-vector sparsity), loaded by
-// the caller BEFORE the MFMA loop; with a full r x T sparsity matrix they are formed here from S.
+// dpf: 1 ./ max(colsum(W)+lambda, flr) of this lane's 16 columns (scalar / r-vector sparsity) -- a constant of the
+// launch, formed once per wave by rp_p2_consts; with a full r x T sparsity matrix dph is formed here from S.
 template <bool OBJ>
 __device__ __forceinline__ void rp_p2_epilogue(const StepArgs& a, const f32x16& acc, float* Hs, int kap, int t0, int lane,
                                                const f32x4 (&dpf)[4], float& shsum) {
@@ -965,7 +982,7 @@ __device__ __forceinline__ void rp_p2_epilogue(const StepArgs& a, const f32x16& 
     const int t = t0 + fl;
     float* hsp = Hs + fl * a.ldh + kap * 32 + 4 * h;
     f32x4 spv[4];  // lambda of this lane's 16 columns: only the objective needs it, so it is fetched here (L2) and used last
-    if (OBJ || a.S) {
+    if ((OBJ && !a.lam_is_u) || a.S) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int k0 = kap * 32 + 8 * g + 4 * h;
@@ -988,21 +1005,34 @@ __device__ __forceinline__ void rp_p2_epilogue(const StepArgs& a, const f32x16& 
         }
         f32x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = hov[g][j] * acc[4 * g + j] * fast_rcp(dp[j]);
+        for (int j = 0; j < 4; ++j) o[j] = hov[g][j] * acc[4 * g + j] * (a.S ? fast_rcp(dp[j]) : dp[j]);  // dpf holds 1 ./ dph
         *reinterpret_cast<f32x4*>(hsp + 8 * g) = o;
     }
     if (OBJ) {
+        if (a.lam_is_u && !a.S) {  // scalar sparsity: sum(S .* H) = lambda * sum(H), one multiply per tile
+            float hs = 0.f;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) shsum += spv[g][j] * hov[g][j];
+                for (int j = 0; j < 4; ++j) hs += hov[g][j];
+            shsum += a.lam_u * hs;
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) shsum += spv[g][j] * hov[g][j];
+        }
     }
 }
 __device__ __forceinline__ void rp_p2_consts(const StepArgs& a, int kap, int lane, f32x4 (&dpf)[4]) {
     const int h = lane >> 5;
     if (!a.S) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) dpf[g] = *reinterpret_cast<const f32x4*>(a.dphv + kap * 32 + 8 * g + 4 * h);
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 d = *reinterpret_cast<const f32x4*>(a.dphv + kap * 32 + 8 * g + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dpf[g][j] = fast_rcp(d[j]);
+        }
     }
 }
 
@@ -1170,6 +1200,13 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
         // ================================ B team: P2 ================================================
         const int wb = w - NA;
         SNMF_STAMP_DECL
+        // 1 ./ dph of this wave's columns: constants of the launch when the wave owns one pair of column tiles (nk <= 8)
+        const bool one_group = a.nk <= 2 * NB;
+        f32x4 dp0[4], dp1[4];
+        if (one_group && wb < a.nk) {
+            rp_p2_consts(a, wb, lane, dp0);
+            if (wb + NB < a.nk) rp_p2_consts(a, wb + NB, lane, dp1);
+        }
         for (int j = 0; j < nmy; ++j) {
             const int t0 = tile_of(j) * Tt;
             float* Hs = lds + (j & 1) * bufsz;
@@ -1185,9 +1222,10 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     f32x16 acc[2] = {zero16(), zero16()};
                     const f32x4* const wp[2] = {reinterpret_cast<const f32x4*>(a.Wk4 + (size_t)kap * a.Fq * 32) + lane,
                                                 reinterpret_cast<const f32x4*>(a.Wk4 + (size_t)(kap + NB) * a.Fq * 32) + lane};
-                    f32x4 dp0[4], dp1[4];
-                    rp_p2_consts(a, kap, lane, dp0);
-                    rp_p2_consts(a, kap + NB, lane, dp1);
+                    if (!one_group) {
+                        rp_p2_consts(a, kap, lane, dp0);
+                        rp_p2_consts(a, kap + NB, lane, dp1);
+                    }
                     contract_shared<2>(acc, wp, sp, a.Fq / 8, xw, xs);
                     SNMF_STAMP(9);
                     rp_p2_epilogue<OBJ>(a, acc[0], Hs, kap, t0, lane, dp0, shsum);
@@ -1196,8 +1234,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                 } else {
                     f32x16 acc[1] = {zero16()};
                     const f32x4* const wp[1] = {reinterpret_cast<const f32x4*>(a.Wk4 + (size_t)kap * a.Fq * 32) + lane};
-                    f32x4 dp0[4];
-                    rp_p2_consts(a, kap, lane, dp0);
+                    if (!one_group) rp_p2_consts(a, kap, lane, dp0);
                     contract_shared<1>(acc, wp, sp, a.Fq / 8, xw, xs);
                     rp_p2_epilogue<OBJ>(a, acc[0], Hs, kap, t0, lane, dp0, shsum);
                 }
@@ -2184,61 +2221,83 @@ struct ApplyArgs {
 // F x r: keeping it in fp64 costs nothing measurable.
 // Q / P: this column of the reduced statistics (global memory in k_wapply, LDS in k_wfused); P == nullptr: KL, the
 // "P" of every row is the row sum sk of H.
+// fixed-order sum over the 256 threads of a workgroup: xor butterfly inside each wave (the same tree on every rank), then
+// the four wave sums in wave order.  One workgroup barrier per call instead of the eight of an LDS tree.
+__device__ __forceinline__ double wg_sum_256(double v, double* scratch /*[4]*/, int tid) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();  // scratch of the previous call has been read
+    if ((tid & 63) == 0) scratch[tid >> 6] = v;
+    __syncthreads();
+    return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+}
+
 __device__ __forceinline__ void wapply_column(const ApplyArgs& a, int k, int tid, const double* Q, const double* P,
                                               double sk, double (&red)[3][256]) {
     double* wc = a.Wc + (size_t)k * a.Fp;
     const bool upd = a.init_mode ? false : (a.w_ind[k] != 0);
+    // This thread's rows f = tid, tid + 256, ... of the column live in registers for the whole epilogue (F <= 1024 + 1
+    // rows: up to NR = 5 per thread; larger F loops again through memory like before).
+    constexpr int NR = 5;
+    const bool in_regs = a.F <= NR * 256;
+    double wv[NR], qv[NR], pv[NR];
+    if (in_regs) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int f = tid + 256 * i;
+            const bool ok = f < a.F;
+            wv[i] = ok ? wc[f] : 0.0;
+            qv[i] = (ok && upd) ? Q[f] : 0.0;
+            pv[i] = (ok && upd) ? (P ? P[f] : sk) : 0.0;
+        }
+    }
     // pass 1: column sums needed by the update
     double cQW = 0.0, cPW = 0.0, cW = 0.0;
     if (upd) {
-        for (int f = tid; f < a.F; f += 256) {
-            double wv = wc[f];
-            cQW += Q[f] * wv;
-            cPW += (P ? P[f] : sk) * wv;
-        }
-        red[0][tid] = cQW;
-        red[1][tid] = cPW;
-        __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
-            if (tid < s) {
-                red[0][tid] += red[0][tid + s];
-                red[1][tid] += red[1][tid + s];
+        if (in_regs) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                cQW += qv[i] * wv[i];
+                cPW += pv[i] * wv[i];
             }
-            __syncthreads();
+        } else {
+            for (int f = tid; f < a.F; f += 256) {
+                const double w0 = wc[f];
+                cQW += Q[f] * w0;
+                cPW += (P ? P[f] : sk) * w0;
+            }
         }
-        cQW = red[0][0];
-        cPW = red[1][0];
-        __syncthreads();
+        cQW = wg_sum_256(cQW, &red[0][0], tid);
+        cPW = wg_sum_256(cPW, &red[1][0], tid);
     }
     // updated (un-normalised) entry: dpw = max(P + W.*colsum(Q.*W), flr); dmw = Q + W.*colsum(P.*W)
-    auto updated = [&](int f) -> double {
-        double wv = wc[f];
+    auto upd_val = [&](double w0, double Qv, double Pv) -> double {
         if (upd) {
-            const double Qv = Q[f];
-            const double Pv = P ? P[f] : sk;
-            double dpw = Pv + wv * cQW;
+            double dpw = Pv + w0 * cQW;
             dpw = dpw > 1e-9 ? dpw : 1e-9;
-            wv = wv * (Qv + wv * cPW) / dpw;
+            w0 = w0 * (Qv + w0 * cPW) / dpw;
         }
-        return wv;
+        return w0;
     };
+    auto updated = [&](int f) -> double { return upd_val(wc[f], upd ? Q[f] : 0.0, upd ? (P ? P[f] : sk) : 0.0); };
     // pass 2: squared norm of the updated column
     double ssq = 0.0;
-    for (int f = tid; f < a.F; f += 256) {
-        const double wv = updated(f);
-        ssq += wv * wv;
+    if (in_regs) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            wv[i] = (tid + 256 * i < a.F) ? upd_val(wv[i], qv[i], pv[i]) : 0.0;
+            ssq += wv[i] * wv[i];
+        }
+    } else {
+        for (int f = tid; f < a.F; f += 256) {
+            const double w1 = updated(f);
+            ssq += w1 * w1;
+        }
     }
-    red[0][tid] = ssq;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) red[0][tid] += red[0][tid + s];
-        __syncthreads();
-    }
-    const double nrm = sqrt(red[0][0]);
-    __syncthreads();
+    const double nrm = sqrt(wg_sum_256(ssq, &red[2][0], tid));
     // pass 3: normalise (ALL columns, :242), write the three images, column sum
-    for (int f = tid; f < a.F; f += 256) {
-        const double wd = updated(f) / nrm;
+    auto emit = [&](int f, double w1) {
+        const double wd = w1 / nrm;
         const float wf = (float)wd;  // operand images: an entry below fp32 range adds < 1e-38*max(h) to Lam, far under the 1e-9 floor
         cW += (double)wf;
         wc[f] = wd;
@@ -2253,15 +2312,18 @@ __device__ __forceinline__ void wapply_column(const ApplyArgs& a, int k, int tid
             const int kap = k >> 5, k32 = k & 31, q = f >> 3, hh = (f >> 2) & 1, e = f & 3;
             a.Wk4[(((size_t)kap * (a.Fq / 8) + q) * 2 + hh) * 128 + k32 * 4 + e] = wf;
         }
+    };
+    if (in_regs) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+            if (tid + 256 * i < a.F) emit(tid + 256 * i, wv[i]);
+    } else {
+        // the updated value is recomputed from the ORIGINAL column: write only after every read of this thread's rows
+        for (int f = tid; f < a.F; f += 256) emit(f, updated(f));
     }
-    red[1][tid] = cW;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) red[1][tid] += red[1][tid + s];
-        __syncthreads();
-    }
+    cW = wg_sum_256(cW, &red[0][0], tid);
     if (tid == 0) {
-        const float cs = (float)red[1][0];
+        const float cs = (float)cW;
         a.colsum[k] = cs;
         a.dphv[k] = fmaxf(cs + a.lamk[k], kFlr);
         if (a.init_mode) a.wn[k] = nrm;
