@@ -190,9 +190,11 @@ def main():
             import glob
             for fn in sorted(glob.glob(os.path.join(_ROOT, "profiles", "r*_traffic.json")))[-1:]:
                 tj = json.load(open(fn))
-                for k, v in tj.items():
-                    if k.startswith("k_" + dom) and ("true, true" in k or dom == "wstats"):
-                        traffic = v["total_bytes"]
+                # the launch that runs in the timed region: the KL update + objective variant of the dominant kernel
+                keys = [k for k in tj if k.startswith("k_" + dom)]
+                pref = [k for k in keys if k.startswith("k_hstep_rp<true") or "true, true" in k] or keys
+                if pref:
+                    traffic = tj[pref[0]]["total_bytes"]
         last_cost = [c for c in cost if c != 0.0]
         ach = flops_half / (fam[dom][0] * 1e-3) / 1e12 if fam[dom][0] > 0 else 0.0
         out = {
