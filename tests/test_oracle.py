@@ -218,3 +218,35 @@ def test_full_size_c2_golden_is_consistent_with_the_oracle_on_a_frame_block():
     _, h2, _ = sparse_nmf(V, dict(cf="kl", sparsity=SPARSITY, max_iter=1, conv_eps=0, init_w=W0, init_h=H0, cost_check=1,
                                   w_update_ind=np.zeros(R_, bool)))
     np.testing.assert_allclose(h1, h2[:, :64], rtol=1e-12)
+
+
+REF_ROOT = os.environ.get("SNMF_REFERENCE", "/root/reference")
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF_ROOT, "basis")), reason="reference tree not present (GPU box)")
+def test_shipped_basis_files_load_through_the_product_reader_and_round_trip(tmp_path):
+    """The dictionaries the reference ships (basis/*/R_100.mat, B_D_u.mat: MAT-5 files written by run_basis_train.m:136
+    and src/NTF_sep_event_RT.m:138-140) load through se_snmf_nat_amd.train.load_basis_mat with the reference's variable
+    names; they have the form run_basis_train.m:113-116 stores (unit-L2 columns + 1e-9); the committed fp32 fixture
+    tests/golden/ref_data.npz is their rounding; and save_basis_mat writes a file the same reader (and MATLAB's load)
+    reads back bit for bit."""
+    from se_snmf_nat_amd.train import load_basis_mat, save_basis_mat
+    ref = np.load(os.path.join(GOLD, "ref_data.npz"))
+    sub = "TASLP_Splice0-SNMF_p2_DD0"
+    for k, (cls, cols) in enumerate((("Clean_train_TIMIT_test", slice(0, 100)), ("CHiME3_bgn_ch6", slice(100, 200)))):
+        m = load_basis_mat(os.path.join(REF_ROOT, "basis", cls, sub, "R_100.mat"))
+        assert {"B_DFT_sub", "B_Mel_sub"} <= set(m)  # the shipped files carry the two dictionaries (the A_* of :136 were not shipped)
+        B = np.asarray(m["B_DFT_sub"], dtype=np.float64)
+        assert B.shape == (513, 100) and m["B_Mel_sub"].shape[1] == 100
+        np.testing.assert_allclose(np.sqrt(((B - 1e-9) ** 2).sum(0)), 1.0, rtol=1e-6)  # :113-114
+        np.testing.assert_array_equal(B.astype(np.float32), ref["B"][:, cols])
+    u = load_basis_mat(os.path.join(REF_ROOT, "B_D_u.mat"))
+    assert {"B_DFT_d", "B_Mel_d"} <= set(u)
+    np.testing.assert_array_equal(np.asarray(u["B_DFT_d"])[:, :50].astype(np.float32), ref["Bu"])
+    np.testing.assert_array_equal(u["B_DFT_d"], u["B_Mel_d"])  # DFT mode: the Mel slots hold the DFT bases (SURVEY.md a14)
+    out = {"B_DFT_sub": B, "B_Mel_sub": np.asarray(m["B_Mel_sub"], float), "A_DFT_sub": 0, "A_Mel_sub": 0}
+    fn = str(tmp_path / "R_100.mat")
+    save_basis_mat(fn, out)
+    back = load_basis_mat(fn)
+    np.testing.assert_array_equal(back["B_DFT_sub"], B)
+    np.testing.assert_array_equal(back["B_Mel_sub"], out["B_Mel_sub"])
