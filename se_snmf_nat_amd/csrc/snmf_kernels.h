@@ -919,6 +919,31 @@ __device__ __forceinline__ void contract_shared(f32x16 (&acc)[NA], const f32x4* 
 #pragma unroll
             for (int i = 0; i < NA; ++i) acc[i] = mfma32(w[i][e], sf[e], acc[i]);
     };
+#ifndef SNMF_RP_DEPTH
+#define SNMF_RP_DEPTH 2
+#endif
+    if (SNMF_RP_DEPTH == 2) {
+        // fragments two stages (16 MFMAs, >= 1024 cycles) ahead: a wave that has the pipe to itself still hides the L2
+        // latency (measured: 570.6 k against 575 k stamped cycles per wave with one stage ahead, within noise on the wall)
+        f32x4 wC[NA], sC;
+        ld(wA, sA, 0);
+        ld(wB, sB, 1);
+        int q = 0;
+        for (; q + 2 < nq; q += 3) {
+            ld(wC, sC, q + 2);
+            SNMF_PIN();
+            mm(wA, sA);
+            ld(wA, sA, q + 3);
+            SNMF_PIN();
+            mm(wB, sB);
+            ld(wB, sB, q + 4);
+            SNMF_PIN();
+            mm(wC, sC);
+        }
+        if (q < nq) mm(wA, sA);
+        if (q + 1 < nq) mm(wB, sB);
+        return;
+    }
     ld(wA, sA, 0);
     int q = 0;
     for (; q + 1 < nq; q += 2) {
@@ -933,9 +958,9 @@ __device__ __forceinline__ void contract_shared(f32x16 (&acc)[NA], const f32x4* 
 }
 
 // P1 epilogue of one 32-row tile: Lam -> ratio in place over the staged V (+ the divergence terms of the previous iterate).
-// VALU work is not free beside another wave's MFMAs (phase stamps: the tile period is the MFMA time PLUS the epilogue
-// time of both waves of a SIMD, whatever the schedule), so the per-element bounds masks of the objective are only
-// evaluated for the tiles that need them: a wave-uniform test picks the unmasked loop for interior tiles.
+// The per-element bounds masks of the objective are only evaluated for the tiles that need them: a wave-uniform test
+// picks the unmasked loop for interior tiles (a quarter of the epilogue's VALU instructions; no measurable effect on
+// the kernel -- a neighbour wave's VALU, LDS or load traffic costs an MFMA-issuing wave nothing, scripts/mfma_valu_overlap.hip).
 template <bool OBJ, bool MASKED>
 __device__ __forceinline__ void rp_p1_epilogue_t(const StepArgs& a, const f32x16& acc, float* Rs, int phi, int t0, int lane,
                                                  float& dsum) {
@@ -1047,7 +1072,12 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
     const int bufsz = Tt * (ldh + ldr);  // floats per buffer: Hs [Tt][ldh] then Rs [Tt][ldr]
     float* wxs = lds + 2 * bufsz;        // [rp] extra row of W
     unsigned* cnt = reinterpret_cast<unsigned*>(wxs + rp);
-    unsigned *ready = cnt, *p1done = cnt + 1, *p2done = cnt + 2;
+    // p1a: "the ratio rows of the row tiles 0..NA-1 are whole" (+NA per tile: each A wave after the epilogue of its FIRST
+    // row tile); p1b: "the whole ratio image is" (+NA+NL per tile: each A wave after its last epilogue, each loader wave
+    // after its share of the extra row).  The B team starts P2 on the first 4*NA k-blocks (rows 0..32*NA-1) at p1a and
+    // needs p1b only for the rest: in steady state both teams leave their MFMA loops together (they share the pipe), and
+    // the A team's epilogue is then the one stretch with nobody in a loop -- B now waits for half of it only.
+    unsigned *ready = cnt, *p1a = cnt + 1, *p1b = cnt + 2, *p2done = cnt + 3;
     double acc_div = 0.0, acc_sh = 0.0;
     if (a.xr) {
         for (int k = threadIdx.x; k < rp; k += NTHR) wxs[k] = a.wx[k];
@@ -1057,7 +1087,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             lds[bsel * bufsz + Tt * ldh + (ii >> 3) * ldr + a.Fm + (ii & 7)] = 0.f;
         }
     }
-    if (threadIdx.x < 3) cnt[threadIdx.x] = 0u;
+    if (threadIdx.x < 4) cnt[threadIdx.x] = 0u;
     __syncthreads();
     // diagnostic operand-reuse experiment (SNMF_PROF builds): 1 = W fragments of even k-blocks only, 2 = W block 0 only,
     // 3 = LDS fragments of even k-blocks only, 4 = LDS block 0 only, 5 = both streams block 0 only
@@ -1086,12 +1116,24 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
         // floor(i / d) = umulhi(i, ceil(2^32 / d)) for 0 <= i < 2^16 (i < 20 * 256 here), d >= 1
         const unsigned invA = (unsigned)((0x100000000ull + (unsigned)rA - 1) / (unsigned)rA);
         const unsigned invB = (unsigned)((0x100000000ull + (unsigned)rB - 1) / (unsigned)rB);
+        // The extra row (F = 32*nf + 1) of a tile is the LOADERS' work, done right after the tile is staged: its dot
+        // products are VALU + LDS work that would otherwise sit on the A team's critical path between the end of its MFMA
+        // loop and the signal P2 waits for.  It needs the whole staged tile, hence the wait for every loader's arrival.
+        const int lw = w - (NA + NB);
+        auto xrow_of = [&](int j) {
+            if (!a.xr) return;
+            rp_await(ready, (unsigned)(NL * (j + 1)), a.stop);
+            float* bH = lds + (j & 1) * bufsz;
+            hstep_p1_xrow<NL, 1, BM_KL, OBJ>(a, bH, bH + Tt * ldh, wxs, tile_of(j) * Tt, lw, lane, true, acc_div);
+            rp_arrive(p1b, lane);
+        };
         for (int j = 0; j < 2 && j < nmy; ++j) {
             float* bH = lds + j * bufsz;
             stage_in2<NLT, PA, PB>(a.Hin + (size_t)tile_of(j) * Tt * rp, bH, Tt, rp, ldh, a.V + (size_t)tile_of(j) * Tt * Fp,
                                    bH + Tt * ldh, Tt, Fp, ldr, lt);
             rp_arrive(ready, lane);
         }
+        for (int j = 0; j < 2 && j < nmy; ++j) xrow_of(j);
         for (int j = 0; j < nmy; ++j) {
             float* bH = lds + (j & 1) * bufsz;
             const bool more = j + 2 < nmy;
@@ -1129,6 +1171,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     stage_in<NLT>(a.Hin + (size_t)tile_of(j + 2) * Tt * rp, bH, Tt, rp, ldh, lt);
                     stage_in<NLT>(a.V + (size_t)tile_of(j + 2) * Tt * Fp, bH + Tt * ldh, Tt, Fp, ldr, lt);
                     rp_arrive(ready, lane);
+                    xrow_of(j + 2);
                 }
                 continue;
             }
@@ -1156,6 +1199,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     *reinterpret_cast<f32x4*>(bH + Tt * ldh + t * ldr + 4 * k4) = xb[b];
                 }
                 rp_arrive(ready, lane);
+                xrow_of(j + 2);
             }
         }
     } else if (w < NA) {
@@ -1180,6 +1224,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     contract_shared<2>(acc, wp, sp, rp / 8, xw, xs);
                     SNMF_STAMP(4);
                     rp_p1_epilogue<OBJ>(a, acc[0], Rs, phi, t0, lane, dsum);
+                    if (phi == w) rp_arrive(p1a, lane);  // row tile w < NA: this wave's share of the first 32*NA ratio rows
                     rp_p1_epilogue<OBJ>(a, acc[1], Rs, phi + NA, t0, lane, dsum);
                     SNMF_STAMP(5);
                 } else {
@@ -1187,12 +1232,13 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     const f32x4* const wp[1] = {reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)phi * rp * 32) + lane};
                     contract_shared<1>(acc, wp, sp, rp / 8, xw, xs);
                     rp_p1_epilogue<OBJ>(a, acc[0], Rs, phi, t0, lane, dsum);
+                    if (phi == w) rp_arrive(p1a, lane);
                 }
             }
+            if (w >= a.nf) rp_arrive(p1a, lane);  // a wave without a row tile still counts
             if (OBJ) acc_div += (double)dsum;
-            hstep_p1_xrow<NA, 1, BM_KL, OBJ>(a, Hs, Rs, wxs, t0, w, lane, true, acc_div);
             SNMF_STAMP(6);
-            rp_arrive(p1done, lane);
+            rp_arrive(p1b, lane);
         }
         SNMF_STAMP_OUT(a.prof + ((size_t)blockIdx.x * (NA + NB) + w) * 12, 12);
         SNMF_STAMP_CLK(a.prof, (size_t)blockIdx.x * (NA + NB) + w);
@@ -1212,11 +1258,14 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             float* Hs = lds + (j & 1) * bufsz;
             const float* Rs = Hs + Tt * ldh;
             SNMF_STAMP(11);
-            rp_await(p1done, (unsigned)(NA * (j + 1)), a.stop);
+            rp_await(p1a, (unsigned)(NA * (j + 1)), a.stop);
             SNMF_STAMP(7);
             const int fl = lane & 31, h = lane >> 5;
             const float* sp = Rs + fl * ldr + 4 * h;
             float shsum = 0.f;
+            // k-blocks over the ratio rows of the row tiles 0..NA-1 (never the extra row's block) / the rest
+            const int nq = a.Fq / 8, nq1 = 4 * (a.nf < NA ? a.nf : NA);
+            const unsigned p1b_target = (unsigned)((NA + (a.xr ? NL : 0)) * (j + 1));
             for (int kap = wb; kap < a.nk; kap += 2 * NB) {
                 if (kap + NB < a.nk) {
                     f32x16 acc[2] = {zero16(), zero16()};
@@ -1226,7 +1275,12 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                         rp_p2_consts(a, kap, lane, dp0);
                         rp_p2_consts(a, kap + NB, lane, dp1);
                     }
-                    contract_shared<2>(acc, wp, sp, a.Fq / 8, xw, xs);
+                    contract_shared<2>(acc, wp, sp, nq1, xw, xs);
+                    rp_await(p1b, p1b_target, a.stop);
+                    if (nq > nq1) {
+                        const f32x4* const wp2[2] = {wp[0] + (size_t)nq1 * 64, wp[1] + (size_t)nq1 * 64};
+                        contract_shared<2>(acc, wp2, sp + 8 * nq1, nq - nq1, xw, xs);
+                    }
                     SNMF_STAMP(9);
                     rp_p2_epilogue<OBJ>(a, acc[0], Hs, kap, t0, lane, dp0, shsum);
                     rp_p2_epilogue<OBJ>(a, acc[1], Hs, kap + NB, t0, lane, dp1, shsum);
@@ -1235,7 +1289,12 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     f32x16 acc[1] = {zero16()};
                     const f32x4* const wp[1] = {reinterpret_cast<const f32x4*>(a.Wk4 + (size_t)kap * a.Fq * 32) + lane};
                     if (!one_group) rp_p2_consts(a, kap, lane, dp0);
-                    contract_shared<1>(acc, wp, sp, a.Fq / 8, xw, xs);
+                    contract_shared<1>(acc, wp, sp, nq1, xw, xs);
+                    rp_await(p1b, p1b_target, a.stop);
+                    if (nq > nq1) {
+                        const f32x4* const wp2[1] = {wp[0] + (size_t)nq1 * 64};
+                        contract_shared<1>(acc, wp2, sp + 8 * nq1, nq - nq1, xw, xs);
+                    }
                     rp_p2_epilogue<OBJ>(a, acc[0], Hs, kap, t0, lane, dp0, shsum);
                 }
             }
