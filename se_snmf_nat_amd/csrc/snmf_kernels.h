@@ -855,18 +855,23 @@ __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(Step
 
 // ============================================================================================
 // k_hstep_rp: the KL H half-step as a ROLE PIPELINE (round 2).  Same arithmetic as k_hstep<8,1,4,BM_KL,OBJ,true>,
-// different schedule.  In k_hstep all eight consumer waves run P1 of a tile, meet at a barrier, then all run P2: the
-// VALU epilogues of the two waves of a SIMD coincide and the matrix pipe idles through them and through the barrier
-// (48.9 k cycles per tile where the pipe needs 33.3 k, round-1 phase stamps).  Here the consumer waves are split by
-// ROLE, one wave of each role per SIMD:
-//     A team (waves 0-3) : P1 of tile i+1   Lam = W*H -> ratio image (in place over the staged V), + the extra row
+// different schedule.  In k_hstep all eight consumer waves run P1 of a tile, meet at a barrier, then all run P2.
+// Here the consumer waves are split by ROLE, one wave of each role per SIMD:
+//     A team (waves 0-3) : P1 of tile i+1   Lam = W*H -> ratio image (in place over the staged V)
 //     B team (waves 4-7) : P2 of tile i     W^T*ratio -> H update in LDS
-//     loaders (waves 8-11): copy the updated H tile i out, bring tile i+2 into the buffer that tile i leaves
-// so that on every SIMD one wave's epilogue, wait or reload always has the OTHER role's MFMA loop running beside it,
-// on a different tile.  No workgroup barrier inside the tile loop: three monotonic LDS counters order the roles
-//     ready  (+NL per tile, loaders)  "tile j is staged"              A waits
-//     p1done (+4  per tile, A team)   "the ratio image of j is whole" B waits
-//     p2done (+4  per tile, B team)   "H_j is updated, its ratio dead" loaders wait
+//     loaders (waves 8-11): copy the updated H tile i out, bring tile i+2 into the buffer that tile i leaves, and
+//                           compute that tile's extra row (F = 32n+1) right after staging it
+// What this buys is NOT "one wave's epilogue under another wave's MFMAs": while a wave issues back-to-back MFMAs of
+// this shape no other wave of its SIMD issues anything (scripts/mfma_valu_overlap.hip), so a SIMD's time is its MFMA
+// cycles plus everything else its waves issue.  What a schedule can avoid is a SIMD on which every wave WAITS.  The two
+// MFMA waves of a SIMD share the pipe and therefore leave their loops together; if P2 of the next tile could only start
+// after the A team's whole epilogue (and the extra row), nobody would issue an MFMA through all of it.  Hence the extra
+// row on the loaders, and P2 in two phases: the first 4*NA k-blocks need only the ratio rows of the row tiles 0..NA-1.
+// No workgroup barrier inside the tile loop: four monotonic LDS counters order the roles
+//     ready  (+NL    per tile, loaders)            "tile j is staged"                          A waits
+//     p1a    (+NA    per tile, A team)             "ratio rows of the row tiles 0..NA-1 whole"  B waits (phase 1)
+//     p1b    (+NA+NL per tile, A team + loaders)   "the whole ratio image is, extra row incl."  B waits (phase 2)
+//     p2done (+NB    per tile, B team)             "H_j is updated, its ratio dead"             loaders wait
 // (dependencies run strictly forward in the tile index, so the waits cannot form a cycle; every wait is a bounded spin
 // that raises DevState::fault instead of hanging).  Each wave owns TWO 32-row (A) / 32-column (B) output tiles whose
 // MFMA chains share every LDS fragment: one ds_read_b128 feeds 8 MFMAs instead of 4, and two independent accumulator
