@@ -91,23 +91,24 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     snmf_plan* pl = nullptr;
     if (snmf_plan_create(g_ctx, &p, &pl) != SNMF_OK) mexErrMsgIdAndTxt("snmf:plan", "%s", snmf_last_error());
     int st = SNMF_OK;
-    auto step = [&](int s) { if (st == SNMF_OK) st = s; };
-    step(snmf_plan_set_mask_f64(pl, mxGetDoubles(mk), (int64_t)F, 0));  // before set_v: turns the plan into an MDI solve
-    step(snmf_plan_set_v_f64(pl, mxGetDoubles(v), (int64_t)F, 0));
-    step(snmf_plan_set_w_f64(pl, mxGetDoubles(w0), (int64_t)F, 0));
-    step(snmf_plan_set_h_f64(pl, mxGetDoubles(h0), (int64_t)r, 0));
-    step(snmf_plan_init(pl));
+    // lazy: a call is only MADE while no earlier one has failed, so the first failure's status AND message survive
+#define STEP(expr) do { if (st == SNMF_OK) st = (expr); } while (0)
+    STEP(snmf_plan_set_mask_f64(pl, mxGetDoubles(mk), (int64_t)F, 0));  // before set_v: turns the plan into an MDI solve
+    STEP(snmf_plan_set_v_f64(pl, mxGetDoubles(v), (int64_t)F, 0));
+    STEP(snmf_plan_set_w_f64(pl, mxGetDoubles(w0), (int64_t)F, 0));
+    STEP(snmf_plan_set_h_f64(pl, mxGetDoubles(h0), (int64_t)r, 0));
+    STEP(snmf_plan_init(pl));
     int32_t n_iter = 0;
-    step(snmf_plan_run(pl, p.max_iter, &n_iter));
+    STEP(snmf_plan_run(pl, p.max_iter, &n_iter));
     mxArray* vm = mxCreateDoubleMatrix(F, T, mxREAL);
     mxArray* wout = mxCreateDoubleMatrix(F, r, mxREAL);
     mxArray* hout = mxCreateDoubleMatrix(r, T, mxREAL);
     mxArray* divv = mxCreateDoubleMatrix(1, p.max_iter > 0 ? p.max_iter : 1, mxREAL);
     mxArray* costv = mxCreateDoubleMatrix(1, p.max_iter > 0 ? p.max_iter : 1, mxREAL);
-    step(snmf_plan_get_v_mdi_f64(pl, mxGetDoubles(vm), (int64_t)F, 0));
-    step(snmf_plan_get_w_f64(pl, mxGetDoubles(wout), (int64_t)F, 0));
-    step(snmf_plan_get_h_f64(pl, mxGetDoubles(hout), (int64_t)r, 0));
-    step(snmf_plan_get_objective(pl, mxGetDoubles(divv), mxGetDoubles(costv), &n_iter));
+    STEP(snmf_plan_get_v_mdi_f64(pl, mxGetDoubles(vm), (int64_t)F, 0));
+    STEP(snmf_plan_get_w_f64(pl, mxGetDoubles(wout), (int64_t)F, 0));
+    STEP(snmf_plan_get_h_f64(pl, mxGetDoubles(hout), (int64_t)r, 0));
+    STEP(snmf_plan_get_objective(pl, mxGetDoubles(divv), mxGetDoubles(costv), &n_iter));
     snmf_plan_destroy(pl);
     mxArray* outs[5] = {vm, wout, hout, divv, costv};
     if (st != SNMF_OK) {

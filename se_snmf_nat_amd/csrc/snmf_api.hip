@@ -41,6 +41,11 @@ static int fail(int code, const char* fmt, ...) {
             return fail(e_ == hipErrorOutOfMemory ? SNMF_ERR_NOMEM : SNMF_ERR_NO_DEVICE, "%s: %s", \
                         #expr, hipGetErrorString(e_));                                             \
     } while (0)
+// lazy chain: the call is only MADE while no earlier one has failed, so the first failure's status AND message survive
+#define SN_STEP(s, expr)                      \
+    do {                                      \
+        if ((s) == SNMF_OK) (s) = (expr);     \
+    } while (0)
 #define SN_TRY(expr)              \
     do {                          \
         int s_ = (expr);          \
@@ -362,6 +367,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     if (!ctx || !out) return fail(SNMF_ERR_INVALID, "NULL argument");
     *out = nullptr;
     SN_TRY(validate_params(p));
+    (void)hipGetLastError();  // start from a clean (sticky, per-thread) HIP error state, see PLAN_CHECK
     HIP_TRY(hipSetDevice(ctx->device));
     snmf_plan* pl = new snmf_plan();
     pl->ctx = ctx;
@@ -692,8 +698,12 @@ static int unpack_out(snmf_plan* pl, const TSrc* src, int rowsP, int rows, int c
     return SNMF_OK;
 }
 
-#define PLAN_CHECK(pl) \
-    if (!(pl)) return fail(SNMF_ERR_INVALID, "plan is NULL")
+// Every plan entry point starts from a clean HIP error state: hipGetLastError() is sticky per thread, so an error some
+// EARLIER, unrelated call left behind (a refused device ordinal, the caller's own HIP code, torch) would otherwise be
+// reported by the first kernel-launch check of this library as if the launch had failed.
+#define PLAN_CHECK(pl)                                           \
+    if (!(pl)) return fail(SNMF_ERR_INVALID, "plan is NULL");    \
+    (void)hipGetLastError()
 
 template <typename T>
 static int set_v(snmf_plan* pl, const T* V, int64_t ld, int dev) {
@@ -1462,26 +1472,25 @@ static int sparse_nmf_impl(snmf_ctx* ctx, const snmf_params* p, const T* V, int6
     snmf_plan* pl = nullptr;
     SN_TRY(snmf_plan_create(ctx, p, &pl));
     int s = SNMF_OK;
-    auto step = [&](int st) { if (s == SNMF_OK) s = st; };
-    step(set_v<T>(pl, V, ldV, 0));
-    step(set_w<T>(pl, W, p->F, 0));
-    step(set_h<T>(pl, H, p->r, 0));
+    SN_STEP(s, set_v<T>(pl, V, ldV, 0));
+    SN_STEP(s, set_w<T>(pl, W, p->F, 0));
+    SN_STEP(s, set_h<T>(pl, H, p->r, 0));
     if (p->sparsity_kind != SNMF_SPARSITY_SCALAR) {
-        if (!sparsity) step(fail(SNMF_ERR_INVALID, "sparsity array required for this sparsity_kind"));
-        else step(set_s<T>(pl, sparsity, 0));
+        if (!sparsity) SN_STEP(s, fail(SNMF_ERR_INVALID, "sparsity array required for this sparsity_kind"));
+        else SN_STEP(s, set_s<T>(pl, sparsity, 0));
     }
-    step(snmf_plan_init(pl));
-    if (s == SNMF_OK) step(snmf_plan_run(pl, p->max_iter, nullptr));
+    SN_STEP(s, snmf_plan_init(pl));
+    if (s == SNMF_OK) SN_STEP(s, snmf_plan_run(pl, p->max_iter, nullptr));
     if (s == SNMF_OK) {
         if (sizeof(T) == 8) {
-            step(snmf_plan_get_w_f64(pl, (double*)W, p->F, 0));
-            step(snmf_plan_get_h_f64(pl, (double*)H, p->r, 0));
+            SN_STEP(s, snmf_plan_get_w_f64(pl, (double*)W, p->F, 0));
+            SN_STEP(s, snmf_plan_get_h_f64(pl, (double*)H, p->r, 0));
         } else {
-            step(snmf_plan_get_w_f32(pl, (float*)W, p->F, 0));
-            step(snmf_plan_get_h_f32(pl, (float*)H, p->r, 0));
+            SN_STEP(s, snmf_plan_get_w_f32(pl, (float*)W, p->F, 0));
+            SN_STEP(s, snmf_plan_get_h_f32(pl, (float*)H, p->r, 0));
         }
     }
-    if (s == SNMF_OK) step(snmf_plan_get_objective(pl, div_out, cost_out, n_iter_out));
+    if (s == SNMF_OK) SN_STEP(s, snmf_plan_get_objective(pl, div_out, cost_out, n_iter_out));
     snmf_plan_destroy(pl);
     return s;
 }
@@ -2303,6 +2312,7 @@ extern "C" int snmf_online_process_f32(snmf_online* o, const float* pcm, int64_t
     if (o->finished) return fail(SNMF_ERR_STATE, "the stream was flushed; create a new separator");
     if (o->failed) return fail(SNMF_ERR_STATE, "an earlier call failed midway through a batch; the separator state is not reusable, create a new one");
     if ((xh_f32 || dh_f32) && !o->p.class_outputs) return fail(SNMF_ERR_STATE, "class outputs were not requested at creation");
+    (void)hipGetLastError();  // clean sticky error state, see PLAN_CHECK
     HIP_TRY(hipSetDevice(o->ctx->device));
     const int sz = o->p.framelength, hop = o->p.frameshift;
     o->pending.insert(o->pending.end(), pcm, pcm + n);

@@ -100,6 +100,7 @@ extern "C" void snmf_multi_destroy(snmf_multi* m) {
         }
     }
     for (int g = 0; g < (int)m->plan.size(); ++g) {
+        if (g >= (int)m->ctx.size() || !m->ctx[g]) continue;  // a rank that never came up (e.g. a bad device ordinal) owns nothing
         hipSetDevice(m->dev[g]);
         for (int q = 0; q < 2; ++q)
             if (g < (int)m->ev[q].size() && m->ev[q][g]) hipEventDestroy(m->ev[q][g]);
@@ -398,26 +399,25 @@ static int sparse_nmf_multi_impl(const int32_t* devices, int32_t n_dev, const sn
     snmf_multi* m = nullptr;
     SN_TRY(snmf_multi_create(devices, n_dev, p, nullptr, &m));
     int s = SNMF_OK;
-    auto step = [&](int st) { if (s == SNMF_OK) s = st; };
-    step(multi_set_cols<T>(m, V, ldV, 0));
-    step(multi_set_w<T>(m, W, p->F));
-    step(multi_set_cols<T>(m, H, p->r, 1));
+    SN_STEP(s, multi_set_cols<T>(m, V, ldV, 0));
+    SN_STEP(s, multi_set_w<T>(m, W, p->F));
+    SN_STEP(s, multi_set_cols<T>(m, H, p->r, 1));
     if (p->sparsity_kind != SNMF_SPARSITY_SCALAR) {
-        if (!sparsity) step(fail(SNMF_ERR_INVALID, "sparsity array required for this sparsity_kind"));
-        else step(multi_set_s<T>(m, sparsity));
+        if (!sparsity) SN_STEP(s, fail(SNMF_ERR_INVALID, "sparsity array required for this sparsity_kind"));
+        else SN_STEP(s, multi_set_s<T>(m, sparsity));
     }
-    step(snmf_multi_init(m));
-    if (s == SNMF_OK) step(snmf_multi_run(m, p->max_iter, nullptr));
+    SN_STEP(s, snmf_multi_init(m));
+    if (s == SNMF_OK) SN_STEP(s, snmf_multi_run(m, p->max_iter, nullptr));
     if (s == SNMF_OK) {
         if (sizeof(T) == 8) {
-            step(snmf_multi_get_w_f64(m, (double*)W, p->F));
-            step(snmf_multi_get_h_f64(m, (double*)H, p->r));
+            SN_STEP(s, snmf_multi_get_w_f64(m, (double*)W, p->F));
+            SN_STEP(s, snmf_multi_get_h_f64(m, (double*)H, p->r));
         } else {
-            step(snmf_multi_get_w_f32(m, (float*)W, p->F));
-            step(snmf_multi_get_h_f32(m, (float*)H, p->r));
+            SN_STEP(s, snmf_multi_get_w_f32(m, (float*)W, p->F));
+            SN_STEP(s, snmf_multi_get_h_f32(m, (float*)H, p->r));
         }
     }
-    if (s == SNMF_OK) step(snmf_multi_get_objective(m, div_out, cost_out, n_iter_out));
+    if (s == SNMF_OK) SN_STEP(s, snmf_multi_get_objective(m, div_out, cost_out, n_iter_out));
     const std::string keep = g_err;
     snmf_multi_destroy(m);
     g_err = keep;

@@ -162,3 +162,17 @@ def test_bad_arguments_are_reported_not_crashed(lib):
     devs[0] = 99
     assert lib.snmf_multi_create(C.c_void_p(devs.ctypes.data), 1, C.byref(sp), None, C.byref(h)) != 0
     assert b"device" in lib.snmf_last_error()
+
+
+def test_a_refused_device_list_leaves_no_sticky_error_behind(gpu_ctx, lib):
+    """hipGetLastError() is sticky per thread: a device list that is refused (ordinal 99) must not make the NEXT,
+    unrelated solve fail at its first kernel-launch check (it did: 'hipGetLastError(): invalid device ordinal')."""
+    from se_snmf_nat_amd import sparse_nmf
+    from se_snmf_nat_amd.api import _make_params
+    sp = _make_params(64, 40, 8, 1.0, 5, 0.0, 1, True, 0, 0.0, None, None)
+    h = C.c_void_p()
+    devs = np.asarray([0, 99], np.int32)
+    assert lib.snmf_multi_create(C.c_void_p(devs.ctypes.data), 2, C.byref(sp), None, C.byref(h)) != 0
+    V, W0, H0 = synth_problem(64, 40, 8)
+    w, _, o = sparse_nmf(V, dict(cf="kl", sparsity=1, max_iter=3, init_w=W0, init_h=H0, cost_check=1), ctx=gpu_ctx)
+    assert np.isfinite(w).all() and o["n_iter"] == 3
