@@ -898,25 +898,37 @@ __device__ __forceinline__ void rp_await(unsigned* c, unsigned target, const int
 
 // acc[i] += sum_q Wfrag_i(q) (x) Sfrag(q), i < NA: NA output tiles that share the LDS operand stream.
 //   wp[i]: this lane's f32x4 of W operand image i, consecutive k-blocks 64 f32x4 apart;  sp: this lane's LDS row.
-// Two named stages (A, B), each one k-block = 4*NA MFMAs; stage X+1's loads are issued before stage X's MFMAs.
-// An odd block count needs no tail code: the clamped prefetch of the last round already holds block nq-1.
+// Three named stages, each one k-block = 4*NA MFMAs, fragments two blocks ahead of their use (a wave that has the pipe
+// to itself still hides the L2 latency).  No tail code: the clamped prefetch of the last rounds re-reads block nq-1.
+// gate(): called between the W loads of the first two blocks and their LDS loads.  W does not depend on the tile, so
+// the caller puts its WAIT for the LDS image there: the L2 round trip of the loop's first fragments (~0.8 k cycles per
+// call, measured with one team's loops removed: a lone A loop ran at 77 cycles per MFMA, a lone two-phase B loop at 86)
+// is then spent while the wave waits anyway.
 // (-DSNMF_PROF diagnostic builds only: wmask / smask re-use operand fragments -- wrong results, same MFMAs -- to
 // measure what the L2 and LDS operand streams cost; StepArgs::stagger_shift carries the selector.)
-template <int NA>
+template <int NA, typename Gate>
 __device__ __forceinline__ void contract_shared(f32x16 (&acc)[NA], const f32x4* const (&wp)[NA], const float* sp, int nq,
-                                                int wmask = -1, int smask = -1) {
-    f32x4 wA[NA], wB[NA], sA, sB;
+                                                int wmask, int smask, Gate gate) {
+    f32x4 wA[NA], wB[NA], wC[NA], sA, sB, sC;
     const int last = nq - 1;
-    auto ld = [&](f32x4 (&w)[NA], f32x4& sf, int q) {
-        const int qq = q < last ? q : last;
+    auto ldw = [&](f32x4 (&w)[NA], int q) {
+        int qq = q < last ? q : last;
 #ifdef SNMF_PROF
-        const int qw = qq & wmask, qs = qq & smask;
-#else
-        const int qw = qq, qs = qq;
+        qq &= wmask;
 #endif
 #pragma unroll
-        for (int i = 0; i < NA; ++i) w[i] = wp[i][(size_t)qw * 64];
-        sf = *reinterpret_cast<const f32x4*>(sp + 8 * qs);
+        for (int i = 0; i < NA; ++i) w[i] = wp[i][(size_t)qq * 64];
+    };
+    auto lds_ = [&](f32x4& sf, int q) {
+        int qq = q < last ? q : last;
+#ifdef SNMF_PROF
+        qq &= smask;
+#endif
+        sf = *reinterpret_cast<const f32x4*>(sp + 8 * qq);
+    };
+    auto ld = [&](f32x4 (&w)[NA], f32x4& sf, int q) {
+        ldw(w, q);
+        lds_(sf, q);
     };
     auto mm = [&](const f32x4 (&w)[NA], const f32x4& sf) {
 #pragma unroll
@@ -924,42 +936,26 @@ __device__ __forceinline__ void contract_shared(f32x16 (&acc)[NA], const f32x4* 
 #pragma unroll
             for (int i = 0; i < NA; ++i) acc[i] = mfma32(w[i][e], sf[e], acc[i]);
     };
-#ifndef SNMF_RP_DEPTH
-#define SNMF_RP_DEPTH 2
-#endif
-    if (SNMF_RP_DEPTH == 2) {
-        // fragments two stages (16 MFMAs, >= 1024 cycles) ahead: a wave that has the pipe to itself still hides the L2
-        // latency (measured: 570.6 k against 575 k stamped cycles per wave with one stage ahead, within noise on the wall)
-        f32x4 wC[NA], sC;
-        ld(wA, sA, 0);
-        ld(wB, sB, 1);
-        int q = 0;
-        for (; q + 2 < nq; q += 3) {
-            ld(wC, sC, q + 2);
-            SNMF_PIN();
-            mm(wA, sA);
-            ld(wA, sA, q + 3);
-            SNMF_PIN();
-            mm(wB, sB);
-            ld(wB, sB, q + 4);
-            SNMF_PIN();
-            mm(wC, sC);
-        }
-        if (q < nq) mm(wA, sA);
-        if (q + 1 < nq) mm(wB, sB);
-        return;
-    }
-    ld(wA, sA, 0);
+    ldw(wA, 0);
+    ldw(wB, 1);
+    SNMF_PIN();
+    gate();
+    lds_(sA, 0);
+    lds_(sB, 1);
     int q = 0;
-    for (; q + 1 < nq; q += 2) {
-        ld(wB, sB, q + 1);
+    for (; q + 2 < nq; q += 3) {
+        ld(wC, sC, q + 2);
         SNMF_PIN();
         mm(wA, sA);
-        ld(wA, sA, q + 2);
+        ld(wA, sA, q + 3);
         SNMF_PIN();
         mm(wB, sB);
+        ld(wB, sB, q + 4);
+        SNMF_PIN();
+        mm(wC, sC);
     }
     if (q < nq) mm(wA, sA);
+    if (q + 1 < nq) mm(wB, sB);
 }
 
 // P1 epilogue of one 32-row tile: Lam -> ratio in place over the staged V (+ the divergence terms of the previous iterate).
@@ -1215,9 +1211,11 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             float* Hs = lds + (j & 1) * bufsz;
             float* Rs = Hs + Tt * ldh;
             SNMF_STAMP(11);
-            rp_await(ready, (unsigned)(NL * (j + 1)), a.stop);
-            SNMF_STAMP(0);
-            SNMF_STAMP_TILE(a.prof, blockIdx.x, j);
+            bool waited = false;
+            auto gate_ready = [&]() {  // the tile's H image: waited for once, behind the first W fragments of the tile
+                if (!waited) rp_await(ready, (unsigned)(NL * (j + 1)), a.stop);
+                waited = true;
+            };
             const int fl = lane & 31, h = lane >> 5;
             const float* sp = Hs + fl * ldh + 4 * h;
             float dsum = 0.f;
@@ -1226,7 +1224,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     f32x16 acc[2] = {zero16(), zero16()};
                     const f32x4* const wp[2] = {reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)phi * rp * 32) + lane,
                                                 reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)(phi + NA) * rp * 32) + lane};
-                    contract_shared<2>(acc, wp, sp, rp / 8, xw, xs);
+                    contract_shared<2>(acc, wp, sp, rp / 8, xw, xs, gate_ready);
                     SNMF_STAMP(4);
                     rp_p1_epilogue<OBJ>(a, acc[0], Rs, phi, t0, lane, dsum);
                     if (phi == w) rp_arrive(p1a, lane);  // row tile w < NA: this wave's share of the first 32*NA ratio rows
@@ -1235,11 +1233,12 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                 } else {
                     f32x16 acc[1] = {zero16()};
                     const f32x4* const wp[1] = {reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)phi * rp * 32) + lane};
-                    contract_shared<1>(acc, wp, sp, rp / 8, xw, xs);
+                    contract_shared<1>(acc, wp, sp, rp / 8, xw, xs, gate_ready);
                     rp_p1_epilogue<OBJ>(a, acc[0], Rs, phi, t0, lane, dsum);
                     if (phi == w) rp_arrive(p1a, lane);
                 }
             }
+            gate_ready();  // (a wave without a row tile has not waited yet)
             if (w >= a.nf) rp_arrive(p1a, lane);  // a wave without a row tile still counts
             if (OBJ) acc_div += (double)dsum;
             SNMF_STAMP(6);
@@ -1263,14 +1262,14 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             float* Hs = lds + (j & 1) * bufsz;
             const float* Rs = Hs + Tt * ldh;
             SNMF_STAMP(11);
-            rp_await(p1a, (unsigned)(NA * (j + 1)), a.stop);
-            SNMF_STAMP(7);
+            auto gate_p1a = [&]() { rp_await(p1a, (unsigned)(NA * (j + 1)), a.stop); };
             const int fl = lane & 31, h = lane >> 5;
             const float* sp = Rs + fl * ldr + 4 * h;
             float shsum = 0.f;
             // k-blocks over the ratio rows of the row tiles 0..NA-1 (never the extra row's block) / the rest
             const int nq = a.Fq / 8, nq1 = 4 * (a.nf < NA ? a.nf : NA);
             const unsigned p1b_target = (unsigned)((NA + (a.xr ? NL : 0)) * (j + 1));
+            auto gate_p1b = [&]() { rp_await(p1b, p1b_target, a.stop); };
             for (int kap = wb; kap < a.nk; kap += 2 * NB) {
                 if (kap + NB < a.nk) {
                     f32x16 acc[2] = {zero16(), zero16()};
@@ -1280,11 +1279,12 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                         rp_p2_consts(a, kap, lane, dp0);
                         rp_p2_consts(a, kap + NB, lane, dp1);
                     }
-                    contract_shared<2>(acc, wp, sp, nq1, xw, xs);
-                    rp_await(p1b, p1b_target, a.stop);
+                    contract_shared<2>(acc, wp, sp, nq1, xw, xs, gate_p1a);
                     if (nq > nq1) {
                         const f32x4* const wp2[2] = {wp[0] + (size_t)nq1 * 64, wp[1] + (size_t)nq1 * 64};
-                        contract_shared<2>(acc, wp2, sp + 8 * nq1, nq - nq1, xw, xs);
+                        contract_shared<2>(acc, wp2, sp + 8 * nq1, nq - nq1, xw, xs, gate_p1b);
+                    } else {
+                        gate_p1b();
                     }
                     SNMF_STAMP(9);
                     rp_p2_epilogue<OBJ>(a, acc[0], Hs, kap, t0, lane, dp0, shsum);
@@ -1294,11 +1294,12 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     f32x16 acc[1] = {zero16()};
                     const f32x4* const wp[1] = {reinterpret_cast<const f32x4*>(a.Wk4 + (size_t)kap * a.Fq * 32) + lane};
                     if (!one_group) rp_p2_consts(a, kap, lane, dp0);
-                    contract_shared<1>(acc, wp, sp, nq1, xw, xs);
-                    rp_await(p1b, p1b_target, a.stop);
+                    contract_shared<1>(acc, wp, sp, nq1, xw, xs, gate_p1a);
                     if (nq > nq1) {
                         const f32x4* const wp2[1] = {wp[0] + (size_t)nq1 * 64};
-                        contract_shared<1>(acc, wp2, sp + 8 * nq1, nq - nq1, xw, xs);
+                        contract_shared<1>(acc, wp2, sp + 8 * nq1, nq - nq1, xw, xs, gate_p1b);
+                    } else {
+                        gate_p1b();
                     }
                     rp_p2_epilogue<OBJ>(a, acc[0], Hs, kap, t0, lane, dp0, shsum);
                 }
