@@ -4,7 +4,7 @@ set -o pipefail
 TAG=${1:-r2a}
 mkdir -p gpurun_out
 echo "== pytest -m gpu" 
-timeout -k 10 900 python -m pytest tests -m gpu -x -q --durations=15 > gpurun_out/${TAG}_pytest.log 2>&1
+timeout -k 10 900 python -X faulthandler -m pytest tests -m gpu -x -q --durations=15 -o faulthandler_timeout=150 > gpurun_out/${TAG}_pytest.log 2>&1
 rc=$?
 tail -5 gpurun_out/${TAG}_pytest.log
 [ $rc -ne 0 ] && exit $rc

@@ -412,7 +412,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     // widest tile whose H image + ratio image fit the 160 KiB LDS.  SNMF_HSTEP_CFG=NWxNT overrides.
     const size_t per_col = (size_t)(pl->ldh + pl->ldr) * 4;
     const size_t lds_cap = 160 * 1024;  // gfx950: 160 KiB per CU, one workgroup may take all of it
-    const size_t lds_extra = (size_t)pl->rp * 4 + 16;  // extra row of W + the roles' LDS counters
+    const size_t lds_extra = (size_t)pl->rp * 4 + 96;  // extra row of W + the roles' progress slots (5 signals x 4 waves)
     const size_t lds1 = 32 * per_col + lds_extra, lds2 = 64 * per_col + lds_extra;
     if (2 * lds1 - lds_extra <= lds_cap) { pl->NWH = 8; pl->NT = 1; pl->NLH = 4; }  // double-buffered
     else if (lds2 <= lds_cap && pl->Tp / 64 >= ctx->n_cu) { pl->NWH = 8; pl->NT = 2; }
@@ -456,15 +456,15 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     pl->n_fg = (pl->nf + pl->NWB - 1) / pl->NWB;
     // H image of k_wstats: rows padded to whole NKT-tile groups (branch-free P4, see the kernel)
     pl->ldhw = std::max(pl->rp, 32 * pl->NKT * pl->n_kg) + 4;
-    if (((size_t)32 * pl->ldhw + (size_t)32 * pl->Fp) * 4 + (size_t)pl->rp * 4 + 16 > lds_cap && pl->NKT == 16)
+    if (((size_t)32 * pl->ldhw + (size_t)32 * pl->Fp) * 4 + (size_t)pl->rp * 4 + 32 > lds_cap && pl->NKT == 16)
         pl->TTW = 16;  // large r: 16-frame tiles (the 32-frame H + V images do not fit the LDS)
     const int n_tiles_w = pl->Tp / pl->TTW;
     {
         const size_t buf = ((size_t)pl->TTW * pl->ldhw + (size_t)pl->TTW * pl->Fp) * 4;
         // loaders + double buffering when the accumulators allow 2 waves per SIMD and LDS has room
-        pl->NLW = (pl->WPS == 2 && 2 * buf + (size_t)pl->rp * 4 + 16 <= lds_cap) ? 4 : 0;
+        pl->NLW = (pl->WPS == 2 && 2 * buf + (size_t)pl->rp * 4 + 32 <= lds_cap) ? 4 : 0;
         if (const char* e = getenv("SNMF_WSTATS_NL")) pl->NLW = (atoi(e) == 4 && pl->NLW == 4) ? 4 : 0;
-        pl->lds_w = std::max<size_t>((pl->NLW ? 2 : 1) * buf + (size_t)pl->rp * 4 + 16,  // + ready/done counters
+        pl->lds_w = std::max<size_t>((pl->NLW ? 2 : 1) * buf + (size_t)pl->rp * 4 + 32,  // + ready/done counters
                                      (size_t)(pl->NWB + pl->NLW) * 64 * sizeof(double));
     }
     const int wg_w = pl->NLW ? 1 : pl->WPS;  // workgroups per CU

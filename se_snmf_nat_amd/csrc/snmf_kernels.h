@@ -867,11 +867,12 @@ __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(Step
 // MFMA waves of a SIMD share the pipe and therefore leave their loops together; if P2 of the next tile could only start
 // after the A team's whole epilogue (and the extra row), nobody would issue an MFMA through all of it.  Hence the extra
 // row on the loaders, and P2 in two phases: the first 4*NA k-blocks need only the ratio rows of the row tiles 0..NA-1.
-// No workgroup barrier inside the tile loop: four monotonic LDS counters order the roles
-//     ready  (+NL    per tile, loaders)            "tile j is staged"                          A waits
-//     p1a    (+NA    per tile, A team)             "ratio rows of the row tiles 0..NA-1 whole"  B waits (phase 1)
-//     p1b    (+NA+NL per tile, A team + loaders)   "the whole ratio image is, extra row incl."  B waits (phase 2)
-//     p2done (+NB    per tile, B team)             "H_j is updated, its ratio dead"             loaders wait
+// No workgroup barrier inside the tile loop: five signals, each four per-wave progress words in LDS, order the roles
+//     ready  (loaders)   "tile j is staged"                          A waits (and the loaders' own extra-row pass)
+//     p1a    (A team)    "ratio rows of the row tiles 0..NA-1 whole"  B waits (phase 1)
+//     p1b    (A team)    "every ratio row tile is whole"              B waits (phase 2)
+//     xdone  (loaders)   "the extra row of the ratio image is done"   B waits (phase 2)
+//     p2done (B team)    "H_j is updated, its ratio dead"             loaders wait
 // (dependencies run strictly forward in the tile index, so the waits cannot form a cycle; every wait is a bounded spin
 // that raises DevState::fault instead of hanging).  Each wave owns TWO 32-row (A) / 32-column (B) output tiles whose
 // MFMA chains share every LDS fragment: one ds_read_b128 feeds 8 MFMAs instead of 4, and two independent accumulator
@@ -880,13 +881,25 @@ __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(Step
 // Fences are LDS-only ("local"): LDS operations of a wave complete in order, and a workgroup-wide release that also
 // drained vmcnt would make the loaders wait for their H stores to be acknowledged by HBM.
 // ============================================================================================
-__device__ __forceinline__ void rp_arrive(unsigned* c, int lane) {
+// Progress slots: every producer wave of a role owns ONE word per signal and writes the number of tiles it has finished;
+// a consumer waits until all four words of the role have reached its tile.  (A single counter incremented by all four
+// waves -- what k_hstep's `sig` and k_wstats' ready / done do -- is a TOTAL: two arrivals of a fast wave can stand in for
+// the missing arrival of a slow one whenever a wave may run a tile ahead of its team.  The loaders stage tiles 0 and 1
+// back to back, so with a total `ready` the A team, or the loaders' own extra-row pass, could start on a tile that one
+// loader wave had not finished staging; a probe over awkward shapes found it.)
+__device__ __forceinline__ void rp_post(unsigned* slots, int wave_in_role, unsigned tiles_done, int lane) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    if (lane == 0) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) __hip_atomic_store(slots + wave_in_role, tiles_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void rp_await(unsigned* c, unsigned target, const int* stop) {
+__device__ __forceinline__ void rp_await(const unsigned* slots, unsigned target, const int* stop) {
     int spin = 0;
-    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+    for (;;) {
+        const unsigned a0 = __hip_atomic_load(slots + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned a1 = __hip_atomic_load(slots + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned a2 = __hip_atomic_load(slots + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned a3 = __hip_atomic_load(slots + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned lo01 = a0 < a1 ? a0 : a1, lo23 = a2 < a3 ? a2 : a3;
+        if ((lo01 < lo23 ? lo01 : lo23) >= target) break;
         if (++spin > kSpinLimit) {
             raise_fault(stop);
             break;
@@ -1074,11 +1087,15 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
     float* wxs = lds + 2 * bufsz;        // [rp] extra row of W
     unsigned* cnt = reinterpret_cast<unsigned*>(wxs + rp);
     // p1a: "the ratio rows of the row tiles 0..NA-1 are whole" (+NA per tile: each A wave after the epilogue of its FIRST
-    // row tile); p1b: "the whole ratio image is" (+NA+NL per tile: each A wave after its last epilogue, each loader wave
-    // after its share of the extra row).  The B team starts P2 on the first 4*NA k-blocks (rows 0..32*NA-1) at p1a and
+    // row tile); p1b: "every row tile is" (+NA per tile: each A wave after its last epilogue); xdone: "the extra row is"
+    // (+NL per tile: each loader wave after its share of it).  The B team starts P2 on the first 4*NA k-blocks (rows 0..32*NA-1) at p1a and
     // needs p1b only for the rest: in steady state both teams leave their MFMA loops together (they share the pipe), and
     // the A team's epilogue is then the one stretch with nobody in a loop -- B now waits for half of it only.
-    unsigned *ready = cnt, *p1a = cnt + 1, *p1b = cnt + 2, *p2done = cnt + 3;
+    // (the counters are TOTALS over the tiles, so each one has a single kind of producer: a counter fed by two roles
+    // could reach a tile's target on the arrivals of the role that runs ahead -- the loaders' extra rows of tiles 0 and
+    // 1 are both done before the A team has finished tile 0)
+    static_assert(NA == 4 && NB == 4 && NL == 4, "four progress slots per role");
+    unsigned *ready = cnt, *p1a = cnt + 4, *p1b = cnt + 8, *p2done = cnt + 12, *xdone = cnt + 16;
     double acc_div = 0.0, acc_sh = 0.0;
     if (a.xr) {
         for (int k = threadIdx.x; k < rp; k += NTHR) wxs[k] = a.wx[k];
@@ -1088,7 +1105,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             lds[bsel * bufsz + Tt * ldh + (ii >> 3) * ldr + a.Fm + (ii & 7)] = 0.f;
         }
     }
-    if (threadIdx.x < 4) cnt[threadIdx.x] = 0u;
+    if (threadIdx.x < 20) cnt[threadIdx.x] = 0u;
     __syncthreads();
     // diagnostic operand-reuse experiment (SNMF_PROF builds): 1 = W fragments of even k-blocks only, 2 = W block 0 only,
     // 3 = LDS fragments of even k-blocks only, 4 = LDS block 0 only, 5 = both streams block 0 only
@@ -1123,16 +1140,16 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
         const int lw = w - (NA + NB);
         auto xrow_of = [&](int j) {
             if (!a.xr) return;
-            rp_await(ready, (unsigned)(NL * (j + 1)), a.stop);
+            rp_await(ready, (unsigned)(j + 1), a.stop);
             float* bH = lds + (j & 1) * bufsz;
             hstep_p1_xrow<NL, 1, BM_KL, OBJ>(a, bH, bH + Tt * ldh, wxs, tile_of(j) * Tt, lw, lane, true, acc_div);
-            rp_arrive(p1b, lane);
+            rp_post(xdone, lw, (unsigned)(j + 1), lane);
         };
         for (int j = 0; j < 2 && j < nmy; ++j) {
             float* bH = lds + j * bufsz;
             stage_in2<NLT, PA, PB>(a.Hin + (size_t)tile_of(j) * Tt * rp, bH, Tt, rp, ldh, a.V + (size_t)tile_of(j) * Tt * Fp,
                                    bH + Tt * ldh, Tt, Fp, ldr, lt);
-            rp_arrive(ready, lane);
+            rp_post(ready, lw, (unsigned)(j + 1), lane);
         }
         for (int j = 0; j < 2 && j < nmy; ++j) xrow_of(j);
         for (int j = 0; j < nmy; ++j) {
@@ -1164,14 +1181,14 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                 for (int b = 0; b < PB; ++b) xb[b] = *reinterpret_cast<const f32x4*>(srcB + 4 * (size_t)cell(b, nB));
             }
             SNMF_PIN();
-            rp_await(p2done, (unsigned)(NB * (j + 1)), a.stop);
+            rp_await(p2done, (unsigned)(j + 1), a.stop);
             float* const dstH = a.Hout + (size_t)tile_of(j) * Tt * rp;
             if (!fits) {  // shape too big for the register path: plain copy-out, then a plain (latency-exposed) refill
                 stage_out<NLT>(dstH, bH, Tt, rp, ldh, lt);
                 if (more) {
                     stage_in<NLT>(a.Hin + (size_t)tile_of(j + 2) * Tt * rp, bH, Tt, rp, ldh, lt);
                     stage_in<NLT>(a.V + (size_t)tile_of(j + 2) * Tt * Fp, bH + Tt * ldh, Tt, Fp, ldr, lt);
-                    rp_arrive(ready, lane);
+                    rp_post(ready, lw, (unsigned)(j + 3), lane);
                     xrow_of(j + 2);
                 }
                 continue;
@@ -1199,7 +1216,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     const int t = (int)__umulhi((unsigned)i, invB), k4 = i - t * rB;
                     *reinterpret_cast<f32x4*>(bH + Tt * ldh + t * ldr + 4 * k4) = xb[b];
                 }
-                rp_arrive(ready, lane);
+                rp_post(ready, lw, (unsigned)(j + 3), lane);
                 xrow_of(j + 2);
             }
         }
@@ -1213,7 +1230,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             SNMF_STAMP(11);
             bool waited = false;
             auto gate_ready = [&]() {  // the tile's H image: waited for once, behind the first W fragments of the tile
-                if (!waited) rp_await(ready, (unsigned)(NL * (j + 1)), a.stop);
+                if (!waited) rp_await(ready, (unsigned)(j + 1), a.stop);
                 waited = true;
             };
             const int fl = lane & 31, h = lane >> 5;
@@ -1227,7 +1244,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     contract_shared<2>(acc, wp, sp, rp / 8, xw, xs, gate_ready);
                     SNMF_STAMP(4);
                     rp_p1_epilogue<OBJ>(a, acc[0], Rs, phi, t0, lane, dsum);
-                    if (phi == w) rp_arrive(p1a, lane);  // row tile w < NA: this wave's share of the first 32*NA ratio rows
+                    if (phi == w) rp_post(p1a, w, (unsigned)(j + 1), lane);  // row tile w < NA: this wave's share of the first 32*NA ratio rows
                     rp_p1_epilogue<OBJ>(a, acc[1], Rs, phi + NA, t0, lane, dsum);
                     SNMF_STAMP(5);
                 } else {
@@ -1235,14 +1252,14 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     const f32x4* const wp[1] = {reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)phi * rp * 32) + lane};
                     contract_shared<1>(acc, wp, sp, rp / 8, xw, xs, gate_ready);
                     rp_p1_epilogue<OBJ>(a, acc[0], Rs, phi, t0, lane, dsum);
-                    if (phi == w) rp_arrive(p1a, lane);
+                    if (phi == w) rp_post(p1a, w, (unsigned)(j + 1), lane);
                 }
             }
             gate_ready();  // (a wave without a row tile has not waited yet)
-            if (w >= a.nf) rp_arrive(p1a, lane);  // a wave without a row tile still counts
+            if (w >= a.nf) rp_post(p1a, w, (unsigned)(j + 1), lane);  // a wave without a row tile still reports
             if (OBJ) acc_div += (double)dsum;
             SNMF_STAMP(6);
-            rp_arrive(p1b, lane);
+            rp_post(p1b, w, (unsigned)(j + 1), lane);
         }
         SNMF_STAMP_OUT(a.prof + ((size_t)blockIdx.x * (NA + NB) + w) * 12, 12);
         SNMF_STAMP_CLK(a.prof, (size_t)blockIdx.x * (NA + NB) + w);
@@ -1262,14 +1279,16 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             float* Hs = lds + (j & 1) * bufsz;
             const float* Rs = Hs + Tt * ldh;
             SNMF_STAMP(11);
-            auto gate_p1a = [&]() { rp_await(p1a, (unsigned)(NA * (j + 1)), a.stop); };
+            auto gate_p1a = [&]() { rp_await(p1a, (unsigned)(j + 1), a.stop); };
             const int fl = lane & 31, h = lane >> 5;
             const float* sp = Rs + fl * ldr + 4 * h;
             float shsum = 0.f;
             // k-blocks over the ratio rows of the row tiles 0..NA-1 (never the extra row's block) / the rest
             const int nq = a.Fq / 8, nq1 = 4 * (a.nf < NA ? a.nf : NA);
-            const unsigned p1b_target = (unsigned)((NA + (a.xr ? NL : 0)) * (j + 1));
-            auto gate_p1b = [&]() { rp_await(p1b, p1b_target, a.stop); };
+            auto gate_p1b = [&]() {
+                rp_await(p1b, (unsigned)(j + 1), a.stop);
+                if (a.xr) rp_await(xdone, (unsigned)(j + 1), a.stop);
+            };
             for (int kap = wb; kap < a.nk; kap += 2 * NB) {
                 if (kap + NB < a.nk) {
                     f32x16 acc[2] = {zero16(), zero16()};
@@ -1305,7 +1324,11 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                 }
             }
             if (OBJ) acc_sh += (double)shsum;
-            rp_arrive(p2done, lane);
+            // a wave WITHOUT a column tile (nk < NB) has waited for nothing yet: it must not run ahead and count towards
+            // p2done of a later tile before the working waves are there (the counters are totals, not per-tile flags)
+            gate_p1a();
+            gate_p1b();
+            rp_post(p2done, wb, (unsigned)(j + 1), lane);
         }
         SNMF_STAMP_OUT(a.prof + ((size_t)blockIdx.x * (NA + NB) + w) * 12, 12);
         SNMF_STAMP_CLK(a.prof, (size_t)blockIdx.x * (NA + NB) + w);
@@ -1822,29 +1845,15 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     // of G), so all they need is "tile i is staged" -- an LDS counter the loader waves bump (`ready`, NL per tile) --
     // and all the loaders need before they refill a buffer is "every consumer is done with tile i-1" (`done`, NWB
     // per tile).  Waits are bounded spins: a lost signal raises DevState::fault (the host then fails the call), never a hang.
-    unsigned* ready = reinterpret_cast<unsigned*>(wxs + rp);
-    unsigned* done = ready + 1;
-    auto arrive = [&](unsigned* c) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    auto await = [&](unsigned* c, unsigned target) {
-        int spin = 0;
-        while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
-            if (++spin > kSpinLimit) {
-                raise_fault(a.stop);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    };
+    // Per-wave progress slots (rp_post / rp_await): a single counter bumped by all four waves is a TOTAL, and a consumer
+    // that drifts a tile ahead of a slow team-mate (nothing synchronises the consumers with each other) could have stood
+    // in for it and let the loaders refill a buffer that wave was still reading.
+    static_assert(NL == 0 || (NL == 4 && NWB == 4), "four progress slots per role");
+    unsigned* ready = reinterpret_cast<unsigned*>(wxs + rp);  // [4] loader waves: tiles staged
+    unsigned* done = ready + 4;                               // [4] consumer waves: tiles finished
     if (NL > 0) {
-        if (threadIdx.x == 0) {
-            *ready = 0u;
-            *done = 0u;
-        }
-        __syncthreads();  // counters and wxs are set
+        if (threadIdx.x < 8) ready[threadIdx.x] = 0u;
+        __syncthreads();  // slots and wxs are set
     }
 
     if (is_loader) {
@@ -1852,12 +1861,12 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         if (tb < te) {
             stage_in<NST>(a.Hin + (size_t)tb * TT * rp, lds, TT, rp, ldh, sid);
             stage_in<NST>(a.V + (size_t)tb * TT * Fp, lds + TT * ldh, TT, Fp, Fp, sid);
-            arrive(ready);
+            rp_post(ready, w - NWB, 1u, lane);
         }
         for (int tile = tb, it = 0; tile < te; ++tile, ++it) {
             const float* cH = lds + (it & 1) * bufsz;
             float* nH = lds + ((it & 1) ^ 1) * bufsz;
-            await(ready, (unsigned)(NL * (it + 1)));  // tile `tile` is complete in buffer it&1 (every loader wave's part)
+            rp_await(ready, (unsigned)(it + 1), a.stop);  // tile `tile` is complete in buffer it&1 (every loader wave's part)
             if (do_s) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -1870,10 +1879,10 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
                 }
             }
             if (tile + 1 < te) {
-                await(done, (unsigned)(NWB * it));  // every consumer has finished tile-1, which lives in nH
+                rp_await(done, (unsigned)it, a.stop);  // every consumer has finished tile-1, which lives in nH
                 stage_in2<NST, 10, 10>(a.Hin + (size_t)(tile + 1) * TT * rp, nH, TT, rp, ldh,
                                        a.V + (size_t)(tile + 1) * TT * Fp, nH + TT * ldh, TT, Fp, Fp, sid);
-                arrive(ready);
+                rp_post(ready, w - NWB, (unsigned)(it + 2), lane);
             }
         }
     }
@@ -1890,7 +1899,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
             stage_in<NST>(a.V + (size_t)t0 * Fp, Vs, TT, Fp, Fp, sid);
             __syncthreads();
         } else {
-            await(ready, (unsigned)(NL * (it + 1)));
+            rp_await(ready, (unsigned)(it + 1), a.stop);
         }
         SNMF_STAMP(1);
         if (NL == 0 && do_s) {
@@ -1951,7 +1960,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         }
         SNMF_STAMP(2);
         if (!active) {
-            if (NL > 0) arrive(done);
+            if (NL > 0) rp_post(done, w, (unsigned)(it + 1), lane);
             continue;
         }
 
@@ -2037,7 +2046,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         SNMF_KTILE(14, b0, b1)
         SNMF_KTILE(15, b1, b0)
 #undef SNMF_KTILE
-        if (NL > 0) arrive(done);  // this wave's last LDS read of the tile fed the MFMAs above
+        if (NL > 0) rp_post(done, w, (unsigned)(it + 1), lane);  // this wave's last LDS read of the tile fed the MFMAs above
         SNMF_STAMP(5);
     }
 #ifdef SNMF_PROF

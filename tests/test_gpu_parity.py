@@ -105,6 +105,12 @@ CASES = [
     ("b3_full", 65, 200, 16, dict(cf="beta", beta=3.0, sparsity=1, max_iter=10), None, None),
     # F + r > 1272: the 32-frame LDS images do not fit -> 16-frame tiles (the reference's exemplar setting R_x = R_d = 500
     # at F = 513, settings/bak_IS16_results/initial_setting_Exemplar.m:47-48; src/bnmf_sep_event_RT_IS16.m:138-154)
+    # small rank / few rows with MANY tiles per workgroup (T > 256 x 32): role-pipeline waves that own no tile must not
+    # run ahead of the working ones (the LDS counters are totals)
+    ("kl_r8_T20000", 257, 20000, 8, dict(cf="kl", sparsity=5, max_iter=4), None, None),
+    ("kl_r70_T12000_F65", 65, 12000, 70, dict(cf="kl", sparsity=1, max_iter=4), None, None),
+    ("kl_r200_T9000_F161", 161, 9000, 200, dict(cf="kl", sparsity=1, max_iter=3), None, None),
+    ("kl_r96_T20000_F97_honly", 97, 20000, 96, dict(cf="kl", sparsity=1, max_iter=3), "none", None),
     ("kl_r1000_honly", 513, 64, 1000, dict(cf="kl", sparsity=5, max_iter=8, conv_eps=1e-3), "none", None),
     ("kl_r1000_full", 513, 300, 1000, dict(cf="kl", sparsity=5, max_iter=4), None, None),
     ("kl_r1000_wonly", 513, 200, 1000, dict(cf="kl", sparsity=5, max_iter=4), None, "none"),
