@@ -16,7 +16,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct Stamp { unsigned long long c0, c1, r0, r1; };
 
-template <int MODE, int PRIO = 0, bool MF = true, int PAD = 0>
+// CH: independent accumulator chains of the MFMA wave (1 = every MFMA waits for the result of the one before it)
+template <int MODE, int PRIO = 0, bool MF = true, int PAD = 0, int CH = 4>
 __global__ __launch_bounds__(512) void k_pair(const float* __restrict__ src, float* __restrict__ out, Stamp* st, int trips,
                                                unsigned long long* polls) {
     __shared__ __attribute__((aligned(16))) float lds[8192];
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(512) void k_pair(const float* __restrict__ src, flo
                 for (int j = 0; j < 8; ++j)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(j + c) & 7], b[(j + 2 * c) & 7], acc[c], 0, 0, 0);
+                        acc[c % CH] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(j + c) & 7], b[(j + 2 * c) & 7], acc[c % CH], 0, 0, 0);
                         // PAD: give the issue port away while the matrix pipe works on the MFMA just issued (64 cycles):
                         // a wave that sits on a not-yet-issuable MFMA keeps every other wave of the SIMD from issuing
                         if (PAD >= 1) asm volatile("s_nop 15");
@@ -187,5 +188,14 @@ int main() {
     run(k_pair<2, 0, true, 3>, "rcp/log neighbour; MFMA wave: 3 x s_nop 15", src, out, st, trips);
     run(k_pair<3, 0, true, 3>, "ds_read_b128 neighbour; MFMA wave: 3 x s_nop 15", src, out, st, trips);
     run(k_pair<5, 0, true, 3>, "s_sleep polling neighbour; MFMA wave: 3 x s_nop 15", src, out, st, trips);
+    // the MFMA wave runs ONE dependent chain: its next MFMA is not issuable until the previous one has finished -- does the
+    // neighbour get the issue slots then, and what does that cost the chain?
+    run(k_pair<0, 0, true, 0, 1>, "one dependent chain, alone", src, out, st, trips);
+    run(k_pair<1, 0, true, 0, 1>, "one dependent chain; v_fma neighbour", src, out, st, trips);
+    run(k_pair<2, 0, true, 0, 1>, "one dependent chain; rcp/log neighbour", src, out, st, trips);
+    run(k_pair<3, 0, true, 0, 1>, "one dependent chain; ds_read_b128 neighbour", src, out, st, trips);
+    run(k_pair<4, 0, true, 0, 1>, "one dependent chain; global_load neighbour", src, out, st, trips);
+    run(k_pair<5, 0, true, 0, 1>, "one dependent chain; s_sleep polling neighbour", src, out, st, trips);
+    run(k_pair<1, 0, true, 0, 2>, "two chains; v_fma neighbour", src, out, st, trips);
     return 0;
 }

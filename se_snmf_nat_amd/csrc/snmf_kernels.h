@@ -100,6 +100,25 @@ struct DevState {
     int pad1;
 };
 // `stop` points at DevState::stop; the fault word sits two ints behind it
+// Index of this wave in its workgroup, as a SCALAR: `threadIdx.x >> 6` alone is a per-lane value to the compiler, and
+// every role switch, row / column-tile loop and operand base pointer derived from it then becomes vector code under exec
+// masks (with the register live ranges of all roles overlapping).  readfirstlane makes the uniformity visible.
+#ifndef SNMF_UNIFORM_W
+#define SNMF_UNIFORM_W 1
+#endif
+#ifndef SNMF_WX
+#define SNMF_WX 0
+#endif
+#ifndef SNMF_BUFW
+#define SNMF_BUFW 1  // W fragments of the MFMA loops through buffer descriptors + scalar offsets (0: 64-bit global loads)
+#endif
+__device__ __forceinline__ int wave_index() {
+#if SNMF_UNIFORM_W
+    return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#else
+    return (int)(threadIdx.x >> 6);
+#endif
+}
 __device__ __forceinline__ void raise_fault(const int* stop) {
     if (stop) atomicExch(const_cast<int*>(stop) + 2, 1);
 }
@@ -209,9 +228,14 @@ __device__ __forceinline__ void mfma_block(f32x16 (&acc)[NT], const f32x4& w, co
 // dependent v_mfma_f32_32x32x2_f32 issues every ~82 cycles when the wave is alone on its SIMD (k_wstats' P3: 128 MFMAs
 // in 10.5 k cycles, round-1 phase stamps) against ~68 for independent accumulators (P4): the pipe waits for the
 // previous result.  Changes the fp32 summation order (even / odd k-blocks), deterministically.
-template <int NT, bool SWAP, int SB, bool DUAL = false>
+// gate(): called once, after the W loads of the first stage have been issued and before the first LDS read: the caller's
+// wait for the LDS image goes there, so the L2 round trip of the first fragments is spent while the wave waits anyway.
+struct NoGate {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <int NT, bool SWAP, int SB, bool DUAL = false, typename Gate = NoGate>
 __device__ __forceinline__ void contract_sb(f32x16 (&acc)[NT], const f32x4* __restrict__ wp, const float* sp,
-                                            int sstride, int nq) {
+                                            int sstride, int nq, Gate gate = Gate()) {
     static_assert(!DUAL || SB == 2, "DUAL pairs the two blocks of a stage");
     f32x4 wA[SB], wB[SB];
     f32x4 sA[SB][NT], sB[SB][NT];
@@ -225,10 +249,12 @@ __device__ __forceinline__ void contract_sb(f32x16 (&acc)[NT], const f32x4* __re
 #pragma unroll
         for (int j = 0; j < SB; ++j) {
             const int qq = (q0 + j) < last ? (q0 + j) : last;
-            w[j] = wp[(size_t)qq * 64];
+            // SNMF_WX (timing experiments only, results wrong): 1 = every k-block uses W fragment 0 (no W loads in the
+            // loop), 2 = LDS fragment 0, 3 = both
+            w[j] = wp[(size_t)((SNMF_WX & 1) ? 0 : qq) * 64];
 #pragma unroll
             for (int tau = 0; tau < NT; ++tau)
-                sf[j][tau] = *reinterpret_cast<const f32x4*>(sp + tau * sstride + 8 * qq);
+                sf[j][tau] = *reinterpret_cast<const f32x4*>(sp + tau * sstride + 8 * ((SNMF_WX & 2) ? 0 : qq));
         }
     };
     auto mmstage = [&](const f32x4 (&w)[SB], const f32x4 (&sf)[SB][NT]) {
@@ -253,7 +279,15 @@ __device__ __forceinline__ void contract_sb(f32x16 (&acc)[NT], const f32x4* __re
     const int nmain = nq - nq % (2 * SB);
     int q = 0;
     if (nmain > 0) {
-        ldstage(wA, sA, 0);
+#pragma unroll
+        for (int j = 0; j < SB; ++j) wA[j] = wp[(size_t)(j < last ? j : last) * 64];
+        SNMF_PIN();
+        gate();
+#pragma unroll
+        for (int j = 0; j < SB; ++j)
+#pragma unroll
+            for (int tau = 0; tau < NT; ++tau)
+                sA[j][tau] = *reinterpret_cast<const f32x4*>(sp + tau * sstride + 8 * (j < last ? j : last));
         for (; q < nmain; q += 2 * SB) {
             ldstage(wB, sB, q + SB);
             SNMF_PIN();
@@ -266,6 +300,10 @@ __device__ __forceinline__ void contract_sb(f32x16 (&acc)[NT], const f32x4* __re
     // remainder (fewer than 2*SB blocks): simple two-deep pipeline
     if (q < nq) {
         f32x4 w0 = wp[(size_t)q * 64];
+        if (nmain == 0) {
+            SNMF_PIN();
+            gate();
+        }
         f32x4 s0[NT];
 #pragma unroll
         for (int tau = 0; tau < NT; ++tau) s0[tau] = *reinterpret_cast<const f32x4*>(sp + tau * sstride + 8 * q);
@@ -281,6 +319,7 @@ __device__ __forceinline__ void contract_sb(f32x16 (&acc)[NT], const f32x4* __re
             for (int tau = 0; tau < NT; ++tau) s0[tau] = s1[tau];
         }
     }
+    if (nq <= 0) gate();
     if (DUAL) {
 #pragma unroll
         for (int tau = 0; tau < NT; ++tau)
@@ -292,6 +331,95 @@ template <int NT, bool SWAP>
 __device__ __forceinline__ void contract(f32x16 (&acc)[NT], const f32x4* __restrict__ wp, const float* sp,
                                          int sstride, int nq) {
     contract_sb<NT, SWAP, 2>(acc, wp, sp, sstride, nq);  // SB = 4 measured slower (registers, no latency win)
+}
+
+// ---- operand fragments WITHOUT vector address arithmetic ------------------------------------------------------------
+// For v_mfma_f32_32x32x2_f32 every other instruction a SIMD issues is time its matrix pipe does not get
+// (scripts/mfma_samewave.hip), and an operand load is not just its own issue slot: with a 64-bit per-lane address
+// (global_load) each W fragment cost ~30 cycles and each LDS fragment ~14 in the loops above -- 78 cycles per MFMA for
+// k_wstats' P3 loop alone on a SIMD where the pipe needs 64 (scripts/p3_loop_probe.hip).  Here the W image is read
+// through a buffer descriptor: lane offset fixed (16 B per lane), k-block offset SCALAR (q * 1024 B on the SALU), LDS
+// fragments at immediate offsets from one moving base, and no clamps on the prefetch past the last block (the W image is
+// bounds-checked by the descriptor, the LDS reads stay inside the workgroup's allocation: callers see to that).  The same
+// probe: 69 cycles per MFMA, 66 with the 32 k-blocks of rp = 256 fully unrolled.
+// The wave index that selects the image block must be scalar (wave_index()).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wimage_rsrc(const float* img, size_t n_floats) {
+    const size_t bytes = n_floats * 4;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img), 0, bytes > 0xfffffff0ull ? (int)0xfffffff0u : (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 ldw_buf(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+}
+// acc += sum_q Sfrag(q) (x) Wfrag(q)  (LDS tile = A operand, W = B: k_wstats' P3), one accumulator chain.
+//   rs / voff / soff0: W image descriptor, this lane's byte offset (16 * lane), byte offset of the image block (scalar)
+//   sp: this lane's LDS row;  gate(): see contract_sb.  UNROLL32: nq == 32 known at compile time (rp = 256).
+template <bool UNROLL32, typename Gate>
+__device__ __forceinline__ void contract_p3_buf(f32x16& acc, __amdgpu_buffer_rsrc_t rs, int voff, int soff0, const float* sp,
+                                                int nq, Gate gate) {
+    f32x4 wA[2], wB[2], sA[2], sB[2];
+    auto ldw = [&](int q) { return ldw_buf(rs, voff, soff0 + q * 1024); };
+    auto mmstage = [&](const f32x4 (&w)[2], const f32x4 (&sf)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = mfma32(sf[j][e], w[j][e], acc);
+    };
+    wA[0] = ldw(0);
+    wA[1] = ldw(1);
+    SNMF_PIN();
+    gate();
+    sA[0] = *reinterpret_cast<const f32x4*>(sp);
+    sA[1] = *reinterpret_cast<const f32x4*>(sp + 8);
+    if (UNROLL32) {
+#pragma unroll
+        for (int q = 0; q < 32; q += 4) {
+            wB[0] = ldw(q + 2);
+            wB[1] = ldw(q + 3);
+            sB[0] = *reinterpret_cast<const f32x4*>(sp + 8 * (q + 2));
+            sB[1] = *reinterpret_cast<const f32x4*>(sp + 8 * (q + 3));
+            SNMF_PIN();
+            mmstage(wA, sA);
+            wA[0] = ldw(q + 4);
+            wA[1] = ldw(q + 5);
+            sA[0] = *reinterpret_cast<const f32x4*>(sp + 8 * (q + 4));
+            sA[1] = *reinterpret_cast<const f32x4*>(sp + 8 * (q + 5));
+            SNMF_PIN();
+            mmstage(wB, sB);
+        }
+        return;
+    }
+    const float* bp = sp;  // moving base: block q + j at bp + 8 * j
+    int q = 0;
+    for (; q + 3 < nq; q += 4) {
+        wB[0] = ldw(q + 2);
+        wB[1] = ldw(q + 3);
+        sB[0] = *reinterpret_cast<const f32x4*>(bp + 16);
+        sB[1] = *reinterpret_cast<const f32x4*>(bp + 24);
+        SNMF_PIN();
+        mmstage(wA, sA);
+        wA[0] = ldw(q + 4);
+        wA[1] = ldw(q + 5);
+        sA[0] = *reinterpret_cast<const f32x4*>(bp + 32);
+        sA[1] = *reinterpret_cast<const f32x4*>(bp + 40);
+        bp += 32;
+        SNMF_PIN();
+        mmstage(wB, sB);
+    }
+    // remainder (nq % 4 blocks): wA / sA hold blocks q, q + 1
+    if (q < nq) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = mfma32(sA[0][e], wA[0][e], acc);
+    }
+    if (q + 1 < nq) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = mfma32(sA[1][e], wA[1][e], acc);
+    }
+    if (q + 2 < nq) {
+        const f32x4 w2 = ldw(q + 2);
+        const f32x4 s2 = *reinterpret_cast<const f32x4*>(bp + 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = mfma32(s2[e], w2[e], acc);
+    }
 }
 
 // Two workgroups share a CU.  Launched together with identical work they would run in lockstep:
@@ -711,7 +839,7 @@ __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(Step
     if (a.stop && *a.stop) return;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int Tt = NT == 1 ? TT : 32 * NT;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = wave_index();
     const int rp = a.rp, Fp = a.Fp, ldh = a.ldh, ldr = a.ldr;
     const int bufsz = Tt * (ldh + ldr);  // floats per buffer: Hs [Tt][ldh] then Rs [Tt][ldr]
     float* wxs = lds + NBUF * bufsz;     // [rp]  extra row of W
@@ -887,9 +1015,34 @@ __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(Step
 // the missing arrival of a slow one whenever a wave may run a tile ahead of its team.  The loaders stage tiles 0 and 1
 // back to back, so with a total `ready` the A team, or the loaders' own extra-row pass, could start on a tile that one
 // loader wave had not finished staging; a probe over awkward shapes found it.)
+// SNMF_WAKEUP = n > 0: a waiting wave sleeps n * 64 cycles between polls instead of 64, and every post pings the
+// workgroup's sleeping waves awake (s_wakeup), so a poll is only spent when some signal has moved.
+#ifndef SNMF_WAKEUP
+#define SNMF_WAKEUP 0
+#endif
+#ifndef SNMF_LEAN_LOADER
+#define SNMF_LEAN_LOADER 1  // k_hstep_rp loaders without index arithmetic (0 = the older per-cell path, 2 / 3 = H / V block only)
+#endif
+#define SNMF_LEAN_H (SNMF_LEAN_LOADER == 1 || SNMF_LEAN_LOADER == 2)
+#define SNMF_LEAN_V (SNMF_LEAN_LOADER == 1 || SNMF_LEAN_LOADER == 3)
+#ifndef SNMF_WSTATS_SB
+#define SNMF_WSTATS_SB 2  // k-blocks per named stage of P3's loop (fragments one stage = 4*SB MFMAs ahead)
+#endif
+#ifndef SNMF_WSTATS_GATE
+#define SNMF_WSTATS_GATE 0
+#endif
+#ifndef SNMF_WSTATS_XL
+#define SNMF_WSTATS_XL 0
+#endif
+#ifndef SNMF_WSTATS_DMA
+#define SNMF_WSTATS_DMA 1  // loader waves of k_wstats stage through LDS-DMA (buffer_load ... lds)
+#endif
 __device__ __forceinline__ void rp_post(unsigned* slots, int wave_in_role, unsigned tiles_done, int lane) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     if (lane == 0) __hip_atomic_store(slots + wave_in_role, tiles_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#if SNMF_WAKEUP > 0
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_wakeup" ::: "memory");
+#endif
 }
 __device__ __forceinline__ void rp_await(const unsigned* slots, unsigned target, const int* stop) {
     int spin = 0;
@@ -904,7 +1057,7 @@ __device__ __forceinline__ void rp_await(const unsigned* slots, unsigned target,
             raise_fault(stop);
             break;
         }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(SNMF_WAKEUP > 0 ? SNMF_WAKEUP : 1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
@@ -964,6 +1117,50 @@ __device__ __forceinline__ void contract_shared(f32x16 (&acc)[NA], const f32x4* 
         SNMF_PIN();
         mm(wB, sB);
         ld(wB, sB, q + 4);
+        SNMF_PIN();
+        mm(wC, sC);
+    }
+    if (q < nq) mm(wA, sA);
+    if (q + 1 < nq) mm(wB, sB);
+}
+
+// contract_shared with the W fragments through the buffer path (see contract_p3_buf): soff[i] = byte offset of image
+// block i (scalar).  LDS fragments at immediate offsets from a base that moves once per three k-blocks; no clamps: the
+// prefetch reads up to two k-blocks (64 B of the LDS row, 2 KB of the image) past the last one.
+template <int NA, typename Gate>
+__device__ __forceinline__ void contract_shared_buf(f32x16 (&acc)[NA], __amdgpu_buffer_rsrc_t rs, int voff, const int (&soff)[NA],
+                                                    const float* sp, int nq, Gate gate) {
+    f32x4 wA[NA], wB[NA], wC[NA], sA, sB, sC;
+    auto ldw = [&](f32x4 (&w)[NA], int q) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) w[i] = ldw_buf(rs, voff, soff[i] + q * 1024);
+    };
+    auto mm = [&](const f32x4 (&w)[NA], const f32x4& sf) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < NA; ++i) acc[i] = mfma32(w[i][e], sf[e], acc[i]);
+    };
+    ldw(wA, 0);
+    ldw(wB, 1);
+    SNMF_PIN();
+    gate();
+    const float* bp = sp;  // moving base: block q + j at bp + 8 * j
+    sA = *reinterpret_cast<const f32x4*>(bp);
+    sB = *reinterpret_cast<const f32x4*>(bp + 8);
+    int q = 0;
+    for (; q + 2 < nq; q += 3) {
+        ldw(wC, q + 2);
+        sC = *reinterpret_cast<const f32x4*>(bp + 16);
+        SNMF_PIN();
+        mm(wA, sA);
+        ldw(wA, q + 3);
+        sA = *reinterpret_cast<const f32x4*>(bp + 24);
+        SNMF_PIN();
+        mm(wB, sB);
+        ldw(wB, q + 4);
+        sB = *reinterpret_cast<const f32x4*>(bp + 32);
+        bp += 24;
         SNMF_PIN();
         mm(wC, sC);
     }
@@ -1081,7 +1278,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
     constexpr int PA = 10, PB = 10;  // f32x4 per loader thread of the H / V block held in registers (as stage_in2)
     if (a.stop && *a.stop) return;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = wave_index();
     const int rp = a.rp, Fp = a.Fp, ldh = a.ldh, ldr = a.ldr;
     const int bufsz = Tt * (ldh + ldr);  // floats per buffer: Hs [Tt][ldh] then Rs [Tt][ldr]
     float* wxs = lds + 2 * bufsz;        // [rp] extra row of W
@@ -1130,7 +1327,11 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
         // ================================ loaders ===================================================
         const int lt = threadIdx.x - (NA + NB) * 64;
         const int rA = rp / 4, nA = Tt * rA, rB = Fp / 4, nB = Tt * rB;
+#if SNMF_LEAN_LOADER
+        const bool fits = (SNMF_LEAN_H ? rp <= 256 : nA <= PA * NLT) && nB < PB * NLT;  // (H: one piece per row; V: the last slot is the straddling cell's)
+#else
         const bool fits = nA <= PA * NLT && nB <= PB * NLT;
+#endif
         // floor(i / d) = umulhi(i, ceil(2^32 / d)) for 0 <= i < 2^16 (i < 20 * 256 here), d >= 1
         const unsigned invA = (unsigned)((0x100000000ull + (unsigned)rA - 1) / (unsigned)rA);
         const unsigned invB = (unsigned)((0x100000000ull + (unsigned)rB - 1) / (unsigned)rB);
@@ -1145,6 +1346,53 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             hstep_p1_xrow<NL, 1, BM_KL, OBJ>(a, bH, bH + Tt * ldh, wxs, tile_of(j) * Tt, lw, lane, true, acc_div);
             rp_post(xdone, lw, (unsigned)(j + 1), lane);
         };
+#if SNMF_LEAN_LOADER
+        // Beside two waves that issue MFMAs back to back a loader wave gets an instruction in only where they stall
+        // (scripts/mfma_valu_overlap.hip), so the time from p2done(j) to ready(j+2) -- which the A team waits for -- is
+        // set by the NUMBER of instructions between them.  That was ~390 (index arithmetic per cell and tile, 64-bit
+        // addresses); this path has none of it:
+        //  * global side through buffer instructions: descriptor (SGPRs, rebuilt per tile) + SCALAR offset of the cell +
+        //    one fixed lane offset;
+        //  * the H block by rows (wave lw takes rows lw, lw+4, ..., one 1 KiB piece each: rp <= 256), so an LDS address is
+        //    (scalar row offset) + the same lane offset: one add per cell and tile;
+        //  * the V block by linear cells (its rows are not a whole number of pieces) with one precomputed LDS offset per
+        //    cell; slots past the end fall back onto the thread's own first cell, the LAST slot is the straddling cell's;
+        //  * lanes past the end of a short H row (rp < 256) duplicate lane 0.
+        // Every access stays unconditional (see below).
+        constexpr int PR = Tt / NL;  // H rows per loader wave
+        const int hv = lane * 4 < rp ? lane * 16 : 0;
+        const unsigned gv = 16u * (unsigned)lt;
+        const int nfB = nB / NLT;  // V cells wholly inside (>= 1)
+        unsigned gbB = (lt + nfB * NLT < nB) ? gv + 16u * (unsigned)(nfB * NLT) : gv;
+        asm volatile("" : "+v"(gbB));
+        int loB[PB];
+#pragma unroll
+        for (int b = 0; b < PB; ++b) {
+            const int ic = b == PB - 1 ? (int)(gbB >> 4) : (b < nfB ? lt + b * NLT : lt);
+            const int t = (int)__umulhi((unsigned)ic, invB), k4 = ic - t * rB;
+            loB[b] = Tt * ldh + t * ldr + 4 * k4;
+            asm volatile("" : "+v"(loB[b]));
+        }
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        auto ldA = [&](__amdgpu_buffer_rsrc_t rs, int i) {
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, hv, (lw + NL * i) * rp * 4, 0));
+        };
+        auto ldB = [&](__amdgpu_buffer_rsrc_t rs, int b) {
+            if (b == PB - 1) return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gbB, 0, 0));
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gv, b < nfB ? b * NLT * 16 : 0, 0));
+        };
+        // (s_nop: a buffer_store_dwordx4 with a REGISTER scalar offset still reads its data registers after it has
+        //  issued -- the compiler reused the first of them for an LDS address in the very next instruction and, in a few
+        //  lanes of a few stores, that address went to memory instead of H (found by scripts/rp_shape_probe.py; LLVM's
+        //  hazard recogniser only pads the store when the scalar offset is NOT a register))
+        auto stA = [&](__amdgpu_buffer_rsrc_t rs, int i, const f32x4& x) {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), rs, hv, (lw + NL * i) * rp * 4, 0);
+            asm volatile("s_nop 2" ::: "memory");
+        };
+        auto rsrc_of = [&](const float* base, int n_cells) {
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, n_cells * 16, 0x00020000);
+        };
+#endif
         for (int j = 0; j < 2 && j < nmy; ++j) {
             float* bH = lds + j * bufsz;
             stage_in2<NLT, PA, PB>(a.Hin + (size_t)tile_of(j) * Tt * rp, bH, Tt, rp, ldh, a.V + (size_t)tile_of(j) * Tt * Fp,
@@ -1175,10 +1423,27 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             if (more && fits) {
                 const float* srcA = a.Hin + (size_t)tile_of(j + 2) * Tt * rp;
                 const float* srcB = a.V + (size_t)tile_of(j + 2) * Tt * Fp;
+#if SNMF_LEAN_LOADER
+                if (SNMF_LEAN_H) {
+#pragma unroll
+                    for (int b = 0; b < PR; ++b) xa[b] = ldA(rsrc_of(srcA, nA), b);
+                } else {
+#pragma unroll
+                    for (int b = 0; b < PA; ++b) xa[b] = *reinterpret_cast<const f32x4*>(srcA + 4 * (size_t)cell(b, nA));
+                }
+                if (SNMF_LEAN_V) {
+#pragma unroll
+                    for (int b = 0; b < PB; ++b) xb[b] = ldB(rsrc_of(srcB, nB), b);
+                } else {
+#pragma unroll
+                    for (int b = 0; b < PB; ++b) xb[b] = *reinterpret_cast<const f32x4*>(srcB + 4 * (size_t)cell(b, nB));
+                }
+#else
 #pragma unroll
                 for (int b = 0; b < PA; ++b) xa[b] = *reinterpret_cast<const f32x4*>(srcA + 4 * (size_t)cell(b, nA));
 #pragma unroll
                 for (int b = 0; b < PB; ++b) xb[b] = *reinterpret_cast<const f32x4*>(srcB + 4 * (size_t)cell(b, nB));
+#endif
             }
             SNMF_PIN();
             rp_await(p2done, (unsigned)(j + 1), a.stop);
@@ -1194,6 +1459,52 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                 continue;
             }
             // the updated H tile leaves (LDS -> registers -> HBM; the stores are only ISSUED here) ...
+#if SNMF_LEAN_LOADER
+            const char* const bHl = reinterpret_cast<const char*>(bH) + hv;  // this lane's column of the H image
+            if (SNMF_LEAN_H) {
+#pragma unroll
+                for (int b = 0; b < PR; ++b) {
+                    const f32x4 ho = *reinterpret_cast<const f32x4*>(bHl + (lw + NL * b) * ldh * 4);
+                    stA(rsrc_of(dstH, nA), b, ho);
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < PA; ++b) {
+                    const int i = cell(b, nA);
+                    const int t = (int)__umulhi((unsigned)i, invA), k4 = i - t * rA;
+                    const f32x4 ho = *reinterpret_cast<const f32x4*>(bH + t * ldh + 4 * k4);
+                    *reinterpret_cast<f32x4*>(dstH + 4 * (size_t)i) = ho;
+                }
+            }
+            if (more) {
+                if (SNMF_LEAN_H) {
+#pragma unroll
+                    for (int b = 0; b < PR; ++b)
+                        *reinterpret_cast<f32x4*>(const_cast<char*>(bHl) + (lw + NL * b) * ldh * 4) = xa[b];
+                } else {
+#pragma unroll
+                    for (int b = 0; b < PA; ++b) {
+                        const int i = cell(b, nA);
+                        const int t = (int)__umulhi((unsigned)i, invA), k4 = i - t * rA;
+                        *reinterpret_cast<f32x4*>(bH + t * ldh + 4 * k4) = xa[b];
+                    }
+                }
+                if (SNMF_LEAN_V) {
+#pragma unroll
+                    for (int b = 0; b < PB; ++b) *reinterpret_cast<f32x4*>(bH + loB[b]) = xb[b];
+                } else {
+#pragma unroll
+                    for (int b = 0; b < PB; ++b) {
+                        const int i = cell(b, nB);
+                        const int t = (int)__umulhi((unsigned)i, invB), k4 = i - t * rB;
+                        *reinterpret_cast<f32x4*>(bH + Tt * ldh + t * ldr + 4 * k4) = xb[b];
+                    }
+                }
+                rp_post(ready, lw, (unsigned)(j + 3), lane);
+                xrow_of(j + 2);
+            }
+            continue;
+#endif
 #pragma unroll
             for (int b = 0; b < PA; ++b) {
                 const int i = cell(b, nA);
@@ -1239,9 +1550,14 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             for (int phi = w; phi < a.nf; phi += 2 * NA) {
                 if (phi + NA < a.nf) {
                     f32x16 acc[2] = {zero16(), zero16()};
+#if SNMF_BUFW
+                    const int so[2] = {phi * rp * 128, (phi + NA) * rp * 128};
+                    contract_shared_buf<2>(acc, wimage_rsrc(a.Wt4, (size_t)a.nf * rp * 32), lane * 16, so, sp, rp / 8, gate_ready);
+#else
                     const f32x4* const wp[2] = {reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)phi * rp * 32) + lane,
                                                 reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)(phi + NA) * rp * 32) + lane};
                     contract_shared<2>(acc, wp, sp, rp / 8, xw, xs, gate_ready);
+#endif
                     SNMF_STAMP(4);
                     rp_p1_epilogue<OBJ>(a, acc[0], Rs, phi, t0, lane, dsum);
                     if (phi == w) rp_post(p1a, w, (unsigned)(j + 1), lane);  // row tile w < NA: this wave's share of the first 32*NA ratio rows
@@ -1249,8 +1565,13 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     SNMF_STAMP(5);
                 } else {
                     f32x16 acc[1] = {zero16()};
+#if SNMF_BUFW
+                    const int so[1] = {phi * rp * 128};
+                    contract_shared_buf<1>(acc, wimage_rsrc(a.Wt4, (size_t)a.nf * rp * 32), lane * 16, so, sp, rp / 8, gate_ready);
+#else
                     const f32x4* const wp[1] = {reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)phi * rp * 32) + lane};
                     contract_shared<1>(acc, wp, sp, rp / 8, xw, xs, gate_ready);
+#endif
                     rp_p1_epilogue<OBJ>(a, acc[0], Rs, phi, t0, lane, dsum);
                     if (phi == w) rp_post(p1a, w, (unsigned)(j + 1), lane);
                 }
@@ -1298,6 +1619,19 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                         rp_p2_consts(a, kap, lane, dp0);
                         rp_p2_consts(a, kap + NB, lane, dp1);
                     }
+#if SNMF_BUFW
+                    {
+                        const __amdgpu_buffer_rsrc_t rsk = wimage_rsrc(a.Wk4, (size_t)a.nk * a.Fq * 32);
+                        const int so[2] = {kap * a.Fq * 128, (kap + NB) * a.Fq * 128};
+                        contract_shared_buf<2>(acc, rsk, lane * 16, so, sp, nq1, gate_p1a);
+                        if (nq > nq1) {
+                            const int so2[2] = {so[0] + nq1 * 1024, so[1] + nq1 * 1024};
+                            contract_shared_buf<2>(acc, rsk, lane * 16, so2, sp + 8 * nq1, nq - nq1, gate_p1b);
+                        } else {
+                            gate_p1b();
+                        }
+                    }
+#else
                     contract_shared<2>(acc, wp, sp, nq1, xw, xs, gate_p1a);
                     if (nq > nq1) {
                         const f32x4* const wp2[2] = {wp[0] + (size_t)nq1 * 64, wp[1] + (size_t)nq1 * 64};
@@ -1305,6 +1639,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     } else {
                         gate_p1b();
                     }
+#endif
                     SNMF_STAMP(9);
                     rp_p2_epilogue<OBJ>(a, acc[0], Hs, kap, t0, lane, dp0, shsum);
                     rp_p2_epilogue<OBJ>(a, acc[1], Hs, kap + NB, t0, lane, dp1, shsum);
@@ -1313,6 +1648,19 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     f32x16 acc[1] = {zero16()};
                     const f32x4* const wp[1] = {reinterpret_cast<const f32x4*>(a.Wk4 + (size_t)kap * a.Fq * 32) + lane};
                     if (!one_group) rp_p2_consts(a, kap, lane, dp0);
+#if SNMF_BUFW
+                    {
+                        const __amdgpu_buffer_rsrc_t rsk = wimage_rsrc(a.Wk4, (size_t)a.nk * a.Fq * 32);
+                        const int so[1] = {kap * a.Fq * 128};
+                        contract_shared_buf<1>(acc, rsk, lane * 16, so, sp, nq1, gate_p1a);
+                        if (nq > nq1) {
+                            const int so2[1] = {so[0] + nq1 * 1024};
+                            contract_shared_buf<1>(acc, rsk, lane * 16, so2, sp + 8 * nq1, nq - nq1, gate_p1b);
+                        } else {
+                            gate_p1b();
+                        }
+                    }
+#else
                     contract_shared<1>(acc, wp, sp, nq1, xw, xs, gate_p1a);
                     if (nq > nq1) {
                         const f32x4* const wp2[1] = {wp[0] + (size_t)nq1 * 64};
@@ -1320,6 +1668,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     } else {
                         gate_p1b();
                     }
+#endif
                     rp_p2_epilogue<OBJ>(a, acc[0], Hs, kap, t0, lane, dp0, shsum);
                 }
             }
@@ -1402,7 +1751,7 @@ __global__ __launch_bounds__(512, 2) void k_hsolve_small(StepArgs a, SmallArgs s
         sa.costh += (size_t)blockIdx.x * sa.max_iter;
         sa.st += blockIdx.x;
     }
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = wave_index();
     const int rp = a.rp, ldh = a.ldh, ldr = a.ldr;
     float* Hs = lds;                 // [32][ldh]
     float* Rs = Hs + Tt * ldh;       // [32][ldr] ratio / den / num image
@@ -1798,7 +2147,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int bufsz = TT * (a.ldh + a.Fp);  // floats per buffer: Hs [TT][ldh] then Vs [TT][Fp]
     float* wxs = lds + NBUF * bufsz;        // [rp] extra row of W
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = wave_index();
     const bool is_loader = NL > 0 && w >= NWB;
     const int fl = lane & 31, h = lane >> 5;
     const int rp = a.rp, Fp = a.Fp, ldh = a.ldh;
@@ -1815,7 +2164,9 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         }
     }
     const bool do_x = a.xr && by == 0 && blockIdx.z == 0;  // extra row: one f-group only
-    constexpr int CPW = TT / NWB;  // columns of the extra-row dot product per wave
+    constexpr bool XL = NL > 0 && SNMF_WSTATS_XL != 0;  // the loader waves do the extra row
+    constexpr int NXW = XL ? NL : NWB;                  // waves that share the extra row
+    constexpr int CPW = TT / NXW;                       // columns of the extra-row dot product per wave
     static_assert(CPW % 4 == 0, "the extra row takes 4 frames x 16 lanes at a time");
     float gx[16];                  // extra row of the slab: lane <-> k = lane + 64*i  (rp <= 1024)
 #pragma unroll
@@ -1837,7 +2188,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     // thread <-> k = sid + j*NST, j < 4 (rp <= 4*NST checked on the host)
     constexpr int NST = NL > 0 ? NL * 64 : NWB * 64;
     const int sid = NL > 0 ? (int)threadIdx.x - NWB * 64 : (int)threadIdx.x;
-    const bool do_s = WM == 0 && by == 0 && blockIdx.z == 0;
+    const bool do_s = WM == 0 && by == 0 && blockIdx.z == 0 && !(SNMF_WX & 4);  // (SNMF_WX & 4: timing experiment without the row sums)
     float ssum[4] = {0.f, 0.f, 0.f, 0.f};
     double acc_div = 0.0;
 
@@ -1856,74 +2207,21 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         __syncthreads();  // slots and wxs are set
     }
 
-    if (is_loader) {
-        // ================================ loader role =========================================
-        if (tb < te) {
-            stage_in<NST>(a.Hin + (size_t)tb * TT * rp, lds, TT, rp, ldh, sid);
-            stage_in<NST>(a.V + (size_t)tb * TT * Fp, lds + TT * ldh, TT, Fp, Fp, sid);
-            rp_post(ready, w - NWB, 1u, lane);
-        }
-        for (int tile = tb, it = 0; tile < te; ++tile, ++it) {
-            const float* cH = lds + (it & 1) * bufsz;
-            float* nH = lds + ((it & 1) ^ 1) * bufsz;
-            rp_await(ready, (unsigned)(it + 1), a.stop);  // tile `tile` is complete in buffer it&1 (every loader wave's part)
-            if (do_s) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int k = sid + j * NST;
-                    if (k < rp) {
-                        float sacc = 0.f;
-                        for (int t = 0; t < TT; ++t) sacc += cH[t * ldh + k];
-                        ssum[j] += sacc;
-                    }
-                }
-            }
-            if (tile + 1 < te) {
-                rp_await(done, (unsigned)it, a.stop);  // every consumer has finished tile-1, which lives in nH
-                stage_in2<NST, 10, 10>(a.Hin + (size_t)(tile + 1) * TT * rp, nH, TT, rp, ldh,
-                                       a.V + (size_t)(tile + 1) * TT * Fp, nH + TT * ldh, TT, Fp, Fp, sid);
-                rp_post(ready, w - NWB, (unsigned)(it + 2), lane);
-            }
-        }
-    }
-
-    SNMF_STAMP_DECL
-    for (int tile = tb, it = 0; tile < te && !is_loader; ++tile, ++it) {
-        const int t0 = tile * TT;
-        SNMF_STAMP(0);
-        float* Hs = lds + (NL > 0 ? (it & 1) * bufsz : 0);  // [32][ldh]
-        float* Vs = Hs + TT * ldh;                            // [TT][Fp]  (no HBM access in the MFMA loops)
-        if (NL == 0) {
-            __syncthreads();
-            stage_in<NST>(a.Hin + (size_t)t0 * rp, Hs, TT, rp, ldh, sid);
-            stage_in<NST>(a.V + (size_t)t0 * Fp, Vs, TT, Fp, Fp, sid);
-            __syncthreads();
-        } else {
-            rp_await(ready, (unsigned)(it + 1), a.stop);
-        }
-        SNMF_STAMP(1);
-        if (NL == 0 && do_s) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = sid + j * NST;
-                if (k < rp) {
-                    float sacc = 0.f;
-                    for (int t = 0; t < TT; ++t) sacc += Hs[t * ldh + k];
-                    ssum[j] += sacc;
-                }
-            }
-        }
-        if (do_x) {
+    // The extra row of one tile (row group 0 only): ratio_x[t] for this wave's CPW columns, then gx[k] += ratio_x[t] * H[k,t].
+    // With loader waves (NL > 0, SNMF_WSTATS_XL) it is THEIR work, done right after the tile is staged: its LDS-latency-bound
+    // dot products then run beside the consumers' MFMA loops instead of in front of them (phase stamps: 3.3 k cycles per
+    // tile on the consumer waves of group 0 for ~0.4 k VALU instructions).
+    auto xrow_tile = [&](const float* xH, const float* xV, int xt0, int xw) {
             // extra row: ratio_x[t] for this wave's CPW columns, then gx[k] += ratio_x[t] * H[k,t]
             float rxv[CPW];
             float dsum = 0.f;
 #pragma unroll
             for (int c0 = 0; c0 < CPW; c0 += 4) {
-                const int tl = w * CPW + c0 + (lane >> 4);
+                const int tl = xw * CPW + c0 + (lane >> 4);
                 const int kl = lane & 15;
-                const float* hrow = Hs + tl * ldh;
-                const int t = t0 + tl;
-                const float v = Vs[tl * Fp + a.Fm];
+                const float* hrow = xH + tl * ldh;
+                const int t = xt0 + tl;
+                const float v = xV[tl * Fp + a.Fm];
                 float rv;
                 if (WM != 3) {
                     float s0 = 0.f, s1 = 0.f;
@@ -1953,11 +2251,138 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
                 if (k < rp) {
                     float g = gx[i];
 #pragma unroll
-                    for (int c = 0; c < CPW; ++c) g += rxv[c] * Hs[(w * CPW + c) * ldh + k];
+                    for (int c = 0; c < CPW; ++c) g += rxv[c] * xH[(xw * CPW + c) * ldh + k];
                     gx[i] = g;
                 }
             }
+    };
+#if SNMF_WSTATS_DMA
+    // ================================ loader role, LDS-DMA =====================================
+    // Beside a wave that issues v_mfma_f32_32x32x2_f32 back to back a second wave of the SIMD gets an instruction in only
+    // where the MFMA wave stalls (scripts/mfma_valu_overlap.hip), so how long a loader takes to stage a tile is set by
+    // how many instructions that takes, not by the bytes: ~300 per tile with loads into registers + ds_write + index
+    // arithmetic + the row sums, which made `ready` arrive late (phase stamps: the consumers waited 1.0 k cycles per tile
+    // for it, and any cycle their loops saved went into that wait).  Here a tile is ~17 buffer_load ... lds per wave
+    // (1 KiB each, scalar addressing: one per padded H row, the V tile as one contiguous block) and the row sums are taken
+    // over the wave's OWN rows (complete as soon as its own DMA has landed) with one ds_read_b128 per row and 256 columns.
+    float rs4[4][4];  // row sums of H over this wave's rows: k = 256 p + 4 lane + e   (rp <= 1024)
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rs4[pp][e] = 0.f;
+    if (is_loader) {
+        typedef __attribute__((address_space(3))) void* lds_ptr_t;
+        const int lw = w - NWB;
+        const int npc = (rp + 255) >> 8;    // 1 KiB pieces per H row
+        const int nVb = TT * Fp * 4;        // bytes of a V tile: contiguous in global memory AND in LDS (no row padding)
+        const int nvc = (nVb + 1023) >> 10;
+        auto dma_tile = [&](int tile, float* dst) {
+            const __amdgpu_buffer_rsrc_t rh =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Hin + (size_t)tile * TT * rp), 0, TT * rp * 4, 0x00020000);
+            for (int t = lw; t < TT; t += NL)
+                for (int pc = 0; pc < npc; ++pc)
+                    if (pc * 256 + lane * 4 < rp)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, (lds_ptr_t)(dst + t * ldh + pc * 256), 16, lane * 16,
+                                                                 (t * rp + pc * 256) * 4, 0, 0);
+            const __amdgpu_buffer_rsrc_t rv =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.V + (size_t)tile * TT * Fp), 0, nVb, 0x00020000);
+            for (int c = lw; c < nvc; c += NL)
+                if (c * 1024 + lane * 16 < nVb)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(dst + TT * ldh + c * 256), 16, lane * 16, c * 1024, 0, 0);
+        };
+        auto sums_of = [&](const float* H) {
+            if (!do_s) return;
+            for (int t = lw; t < TT; t += NL)
+#pragma unroll
+                for (int pc = 0; pc < 4; ++pc)
+                    if (pc < npc && pc * 256 + lane * 4 < rp) {
+                        const f32x4 hv = *reinterpret_cast<const f32x4*>(H + t * ldh + pc * 256 + lane * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) rs4[pc][e] += hv[e];
+                    }
+        };
+        if (tb < te) {
+            dma_tile(tb, lds);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing else orders a ds_read behind an LDS-DMA
+            sums_of(lds);
+            rp_post(ready, lw, 1u, lane);
         }
+        for (int tile = tb, it = 0; tile + 1 < te; ++tile, ++it) {
+            float* nH = lds + ((it & 1) ^ 1) * bufsz;
+            rp_await(done, (unsigned)it, a.stop);  // every consumer has finished tile-1, which lives in nH
+            dma_tile(tile + 1, nH);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            sums_of(nH);
+            rp_post(ready, lw, (unsigned)(it + 2), lane);
+        }
+    }
+    if (false) {
+#else
+    if (is_loader) {
+#endif
+        // ================================ loader role =========================================
+        if (tb < te) {
+            stage_in<NST>(a.Hin + (size_t)tb * TT * rp, lds, TT, rp, ldh, sid);
+            stage_in<NST>(a.V + (size_t)tb * TT * Fp, lds + TT * ldh, TT, Fp, Fp, sid);
+            rp_post(ready, w - NWB, 1u, lane);
+        }
+        for (int tile = tb, it = 0; tile < te; ++tile, ++it) {
+            const float* cH = lds + (it & 1) * bufsz;
+            float* nH = lds + ((it & 1) ^ 1) * bufsz;
+            rp_await(ready, (unsigned)(it + 1), a.stop);  // tile `tile` is complete in buffer it&1 (every loader wave's part)
+            if (do_s) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = sid + j * NST;
+                    if (k < rp) {
+                        float sacc = 0.f;
+                        for (int t = 0; t < TT; ++t) sacc += cH[t * ldh + k];
+                        ssum[j] += sacc;
+                    }
+                }
+            }
+            if (XL && do_x) xrow_tile(cH, cH + TT * ldh, tile * TT, w - NWB);
+            if (tile + 1 < te) {
+                rp_await(done, (unsigned)it, a.stop);  // every consumer has finished tile-1, which lives in nH
+                stage_in2<NST, 10, 10>(a.Hin + (size_t)(tile + 1) * TT * rp, nH, TT, rp, ldh,
+                                       a.V + (size_t)(tile + 1) * TT * Fp, nH + TT * ldh, TT, Fp, Fp, sid);
+                rp_post(ready, w - NWB, (unsigned)(it + 2), lane);
+            }
+        }
+    }
+
+    SNMF_STAMP_DECL
+    for (int tile = tb, it = 0; tile < te && !is_loader; ++tile, ++it) {
+        const int t0 = tile * TT;
+        SNMF_STAMP(0);
+        float* Hs = lds + (NL > 0 ? (it & 1) * bufsz : 0);  // [32][ldh]
+        float* Vs = Hs + TT * ldh;                            // [TT][Fp]  (no HBM access in the MFMA loops)
+        if (NL == 0) {
+            __syncthreads();
+            stage_in<NST>(a.Hin + (size_t)t0 * rp, Hs, TT, rp, ldh, sid);
+            stage_in<NST>(a.V + (size_t)t0 * Fp, Vs, TT, Fp, Fp, sid);
+            __syncthreads();
+        }
+        // NL > 0: the wait for the staged tile.  A wave that goes straight into P3 takes it behind P3's first W loads.
+        bool waited = NL == 0;
+        auto gate_ready = [&]() {
+            if (!waited) rp_await(ready, (unsigned)(it + 1), a.stop);
+            waited = true;
+        };
+        if (!SNMF_WSTATS_GATE || (do_x && !XL) || !active || WM == 3) gate_ready();
+        SNMF_STAMP(1);
+        if (NL == 0 && do_s) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = sid + j * NST;
+                if (k < rp) {
+                    float sacc = 0.f;
+                    for (int t = 0; t < TT; ++t) sacc += Hs[t * ldh + k];
+                    ssum[j] += sacc;
+                }
+            }
+        }
+        if (do_x && !XL) xrow_tile(Hs, Vs, t0, w);
         SNMF_STAMP(2);
         if (!active) {
             if (NL > 0) rp_post(done, w, (unsigned)(it + 1), lane);
@@ -1972,7 +2397,16 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
 #ifndef SNMF_WSTATS_DUAL
 #define SNMF_WSTATS_DUAL 0  // measured on C2: 0.2488 ms with the two chains against 0.2475 without -- the dependent chain is not what P3 waits for
 #endif
-            contract_sb<1, true, 2, SNMF_WSTATS_DUAL != 0>(acc1, wp, Hs + (fl & (TT - 1)) * ldh + 4 * h, 0, rp / 8);
+#if SNMF_BUFW
+            {
+                const __amdgpu_buffer_rsrc_t rsw = wimage_rsrc(a.Wt4, (size_t)a.nf * rp * 32);
+                const float* spl = Hs + (fl & (TT - 1)) * ldh + 4 * h;
+                if (rp == 256) contract_p3_buf<true>(acc1[0], rsw, lane * 16, phi * rp * 128, spl, 32, gate_ready);
+                else contract_p3_buf<false>(acc1[0], rsw, lane * 16, phi * rp * 128, spl, rp / 8, gate_ready);
+            }
+#else
+            contract_sb<1, true, SNMF_WSTATS_SB, SNMF_WSTATS_DUAL != 0>(acc1, wp, Hs + (fl & (TT - 1)) * ldh + 4 * h, 0, rp / 8, gate_ready);
+#endif
             SNMF_STAMP(3);
             const f32x16 acc = acc1[0];
             // lane (f = fl, h), reg -> t = t0 + drow(reg,h)
@@ -2074,6 +2508,30 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
             }
         }
     }
+#if SNMF_WSTATS_DMA
+    if (NL > 0) {
+        if (do_s) {  // fixed-order sum of the loader waves' partial row sums, through LDS
+            __syncthreads();
+            float* red = lds;  // [NL][rp]
+            if (is_loader) {
+#pragma unroll
+                for (int pc = 0; pc < 4; ++pc)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = pc * 256 + lane * 4 + e;
+                        if (k < rp) red[(w - NWB) * rp + k] = rs4[pc][e];
+                    }
+            }
+            __syncthreads();
+            for (int k = threadIdx.x; k < rp; k += NTHR) {
+                float sk = 0.f;
+                for (int ww = 0; ww < NL; ++ww) sk += red[ww * rp + k];
+                a.spart[(size_t)chunk * rp + k] = sk;
+            }
+            __syncthreads();
+        }
+    } else
+#endif
     if (do_s && sid >= 0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -2084,19 +2542,20 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     if (do_x) {
         // fixed-order sum of the consumers' partial extra rows, through LDS
         __syncthreads();
-        float* red = lds;  // [NWB][rp]  (NWB*rp <= 32*ldh)
-        if (!is_loader) {
+        float* red = lds;  // [NXW][rp]  (NXW*rp <= 32*ldh)
+        if (XL ? is_loader : !is_loader) {
+            const int xw = XL ? w - NWB : w;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int k = lane + 64 * i;
-                if (k < rp) red[w * rp + k] = gx[i];
+                if (k < rp) red[xw * rp + k] = gx[i];
             }
         }
         __syncthreads();
         float* slab = a.slabs + ((size_t)chunk * n_mat + mat_index) * rp * Fp;
         for (int k = threadIdx.x; k < rp; k += NTHR) {
             float s = 0.f;
-            for (int ww = 0; ww < NWB; ++ww) s += red[ww * rp + k];
+            for (int ww = 0; ww < NXW; ++ww) s += red[ww * rp + k];
             slab[(size_t)k * Fp + a.Fm] = s;
         }
         __syncthreads();
