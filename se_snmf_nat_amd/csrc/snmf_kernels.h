@@ -1292,7 +1292,9 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
     // could reach a tile's target on the arrivals of the role that runs ahead -- the loaders' extra rows of tiles 0 and
     // 1 are both done before the A team has finished tile 0)
     static_assert(NA == 4 && NB == 4 && NL == 4, "four progress slots per role");
-    unsigned *ready = cnt, *p1a = cnt + 4, *p1b = cnt + 8, *p2done = cnt + 12, *xdone = cnt + 16;
+    // vready: "the tile's V block is staged" -- a signal of its own because the A team needs V only in its epilogues: the
+    // loaders commit the H block first and post `ready`, so the V commit is off the path the A team's next loop waits for.
+    unsigned *ready = cnt, *p1a = cnt + 4, *p1b = cnt + 8, *p2done = cnt + 12, *xdone = cnt + 16, *vready = cnt + 20;
     double acc_div = 0.0, acc_sh = 0.0;
     if (a.xr) {
         for (int k = threadIdx.x; k < rp; k += NTHR) wxs[k] = a.wx[k];
@@ -1302,7 +1304,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             lds[bsel * bufsz + Tt * ldh + (ii >> 3) * ldr + a.Fm + (ii & 7)] = 0.f;
         }
     }
-    if (threadIdx.x < 20) cnt[threadIdx.x] = 0u;
+    if (threadIdx.x < 24) cnt[threadIdx.x] = 0u;
     __syncthreads();
     // diagnostic operand-reuse experiment (SNMF_PROF builds): 1 = W fragments of even k-blocks only, 2 = W block 0 only,
     // 3 = LDS fragments of even k-blocks only, 4 = LDS block 0 only, 5 = both streams block 0 only
@@ -1342,6 +1344,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
         auto xrow_of = [&](int j) {
             if (!a.xr) return;
             rp_await(ready, (unsigned)(j + 1), a.stop);
+            rp_await(vready, (unsigned)(j + 1), a.stop);
             float* bH = lds + (j & 1) * bufsz;
             hstep_p1_xrow<NL, 1, BM_KL, OBJ>(a, bH, bH + Tt * ldh, wxs, tile_of(j) * Tt, lw, lane, true, acc_div);
             rp_post(xdone, lw, (unsigned)(j + 1), lane);
@@ -1398,6 +1401,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             stage_in2<NLT, PA, PB>(a.Hin + (size_t)tile_of(j) * Tt * rp, bH, Tt, rp, ldh, a.V + (size_t)tile_of(j) * Tt * Fp,
                                    bH + Tt * ldh, Tt, Fp, ldr, lt);
             rp_post(ready, lw, (unsigned)(j + 1), lane);
+            rp_post(vready, lw, (unsigned)(j + 1), lane);
         }
         for (int j = 0; j < 2 && j < nmy; ++j) xrow_of(j);
         for (int j = 0; j < nmy; ++j) {
@@ -1454,6 +1458,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     stage_in<NLT>(a.Hin + (size_t)tile_of(j + 2) * Tt * rp, bH, Tt, rp, ldh, lt);
                     stage_in<NLT>(a.V + (size_t)tile_of(j + 2) * Tt * Fp, bH + Tt * ldh, Tt, Fp, ldr, lt);
                     rp_post(ready, lw, (unsigned)(j + 3), lane);
+                    rp_post(vready, lw, (unsigned)(j + 3), lane);
                     xrow_of(j + 2);
                 }
                 continue;
@@ -1462,10 +1467,15 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
 #if SNMF_LEAN_LOADER
             const char* const bHl = reinterpret_cast<const char*>(bH) + hv;  // this lane's column of the H image
             if (SNMF_LEAN_H) {
+                // (four LDS reads in flight at a time: one read, one wait, one store at a time put eight LDS latencies
+                //  between p2done and ready)
 #pragma unroll
-                for (int b = 0; b < PR; ++b) {
-                    const f32x4 ho = *reinterpret_cast<const f32x4*>(bHl + (lw + NL * b) * ldh * 4);
-                    stA(rsrc_of(dstH, nA), b, ho);
+                for (int b0 = 0; b0 < PR; b0 += 4) {
+                    f32x4 ho[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) ho[u] = *reinterpret_cast<const f32x4*>(bHl + (lw + NL * (b0 + u)) * ldh * 4);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) stA(rsrc_of(dstH, nA), b0 + u, ho[u]);
                 }
             } else {
 #pragma unroll
@@ -1489,6 +1499,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                         *reinterpret_cast<f32x4*>(bH + t * ldh + 4 * k4) = xa[b];
                     }
                 }
+                rp_post(ready, lw, (unsigned)(j + 3), lane);
                 if (SNMF_LEAN_V) {
 #pragma unroll
                     for (int b = 0; b < PB; ++b) *reinterpret_cast<f32x4*>(bH + loB[b]) = xb[b];
@@ -1500,7 +1511,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                         *reinterpret_cast<f32x4*>(bH + Tt * ldh + t * ldr + 4 * k4) = xb[b];
                     }
                 }
-                rp_post(ready, lw, (unsigned)(j + 3), lane);
+                rp_post(vready, lw, (unsigned)(j + 3), lane);
                 xrow_of(j + 2);
             }
             continue;
@@ -1528,6 +1539,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     *reinterpret_cast<f32x4*>(bH + Tt * ldh + t * ldr + 4 * k4) = xb[b];
                 }
                 rp_post(ready, lw, (unsigned)(j + 3), lane);
+                rp_post(vready, lw, (unsigned)(j + 3), lane);
                 xrow_of(j + 2);
             }
         }
@@ -1544,6 +1556,11 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                 if (!waited) rp_await(ready, (unsigned)(j + 1), a.stop);
                 waited = true;
             };
+            bool vwaited = false;
+            auto gate_v = [&]() {  // the tile's V block: needed by the epilogues only
+                if (!vwaited) rp_await(vready, (unsigned)(j + 1), a.stop);
+                vwaited = true;
+            };
             const int fl = lane & 31, h = lane >> 5;
             const float* sp = Hs + fl * ldh + 4 * h;
             float dsum = 0.f;
@@ -1559,6 +1576,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     contract_shared<2>(acc, wp, sp, rp / 8, xw, xs, gate_ready);
 #endif
                     SNMF_STAMP(4);
+                    gate_v();
                     rp_p1_epilogue<OBJ>(a, acc[0], Rs, phi, t0, lane, dsum);
                     if (phi == w) rp_post(p1a, w, (unsigned)(j + 1), lane);  // row tile w < NA: this wave's share of the first 32*NA ratio rows
                     rp_p1_epilogue<OBJ>(a, acc[1], Rs, phi + NA, t0, lane, dsum);
@@ -1572,11 +1590,13 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     const f32x4* const wp[1] = {reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)phi * rp * 32) + lane};
                     contract_shared<1>(acc, wp, sp, rp / 8, xw, xs, gate_ready);
 #endif
+                    gate_v();
                     rp_p1_epilogue<OBJ>(a, acc[0], Rs, phi, t0, lane, dsum);
                     if (phi == w) rp_post(p1a, w, (unsigned)(j + 1), lane);
                 }
             }
             gate_ready();  // (a wave without a row tile has not waited yet)
+            gate_v();
             if (w >= a.nf) rp_post(p1a, w, (unsigned)(j + 1), lane);  // a wave without a row tile still reports
             if (OBJ) acc_div += (double)dsum;
             SNMF_STAMP(6);
@@ -2168,7 +2188,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     constexpr int NXW = XL ? NL : NWB;                  // waves that share the extra row
     constexpr int CPW = TT / NXW;                       // columns of the extra-row dot product per wave
     static_assert(CPW % 4 == 0, "the extra row takes 4 frames x 16 lanes at a time");
-    float gx[16];                  // extra row of the slab: lane <-> k = lane + 64*i  (rp <= 1024)
+    float gx[16];                  // extra row of the slab: lane <-> k = 256*(i/4) + 4*lane + i%4  (rp <= 1024)
 #pragma unroll
     for (int i = 0; i < 16; ++i) gx[i] = 0.f;
     if (do_x && WM != 3)
@@ -2245,14 +2265,17 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
                     rxv[c0 + c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv), 16 * c));
             }
             if (OBJ) acc_div += (double)dsum;
+            // (one ds_read_b128 per column and 256 rows of H: beside its own MFMAs every instruction of this wave counts)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int k = lane + 64 * i;
-                if (k < rp) {
-                    float g = gx[i];
+            for (int pc = 0; pc < 4; ++pc) {
+                const int k0 = 256 * pc + 4 * lane;
+                if (k0 < rp) {
 #pragma unroll
-                    for (int c = 0; c < CPW; ++c) g += rxv[c] * xH[(xw * CPW + c) * ldh + k];
-                    gx[i] = g;
+                    for (int c = 0; c < CPW; ++c) {
+                        const f32x4 hv = *reinterpret_cast<const f32x4*>(xH + (xw * CPW + c) * ldh + k0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) gx[4 * pc + e] += rxv[c] * hv[e];
+                    }
                 }
             }
     };
@@ -2547,7 +2570,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
             const int xw = XL ? w - NWB : w;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int k = lane + 64 * i;
+                const int k = 256 * (i >> 2) + 4 * lane + (i & 3);
                 if (k < rp) red[xw * rp + k] = gx[i];
             }
         }
