@@ -99,26 +99,11 @@ struct DevState {
     int fault;     // a bounded device-side wait (LDS producer/consumer counters) gave up: results are invalid
     int pad1;
 };
-// `stop` points at DevState::stop; the fault word sits two ints behind it
 // Index of this wave in its workgroup, as a SCALAR: `threadIdx.x >> 6` alone is a per-lane value to the compiler, and
 // every role switch, row / column-tile loop and operand base pointer derived from it then becomes vector code under exec
 // masks (with the register live ranges of all roles overlapping).  readfirstlane makes the uniformity visible.
-#ifndef SNMF_UNIFORM_W
-#define SNMF_UNIFORM_W 1
-#endif
-#ifndef SNMF_WX
-#define SNMF_WX 0
-#endif
-#ifndef SNMF_BUFW
-#define SNMF_BUFW 1  // W fragments of the MFMA loops through buffer descriptors + scalar offsets (0: 64-bit global loads)
-#endif
-__device__ __forceinline__ int wave_index() {
-#if SNMF_UNIFORM_W
-    return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-#else
-    return (int)(threadIdx.x >> 6);
-#endif
-}
+__device__ __forceinline__ int wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+// `stop` points at DevState::stop; the fault word sits two ints behind it
 __device__ __forceinline__ void raise_fault(const int* stop) {
     if (stop) atomicExch(const_cast<int*>(stop) + 2, 1);
 }
@@ -249,12 +234,10 @@ __device__ __forceinline__ void contract_sb(f32x16 (&acc)[NT], const f32x4* __re
 #pragma unroll
         for (int j = 0; j < SB; ++j) {
             const int qq = (q0 + j) < last ? (q0 + j) : last;
-            // SNMF_WX (timing experiments only, results wrong): 1 = every k-block uses W fragment 0 (no W loads in the
-            // loop), 2 = LDS fragment 0, 3 = both
-            w[j] = wp[(size_t)((SNMF_WX & 1) ? 0 : qq) * 64];
+            w[j] = wp[(size_t)qq * 64];
 #pragma unroll
             for (int tau = 0; tau < NT; ++tau)
-                sf[j][tau] = *reinterpret_cast<const f32x4*>(sp + tau * sstride + 8 * ((SNMF_WX & 2) ? 0 : qq));
+                sf[j][tau] = *reinterpret_cast<const f32x4*>(sp + tau * sstride + 8 * qq);
         }
     };
     auto mmstage = [&](const f32x4 (&w)[SB], const f32x4 (&sf)[SB][NT]) {
@@ -995,8 +978,9 @@ __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(Step
 // MFMA waves of a SIMD share the pipe and therefore leave their loops together; if P2 of the next tile could only start
 // after the A team's whole epilogue (and the extra row), nobody would issue an MFMA through all of it.  Hence the extra
 // row on the loaders, and P2 in two phases: the first 4*NA k-blocks need only the ratio rows of the row tiles 0..NA-1.
-// No workgroup barrier inside the tile loop: five signals, each four per-wave progress words in LDS, order the roles
-//     ready  (loaders)   "tile j is staged"                          A waits (and the loaders' own extra-row pass)
+// No workgroup barrier inside the tile loop: six signals, each four per-wave progress words in LDS, order the roles
+//     ready  (loaders)   "the H block of tile j is staged"           A waits (loop), and the loaders' extra-row pass
+//     vready (loaders)   "the V block of tile j is staged"           A waits (epilogues), and the extra-row pass
 //     p1a    (A team)    "ratio rows of the row tiles 0..NA-1 whole"  B waits (phase 1)
 //     p1b    (A team)    "every ratio row tile is whole"              B waits (phase 2)
 //     xdone  (loaders)   "the extra row of the ratio image is done"   B waits (phase 2)
@@ -1006,6 +990,11 @@ __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(Step
 // MFMA chains share every LDS fragment: one ds_read_b128 feeds 8 MFMAs instead of 4, and two independent accumulator
 // chains alternate in the pipe.  The loaders fetch tile i+2 into REGISTERS before they wait for p2done(i), so the
 // reload that sits between P2(i) and P1(i+2) is an LDS write, not an HBM round trip.
+// The loaders are the part to keep SHORT: beside two MFMA waves a loader wave gets an instruction in only where they
+// stall, so the time from p2done(i) to ready(i+2) -- a dependency cycle of two tile periods runs through it -- is the
+// number of instructions in between times tens of cycles.  With ~390 of them (index arithmetic per cell, 64-bit
+// addresses) the kernel took 0.2595 ms on C2; with ~60 (buffer instructions with scalar offsets, a row mapping for the H
+// block, one precomputed LDS offset per V cell) 0.246 ms.
 // Fences are LDS-only ("local"): LDS operations of a wave complete in order, and a workgroup-wide release that also
 // drained vmcnt would make the loaders wait for their H stores to be acknowledged by HBM.
 // ============================================================================================
@@ -1015,34 +1004,17 @@ __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(Step
 // the missing arrival of a slow one whenever a wave may run a tile ahead of its team.  The loaders stage tiles 0 and 1
 // back to back, so with a total `ready` the A team, or the loaders' own extra-row pass, could start on a tile that one
 // loader wave had not finished staging; a probe over awkward shapes found it.)
-// SNMF_WAKEUP = n > 0: a waiting wave sleeps n * 64 cycles between polls instead of 64, and every post pings the
-// workgroup's sleeping waves awake (s_wakeup), so a poll is only spent when some signal has moved.
-#ifndef SNMF_WAKEUP
-#define SNMF_WAKEUP 0
-#endif
 #ifndef SNMF_LEAN_LOADER
 #define SNMF_LEAN_LOADER 1  // k_hstep_rp loaders without index arithmetic (0 = the older per-cell path, 2 / 3 = H / V block only)
 #endif
 #define SNMF_LEAN_H (SNMF_LEAN_LOADER == 1 || SNMF_LEAN_LOADER == 2)
 #define SNMF_LEAN_V (SNMF_LEAN_LOADER == 1 || SNMF_LEAN_LOADER == 3)
-#ifndef SNMF_WSTATS_SB
-#define SNMF_WSTATS_SB 2  // k-blocks per named stage of P3's loop (fragments one stage = 4*SB MFMAs ahead)
-#endif
-#ifndef SNMF_WSTATS_GATE
-#define SNMF_WSTATS_GATE 0
-#endif
-#ifndef SNMF_WSTATS_XL
-#define SNMF_WSTATS_XL 0
-#endif
 #ifndef SNMF_WSTATS_DMA
 #define SNMF_WSTATS_DMA 1  // loader waves of k_wstats stage through LDS-DMA (buffer_load ... lds)
 #endif
 __device__ __forceinline__ void rp_post(unsigned* slots, int wave_in_role, unsigned tiles_done, int lane) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     if (lane == 0) __hip_atomic_store(slots + wave_in_role, tiles_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#if SNMF_WAKEUP > 0
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_wakeup" ::: "memory");
-#endif
 }
 __device__ __forceinline__ void rp_await(const unsigned* slots, unsigned target, const int* stop) {
     int spin = 0;
@@ -1057,7 +1029,7 @@ __device__ __forceinline__ void rp_await(const unsigned* slots, unsigned target,
             raise_fault(stop);
             break;
         }
-        __builtin_amdgcn_s_sleep(SNMF_WAKEUP > 0 ? SNMF_WAKEUP : 1);
+        __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
@@ -2184,9 +2156,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         }
     }
     const bool do_x = a.xr && by == 0 && blockIdx.z == 0;  // extra row: one f-group only
-    constexpr bool XL = NL > 0 && SNMF_WSTATS_XL != 0;  // the loader waves do the extra row
-    constexpr int NXW = XL ? NL : NWB;                  // waves that share the extra row
-    constexpr int CPW = TT / NXW;                       // columns of the extra-row dot product per wave
+    constexpr int CPW = TT / NWB;  // columns of the extra-row dot product per wave
     static_assert(CPW % 4 == 0, "the extra row takes 4 frames x 16 lanes at a time");
     float gx[16];                  // extra row of the slab: lane <-> k = 256*(i/4) + 4*lane + i%4  (rp <= 1024)
 #pragma unroll
@@ -2208,7 +2178,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     // thread <-> k = sid + j*NST, j < 4 (rp <= 4*NST checked on the host)
     constexpr int NST = NL > 0 ? NL * 64 : NWB * 64;
     const int sid = NL > 0 ? (int)threadIdx.x - NWB * 64 : (int)threadIdx.x;
-    const bool do_s = WM == 0 && by == 0 && blockIdx.z == 0 && !(SNMF_WX & 4);  // (SNMF_WX & 4: timing experiment without the row sums)
+    const bool do_s = WM == 0 && by == 0 && blockIdx.z == 0;
     float ssum[4] = {0.f, 0.f, 0.f, 0.f};
     double acc_div = 0.0;
 
@@ -2228,9 +2198,8 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     }
 
     // The extra row of one tile (row group 0 only): ratio_x[t] for this wave's CPW columns, then gx[k] += ratio_x[t] * H[k,t].
-    // With loader waves (NL > 0, SNMF_WSTATS_XL) it is THEIR work, done right after the tile is staged: its LDS-latency-bound
-    // dot products then run beside the consumers' MFMA loops instead of in front of them (phase stamps: 3.3 k cycles per
-    // tile on the consumer waves of group 0 for ~0.4 k VALU instructions).
+    // It stays on the CONSUMER waves: moved to the loader waves -- which only get an instruction in where their SIMD's
+    // MFMA wave stalls -- it delayed the staging of the next tile (k_wstats 0.249 -> 0.277 ms on C2).
     auto xrow_tile = [&](const float* xH, const float* xV, int xt0, int xw) {
             // extra row: ratio_x[t] for this wave's CPW columns, then gx[k] += ratio_x[t] * H[k,t]
             float rxv[CPW];
@@ -2364,7 +2333,6 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
                     }
                 }
             }
-            if (XL && do_x) xrow_tile(cH, cH + TT * ldh, tile * TT, w - NWB);
             if (tile + 1 < te) {
                 rp_await(done, (unsigned)it, a.stop);  // every consumer has finished tile-1, which lives in nH
                 stage_in2<NST, 10, 10>(a.Hin + (size_t)(tile + 1) * TT * rp, nH, TT, rp, ldh,
@@ -2386,13 +2354,9 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
             stage_in<NST>(a.V + (size_t)t0 * Fp, Vs, TT, Fp, Fp, sid);
             __syncthreads();
         }
-        // NL > 0: the wait for the staged tile.  A wave that goes straight into P3 takes it behind P3's first W loads.
-        bool waited = NL == 0;
-        auto gate_ready = [&]() {
-            if (!waited) rp_await(ready, (unsigned)(it + 1), a.stop);
-            waited = true;
-        };
-        if (!SNMF_WSTATS_GATE || (do_x && !XL) || !active || WM == 3) gate_ready();
+        // NL > 0: the wait for the staged tile.  (Taken behind P3's first W loads instead, as k_hstep_rp does with its
+        // waits, it cost 5 %: 0.236 -> 0.247 ms.)
+        if (NL > 0) rp_await(ready, (unsigned)(it + 1), a.stop);
         SNMF_STAMP(1);
         if (NL == 0 && do_s) {
 #pragma unroll
@@ -2405,7 +2369,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
                 }
             }
         }
-        if (do_x && !XL) xrow_tile(Hs, Vs, t0, w);
+        if (do_x) xrow_tile(Hs, Vs, t0, w);
         SNMF_STAMP(2);
         if (!active) {
             if (NL > 0) rp_post(done, w, (unsigned)(it + 1), lane);
@@ -2424,11 +2388,11 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
             {
                 const __amdgpu_buffer_rsrc_t rsw = wimage_rsrc(a.Wt4, (size_t)a.nf * rp * 32);
                 const float* spl = Hs + (fl & (TT - 1)) * ldh + 4 * h;
-                if (rp == 256) contract_p3_buf<true>(acc1[0], rsw, lane * 16, phi * rp * 128, spl, 32, gate_ready);
-                else contract_p3_buf<false>(acc1[0], rsw, lane * 16, phi * rp * 128, spl, rp / 8, gate_ready);
+                if (rp == 256) contract_p3_buf<true>(acc1[0], rsw, lane * 16, phi * rp * 128, spl, 32, NoGate());
+                else contract_p3_buf<false>(acc1[0], rsw, lane * 16, phi * rp * 128, spl, rp / 8, NoGate());
             }
 #else
-            contract_sb<1, true, SNMF_WSTATS_SB, SNMF_WSTATS_DUAL != 0>(acc1, wp, Hs + (fl & (TT - 1)) * ldh + 4 * h, 0, rp / 8, gate_ready);
+            contract_sb<1, true, 2, SNMF_WSTATS_DUAL != 0>(acc1, wp, Hs + (fl & (TT - 1)) * ldh + 4 * h, 0, rp / 8);
 #endif
             SNMF_STAMP(3);
             const f32x16 acc = acc1[0];
@@ -2565,20 +2529,19 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     if (do_x) {
         // fixed-order sum of the consumers' partial extra rows, through LDS
         __syncthreads();
-        float* red = lds;  // [NXW][rp]  (NXW*rp <= 32*ldh)
-        if (XL ? is_loader : !is_loader) {
-            const int xw = XL ? w - NWB : w;
+        float* red = lds;  // [NWB][rp]  (NWB*rp <= 32*ldh)
+        if (!is_loader) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int k = 256 * (i >> 2) + 4 * lane + (i & 3);
-                if (k < rp) red[xw * rp + k] = gx[i];
+                if (k < rp) red[w * rp + k] = gx[i];
             }
         }
         __syncthreads();
         float* slab = a.slabs + ((size_t)chunk * n_mat + mat_index) * rp * Fp;
         for (int k = threadIdx.x; k < rp; k += NTHR) {
             float s = 0.f;
-            for (int ww = 0; ww < NXW; ++ww) s += red[ww * rp + k];
+            for (int ww = 0; ww < NWB; ++ww) s += red[ww * rp + k];
             slab[(size_t)k * Fp + a.Fm] = s;
         }
         __syncthreads();
