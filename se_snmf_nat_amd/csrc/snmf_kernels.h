@@ -1004,6 +1004,9 @@ __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(Step
 // the missing arrival of a slow one whenever a wave may run a tile ahead of its team.  The loaders stage tiles 0 and 1
 // back to back, so with a total `ready` the A team, or the loaders' own extra-row pass, could start on a tile that one
 // loader wave had not finished staging; a probe over awkward shapes found it.)
+#ifndef SNMF_BUFW
+#define SNMF_BUFW 1  // W fragments of the MFMA loops through buffer descriptors + scalar offsets (0: 64-bit global loads)
+#endif
 #ifndef SNMF_LEAN_LOADER
 #define SNMF_LEAN_LOADER 1  // k_hstep_rp loaders without index arithmetic (0 = the older per-cell path, 2 / 3 = H / V block only)
 #endif
