@@ -102,6 +102,9 @@ struct DevState {
 // Index of this wave in its workgroup, as a SCALAR: `threadIdx.x >> 6` alone is a per-lane value to the compiler, and
 // every role switch, row / column-tile loop and operand base pointer derived from it then becomes vector code under exec
 // masks (with the register live ranges of all roles overlapping).  readfirstlane makes the uniformity visible.
+#ifndef SNMF_BUFW
+#define SNMF_BUFW 1  // W fragments of the MFMA loops through buffer descriptors + scalar offsets (0: 64-bit global loads)
+#endif
 __device__ __forceinline__ int wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 // `stop` points at DevState::stop; the fault word sits two ints behind it
 __device__ __forceinline__ void raise_fault(const int* stop) {
@@ -333,6 +336,53 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wimage_rsrc(const float* img, 
 __device__ __forceinline__ f32x4 ldw_buf(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
 }
+// contract<NT, SWAP> on the buffer path: the same k-block order per accumulator (bit-identical results), W fragments by
+// descriptor + scalar offset, LDS fragments at immediate offsets from one moving base per frame sub-tile, no clamps.
+template <int NT, bool SWAP>
+__device__ __forceinline__ void contract_buf(f32x16 (&acc)[NT], __amdgpu_buffer_rsrc_t rs, int voff, int soff0, const float* sp,
+                                             int sstride, int nq) {
+    f32x4 wA[2], wB[2], sA[2][NT], sB[2][NT];
+    auto ldw = [&](int q) { return ldw_buf(rs, voff, soff0 + q * 1024); };
+    const float* bp[NT];  // moving bases: block q + j of sub-tile tau at bp[tau] + 8 * j
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau) bp[tau] = sp + tau * sstride;
+    auto lds2 = [&](f32x4 (&sf)[2][NT], int j0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int tau = 0; tau < NT; ++tau) sf[j][tau] = *reinterpret_cast<const f32x4*>(bp[tau] + 8 * (j0 + j));
+    };
+    wA[0] = ldw(0);
+    wA[1] = ldw(1);
+    lds2(sA, 0);
+    int q = 0;
+    for (; q + 3 < nq; q += 4) {
+        wB[0] = ldw(q + 2);
+        wB[1] = ldw(q + 3);
+        lds2(sB, 2);
+        SNMF_PIN();
+        mfma_block<NT, SWAP>(acc, wA[0], sA[0]);
+        mfma_block<NT, SWAP>(acc, wA[1], sA[1]);
+        wA[0] = ldw(q + 4);
+        wA[1] = ldw(q + 5);
+        lds2(sA, 4);
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau) bp[tau] += 32;
+        SNMF_PIN();
+        mfma_block<NT, SWAP>(acc, wB[0], sB[0]);
+        mfma_block<NT, SWAP>(acc, wB[1], sB[1]);
+    }
+    // remainder (nq % 4 blocks): wA / sA hold blocks q, q + 1
+    if (q < nq) mfma_block<NT, SWAP>(acc, wA[0], sA[0]);
+    if (q + 1 < nq) mfma_block<NT, SWAP>(acc, wA[1], sA[1]);
+    if (q + 2 < nq) {
+        const f32x4 w2 = ldw(q + 2);
+        f32x4 s2[NT];
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau) s2[tau] = *reinterpret_cast<const f32x4*>(bp[tau] + 16);
+        mfma_block<NT, SWAP>(acc, w2, s2);
+    }
+}
 // acc += sum_q Sfrag(q) (x) Wfrag(q)  (LDS tile = A operand, W = B: k_wstats' P3), one accumulator chain.
 //   rs / voff / soff0: W image descriptor, this lane's byte offset (16 * lane), byte offset of the image block (scalar)
 //   sp: this lane's LDS row;  gate(): see contract_sb.  UNROLL32: nq == 32 known at compile time (rp = 256).
@@ -557,7 +607,12 @@ __device__ __forceinline__ void hstep_p1_tiles(const StepArgs& a, float* Hs, flo
                     if (MDI) mfr[tau][g] = *reinterpret_cast<const f32x4*>(a.M + off);
                 }
         }
+#if SNMF_BUFW
+        contract_buf<NT, false>(acc, wimage_rsrc(a.Wt4, (size_t)a.nf * rp * 32), lane * 16, phi * rp * 128, Hs + flt * ldh + 4 * h,
+                                32 * ldh, rp / 8);
+#else
         contract<NT, false>(acc, wp, Hs + flt * ldh + 4 * h, 32 * ldh, rp / 8);
+#endif
         // epilogue: lane (t = fl, h), reg -> f = 32*phi + drow(reg,h)
         float dsum = 0.f;
 #pragma unroll
@@ -749,7 +804,12 @@ __device__ __forceinline__ void hstep_p2(const StepArgs& a, float* Hs, const flo
                 if (OBJ || BM != BM_KL) spf[g] = *reinterpret_cast<const f32x4*>(a.lamk + k0);
             }
         }
+#if SNMF_BUFW
+        contract_buf<NT, false>(acc, wimage_rsrc(a.Wk4, (size_t)a.nk * a.Fq * 32), lane * 16, kap * a.Fq * 128,
+                                Rs + flt * ldr + 4 * h, 32 * ldr, a.Fq / 8);
+#else
         contract<NT, false>(acc, wp, Rs + flt * ldr + 4 * h, 32 * ldr, a.Fq / 8);
+#endif
         // epilogue: lane (t = fl, h), reg -> k = 32*kap + drow(reg,h)
         float shsum = 0.f;
 #pragma unroll
@@ -1004,9 +1064,6 @@ __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(Step
 // the missing arrival of a slow one whenever a wave may run a tile ahead of its team.  The loaders stage tiles 0 and 1
 // back to back, so with a total `ready` the A team, or the loaders' own extra-row pass, could start on a tile that one
 // loader wave had not finished staging; a probe over awkward shapes found it.)
-#ifndef SNMF_BUFW
-#define SNMF_BUFW 1  // W fragments of the MFMA loops through buffer descriptors + scalar offsets (0: 64-bit global loads)
-#endif
 #ifndef SNMF_LEAN_LOADER
 #define SNMF_LEAN_LOADER 1  // k_hstep_rp loaders without index arithmetic (0 = the older per-cell path, 2 / 3 = H / V block only)
 #endif
