@@ -1064,6 +1064,9 @@ __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(Step
 // the missing arrival of a slow one whenever a wave may run a tile ahead of its team.  The loaders stage tiles 0 and 1
 // back to back, so with a total `ready` the A team, or the loaders' own extra-row pass, could start on a tile that one
 // loader wave had not finished staging; a probe over awkward shapes found it.)
+#ifndef SNMF_XROW_A
+#define SNMF_XROW_A 1  // k_hstep_rp: the extra row is the A team's work, after its last epilogue (0: the loader waves')
+#endif
 #ifndef SNMF_LEAN_LOADER
 #define SNMF_LEAN_LOADER 1  // k_hstep_rp loaders without index arithmetic (0 = the older per-cell path, 2 / 3 = H / V block only)
 #endif
@@ -1374,7 +1377,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
         // loop and the signal P2 waits for.  It needs the whole staged tile, hence the wait for every loader's arrival.
         const int lw = w - (NA + NB);
         auto xrow_of = [&](int j) {
-            if (!a.xr) return;
+            if (!a.xr || SNMF_XROW_A) return;
             rp_await(ready, (unsigned)(j + 1), a.stop);
             rp_await(vready, (unsigned)(j + 1), a.stop);
             float* bH = lds + (j & 1) * bufsz;
@@ -1633,6 +1636,16 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             if (OBJ) acc_div += (double)dsum;
             SNMF_STAMP(6);
             rp_post(p1b, w, (unsigned)(j + 1), lane);
+#if SNMF_XROW_A
+            // The extra row (F = 32n+1): 8 frames per A wave, AFTER p1b -- the B team's P2 needs it for its very last
+            // k-block only (xdone), so it is off every critical path, and on an MFMA wave its ~80 instructions cost their
+            // issue cycles; on the loader waves, which only get an instruction in where the MFMA waves stall, they cost
+            // 4.3 % of the kernel (0.2485 -> 0.2379 ms with the arithmetic removed).
+            if (a.xr) {
+                hstep_p1_xrow<NA, 1, BM_KL, OBJ>(a, Hs, Rs, wxs, t0, w, lane, true, acc_div);
+                rp_post(xdone, w, (unsigned)(j + 1), lane);
+            }
+#endif
         }
         SNMF_STAMP_OUT(a.prof + ((size_t)blockIdx.x * (NA + NB) + w) * 12, 12);
         SNMF_STAMP_CLK(a.prof, (size_t)blockIdx.x * (NA + NB) + w);
@@ -1658,10 +1671,13 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             float shsum = 0.f;
             // k-blocks over the ratio rows of the row tiles 0..NA-1 (never the extra row's block) / the rest
             const int nq = a.Fq / 8, nq1 = 4 * (a.nf < NA ? a.nf : NA);
+            constexpr bool XLAST = SNMF_XROW_A && SNMF_BUFW;  // the extra row's k-block is a phase of its own, gated by xdone
+            const int nqm = (XLAST && a.xr) ? nq - 1 : nq;       // k-blocks over the ratio rows proper
             auto gate_p1b = [&]() {
                 rp_await(p1b, (unsigned)(j + 1), a.stop);
-                if (a.xr) rp_await(xdone, (unsigned)(j + 1), a.stop);
+                if (a.xr && !XLAST) rp_await(xdone, (unsigned)(j + 1), a.stop);
             };
+            auto gate_x = [&]() { rp_await(xdone, (unsigned)(j + 1), a.stop); };
             for (int kap = wb; kap < a.nk; kap += 2 * NB) {
                 if (kap + NB < a.nk) {
                     f32x16 acc[2] = {zero16(), zero16()};
@@ -1676,11 +1692,15 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                         const __amdgpu_buffer_rsrc_t rsk = wimage_rsrc(a.Wk4, (size_t)a.nk * a.Fq * 32);
                         const int so[2] = {kap * a.Fq * 128, (kap + NB) * a.Fq * 128};
                         contract_shared_buf<2>(acc, rsk, lane * 16, so, sp, nq1, gate_p1a);
-                        if (nq > nq1) {
+                        if (nqm > nq1) {
                             const int so2[2] = {so[0] + nq1 * 1024, so[1] + nq1 * 1024};
-                            contract_shared_buf<2>(acc, rsk, lane * 16, so2, sp + 8 * nq1, nq - nq1, gate_p1b);
+                            contract_shared_buf<2>(acc, rsk, lane * 16, so2, sp + 8 * nq1, nqm - nq1, gate_p1b);
                         } else {
                             gate_p1b();
+                        }
+                        if (nq > nqm) {
+                            const int so3[2] = {so[0] + nqm * 1024, so[1] + nqm * 1024};
+                            contract_shared_buf<2>(acc, rsk, lane * 16, so3, sp + 8 * nqm, nq - nqm, gate_x);
                         }
                     }
 #else
@@ -1705,11 +1725,15 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                         const __amdgpu_buffer_rsrc_t rsk = wimage_rsrc(a.Wk4, (size_t)a.nk * a.Fq * 32);
                         const int so[1] = {kap * a.Fq * 128};
                         contract_shared_buf<1>(acc, rsk, lane * 16, so, sp, nq1, gate_p1a);
-                        if (nq > nq1) {
+                        if (nqm > nq1) {
                             const int so2[1] = {so[0] + nq1 * 1024};
-                            contract_shared_buf<1>(acc, rsk, lane * 16, so2, sp + 8 * nq1, nq - nq1, gate_p1b);
+                            contract_shared_buf<1>(acc, rsk, lane * 16, so2, sp + 8 * nq1, nqm - nq1, gate_p1b);
                         } else {
                             gate_p1b();
+                        }
+                        if (nq > nqm) {
+                            const int so3[1] = {so[0] + nqm * 1024};
+                            contract_shared_buf<1>(acc, rsk, lane * 16, so3, sp + 8 * nqm, nq - nqm, gate_x);
                         }
                     }
 #else
@@ -1729,6 +1753,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             // p2done of a later tile before the working waves are there (the counters are totals, not per-tile flags)
             gate_p1a();
             gate_p1b();
+            if (a.xr) gate_x();
             rp_post(p2done, wb, (unsigned)(j + 1), lane);
         }
         SNMF_STAMP_OUT(a.prof + ((size_t)blockIdx.x * (NA + NB) + w) * 12, 12);
