@@ -390,7 +390,13 @@ template <bool UNROLL32, typename Gate>
 __device__ __forceinline__ void contract_p3_buf(f32x16& acc, __amdgpu_buffer_rsrc_t rs, int voff, int soff0, const float* sp,
                                                 int nq, Gate gate) {
     f32x4 wA[2], wB[2], sA[2], sB[2];
-    auto ldw = [&](int q) { return ldw_buf(rs, voff, soff0 + q * 1024); };
+    // k-block q: its 4 KiB group (q >> 2) on the scalar offset, its place in the group as the instruction's 12-bit
+    // immediate; the scalar base is made opaque so that the unrolled loop's offsets are re-derived per call on the SALU
+    // instead of being hoisted out of the caller's tile loop into 32 live scalars (they were spilled to VGPR lanes and
+    // read back with a v_readlane per load: k_wstats 0.2360 -> 0.2336 ms without that)
+    int sbase = soff0;
+    asm volatile("" : "+s"(sbase));
+    auto ldw = [&](int q) { return ldw_buf(rs, voff + (q & 3) * 1024, sbase + (q >> 2) * 4096); };
     auto mmstage = [&](const f32x4 (&w)[2], const f32x4 (&sf)[2]) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
