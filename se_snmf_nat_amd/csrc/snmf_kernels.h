@@ -1036,20 +1036,21 @@ __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(Step
 // Here the consumer waves are split by ROLE, one wave of each role per SIMD:
 //     A team (waves 0-3) : P1 of tile i+1   Lam = W*H -> ratio image (in place over the staged V)
 //     B team (waves 4-7) : P2 of tile i     W^T*ratio -> H update in LDS
-//     loaders (waves 8-11): copy the updated H tile i out, bring tile i+2 into the buffer that tile i leaves, and
-//                           compute that tile's extra row (F = 32n+1) right after staging it
+//     loaders (waves 8-11): copy the updated H tile i out and bring tile i+2 into the buffer that tile i leaves
+//     (the extra row, F = 32n+1, is the A team's work after its last epilogue of a tile)
 // What this buys is NOT "one wave's epilogue under another wave's MFMAs": while a wave issues back-to-back MFMAs of
 // this shape no other wave of its SIMD issues anything (scripts/mfma_valu_overlap.hip), so a SIMD's time is its MFMA
 // cycles plus everything else its waves issue.  What a schedule can avoid is a SIMD on which every wave WAITS.  The two
 // MFMA waves of a SIMD share the pipe and therefore leave their loops together; if P2 of the next tile could only start
-// after the A team's whole epilogue (and the extra row), nobody would issue an MFMA through all of it.  Hence the extra
-// row on the loaders, and P2 in two phases: the first 4*NA k-blocks need only the ratio rows of the row tiles 0..NA-1.
+// after the A team's whole epilogue (and the extra row), nobody would issue an MFMA through all of it.  Hence P2 in
+// phases: the first 4*NA k-blocks need only the ratio rows of the row tiles 0..NA-1, the rest every row tile, and only
+// the very last k-block the extra row, which the A team computes after everything else.
 // No workgroup barrier inside the tile loop: six signals, each four per-wave progress words in LDS, order the roles
 //     ready  (loaders)   "the H block of tile j is staged"           A waits (loop), and the loaders' extra-row pass
 //     vready (loaders)   "the V block of tile j is staged"           A waits (epilogues), and the extra-row pass
 //     p1a    (A team)    "ratio rows of the row tiles 0..NA-1 whole"  B waits (phase 1)
 //     p1b    (A team)    "every ratio row tile is whole"              B waits (phase 2)
-//     xdone  (loaders)   "the extra row of the ratio image is done"   B waits (phase 2)
+//     xdone  (A team)    "the extra row of the ratio image is done"   B waits (last k-block)
 //     p2done (B team)    "H_j is updated, its ratio dead"             loaders wait
 // (dependencies run strictly forward in the tile index, so the waits cannot form a cycle; every wait is a bounded spin
 // that raises DevState::fault instead of hanging).  Each wave owns TWO 32-row (A) / 32-column (B) output tiles whose
