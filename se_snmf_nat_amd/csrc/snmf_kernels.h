@@ -1325,14 +1325,13 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
     const int bufsz = Tt * (ldh + ldr);  // floats per buffer: Hs [Tt][ldh] then Rs [Tt][ldr]
     float* wxs = lds + 2 * bufsz;        // [rp] extra row of W
     unsigned* cnt = reinterpret_cast<unsigned*>(wxs + rp);
-    // p1a: "the ratio rows of the row tiles 0..NA-1 are whole" (+NA per tile: each A wave after the epilogue of its FIRST
-    // row tile); p1b: "every row tile is" (+NA per tile: each A wave after its last epilogue); xdone: "the extra row is"
-    // (+NL per tile: each loader wave after its share of it).  The B team starts P2 on the first 4*NA k-blocks (rows 0..32*NA-1) at p1a and
-    // needs p1b only for the rest: in steady state both teams leave their MFMA loops together (they share the pipe), and
-    // the A team's epilogue is then the one stretch with nobody in a loop -- B now waits for half of it only.
-    // (the counters are TOTALS over the tiles, so each one has a single kind of producer: a counter fed by two roles
-    // could reach a tile's target on the arrivals of the role that runs ahead -- the loaders' extra rows of tiles 0 and
-    // 1 are both done before the A team has finished tile 0)
+    // p1a: "the ratio rows of the row tiles 0..NA-1 are whole" (each A wave after the epilogue of its FIRST row tile);
+    // p1b: "every row tile is" (each A wave after its last epilogue); xdone: "the extra row is" (each A wave after its
+    // share of it; with SNMF_XROW_A = 0 each loader wave).  The B team starts P2 on the first 4*NA k-blocks (rows
+    // 0..32*NA-1) at p1a, needs p1b for the rest and xdone for the extra row's k-block only: in steady state both teams
+    // leave their MFMA loops together (they share the pipe), and the A team's epilogue is then the one stretch with nobody
+    // in a loop -- B waits for half of it only.  Every signal is four per-wave progress words (rp_post / rp_await), so
+    // each has a single kind of producer and a wave that runs ahead cannot stand in for one that lags.
     static_assert(NA == 4 && NB == 4 && NL == 4, "four progress slots per role");
     // vready: "the tile's V block is staged" -- a signal of its own because the A team needs V only in its epilogues: the
     // loaders commit the H block first and post `ready`, so the V commit is off the path the A team's next loop waits for.
@@ -1379,9 +1378,8 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
         // floor(i / d) = umulhi(i, ceil(2^32 / d)) for 0 <= i < 2^16 (i < 20 * 256 here), d >= 1
         const unsigned invA = (unsigned)((0x100000000ull + (unsigned)rA - 1) / (unsigned)rA);
         const unsigned invB = (unsigned)((0x100000000ull + (unsigned)rB - 1) / (unsigned)rB);
-        // The extra row (F = 32*nf + 1) of a tile is the LOADERS' work, done right after the tile is staged: its dot
-        // products are VALU + LDS work that would otherwise sit on the A team's critical path between the end of its MFMA
-        // loop and the signal P2 waits for.  It needs the whole staged tile, hence the wait for every loader's arrival.
+        // SNMF_XROW_A = 0 only: the extra row (F = 32*nf + 1) of a tile as the LOADERS' work, done right after the tile is
+        // staged (it needs the whole staged tile, hence the waits for every loader's arrival).  Default: the A team's.
         const int lw = w - (NA + NB);
         auto xrow_of = [&](int j) {
             if (!a.xr || SNMF_XROW_A) return;
