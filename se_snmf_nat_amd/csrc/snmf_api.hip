@@ -305,6 +305,18 @@ extern "C" void snmf_plan_destroy(snmf_plan* pl) {
         const char* const* nm = wlast ? nmw : nmh;
         fprintf(stderr, "[SNMF_PROF] %s phase shares (avg cycles/wave = %.0f):", wlast ? "k_wstats" : "k_hstep", all / nw);
         for (int j = 0; j < 12; ++j) fprintf(stderr, " %s=%.1f%%", nm[j], 100.0 * tot[j] / all);
+        if (!wlast && pl->hstep_rp && pl->NWH == 8) {
+            // role pipeline: waves 0-3 of a workgroup are the A team (slots: 4 = wait for ready + contraction, 5 = wait
+            // for V + epilogues, 6 = bookkeeping, 11 = post p1b + extra row), waves 4-7 the B team (9 = gates +
+            // contraction, 10 = epilogues, 11 = post p2done + loop top)
+            double ta[12] = {0}, tb[12] = {0}, sa = 0, sb = 0;
+            for (int i = 0; i < nw; ++i)
+                for (int j = 0; j < 12; ++j) ((i & 7) < 4 ? ta : tb)[j] += (double)hp[(size_t)i * 12 + j];
+            for (int j = 0; j < 12; ++j) { sa += ta[j]; sb += tb[j]; }
+            fprintf(stderr, " | A team (cycles/wave %.0f): loop+wait %.1f%% epilogues %.1f%% other %.1f%% p1b+xrow %.1f%% | B team (%.0f): gates+loop %.1f%% epilogues %.1f%% post+top %.1f%%",
+                    sa / (nw / 2), 100 * ta[4] / sa, 100 * ta[5] / sa, 100 * ta[6] / sa, 100 * ta[11] / sa, sb / (nw / 2), 100 * tb[9] / sb,
+                    100 * tb[10] / sb, 100 * tb[11] / sb);
+        }
         std::vector<unsigned long long> hc((size_t)2 * nw);
         hipMemcpy(hc.data(), pl->prof + 98304 + (wlast ? (size_t)2 * 4096 : 0), hc.size() * 8, hipMemcpyDeviceToHost);
         std::vector<double> ghz, span;
