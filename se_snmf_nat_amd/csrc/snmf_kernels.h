@@ -2398,11 +2398,9 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
             rp_post(ready, lw, (unsigned)(it + 2), lane);
         }
     }
-    if (false) {
 #else
     if (is_loader) {
-#endif
-        // ================================ loader role =========================================
+        // ================================ loader role, through registers (SNMF_WSTATS_DMA = 0) ==
         if (tb < te) {
             stage_in<NST>(a.Hin + (size_t)tb * TT * rp, lds, TT, rp, ldh, sid);
             stage_in<NST>(a.V + (size_t)tb * TT * Fp, lds + TT * ldh, TT, Fp, Fp, sid);
@@ -2431,6 +2429,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
             }
         }
     }
+#endif
 
     SNMF_STAMP_DECL
     for (int tile = tb, it = 0; tile < te && !is_loader; ++tile, ++it) {
