@@ -161,3 +161,31 @@ def test_bench_launches_its_own_ranks():
     assert d["scaling"] == "strong" and "frames/2" in d["config"]["parallelism"]
     assert len(d["roofline"]["kernel_ms_per_rank"]) == 2 and all(k["hstep"] > 0 for k in d["roofline"]["kernel_ms_per_rank"])
     assert d["final_cost"] and d["final_cost"] > 0
+
+
+def test_bench_single_gpu_line_keeps_the_contract():
+    """One GPU, default launcher-less invocation: ONE JSON line with the contract's keys, the roofline object (bound,
+    achieved, peak, unit, frac, traffic, measured on the engine's stream with HIP events) and -- with the CPU leg on -- the
+    cpu_baseline object.  Small T so that the oracle's sample takes seconds."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    pr = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2", "--T", "6400", "--r", "64"],
+                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, pr.stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["value"] > 0 and d["higher_is_better"] is True
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None and "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == pytest.approx(157.3)
+    assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"]) and 0 < rf["frac"] < 1 and "traffic" in rf
+    assert rf["kernel_ms"]["hstep"] > 0 and rf["kernel_ms"]["wstats"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("port", "reference") and cb["sample"]
