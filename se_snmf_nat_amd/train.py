@@ -20,11 +20,13 @@ def run_basis_train_signal(s_full, R, p, *, DC_bin=None, sample_idx=None, ctx=No
     """run_basis_train.m:58-136.  `p`: the reference's settings fields (front-end fields of
     frontend.default_params() plus cf/sparsity/max_iter/conv_eps/cost_check, cluster_buff,
     train_Exemplar).  sample_idx: the exemplar columns (1-based like randsample, :81); default = a
-    seeded numpy draw standing in for MATLAB's rng(1); randsample(...)."""
+    seeded numpy draw standing in for MATLAB's rng(1); randsample(...).  cluster_buff > 1: the dictionary is trained
+    with cluster_buff*R atoms and reduced to R by kmeans.reduce_rank (:118-127; p["kmeans_seed"] seeds its draws)."""
     p = dict(p)
     cluster_buff = int(p.get("cluster_buff", 1))
-    if cluster_buff > 1:
-        raise SnmfError(8, "cluster_buff > 1 (k-means rank reduction, run_basis_train.m:118-129) is not implemented")
+    if cluster_buff > 1 and p.get("train_Exemplar", 0):
+        # :125-126 index the activation matrices, which :95-96 set to the scalar 0 in exemplar mode: MATLAB stops there too
+        raise SnmfError(3, "cluster_buff > 1 needs train_Exemplar = 0 (run_basis_train.m:125-126 index A_*_init, a scalar otherwise)")
     if p.get("domain_DD", 0):
         # run_basis_train.m:64-67 replaces the features by TF_DD(TF_mag, p); that transform is not part of this path
         # (the shipped settings leave domain_DD = 0), and silently training on the wrong features would be worse
@@ -54,6 +56,9 @@ def run_basis_train_signal(s_full, R, p, *, DC_bin=None, sample_idx=None, ctx=No
         B_Mel, A_Mel, _ = sparse_nmf(TF_Mel, q, ctx=ctx)  # :91
     B_DFT = B_DFT / np.sqrt((B_DFT ** 2).sum(0)) + 1e-9  # :113-114
     B_Mel = B_Mel / np.sqrt((B_Mel ** 2).sum(0)) + 1e-9  # :115-116
+    if cluster_buff > 1:  # :118-127: keep one basis vector per cluster of the Mel dictionary (host logic, as in the reference)
+        from .kmeans import reduce_rank
+        B_Mel, B_DFT, A_DFT, A_Mel, _ = reduce_rank(B_Mel, B_DFT, A_DFT, A_Mel, int(R), seed=int(p.get("kmeans_seed", 1)))
     return {"B_DFT_sub": B_DFT, "B_Mel_sub": B_Mel, "A_DFT_sub": A_DFT, "A_Mel_sub": A_Mel}  # :130-134
 
 

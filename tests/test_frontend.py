@@ -162,6 +162,34 @@ def test_basis_training_caller_end_to_end(gpu_ctx, tmp_path):
 
 
 @pytest.mark.gpu
+def test_basis_training_with_kmeans_rank_reduction(gpu_ctx):
+    """run_basis_train.m:118-129 (cluster_buff > 1): the dictionary is trained with cluster_buff*R atoms and reduced to
+    R by clustering the Mel atoms; the SAME atoms are kept in both dictionaries and both activation matrices.  Checked
+    against the un-reduced run (cluster_buff = 1, R' = cluster_buff*R, same exemplar columns) + the loop restatement of
+    the clustering on that run's Mel dictionary."""
+    from oracle import kmeans_oracle
+    from se_snmf_nat_amd import train
+    from se_snmf_nat_amd.api import SnmfError
+    s = np.load(os.path.join(GOLD, "frontend_audio.npz"))["samples"].astype(np.float64)
+    base = dict(fo.default_params(), cf="kl", sparsity=5, max_iter=15, conv_eps=0, cost_check=1, train_Exemplar=0)
+    idx = np.random.RandomState(5).choice(114, size=16, replace=False) + 1
+    full = train.run_basis_train_signal(s, 16, dict(base, cluster_buff=1), sample_idx=idx, ctx=gpu_ctx)
+    red = train.run_basis_train_signal(s, 8, dict(base, cluster_buff=2, kmeans_seed=3), sample_idx=idx, ctx=gpu_ctx)
+    _, _, D = kmeans_oracle.kmeans_cityblock(full["B_Mel_sub"].T, 8, seed=3)
+    assert red["B_DFT_sub"].shape == (513, 8) and red["B_Mel_sub"].shape == (64, 8) and red["A_DFT_sub"].shape[0] == 8
+    # which atoms were kept: every reduced column is one of the 16 trained ones, bit for bit
+    keep = np.array([int(np.flatnonzero((full["B_Mel_sub"] == red["B_Mel_sub"][:, [j]]).all(0))[0]) for j in range(8)])
+    # ... the one nearest to its cluster's centroid (a two-member cluster has both members equidistant from their median,
+    # so WHICH of the two is kept is a matter of rounding -- in MATLAB as here; the distance is what is checked)
+    np.testing.assert_allclose(D[keep, np.arange(8)], D.min(0), rtol=1e-12, atol=1e-15)
+    np.testing.assert_array_equal(red["B_DFT_sub"], full["B_DFT_sub"][:, keep])
+    np.testing.assert_array_equal(red["A_DFT_sub"], full["A_DFT_sub"][keep])
+    np.testing.assert_array_equal(red["A_Mel_sub"], full["A_Mel_sub"][keep])
+    with pytest.raises(SnmfError):  # :125-126 would index a scalar in MATLAB
+        train.run_basis_train_signal(s, 8, dict(base, cluster_buff=2, train_Exemplar=1), sample_idx=idx, ctx=gpu_ctx)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mel", [False, True], ids=["run_basis_DNMF", "run_basis_DNMF_Mel"])
 def test_dnmf_callers_from_waveforms(gpu_ctx, mel):
     """run_basis_DNMF.m / run_basis_DNMF_Mel.m with the reference's signature (x, d, B, p): equal-length cut,
