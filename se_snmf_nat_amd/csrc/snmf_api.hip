@@ -468,15 +468,15 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     pl->n_fg = (pl->nf + pl->NWB - 1) / pl->NWB;
     // H image of k_wstats: rows padded to whole NKT-tile groups (branch-free P4, see the kernel)
     pl->ldhw = std::max(pl->rp, 32 * pl->NKT * pl->n_kg) + 4;
-    if (((size_t)32 * pl->ldhw + (size_t)32 * pl->Fp) * 4 + (size_t)pl->rp * 4 + 32 > lds_cap && pl->NKT == 16)
+    if (((size_t)32 * pl->ldhw + (size_t)32 * pl->Fp) * 4 + (size_t)pl->rp * 4 + 288 > lds_cap && pl->NKT == 16)
         pl->TTW = 16;  // large r: 16-frame tiles (the 32-frame H + V images do not fit the LDS)
     const int n_tiles_w = pl->Tp / pl->TTW;
     {
         const size_t buf = ((size_t)pl->TTW * pl->ldhw + (size_t)pl->TTW * pl->Fp) * 4;
         // loaders + double buffering when the accumulators allow 2 waves per SIMD and LDS has room
-        pl->NLW = (pl->WPS == 2 && 2 * buf + (size_t)pl->rp * 4 + 32 <= lds_cap) ? 4 : 0;
+        pl->NLW = (pl->WPS == 2 && 2 * buf + (size_t)pl->rp * 4 + 288 <= lds_cap) ? 4 : 0;
         if (const char* e = getenv("SNMF_WSTATS_NL")) pl->NLW = (atoi(e) == 4 && pl->NLW == 4) ? 4 : 0;
-        pl->lds_w = std::max<size_t>((pl->NLW ? 2 : 1) * buf + (size_t)pl->rp * 4 + 32,  // + ready/done counters
+        pl->lds_w = std::max<size_t>((pl->NLW ? 2 : 1) * buf + (size_t)pl->rp * 4 + 288,  // + ready/done slots + the extra row's V values [2][32]
                                      (size_t)(pl->NWB + pl->NLW) * 64 * sizeof(double));
     }
     const int wg_w = pl->NLW ? 1 : pl->WPS;  // workgroups per CU

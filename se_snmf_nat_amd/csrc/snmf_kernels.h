@@ -2282,6 +2282,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     static_assert(NL == 0 || (NL == 4 && NWB == 4), "four progress slots per role");
     unsigned* ready = reinterpret_cast<unsigned*>(wxs + rp);  // [4] loader waves: tiles staged
     unsigned* done = ready + 4;                               // [4] consumer waves: tiles finished
+    float* vx = reinterpret_cast<float*>(done + 4);           // [2][32] V of the extra row, one value per frame (DMA loaders)
     if (NL > 0) {
         if (threadIdx.x < 8) ready[threadIdx.x] = 0u;
         __syncthreads();  // slots and wxs are set
@@ -2290,7 +2291,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     // The extra row of one tile (row group 0 only): ratio_x[t] for this wave's CPW columns, then gx[k] += ratio_x[t] * H[k,t].
     // It stays on the CONSUMER waves: moved to the loader waves -- which only get an instruction in where their SIMD's
     // MFMA wave stalls -- it delayed the staging of the next tile (k_wstats 0.249 -> 0.277 ms on C2).
-    auto xrow_tile = [&](const float* xH, const float* xV, int xt0, int xw) {
+    auto xrow_tile = [&](const float* xH, const float* xV, int xt0, int xw, const float* vxc = nullptr) {
             // extra row: ratio_x[t] for this wave's CPW columns, then gx[k] += ratio_x[t] * H[k,t]
             float rxv[CPW];
             float dsum = 0.f;
@@ -2300,7 +2301,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
                 const int kl = lane & 15;
                 const float* hrow = xH + tl * ldh;
                 const int t = xt0 + tl;
-                const float v = xV[tl * Fp + a.Fm];
+                const float v = vxc ? vxc[tl] : xV[tl * Fp + a.Fm];  // (DMA loaders keep the extra row's V values in a compact array)
                 float rv;
                 if (WM != 3) {
                     float s0 = 0.f, s1 = 0.f;
@@ -2356,8 +2357,12 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         typedef __attribute__((address_space(3))) void* lds_ptr_t;
         const int lw = w - NWB;
         const int npc = (rp + 255) >> 8;    // 1 KiB pieces per H row
-        const int nVb = TT * Fp * 4;        // bytes of a V tile: contiguous in global memory AND in LDS (no row padding)
-        const int nvc = (nVb + 1023) >> 10;
+        const int nVb = TT * Fp * 4;        // bytes of a V tile
+        // V: only the columns of THIS workgroup's row group (a.Fm rows in groups of 32*NWB) -- every frame row in one piece of
+        // up to 512 B -- and, for the group that owns it, the extra row's 32 values into a compact array: with two row groups
+        // the V block crosses L2 once per iteration instead of twice (447 -> 344 MB per launch on C2)
+        const int c0 = by * NWB * 32;                                  // first column (float) of the group
+        const int cw = (a.Fm - c0 < NWB * 32 ? a.Fm - c0 : NWB * 32);  // its width in floats (multiple of 32)
         auto dma_tile = [&](int tile, float* dst) {
             const __amdgpu_buffer_rsrc_t rh =
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Hin + (size_t)tile * TT * rp), 0, TT * rp * 4, 0x00020000);
@@ -2368,9 +2373,13 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
                                                                  (t * rp + pc * 256) * 4, 0, 0);
             const __amdgpu_buffer_rsrc_t rv =
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.V + (size_t)tile * TT * Fp), 0, nVb, 0x00020000);
-            for (int c = lw; c < nvc; c += NL)
-                if (c * 1024 + lane * 16 < nVb)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(dst + TT * ldh + c * 256), 16, lane * 16, c * 1024, 0, 0);
+            for (int t = lw; t < TT; t += NL)
+                for (int pc = 0; pc * 256 < cw; ++pc)
+                    if (pc * 256 + lane * 4 < cw)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(dst + TT * ldh + t * Fp + c0 + pc * 256), 16, lane * 16,
+                                                                 (t * Fp + c0 + pc * 256) * 4, 0, 0);
+            if (do_x && lw == 0 && lane < TT)  // one dword per frame: V[Fm, t] -> vx[buffer][t]
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(vx + (dst == lds ? 0 : 32)), 4, lane * Fp * 4, a.Fm * 4, 0, 0);
         };
         auto sums_of = [&](const float* H) {
             if (!do_s) return;
@@ -2458,7 +2467,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
                 }
             }
         }
-        if (do_x) xrow_tile(Hs, Vs, t0, w);
+        if (do_x) xrow_tile(Hs, Vs, t0, w, (NL > 0 && SNMF_WSTATS_DMA) ? vx + (it & 1) * 32 : nullptr);
         SNMF_STAMP(2);
         if (!active) {
             if (NL > 0) rp_post(done, w, (unsigned)(it + 1), lane);
