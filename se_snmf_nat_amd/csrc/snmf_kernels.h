@@ -2346,7 +2346,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     // how many instructions that takes, not by the bytes: ~300 per tile with loads into registers + ds_write + index
     // arithmetic + the row sums, which made `ready` arrive late (phase stamps: the consumers waited 1.0 k cycles per tile
     // for it, and any cycle their loops saved went into that wait).  Here a tile is ~17 buffer_load ... lds per wave
-    // (1 KiB each, scalar addressing: one per padded H row, the V tile as one contiguous block) and the row sums are taken
+    // (scalar addressing: one 1 KiB piece per padded H row, one piece per frame row for this row group's columns of V) and the row sums are taken
     // over the wave's OWN rows (complete as soon as its own DMA has landed) with one ds_read_b128 per row and 256 columns.
     float rs4[4][4];  // row sums of H over this wave's rows: k = 256 p + 4 lane + e   (rp <= 1024)
 #pragma unroll
