@@ -9,7 +9,8 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 FIXED = [(65, 70, 12000), (65, 70, 6000), (65, 128, 12000), (129, 70, 12000), (65, 32, 12000), (64, 70, 12000), (97, 96, 20000),
-         (257, 40, 20000), (33, 8, 30000), (161, 200, 9000), (257, 256, 30000), (225, 100, 17000)]
+         (257, 40, 20000), (33, 8, 30000), (161, 200, 9000), (257, 256, 30000), (225, 100, 17000), (513, 64, 12000), (513, 200, 9000),
+         (385, 100, 12000)]
 
 
 def shapes(n_random):

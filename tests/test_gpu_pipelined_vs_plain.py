@@ -17,7 +17,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 SHAPES = [(65, 70, 12000), (129, 70, 12000), (65, 32, 12000), (64, 70, 12000), (97, 96, 20000), (257, 40, 20000),
-          (33, 8, 30000), (161, 200, 9000), (257, 256, 30000), (225, 100, 17000)]
+          (33, 8, 30000), (161, 200, 9000), (257, 256, 30000), (225, 100, 17000), (513, 64, 12000), (385, 100, 12000)]  # (the last two: four / four row groups in k_wstats)
 
 
 def _run(ctx, V, W0, H0, r, *, h_only, iters):
