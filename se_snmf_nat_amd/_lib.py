@@ -15,8 +15,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libsnmf_hip.so")
 SRC = [os.path.join(_HERE, "csrc", "snmf_api.hip")]
-HDRS = [os.path.join(_HERE, "csrc", "snmf_kernels.h"), os.path.join(_HERE, "csrc", "snmf_frontend.h"),
-        os.path.join(_HERE, "csrc", "snmf_online.h"), os.path.join(_ROOT, "include", "snmf.h")]
+import glob as _glob
+# every header the translation unit includes (an edit to any of them must rebuild the library)
+HDRS = sorted(_glob.glob(os.path.join(_HERE, "csrc", "*.h"))) + [os.path.join(_ROOT, "include", "snmf.h")]
 
 # every symbol include/snmf.h declares
 SYMBOLS = [

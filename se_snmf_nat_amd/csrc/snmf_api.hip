@@ -219,6 +219,11 @@ struct snmf_plan {
     int NT = 1, NWH = 8, NLH = 0;  // k_hstep: frame tile = 32*NT, NWH consumer + NLH loader waves
     int TTH = 32, TTW = 32;        // frames per tile of k_hstep (NT == 1) / k_wstats; 16 = narrow tiles (images too big for 32 frames)
     bool hstep_rp = true;          // KL update launches of the (8, 1, 4) geometry use the role pipeline k_hstep_rp (SNMF_HSTEP_RP=0: k_hstep)
+    // k_hstep_rp launch geometry: tiles [0, rp_full) through the pipeline on rp_grid workgroups, the tiles of the last
+    // partial round [rp_full, rp_tiles) cut into rp_S row parts, one workgroup each (rp_S = 0: no split)
+    int rp_tiles = 0, rp_full = 0, rp_S = 0, rp_grid = 1;
+    float* part_buf = nullptr;     // partial numerators of the split tiles [rp_grid][32][rp]
+    unsigned* part_cnt = nullptr;  // arrivals per split tile (monotonic)
     int NKT = 8, NWB = 4, WPS = 2, NLW = 0;  // k_wstats template geometry (NLW loader waves)
     int n_fg = 1, n_kg = 1, n_chunks = 1;
     int n_ch1 = 0;  // k_wstats: chunks of row group 1 when the two row groups are split unevenly (else 0)
@@ -284,92 +289,20 @@ static int validate_params(const snmf_params* p) {
     return SNMF_OK;
 }
 
+#ifdef SNMF_PROF
+#include "snmf_prof.h"
+#endif
+
 extern "C" void snmf_plan_destroy(snmf_plan* pl) {
     if (!pl) return;
     hipSetDevice(pl->ctx->device);
     hipStreamSynchronize(pl->ctx->stream);
 #ifdef SNMF_PROF
-    if (pl->prof) {  // diagnostic build: phase shares of the LAST big-kernel launch
-        const bool wlast = getenv("SNMF_PROF_W") != nullptr;
-        const int nw = wlast ? pl->n_chunks * pl->n_fg * pl->NWB : pl->grid_h * pl->NWH;
-        std::vector<unsigned long long> hp((size_t)nw * 12);
-        hipMemcpy(hp.data(), pl->prof + (wlast ? (size_t)4096 * 12 : 0), hp.size() * 8, hipMemcpyDeviceToHost);
-        double tot[12] = {0};
-        for (int i = 0; i < nw; ++i)
-            for (int j = 0; j < 12; ++j) tot[j] += (double)hp[(size_t)i * 12 + j];
-        double all = 0;
-        for (int j = 0; j < 12; ++j) all += tot[j];
-        static const char* nmh[12] = {"bar_top", "stage", "bar_stage", "p1_pre", "p1_mfma", "p1_epi", "xrow", "bar_p2",
-                                      "p2_pre", "p2_mfma", "p2_epi", "stage_out"};
-        static const char* nmw[12] = {"loop", "barrier", "ssum+xrow", "p3_mfma", "p3_epi", "p4_mfma", "-", "-", "-", "-", "-", "-"};
-        const char* const* nm = wlast ? nmw : nmh;
-        fprintf(stderr, "[SNMF_PROF] %s phase shares (avg cycles/wave = %.0f):", wlast ? "k_wstats" : "k_hstep", all / nw);
-        for (int j = 0; j < 12; ++j) fprintf(stderr, " %s=%.1f%%", nm[j], 100.0 * tot[j] / all);
-        if (!wlast && pl->hstep_rp && pl->NWH == 8) {
-            // role pipeline: waves 0-3 of a workgroup are the A team (slots: 4 = wait for ready + contraction, 5 = wait
-            // for V + epilogues, 6 = bookkeeping, 11 = post p1b + extra row), waves 4-7 the B team (9 = gates +
-            // contraction, 10 = epilogues, 11 = post p2done + loop top)
-            double ta[12] = {0}, tb[12] = {0}, sa = 0, sb = 0;
-            for (int i = 0; i < nw; ++i)
-                for (int j = 0; j < 12; ++j) ((i & 7) < 4 ? ta : tb)[j] += (double)hp[(size_t)i * 12 + j];
-            for (int j = 0; j < 12; ++j) { sa += ta[j]; sb += tb[j]; }
-            fprintf(stderr, " | A team (cycles/wave %.0f): loop+wait %.1f%% epilogues %.1f%% other %.1f%% p1b+xrow %.1f%% | B team (%.0f): gates+loop %.1f%% epilogues %.1f%% post+top %.1f%%",
-                    sa / (nw / 2), 100 * ta[4] / sa, 100 * ta[5] / sa, 100 * ta[6] / sa, 100 * ta[11] / sa, sb / (nw / 2), 100 * tb[9] / sb,
-                    100 * tb[10] / sb, 100 * tb[11] / sb);
-        }
-        std::vector<unsigned long long> hc((size_t)2 * nw);
-        hipMemcpy(hc.data(), pl->prof + 98304 + (wlast ? (size_t)2 * 4096 : 0), hc.size() * 8, hipMemcpyDeviceToHost);
-        std::vector<double> ghz, span;
-        for (int i = 0; i < nw; ++i)
-            if (hc[2 * i + 1]) {
-                ghz.push_back((double)hc[2 * i] / (double)hc[2 * i + 1] * 0.1);
-                span.push_back((double)hc[2 * i + 1] * 0.01);
-            }
-        {   // when did the waves start and end, relative to the first start (100 MHz ticks -> us)
-            std::vector<unsigned long long> hs0((size_t)nw);
-            hipMemcpy(hs0.data(), pl->prof + 98304 + 16384 + (wlast ? (size_t)4096 : 0), hs0.size() * 8, hipMemcpyDeviceToHost);
-            std::vector<double> st, en;
-            unsigned long long t0 = ~0ull;
-            for (int i = 0; i < nw; ++i)
-                if (hs0[i]) t0 = std::min(t0, hs0[i]);
-            for (int i = 0; i < nw; ++i)
-                if (hs0[i]) {
-                    st.push_back((double)(hs0[i] - t0) * 0.01);
-                    en.push_back((double)(hs0[i] - t0 + hc[2 * i + 1]) * 0.01);
-                }
-            if (!st.empty()) {
-                std::sort(st.begin(), st.end());
-                std::sort(en.begin(), en.end());
-                auto q = [](const std::vector<double>& v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
-                fprintf(stderr, " | wave start us (10/50/90/100 %%): %.1f %.1f %.1f %.1f; wave end us (0/10/50/90/100 %%): %.1f %.1f %.1f %.1f %.1f",
-                        q(st, .1), q(st, .5), q(st, .9), q(st, 1.), q(en, 0.), q(en, .1), q(en, .5), q(en, .9), q(en, 1.));
-            }
-        }
-        if (!wlast) {  // per-tile periods of consumer wave 0: the first workgroup, one from the middle, the last
-            std::vector<unsigned long long> tt((size_t)16384);
-            hipMemcpy(tt.data(), pl->prof + 98304 + 24576, tt.size() * 8, hipMemcpyDeviceToHost);
-            const int wgs[3] = {0, pl->grid_h / 2, pl->grid_h - 1};
-            for (int wi = 0; wi < 3; ++wi) {
-                const int b = wgs[wi];
-                if (b < 0 || b >= 1024) continue;
-                fprintf(stderr, " | wg %d tile periods us:", b);
-                for (int i = 1; i < 16 && tt[(size_t)b * 16 + i]; ++i)
-                    fprintf(stderr, " %.1f", (double)(tt[(size_t)b * 16 + i] - tt[(size_t)b * 16 + i - 1]) * 0.01);
-            }
-        }
-        if (!ghz.empty()) {
-            std::sort(ghz.begin(), ghz.end());
-            std::sort(span.begin(), span.end());
-            fprintf(stderr, " | in-kernel clock %.3f GHz (median of %zu waves; min %.3f max %.3f), stamped span %.1f us median, %.1f max",
-                    ghz[ghz.size() / 2], ghz.size(), ghz.front(), ghz.back(), span[span.size() / 2], span.back());
-        }
-        fprintf(stderr, "\n");
-        hipFree(pl->prof);
-    }
+    snmf_prof_report(pl);
 #endif
     void* ptrs[] = {pl->V,     pl->H[0],  pl->H[1], pl->Wc,   pl->Wt4,   pl->Wk4,  pl->dphv, pl->colsum, pl->lamk,
                     pl->S,     pl->slabs, pl->spart, pl->part, pl->stats, pl->divh, pl->costh, pl->wn,    pl->st,
-                    pl->w_ind, pl->staging, pl->wx, pl->Wcf, pl->M};
+                    pl->w_ind, pl->staging, pl->wx, pl->Wcf, pl->M, pl->part_buf, pl->part_cnt};
     for (void* q : ptrs)
         if (q) hipFree(q);
     delete pl;
@@ -421,10 +354,10 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     pl->ldr = pl->Fq + 4;
     // k_hstep geometry: prefer two 4-wave workgroups per CU on 32-frame tiles (their phases
     // de-synchronise and keep the matrix pipe fed); otherwise one 8-wave workgroup per CU on the
-    // widest tile whose H image + ratio image fit the 160 KiB LDS.  SNMF_HSTEP_CFG=NWxNT overrides.
+    // widest tile whose H image + ratio image fit the 160 KiB LDS.
     const size_t per_col = (size_t)(pl->ldh + pl->ldr) * 4;
     const size_t lds_cap = 160 * 1024;  // gfx950: 160 KiB per CU, one workgroup may take all of it
-    const size_t lds_extra = (size_t)pl->rp * 4 + 96;  // extra row of W + the roles' progress slots (5 signals x 4 waves)
+    const size_t lds_extra = (size_t)pl->rp * 4 + 128;  // extra row of W + the roles' progress slots (6 signals x 4 waves) + the split tile's flag
     const size_t lds1 = 32 * per_col + lds_extra, lds2 = 64 * per_col + lds_extra;
     if (2 * lds1 - lds_extra <= lds_cap) { pl->NWH = 8; pl->NT = 1; pl->NLH = 4; }  // double-buffered
     else if (lds2 <= lds_cap && pl->Tp / 64 >= ctx->n_cu) { pl->NWH = 8; pl->NT = 2; }
@@ -438,16 +371,6 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         return fail(SNMF_ERR_UNSUPPORTED, "F + r = %d too large for the %zu-byte LDS tile (limit F+r <= %zu)", F + r,
                     lds_cap, lds_cap / 64 - 16);
     }
-    if (const char* e = getenv("SNMF_HSTEP_CFG")) {
-        int nw = 0, nt = 0;
-        int nl = 0;
-        const int got = sscanf(e, "%dx%dx%d", &nw, &nt, &nl);
-        if (got >= 2 && (nw == 4 || nw == 8) && (nt == 1 || nt == 2) && (nt == 1 ? lds1 : lds2) <= lds_cap) {
-            pl->NWH = nw;
-            pl->NT = nt;
-            pl->NLH = (got == 3 && (nl == 4) && nw == 8 && nt == 1 && 2 * lds1 - lds_extra <= lds_cap) ? nl : 0;
-        }
-    }
     if (const char* e = getenv("SNMF_HSTEP_RP")) pl->hstep_rp = atoi(e) != 0;
     pl->lds_h = std::max<size_t>(pl->NLH ? 2 * lds1 - lds_extra : (pl->NT == 1 ? (size_t)pl->TTH * per_col + lds_extra : lds2),
                                  2 * kMaxNW * 64 * sizeof(double));
@@ -456,8 +379,29 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     const int n_tiles_h = pl->Tp / (pl->TTH * pl->NT);
     // without loaders the NT == 1 kernels are register-bounded for two workgroups per CU
     int wg_per_cu = (pl->lds_h * 2 <= lds_cap && pl->NT == 1 && !pl->NLH) ? 2 : 1;
-    if (const char* e = getenv("SNMF_WGPCU")) wg_per_cu = std::max(1, std::min(wg_per_cu, atoi(e)));  // experiments
     pl->grid_h = std::max(1, std::min(n_tiles_h, ctx->n_cu * wg_per_cu));
+    // k_hstep_rp: only tiles that hold a frame (the pad tiles of both H buffers are zero and stay zero), and the last
+    // PARTIAL round split by rows over the workgroups that would idle through it (snmf_kernels.h, "the split last round"):
+    // 4 parts per tile when 4 * (tiles of that round) workgroups exist, else 2, else the round stays whole.
+    // SNMF_HSTEP_SPLIT=0 keeps every tile in the pipeline (tests compare the two).
+    {
+        const int G = ctx->n_cu;
+        pl->rp_tiles = (T + 31) / 32;
+        pl->rp_full = pl->rp_tiles;
+        pl->rp_grid = std::max(1, std::min(pl->rp_tiles, G));
+        pl->rp_S = 0;
+        const char* e = getenv("SNMF_HSTEP_SPLIT");
+        if (pl->NLH == 4 && !(e && atoi(e) == 0)) {
+            const int full = pl->rp_tiles >= G ? (pl->rp_tiles / G) * G : 0, R = pl->rp_tiles - full;
+            int S = R > 0 ? (4 * R <= G ? 4 : (2 * R <= G ? 2 : 0)) : 0;
+            while (S > pl->nf) S >>= 1;
+            if (S >= 2) {
+                pl->rp_S = S;
+                pl->rp_full = full;
+                pl->rp_grid = full ? G : R * S;
+            }
+        }
+    }
     // k_wstats geometry: 4-wave workgroups, each wave owns one 32-row tile x NKT 32-column tiles of
     // the statistics in registers.  NKT <= 8 (128 accumulator VGPRs): two workgroups per CU.
     if (pl->nk <= 4) { pl->NKT = 4; pl->WPS = 2; }
@@ -483,12 +427,11 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     pl->n_chunks = std::max(1, std::min(n_tiles_w, ctx->n_cu * wg_w / std::max(1, pl->n_fg * pl->n_kg)));
     // Two row groups, only group 0 carries the extra row: deal the workgroups out so that both finish together.
     // Relative cost x of the extra row per tile: ~2.1 k cycles at rp = 256 against 21 k for the two MFMA loops (phase
-    // stamps; a sweep of the split point on C2 has its optimum where this x puts it: 131..135 chunks for group 0,
-    // k_wstats 0.2573 -> 0.2481 ms).  Only for launches without the objective pass (full updates: the objective
+    // stamps; a sweep of the split point on C2 had its optimum where this x puts it: 131..135 chunks for group 0,
+    // k_wstats 0.2573 -> 0.2481 ms, profiles/r02_experiments.md).  Only for launches without the objective pass (full updates: the objective
     // rides on k_hstep).
     pl->n_ch1 = 0;
-    if (pl->xr && pl->n_fg == 2 && pl->n_kg == 1 && pl->NLW && pl->upd_h && pl->upd_w && n_tiles_w >= 4 * pl->n_chunks &&
-        !getenv("SNMF_NO_WSPLIT")) {
+    if (pl->xr && pl->n_fg == 2 && pl->n_kg == 1 && pl->NLW && pl->upd_h && pl->upd_w && n_tiles_w >= 4 * pl->n_chunks) {
         const int tot = 2 * pl->n_chunks;
         const double x = (600.0 + 6.0 * pl->rp) / (82.0 * (pl->rp / 2 + 16 * pl->nk));
         auto cost = [&](int n0) {
@@ -498,17 +441,13 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         int best = pl->n_chunks;
         for (int n0 = pl->n_chunks + 1; n0 <= pl->n_chunks + pl->n_chunks / 4; ++n0)
             if (cost(n0) < cost(best) - 1e-9) best = n0;
-        if (const char* e = getenv("SNMF_WSPLIT")) {  // experiments: chunks of row group 0
-            const int n0 = atoi(e);
-            if (n0 > pl->n_chunks && n0 < tot) best = n0;
-        }
         if (best != pl->n_chunks) {
             pl->n_ch1 = tot - best;
             pl->n_chunks = best;
         }
     }
     // start-up stagger (cycles) of the second half of each grid: about half a tile period when two
-    // workgroups share a CU.  SNMF_STAGGER=<h>,<w> overrides (0 disables).
+    // workgroups share a CU.
     {
         const int mf_h = (pl->nf + pl->NWH - 1) / pl->NWH * pl->NT * (pl->rp / 2) +
                          (pl->nk + pl->NWH - 1) / pl->NWH * pl->NT * (pl->Fq / 2);
@@ -516,13 +455,6 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         const int mf_w = pl->rp / 2 + 16 * pl->NKT;
         pl->stagger_w = 0;
         (void)mf_w;
-        if (const char* e = getenv("SNMF_STAGGER")) {
-            int sh = 0, sw = 0;
-            if (sscanf(e, "%d,%d", &sh, &sw) == 2) {
-                pl->stagger_h = sh;
-                pl->stagger_w = sw;
-            }
-        }
     }
     if (pl->lds_w > lds_cap) {
         delete pl;
@@ -539,10 +471,13 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     {
         const size_t need = ((size_t)32 * (pl->ldh + pl->ldr) + ((pl->rp + 3) & ~3)) * 4 + 2 * 512 * sizeof(double);
         pl->small_ok = pl->upd_h && !pl->upd_w && need <= lds_cap;   // shape admits the persistent kernel
-        pl->small = pl->small_ok && T <= 32 && !getenv("SNMF_NO_SMALL");
+        // SNMF_NO_SMALL (tests): 1 = no persistent kernel at all (the plan loop), 2 = no register-resident frame kernel
+        const char* ns = getenv("SNMF_NO_SMALL");
+        const int no_small = ns ? atoi(ns) : 0;
+        pl->small = pl->small_ok && T <= 32 && no_small != 1;
         pl->lds_small = need;
         // one frame per solve: register-resident dictionary (k_hsolve_frame), F <= 64*FB + 1, r <= 8*KB
-        if (pl->small_ok && !getenv("SNMF_NO_FRAME")) {
+        if (pl->small_ok && no_small == 0) {
             static const int fbs[2] = {4, 8}, kbs[2] = {16, 25};
             for (int fi = 0; fi < 2 && !pl->frame_fb; ++fi)
                 for (int ki = 0; ki < 2 && !pl->frame_fb; ++ki)
@@ -578,7 +513,12 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         A(dalloc(&pl->slabs, (size_t)pl->n_chunks * pl->n_mat * nW));
         A(dalloc(&pl->spart, (size_t)pl->n_chunks * pl->rp));
     }
+    if (pl->rp_S) {
+        A(dalloc(&pl->part_buf, (size_t)pl->rp_grid * 32 * pl->rp));
+        A(dalloc(&pl->part_cnt, (size_t)(pl->rp_tiles - pl->rp_full)));
+    }
     pl->n_part = std::max(std::max(pl->grid_h, pl->grid_mdi), pl->n_chunks * pl->n_fg);
+    pl->n_part = std::max(pl->n_part, pl->rp_grid);
     pl->n_part = std::max(pl->n_part, 1024);
     A(dalloc(&pl->part, (size_t)2 * pl->n_part));
     A(dalloc(&pl->stats, (size_t)pl->n_mat * nW + pl->rp + 2));
@@ -601,6 +541,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     hipMemsetAsync(pl->Wt4, 0, nWt * 4, st);
     hipMemsetAsync(pl->Wk4, 0, nWk * 4, st);
     hipMemsetAsync(pl->wx, 0, (size_t)pl->rp * 4, st);
+    if (pl->part_cnt) hipMemsetAsync(pl->part_cnt, 0, (size_t)(pl->rp_tiles - pl->rp_full) * 4, st);
     if (pl->slabs) hipMemsetAsync(pl->slabs, 0, (size_t)pl->n_chunks * pl->n_mat * nW * 4, st);
     hipMemsetAsync(pl->H[0], 0, nH * 4, st);
     hipMemsetAsync(pl->H[1], 0, nH * 4, st);
@@ -634,11 +575,17 @@ extern "C" int64_t snmf_plan_stats_len(const snmf_plan* pl) {
 extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
     if (!pl || !buf) return fail(SNMF_ERR_INVALID, "NULL argument");
     const bool kl_pipe = pl->NWH == 8 && pl->NLH == 4 && pl->bm == BM_KL && pl->upd_h && !pl->M && pl->hstep_rp;
+    char hs[160];
+    if (kl_pipe)
+        snprintf(hs, sizeof hs, "k_hstep_rp (4 P1 + 4 P2 + 4 loader waves; %d of %d tiles pipelined, last round split %d ways, grid %d)",
+                 pl->rp_full, pl->rp_tiles, pl->rp_S, pl->rp_grid);
+    else
+        snprintf(hs, sizeof hs, "k_hstep");
     snprintf(buf, n,
              "F=%d T=%d r=%d beta=%g | Fm=%d(+%d VALU row) rp=%d Tp=%d | hstep: %s, tile=%d frames, grid=%d x %d thr, lds=%zu B | "
              "wstats: NK=%d waves=%d+%d grid=(%d chunks,%d fgroups,%d kgroups; group-1 chunks %d) lds=%zu B | n_cu=%d",
-             pl->p.F, pl->p.T, pl->p.r, pl->p.beta, pl->Fm, pl->xr, pl->rp, pl->Tp,
-             kl_pipe ? "k_hstep_rp (4 P1 + 4 P2 + 4 loader waves)" : "k_hstep", pl->TTH * pl->NT, pl->grid_h, (pl->NWH + pl->NLH) * 64,
+             pl->p.F, pl->p.T, pl->p.r, pl->p.beta, pl->Fm, pl->xr, pl->rp, pl->Tp, hs, pl->TTH * pl->NT,
+             kl_pipe ? pl->rp_grid : pl->grid_h, (pl->NWH + pl->NLH) * 64,
              pl->lds_h, pl->NKT, pl->NWB, pl->NLW, pl->n_chunks, pl->n_fg, pl->n_kg, pl->n_ch1 ? pl->n_ch1 : pl->n_chunks, pl->lds_w,
              pl->ctx->n_cu);
     return SNMF_OK;
@@ -808,7 +755,6 @@ static StepArgs make_args(snmf_plan* pl) {
     a.part = pl->part;
     a.stop = &pl->st->stop;
     a.stagger_shift = -1;
-    if (const char* e = getenv("SNMF_STAGGER_SHIFT")) a.stagger_shift = atoi(e);
     a.prof = pl->prof;
     a.wx = pl->wx;
     a.Fm = pl->Fm;
@@ -899,9 +845,15 @@ static int launch_hstep(snmf_plan* pl, bool obj, bool upd) {
     }
     if (pl->NWH == 8 && pl->NLH == 4) {
         if (pl->hstep_rp && pl->bm == BM_KL && upd) {  // KL update launches: the role pipeline (k_hstep_rp)
-            dim3 g(pl->grid_h), b(768);
-            return obj ? launch_big(k_hstep_rp<true>, g, b, pl->lds_h, pl->ctx->stream, a)
-                       : launch_big(k_hstep_rp<false>, g, b, pl->lds_h, pl->ctx->stream, a);
+            dim3 g(pl->rp_grid), b(768);
+            a.n_tiles = pl->rp_tiles;
+            a.n_full = pl->rp_full;
+            a.part_S = pl->rp_S;
+            a.part_buf = pl->part_buf;
+            a.part_cnt = pl->part_cnt;
+            SN_TRY(obj ? launch_big(k_hstep_rp<true>, g, b, pl->lds_h, pl->ctx->stream, a)
+                       : launch_big(k_hstep_rp<false>, g, b, pl->lds_h, pl->ctx->stream, a));
+            return SNMF_OK;
         }
         return launch_hstep_g<8, 1, 4>(pl, a, obj, upd);
     }
@@ -1016,27 +968,6 @@ static int launch_wapply(snmf_plan* pl, const double* stats, int check_it, bool 
     return SNMF_OK;
 }
 
-// k_reduce + k_wapply in one launch (single-rank solves): positions per thread NP = ceil(Fp/4 / 32)
-static int wfused_np(const snmf_plan* pl) { return (pl->Fp / 4 + 31) / 32; }
-static int launch_wfused(snmf_plan* pl, bool do_obj, int n_part, bool sh_const, int check_it) {
-    const ReduceArgs ra = make_reduce_args(pl, pl->stats, true, do_obj, n_part, sh_const);
-    const ApplyArgs aa = make_apply_args(pl, pl->stats, check_it, true, false);
-    const size_t lds = (size_t)pl->n_mat * pl->Fp * sizeof(double);
-    ScopedTimer tm(pl->ctx, FAM_WAPPLY);
-    dim3 g(pl->p.r), b(256);
-    hipStream_t st = pl->ctx->stream;
-    switch (wfused_np(pl)) {
-        case 1: hipLaunchKernelGGL(k_wfused<1>, g, b, lds, st, ra, aa); break;
-        case 2: hipLaunchKernelGGL(k_wfused<2>, g, b, lds, st, ra, aa); break;
-        case 3: hipLaunchKernelGGL(k_wfused<3>, g, b, lds, st, ra, aa); break;
-        case 4: hipLaunchKernelGGL(k_wfused<4>, g, b, lds, st, ra, aa); break;
-        case 5: hipLaunchKernelGGL(k_wfused<5>, g, b, lds, st, ra, aa); break;
-        default: return fail(SNMF_ERR_INTERNAL, "k_wfused: F too large (caller must use the two-launch path)");
-    }
-    HIP_TRY(hipGetLastError());
-    return SNMF_OK;
-}
-
 static int launch_check(snmf_plan* pl, const double* stats, int it) {
     const size_t off = (size_t)pl->n_mat * pl->rp * pl->Fp + pl->rp;
     hipLaunchKernelGGL(k_check, dim3(1), dim3(64), 0, pl->ctx->stream, stats, off, pl->divh, pl->costh, pl->st, it,
@@ -1100,8 +1031,13 @@ extern "C" int snmf_plan_init(snmf_plan* pl) {
 // iterate j-1 is produced by the first pass of iteration j that forms Lam = W_{j-1} * H_{j-1}.
 static bool want_obj(const snmf_plan* pl, int j) { return pl->p.cost_check && j > 1; }
 // objective partials written by an H-UPDATE launch of k_hstep* (= its grid; the objective-only launches use grid_h)
+static bool hupd_is_rp(const snmf_plan* pl) {
+    return !pl->M && pl->NWH == 8 && pl->NLH == 4 && pl->hstep_rp && pl->bm == BM_KL;
+}
 static int hupd_parts(const snmf_plan* pl) {
-    return pl->M ? pl->grid_mdi : pl->grid_h;
+    if (pl->M) return pl->grid_mdi;
+    if (hupd_is_rp(pl)) return pl->rp_grid;
+    return pl->grid_h;
 }
 
 extern "C" int snmf_plan_hstep(snmf_plan* pl) {
@@ -1289,25 +1225,10 @@ extern "C" int snmf_plan_run(snmf_plan* pl, int32_t n_iters, int32_t* iters_done
     const bool can_stop = pl->p.cost_check && pl->p.conv_eps > 0.0;
     int since_poll = 0;
     bool stopped = false;
-    // single-rank solve: nothing is exchanged between the slab reduction and the W epilogue, so they can be ONE launch
-    // (k_wfused).  Measured on C2 it is not faster than the pair (22.8 us against 11.6 + 10.0: one workgroup per column
-    // is too little parallelism for the 35 MB of slabs), so it stays opt-in: SNMF_WFUSED=1.
-    const char* wf_env = getenv("SNMF_WFUSED");
-    const bool fused = pl->upd_w && wfused_np(pl) <= 5 && wf_env && atoi(wf_env) != 0;
     while (pl->it_done < target) {
         SN_TRY(snmf_plan_hstep(pl));
-        if (fused) {
-            const int j = pl->it_done + 1;
-            const bool obj = want_obj(pl, j);
-            const bool mdi_wonly = pl->M && !pl->upd_h;  // objective partials come from the MDI Lam pass of snmf_plan_hstep
-            SN_TRY(launch_wstats(pl, obj && !pl->upd_h && !mdi_wonly));
-            const int n_part = pl->upd_h ? hupd_parts(pl) : pl->M ? pl->grid_mdi : pl->n_chunks * pl->n_fg;
-            SN_TRY(launch_wfused(pl, obj, n_part, !pl->upd_h, obj ? j - 1 : 0));
-            pl->it_done = j;
-        } else {
-            SN_TRY(snmf_plan_wstats(pl, pl->stats));
-            SN_TRY(snmf_plan_wapply(pl, pl->stats));
-        }
+        SN_TRY(snmf_plan_wstats(pl, pl->stats));
+        SN_TRY(snmf_plan_wapply(pl, pl->stats));
         if (can_stop && ++since_poll >= 4) {
             since_poll = 0;
             DevState hs{};

@@ -102,9 +102,6 @@ struct DevState {
 // Index of this wave in its workgroup, as a SCALAR: `threadIdx.x >> 6` alone is a per-lane value to the compiler, and
 // every role switch, row / column-tile loop and operand base pointer derived from it then becomes vector code under exec
 // masks (with the register live ranges of all roles overlapping).  readfirstlane makes the uniformity visible.
-#ifndef SNMF_BUFW
-#define SNMF_BUFW 1  // W fragments of the MFMA loops through buffer descriptors + scalar offsets (0: 64-bit global loads)
-#endif
 __device__ __forceinline__ int wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 // `stop` points at DevState::stop; the fault word sits two ints behind it
 __device__ __forceinline__ void raise_fault(const int* stop) {
@@ -153,6 +150,13 @@ struct StepArgs {
     int ldh, ldr;         // LDS leading dimensions (floats)
     int stagger;          // cycles by which half of the workgroups start late (0 = off)
     int stagger_shift;    // which half: bit `shift` of the linear block id (-1: upper half of the grid)
+    // k_hstep_rp, split last round: tiles [n_full, n_tiles) are cut into part_S row parts (part p = the 32-row tiles
+    // phi = p, p + part_S, ...; the last part also owns the extra row), one workgroup each; their partial W^T*ratio
+    // numerators go to part_buf [(tile - n_full) * part_S + p][rp / 32][4][64] f32x4 (MFMA fragment order) and the last
+    // of a tile's workgroups to arrive adds them in part order and applies the H update.  part_S = 0: no split.
+    int n_full, part_S;
+    float* part_buf;
+    unsigned* part_cnt;   // [n_tiles - n_full] arrivals per split tile (monotonic; a launch adds part_S to each)
     int lam_is_u;         // scalar sparsity: every real row has the same lambda (pad rows of H are zero anyway)
     float lam_u;          // ... that lambda
     float beta, inv_bb1;
@@ -191,12 +195,8 @@ struct StepArgs {
         __builtin_amdgcn_sched_barrier(0);  \
     } while (0)
 
-// acc[tau] += sum over k-blocks q of  Wfrag(q) (x) Sfrag_tau(q)
-//   wp : this lane's f32x4 of the W operand image, consecutive k-blocks 64 f32x4 apart (L2/HBM)
-//   sp : this lane's row of the LDS image (H tile or ratio tile), k-block q at sp + 8q,
-//        frame sub-tile tau a further tau*sstride floats on
+// One k-block of a contraction: four MFMAs per frame sub-tile from one f32x4 of W and one f32x4 per sub-tile of the LDS image.
 //   SWAP=false: W is the MFMA A operand (P1, P2);  SWAP=true: the LDS tile is A (P3).
-// W fragments are prefetched two k-blocks ahead, LDS fragments one ahead.
 template <int NT, bool SWAP>
 __device__ __forceinline__ void mfma_block(f32x16 (&acc)[NT], const f32x4& w, const f32x4 (&sf)[NT]) {
 #pragma unroll
@@ -209,115 +209,12 @@ __device__ __forceinline__ void mfma_block(f32x16 (&acc)[NT], const f32x4& w, co
     }
 }
 
-// The loop is unrolled by two SB-block stages held in NAMED registers (A, B): rotating buffers with
-// register copies would make the copy wait for the load it has just issued.  Stage X+1's loads are
-// issued before stage X's 4*SB*NT MFMAs (256*SB*NT cycles alone), which is what hides the L2 latency.
-// DUAL: the two k-blocks of a stage feed two INDEPENDENT accumulator chains (summed at the end).  A single chain of
-// dependent v_mfma_f32_32x32x2_f32 issues every ~82 cycles when the wave is alone on its SIMD (k_wstats' P3: 128 MFMAs
-// in 10.5 k cycles, round-1 phase stamps) against ~68 for independent accumulators (P4): the pipe waits for the
-// previous result.  Changes the fp32 summation order (even / odd k-blocks), deterministically.
-// gate(): called once, after the W loads of the first stage have been issued and before the first LDS read: the caller's
-// wait for the LDS image goes there, so the L2 round trip of the first fragments is spent while the wave waits anyway.
+// gate(): called once by the contraction loops that take one, after the W loads of the first stage have been issued and
+// before the first LDS read: the caller's wait for the LDS image goes there, so the L2 round trip of the first fragments is
+// spent while the wave waits anyway.
 struct NoGate {
     __device__ __forceinline__ void operator()() const {}
 };
-template <int NT, bool SWAP, int SB, bool DUAL = false, typename Gate = NoGate>
-__device__ __forceinline__ void contract_sb(f32x16 (&acc)[NT], const f32x4* __restrict__ wp, const float* sp,
-                                            int sstride, int nq, Gate gate = Gate()) {
-    static_assert(!DUAL || SB == 2, "DUAL pairs the two blocks of a stage");
-    f32x4 wA[SB], wB[SB];
-    f32x4 sA[SB][NT], sB[SB][NT];
-    f32x16 acc2[NT];
-    if (DUAL) {
-#pragma unroll
-        for (int tau = 0; tau < NT; ++tau) acc2[tau] = zero16();
-    }
-    const int last = nq - 1;
-    auto ldstage = [&](f32x4 (&w)[SB], f32x4 (&sf)[SB][NT], int q0) {
-#pragma unroll
-        for (int j = 0; j < SB; ++j) {
-            const int qq = (q0 + j) < last ? (q0 + j) : last;
-            w[j] = wp[(size_t)qq * 64];
-#pragma unroll
-            for (int tau = 0; tau < NT; ++tau)
-                sf[j][tau] = *reinterpret_cast<const f32x4*>(sp + tau * sstride + 8 * qq);
-        }
-    };
-    auto mmstage = [&](const f32x4 (&w)[SB], const f32x4 (&sf)[SB][NT]) {
-        if (DUAL) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int tau = 0; tau < NT; ++tau) {
-                    if (SWAP) {
-                        acc[tau] = mfma32(sf[0][tau][e], w[0][e], acc[tau]);
-                        acc2[tau] = mfma32(sf[1][tau][e], w[1][e], acc2[tau]);
-                    } else {
-                        acc[tau] = mfma32(w[0][e], sf[0][tau][e], acc[tau]);
-                        acc2[tau] = mfma32(w[1][e], sf[1][tau][e], acc2[tau]);
-                    }
-                }
-        } else {
-#pragma unroll
-            for (int j = 0; j < SB; ++j) mfma_block<NT, SWAP>(acc, w[j], sf[j]);
-        }
-    };
-    const int nmain = nq - nq % (2 * SB);
-    int q = 0;
-    if (nmain > 0) {
-#pragma unroll
-        for (int j = 0; j < SB; ++j) wA[j] = wp[(size_t)(j < last ? j : last) * 64];
-        SNMF_PIN();
-        gate();
-#pragma unroll
-        for (int j = 0; j < SB; ++j)
-#pragma unroll
-            for (int tau = 0; tau < NT; ++tau)
-                sA[j][tau] = *reinterpret_cast<const f32x4*>(sp + tau * sstride + 8 * (j < last ? j : last));
-        for (; q < nmain; q += 2 * SB) {
-            ldstage(wB, sB, q + SB);
-            SNMF_PIN();
-            mmstage(wA, sA);
-            ldstage(wA, sA, q + 2 * SB);  // clamped past the end; harmless re-read of the last block
-            SNMF_PIN();
-            mmstage(wB, sB);
-        }
-    }
-    // remainder (fewer than 2*SB blocks): simple two-deep pipeline
-    if (q < nq) {
-        f32x4 w0 = wp[(size_t)q * 64];
-        if (nmain == 0) {
-            SNMF_PIN();
-            gate();
-        }
-        f32x4 s0[NT];
-#pragma unroll
-        for (int tau = 0; tau < NT; ++tau) s0[tau] = *reinterpret_cast<const f32x4*>(sp + tau * sstride + 8 * q);
-        for (; q < nq; ++q) {
-            const int qn = q + 1 < nq ? q + 1 : q;
-            const f32x4 w1 = wp[(size_t)qn * 64];
-            f32x4 s1[NT];
-#pragma unroll
-            for (int tau = 0; tau < NT; ++tau) s1[tau] = *reinterpret_cast<const f32x4*>(sp + tau * sstride + 8 * qn);
-            mfma_block<NT, SWAP>(acc, w0, s0);
-            w0 = w1;
-#pragma unroll
-            for (int tau = 0; tau < NT; ++tau) s0[tau] = s1[tau];
-        }
-    }
-    if (nq <= 0) gate();
-    if (DUAL) {
-#pragma unroll
-        for (int tau = 0; tau < NT; ++tau)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[tau][i] += acc2[tau][i];
-    }
-}
-template <int NT, bool SWAP>
-__device__ __forceinline__ void contract(f32x16 (&acc)[NT], const f32x4* __restrict__ wp, const float* sp,
-                                         int sstride, int nq) {
-    contract_sb<NT, SWAP, 2>(acc, wp, sp, sstride, nq);  // SB = 4 measured slower (registers, no latency win)
-}
 
 // ---- operand fragments WITHOUT vector address arithmetic ------------------------------------------------------------
 // For v_mfma_f32_32x32x2_f32 every other instruction a SIMD issues is time its matrix pipe does not get
@@ -336,7 +233,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wimage_rsrc(const float* img, 
 __device__ __forceinline__ f32x4 ldw_buf(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
 }
-// contract<NT, SWAP> on the buffer path: the same k-block order per accumulator (bit-identical results), W fragments by
+// acc[tau] += sum over k-blocks q of Wfrag(q) (x) Sfrag_tau(q): W fragments by
 // descriptor + scalar offset, LDS fragments at immediate offsets from one moving base per frame sub-tile, no clamps.
 template <int NT, bool SWAP>
 __device__ __forceinline__ void contract_buf(f32x16 (&acc)[NT], __amdgpu_buffer_rsrc_t rs, int voff, int soff0, const float* sp,
@@ -613,12 +510,8 @@ __device__ __forceinline__ void hstep_p1_tiles(const StepArgs& a, float* Hs, flo
                     if (MDI) mfr[tau][g] = *reinterpret_cast<const f32x4*>(a.M + off);
                 }
         }
-#if SNMF_BUFW
         contract_buf<NT, false>(acc, wimage_rsrc(a.Wt4, (size_t)a.nf * rp * 32), lane * 16, phi * rp * 128, Hs + flt * ldh + 4 * h,
                                 32 * ldh, rp / 8);
-#else
-        contract<NT, false>(acc, wp, Hs + flt * ldh + 4 * h, 32 * ldh, rp / 8);
-#endif
         // epilogue: lane (t = fl, h), reg -> f = 32*phi + drow(reg,h)
         float dsum = 0.f;
 #pragma unroll
@@ -682,6 +575,17 @@ __device__ __forceinline__ float wave_sum_f(float v) {
            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16)) +
            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)) +
            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+}
+
+// fixed-order sum over the 256 threads of a workgroup: xor butterfly inside each wave (the same tree on every rank), then
+// the four wave sums in wave order.  One workgroup barrier per call instead of the eight of an LDS tree.
+__device__ __forceinline__ double wg_sum_256(double v, double* scratch /*[4]*/, int tid) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();  // scratch of the previous call has been read
+    if ((tid & 63) == 0) scratch[tid >> 6] = v;
+    __syncthreads();
+    return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
 }
 
 // extra row (F = 32*nf + 1): lam_x[t] = sum_k W[Fm,k] H[k,t] on the VALU, 4 columns x 16 lanes at a time
@@ -810,12 +714,8 @@ __device__ __forceinline__ void hstep_p2(const StepArgs& a, float* Hs, const flo
                 if (OBJ || BM != BM_KL) spf[g] = *reinterpret_cast<const f32x4*>(a.lamk + k0);
             }
         }
-#if SNMF_BUFW
         contract_buf<NT, false>(acc, wimage_rsrc(a.Wk4, (size_t)a.nk * a.Fq * 32), lane * 16, kap * a.Fq * 128,
                                 Rs + flt * ldr + 4 * h, 32 * ldr, a.Fq / 8);
-#else
-        contract<NT, false>(acc, wp, Rs + flt * ldr + 4 * h, 32 * ldr, a.Fq / 8);
-#endif
         // epilogue: lane (t = fl, h), reg -> k = 32*kap + drow(reg,h)
         float shsum = 0.f;
 #pragma unroll
@@ -902,10 +802,7 @@ __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(Step
         }
     }
     constexpr int NPASS = (BM == BM_KL) ? 1 : 2;
-#ifndef SNMF_HSTEP_SIG
-#define SNMF_HSTEP_SIG 1
-#endif
-    constexpr bool SIG = SNMF_HSTEP_SIG && NL > 0 && UPD && NPASS == 1;
+    constexpr bool SIG = NL > 0 && UPD && NPASS == 1;
     unsigned* sig = reinterpret_cast<unsigned*>(wxs + rp);  // consumers' "P2 of the previous tile done" count
     if (SIG && threadIdx.x == 0) *sig = 0u;
 
@@ -1071,17 +968,6 @@ __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(Step
 // the missing arrival of a slow one whenever a wave may run a tile ahead of its team.  The loaders stage tiles 0 and 1
 // back to back, so with a total `ready` the A team, or the loaders' own extra-row pass, could start on a tile that one
 // loader wave had not finished staging; a probe over awkward shapes found it.)
-#ifndef SNMF_XROW_A
-#define SNMF_XROW_A 1  // k_hstep_rp: the extra row is the A team's work, after its last epilogue (0: the loader waves')
-#endif
-#ifndef SNMF_LEAN_LOADER
-#define SNMF_LEAN_LOADER 1  // k_hstep_rp loaders without index arithmetic (0 = the older per-cell path, 2 / 3 = H / V block only)
-#endif
-#define SNMF_LEAN_H (SNMF_LEAN_LOADER == 1 || SNMF_LEAN_LOADER == 2)
-#define SNMF_LEAN_V (SNMF_LEAN_LOADER == 1 || SNMF_LEAN_LOADER == 3)
-#ifndef SNMF_WSTATS_DMA
-#define SNMF_WSTATS_DMA 1  // loader waves of k_wstats stage through LDS-DMA (buffer_load ... lds)
-#endif
 __device__ __forceinline__ void rp_post(unsigned* slots, int wave_in_role, unsigned tiles_done, int lane) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     if (lane == 0) __hip_atomic_store(slots + wave_in_role, tiles_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1104,70 +990,14 @@ __device__ __forceinline__ void rp_await(const unsigned* slots, unsigned target,
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// acc[i] += sum_q Wfrag_i(q) (x) Sfrag(q), i < NA: NA output tiles that share the LDS operand stream.
-//   wp[i]: this lane's f32x4 of W operand image i, consecutive k-blocks 64 f32x4 apart;  sp: this lane's LDS row.
-// Three named stages, each one k-block = 4*NA MFMAs, fragments two blocks ahead of their use (a wave that has the pipe
-// to itself still hides the L2 latency).  No tail code: the clamped prefetch of the last rounds re-reads block nq-1.
+// acc[i] += sum_q Wfrag_i(q) (x) Sfrag(q), i < NA: NA output tiles that share the LDS operand stream (one ds_read_b128
+// feeds 4 * NA MFMAs).  Three named stages, each one k-block, fragments two blocks ahead of their use (a wave that has
+// the pipe to itself still hides the L2 latency).
 // gate(): called between the W loads of the first two blocks and their LDS loads.  W does not depend on the tile, so
 // the caller puts its WAIT for the LDS image there: the L2 round trip of the loop's first fragments (~0.8 k cycles per
 // call, measured with one team's loops removed: a lone A loop ran at 77 cycles per MFMA, a lone two-phase B loop at 86)
 // is then spent while the wave waits anyway.
-// (-DSNMF_PROF diagnostic builds only: wmask / smask re-use operand fragments -- wrong results, same MFMAs -- to
-// measure what the L2 and LDS operand streams cost; StepArgs::stagger_shift carries the selector.)
-template <int NA, typename Gate>
-__device__ __forceinline__ void contract_shared(f32x16 (&acc)[NA], const f32x4* const (&wp)[NA], const float* sp, int nq,
-                                                int wmask, int smask, Gate gate) {
-    f32x4 wA[NA], wB[NA], wC[NA], sA, sB, sC;
-    const int last = nq - 1;
-    auto ldw = [&](f32x4 (&w)[NA], int q) {
-        int qq = q < last ? q : last;
-#ifdef SNMF_PROF
-        qq &= wmask;
-#endif
-#pragma unroll
-        for (int i = 0; i < NA; ++i) w[i] = wp[i][(size_t)qq * 64];
-    };
-    auto lds_ = [&](f32x4& sf, int q) {
-        int qq = q < last ? q : last;
-#ifdef SNMF_PROF
-        qq &= smask;
-#endif
-        sf = *reinterpret_cast<const f32x4*>(sp + 8 * qq);
-    };
-    auto ld = [&](f32x4 (&w)[NA], f32x4& sf, int q) {
-        ldw(w, q);
-        lds_(sf, q);
-    };
-    auto mm = [&](const f32x4 (&w)[NA], const f32x4& sf) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int i = 0; i < NA; ++i) acc[i] = mfma32(w[i][e], sf[e], acc[i]);
-    };
-    ldw(wA, 0);
-    ldw(wB, 1);
-    SNMF_PIN();
-    gate();
-    lds_(sA, 0);
-    lds_(sB, 1);
-    int q = 0;
-    for (; q + 2 < nq; q += 3) {
-        ld(wC, sC, q + 2);
-        SNMF_PIN();
-        mm(wA, sA);
-        ld(wA, sA, q + 3);
-        SNMF_PIN();
-        mm(wB, sB);
-        ld(wB, sB, q + 4);
-        SNMF_PIN();
-        mm(wC, sC);
-    }
-    if (q < nq) mm(wA, sA);
-    if (q + 1 < nq) mm(wB, sB);
-}
-
-// contract_shared with the W fragments through the buffer path (see contract_p3_buf): soff[i] = byte offset of image
-// block i (scalar).  LDS fragments at immediate offsets from a base that moves once per three k-blocks; no clamps: the
+// W fragments through the buffer path (see contract_p3_buf): soff[i] = byte offset of image block i (scalar).  LDS fragments at immediate offsets from a base that moves once per three k-blocks; no clamps: the
 // prefetch reads up to two k-blocks (64 B of the LDS row, 2 KB of the image) past the last one.
 template <int NA, typename Gate>
 __device__ __forceinline__ void contract_shared_buf(f32x16 (&acc)[NA], __amdgpu_buffer_rsrc_t rs, int voff, const int (&soff)[NA],
@@ -1314,6 +1144,254 @@ __device__ __forceinline__ void rp_p2_consts(const StepArgs& a, int kap, int lan
     }
 }
 
+// ---- the split last round of k_hstep_rp ------------------------------------------------------------------------------
+// n_tiles tiles on G workgroups are ceil(n_tiles / G) rounds of the pipeline, and in the last one only n_tiles mod G
+// workgroups have a tile (C2: 3125 tiles on 256 -> 53 workgroups work through a 13th tile period while 203 CUs idle,
+// 6-7 % of the launch).  A tile can be cut by ROWS without duplicating any work: P1 needs only a workgroup's own rows of
+// W and V (and the whole H tile), and P2 is linear in the ratio rows, so part p of S forms the ratio rows of its own
+// 32-row tiles phi = p, p + S, ... and contracts W^T*ratio over exactly those rows -- a PARTIAL numerator [rp x 32].
+// The tiles of the last partial round are dealt out S parts each over the workgroups that would otherwise idle, and a
+// workgroup's part is simply one more tile of its list (staged by the loaders like any other, index nmy):
+//   A team: P1 of the part's row tiles, under the B team's P2 of the last whole tile (the pipeline's drain).  A part with
+//       at most two row tiles (F = 257, S = 4) is ALSO cut in two over k so that all four A waves have an item; the two
+//       partial Lam tiles of a row tile meet in the ratio image's cells of row tiles the part does not own;
+//   B team: W^T*ratio over the part's k-blocks (4 per own row tile, + the extra row's for the last part) -> partial
+//       numerator to HBM in MFMA fragment order, through agent-scope (sc1, write-through) stores;
+//   the LAST of a tile's S workgroups to arrive (one agent-scope counter per tile; nobody waits for anybody) adds the S
+//       partials in part order -- sc1 loads, so no stale L2 line of its XCD can answer -- and applies the H update from
+//       the H tile it has in LDS anyway, exactly as rp_p2_epilogue forms it (+ the tile's share of sum(S .* H)).
+// Summation order of a split tile: Lam possibly in two k ranges, the numerator in S row parts -- fp32, a few ulp from
+// the one-workgroup order of the pipelined tiles (tests/test_gpu_pipelined_vs_plain.py states the tolerance).
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int kAuxSC1 = 16;  // cache-policy bit of the raw buffer builtins: sc1 = agent scope (coherent across the XCDs' L2s)
+// 16-byte buffer store.  A buffer_store_dwordx4 with a REGISTER scalar offset still reads its data registers after it
+// has issued (found by scripts/rp_shape_probe.py in round 2: the compiler reused one for an LDS address in the very next
+// instruction and the address reached memory; LLVM's hazard recogniser pads only immediate offsets): the s_nop carries
+// the data registers as operands, so nothing can be scheduled between the store and the padding that rewrites them.
+template <int AUX = 0>
+__device__ __forceinline__ void buf_store_b128(__amdgpu_buffer_rsrc_t rs, int voff, int soff, f32x4 x) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, x), rs, voff, soff, AUX);
+    asm volatile("s_nop 2" : "+v"(x) : : "memory");
+}
+// scratch cells of item `it` of a k-split part (S >= 4, nf = nrt * S): the it-th row tile the part does not own
+__device__ __forceinline__ int part_scratch_tile(int it, int pp, int S) {
+    const int q = it / (S - 1), rr = it - q * (S - 1);
+    return q * S + (pp + 1 + rr) % S;
+}
+
+struct PartGeo {
+    int S, pp, nrt;  // parts per tile, this workgroup's part, its row tiles phi = pp + i * S
+    bool ks2;        // P1 also cut in two over k (parts of at most two row tiles)
+    bool own_x;      // the last part owns the extra row
+};
+__device__ __forceinline__ PartGeo part_geo(const StepArgs& a) {
+    PartGeo g;
+    g.S = a.part_S;
+    g.pp = (int)blockIdx.x % g.S;
+    g.nrt = g.pp < a.nf ? (a.nf - 1 - g.pp) / g.S + 1 : 0;
+    g.ks2 = g.nrt <= 2 && g.S >= 4 && a.nf == g.nrt * g.S;
+    g.own_x = a.xr && g.pp == g.S - 1;
+    return g;
+}
+// The three steps of a split tile run AFTER the tile loops of their role, not as a branch inside them: the loops sit at
+// the 168-VGPR limit of three waves per SIMD, and with the part's code in the loop body the pipelined tiles got 5 % slower
+// (22 spilled VGPRs); as real (not inlined) functions they need scratch for their arguments and are slower still.
+// A team, wave w: P1 of the part's row tiles; returns the divergence terms (OBJ).  cnt: the kernel's progress slots.
+template <bool OBJ>
+__device__ __forceinline__ double rp_part_p1(const StepArgs& a, float* Hs, const float* wxs, unsigned* cnt, int j, int ptile, int w, int lane) {
+    constexpr int NA = 4;
+    const PartGeo pg = part_geo(a);
+    const int rp = a.rp, ldh = a.ldh, ldr = a.ldr, pS = pg.S, pp = pg.pp, pnrt = pg.nrt;
+    unsigned *ready = cnt, *p1a = cnt + 4, *p1b = cnt + 8, *xdone = cnt + 16, *vready = cnt + 20;
+    float* Rs = Hs + 32 * ldh;
+    const int t0 = ptile * 32, fl = lane & 31, h = lane >> 5;
+    const float* sp = Hs + fl * ldh + 4 * h;
+    bool waited = false, vwaited = false;
+    auto gate_ready = [&]() {
+        if (!waited) rp_await(ready, (unsigned)(j + 1), a.stop);
+        waited = true;
+    };
+    auto gate_v = [&]() {
+        if (!vwaited) rp_await(vready, (unsigned)(j + 1), a.stop);
+        vwaited = true;
+    };
+    float dsum = 0.f;
+    double acc_div = 0.0;
+    const __amdgpu_buffer_rsrc_t rsw = wimage_rsrc(a.Wt4, (size_t)a.nf * rp * 32);
+    if (!pg.ks2) {
+        for (int i = w; i < pnrt; i += NA) {
+            const int phi = pp + i * pS;
+            f32x16 acc[1] = {zero16()};
+            const int so[1] = {phi * rp * 128};
+            contract_shared_buf<1>(acc, rsw, lane * 16, so, sp, rp / 8, gate_ready);
+            gate_v();
+            rp_p1_epilogue<OBJ>(a, acc[0], Rs, phi, t0, lane, dsum);
+        }
+        gate_ready();
+        gate_v();
+        rp_post(p1a, w, (unsigned)(j + 1), lane);
+    } else {
+        // item w = (row tile w >> 1, k half w & 1): partial Lam -> the cells of a row tile the part does not own
+        const int nqs = rp / 16, it_i = w >> 1, it_k = w & 1;
+        if (w < 2 * pnrt) {
+            f32x16 acc[1] = {zero16()};
+            const int so[1] = {(pp + it_i * pS) * rp * 128 + it_k * nqs * 1024};
+            contract_shared_buf<1>(acc, rsw, lane * 16, so, sp + 8 * it_k * nqs, nqs, gate_ready);
+            gate_v();  // (the V commit of the loaders must not land on top of the scratch cells)
+            float* d = Rs + fl * ldr + part_scratch_tile(w, pp, pS) * 32 + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 o = {acc[0][4 * g], acc[0][4 * g + 1], acc[0][4 * g + 2], acc[0][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(d + 8 * g) = o;
+            }
+        }
+        gate_ready();
+        gate_v();
+        rp_post(p1a, w, (unsigned)(j + 1), lane);  // "my partial Lam tile is in its cells"
+        rp_await(p1a, (unsigned)(j + 1), a.stop);
+        if (w < 2 * pnrt) {  // wave w: rows 16 (w & 1) .. + 15 of row tile w >> 1: Lam = the two k halves, in order
+            const int phi = pp + it_i * pS;
+            const float* s0 = Rs + fl * ldr + part_scratch_tile(2 * it_i, pp, pS) * 32 + 4 * h;
+            const float* s1 = Rs + fl * ldr + part_scratch_tile(2 * it_i + 1, pp, pS) * 32 + 4 * h;
+            float* rsp = Rs + fl * ldr + phi * 32 + 4 * h;
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg) {
+                const int g = 2 * it_k + gg;
+                const f32x4 l0 = *reinterpret_cast<const f32x4*>(s0 + 8 * g), l1 = *reinterpret_cast<const f32x4*>(s1 + 8 * g);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(rsp + 8 * g);
+                f32x4 o;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float lam = fmaxf(l0[jj] + l1[jj], kFlr);
+                    if (OBJ) {
+                        const int f = phi * 32 + 8 * g + 4 * h + jj;
+                        const float dv = div_term<BM_KL>(v[jj], lam, a.beta, a.inv_bb1);
+                        dsum += (f < a.F && t0 + fl < a.T) ? dv : 0.f;
+                    }
+                    o[jj] = v[jj] * fast_rcp(lam);
+                }
+                *reinterpret_cast<f32x4*>(rsp + 8 * g) = o;
+            }
+        }
+    }
+    if (OBJ) acc_div += (double)dsum;
+    rp_post(p1b, w, (unsigned)(j + 1), lane);
+    if (pg.own_x) {
+        hstep_p1_xrow<NA, 1, BM_KL, OBJ>(a, Hs, Rs, wxs, t0, w, lane, true, acc_div);
+        rp_post(xdone, w, (unsigned)(j + 1), lane);
+    }
+    return acc_div;
+}
+// B team, wave wb: W^T*ratio over the part's own ratio rows -> partial numerator (fragment order [kap][g][lane]).  The
+// part's k-blocks are scattered over the contraction axis (4 per own row tile, + the extra row's): block i of the list
+// sits at blk(i); a ring of four fragment sets keeps three blocks' loads in flight.
+__device__ __forceinline__ void rp_part_p2(const StepArgs& a, const float* Rs, unsigned* cnt, int j, int wb, int lane) {
+    constexpr int NB = 4;
+    const PartGeo pg = part_geo(a);
+    const int rp = a.rp, ldr = a.ldr, pS = pg.S, pp = pg.pp, pnrt = pg.nrt;
+    const int fl = lane & 31, h = lane >> 5;
+    const float* sp = Rs + fl * ldr + 4 * h;
+    rp_await(cnt + 8, (unsigned)(j + 1), a.stop);                  // p1b
+    if (pg.own_x) rp_await(cnt + 16, (unsigned)(j + 1), a.stop);  // xdone
+    const __amdgpu_buffer_rsrc_t rsk = wimage_rsrc(a.Wk4, (size_t)a.nk * a.Fq * 32);
+    const __amdgpu_buffer_rsrc_t rsp_ = __builtin_amdgcn_make_buffer_rsrc(a.part_buf + (size_t)blockIdx.x * 32 * rp, 0, 32 * rp * 4, 0x00020000);
+    const int nb = 4 * pnrt + (pg.own_x ? 1 : 0);
+    auto blk = [&](int i) { return i < 4 * pnrt ? 4 * (pp + (i >> 2) * pS) + (i & 3) : 4 * a.nf; };
+    for (int kap = wb; kap < a.nk; kap += 2 * NB) {
+        const bool two = kap + NB < a.nk;
+        const int kap1 = two ? kap + NB : kap;
+        f32x16 acc[2] = {zero16(), zero16()};
+        f32x4 wq0[4], wq1[4], sq[4];
+        auto ldq = [&](int u, int i) {
+            const int b = blk(i);
+            wq0[u] = ldw_buf(rsk, lane * 16, kap * a.Fq * 128 + b * 1024);
+            wq1[u] = ldw_buf(rsk, lane * 16, kap1 * a.Fq * 128 + b * 1024);
+            sq[u] = *reinterpret_cast<const f32x4*>(sp + 8 * b);
+        };
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (u < nb) ldq(u, u);
+        SNMF_PIN();
+        for (int i0 = 0; i0 < nb; i0 += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i0 + u < nb) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[0] = mfma32(wq0[u][e], sq[u][e], acc[0]);
+                        acc[1] = mfma32(wq1[u][e], sq[u][e], acc[1]);
+                    }
+                }
+                if (i0 + u + 4 < nb) ldq(u, i0 + u + 4);
+                SNMF_PIN();
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (c == 1 && !two) break;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 o = {acc[c][4 * g], acc[c][4 * g + 1], acc[c][4 * g + 2], acc[c][4 * g + 3]};
+                buf_store_b128<kAuxSC1>(rsp_, lane * 16, ((c ? kap1 : kap) * 1024 + g * 256) * 4, o);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partial is at the coherence point before this wave reports
+}
+// All waves: whoever bumps the tile's counter to a multiple of S is the last of its S workgroups and finishes the tile:
+// numerator = the S partials in part order, then H <- H .* dmh ./ dph as rp_p2_epilogue forms it; returns the tile's
+// share of sum(S .* H) of the previous iterate (OBJ).  Hs: the split tile's H block, staged for P1.
+template <bool OBJ>
+__device__ __forceinline__ double rp_part_finish(const StepArgs& a, const float* Hs, unsigned* plast, int ptile, int n_full) {
+    constexpr int NTHR = 768, Tt = 32;
+    const PartGeo pg = part_geo(a);
+    const int rp = a.rp, ldh = a.ldh, pS = pg.S;
+    __syncthreads();  // every wave of the B team has waited for its partial stores
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(a.part_cnt + (ptile - n_full), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *plast = (old % (unsigned)pS == (unsigned)pS - 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!*plast) return 0.0;
+    const int u0 = (int)blockIdx.x - pg.pp;  // first of the tile's S units
+    const __amdgpu_buffer_rsrc_t rsp_ = __builtin_amdgcn_make_buffer_rsrc(a.part_buf + (size_t)u0 * Tt * rp, 0, pS * Tt * rp * 4, 0x00020000);
+    float shsum = 0.f;
+    for (int idx = threadIdx.x; idx < a.nk * 256; idx += NTHR) {
+        const int kap = idx >> 8, g = (idx >> 6) & 3, ln = idx & 63, fl = ln & 31, h = ln >> 5;
+        f32x4 x[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+            if (p < pS) x[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsp_, idx * 16, p * Tt * rp * 4, kAuxSC1));
+        const int t = ptile * Tt + fl, k0 = kap * 32 + 8 * g + 4 * h;
+        const f32x4 ho = *reinterpret_cast<const f32x4*>(Hs + fl * ldh + k0);
+        f32x4 spv = {0.f, 0.f, 0.f, 0.f}, o, den;
+        if (a.S) {
+            spv = *reinterpret_cast<const f32x4*>(a.S + (size_t)t * rp + k0);
+            const f32x4 cs = *reinterpret_cast<const f32x4*>(a.colsum + k0);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) den[jj] = fmaxf(cs[jj] + spv[jj], kFlr);
+        } else {
+            if (OBJ && !a.lam_is_u) spv = *reinterpret_cast<const f32x4*>(a.lamk + k0);
+            den = *reinterpret_cast<const f32x4*>(a.dphv + k0);
+        }
+        f32x4 num = x[0];
+#pragma unroll
+        for (int p = 1; p < 8; ++p)
+            if (p < pS) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) num[jj] += x[p][jj];
+            }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) o[jj] = ho[jj] * num[jj] * fast_rcp(den[jj]);
+        *reinterpret_cast<f32x4*>(a.Hout + (size_t)t * rp + k0) = o;
+        if (OBJ) {
+            if (a.lam_is_u && !a.S) shsum += a.lam_u * ((ho[0] + ho[1]) + (ho[2] + ho[3]));
+            else shsum += (spv[0] * ho[0] + spv[1] * ho[1]) + (spv[2] * ho[2] + spv[3] * ho[3]);
+        }
+    }
+    return (double)shsum;
+}
+
 template <bool OBJ>
 __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
     constexpr int NA = 4, NB = 4, NL = 4, NTHR = (NA + NB + NL) * 64, NLT = NL * 64, Tt = 32;
@@ -1327,7 +1405,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
     unsigned* cnt = reinterpret_cast<unsigned*>(wxs + rp);
     // p1a: "the ratio rows of the row tiles 0..NA-1 are whole" (each A wave after the epilogue of its FIRST row tile);
     // p1b: "every row tile is" (each A wave after its last epilogue); xdone: "the extra row is" (each A wave after its
-    // share of it; with SNMF_XROW_A = 0 each loader wave).  The B team starts P2 on the first 4*NA k-blocks (rows
+    // share of it).  The B team starts P2 on the first 4*NA k-blocks (rows
     // 0..32*NA-1) at p1a, needs p1b for the rest and xdone for the extra row's k-block only: in steady state both teams
     // leave their MFMA loops together (they share the pipe), and the A team's epilogue is then the one stretch with nobody
     // in a loop -- B waits for half of it only.  Every signal is four per-wave progress words (rp_post / rp_await), so
@@ -1345,51 +1423,26 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             lds[bsel * bufsz + Tt * ldh + (ii >> 3) * ldr + a.Fm + (ii & 7)] = 0.f;
         }
     }
-    if (threadIdx.x < 24) cnt[threadIdx.x] = 0u;
+    if (threadIdx.x < 25) cnt[threadIdx.x] = 0u;
     __syncthreads();
-    // diagnostic operand-reuse experiment (SNMF_PROF builds): 1 = W fragments of even k-blocks only, 2 = W block 0 only,
-    // 3 = LDS fragments of even k-blocks only, 4 = LDS block 0 only, 5 = both streams block 0 only
-    const int xsel = a.stagger_shift;
-    const int xw = (xsel == 1) ? ~1 : (xsel == 2 || xsel == 5) ? 0 : -1, xs = (xsel == 3) ? ~1 : (xsel == 4 || xsel == 5) ? 0 : -1;
-    const int nmy = blockIdx.x < (unsigned)a.n_tiles ? (a.n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-    auto tile_of = [&](int j) { return (int)blockIdx.x + j * (int)gridDim.x; };
+    // Tiles [0, n_full) go through the pipeline, dealt out round-robin.  The tiles of the last PARTIAL round,
+    // [n_full, n_tiles), are split over part_S workgroups each: workgroup u < (n_tiles - n_full) * part_S
+    // takes part u % part_S of tile n_full + u / part_S as one more staged tile AFTER its pipelined ones.
+    const int n_full = a.part_S > 0 ? a.n_full : a.n_tiles;
+    const int nmy = (int)blockIdx.x < n_full ? (n_full - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const bool has_part = a.part_S > 0 && (int)blockIdx.x < (a.n_tiles - n_full) * a.part_S;
+    const int ptile = has_part ? n_full + (int)blockIdx.x / a.part_S : 0;
+    const int nst = nmy + (has_part ? 1 : 0);  // tiles the loaders stage and the teams work on
+    auto tile_of = [&](int j) { return j < nmy ? (int)blockIdx.x + j * (int)gridDim.x : ptile; };
 
-    // Wave priorities (experiments, SNMF_STAGGER=<n>,0; measured on C2, none helps: 5 and 2 cost 3 %, 3 and 4 change
-    // nothing): 0 = none (default), 5 = loaders 3 / A 2, 2 = loaders 3 / B 2, 3 = A 2 only, 4 = A 3 / loaders 2.
-    {
-        const int role = w >= NA + NB ? 2 : (w < NA ? 0 : 1);
-        switch (a.stagger) {
-            case 5: if (role == 2) __builtin_amdgcn_s_setprio(3); else if (role == 0) __builtin_amdgcn_s_setprio(2); break;
-            case 2: if (role == 2) __builtin_amdgcn_s_setprio(3); else if (role == 1) __builtin_amdgcn_s_setprio(2); break;
-            case 3: if (role == 0) __builtin_amdgcn_s_setprio(2); break;
-            case 4: if (role == 0) __builtin_amdgcn_s_setprio(3); else if (role == 2) __builtin_amdgcn_s_setprio(2); break;
-            default: break;
-        }
-    }
     if (w >= NA + NB) {
         // ================================ loaders ===================================================
         const int lt = threadIdx.x - (NA + NB) * 64;
         const int rA = rp / 4, nA = Tt * rA, rB = Fp / 4, nB = Tt * rB;
-#if SNMF_LEAN_LOADER
-        const bool fits = (SNMF_LEAN_H ? rp <= 256 : nA <= PA * NLT) && nB < PB * NLT;  // (H: one piece per row; V: the last slot is the straddling cell's)
-#else
-        const bool fits = nA <= PA * NLT && nB <= PB * NLT;
-#endif
+        const bool fits = rp <= 256 && nB < PB * NLT;  // (H: one piece per row; V: the last slot is the straddling cell's)
         // floor(i / d) = umulhi(i, ceil(2^32 / d)) for 0 <= i < 2^16 (i < 20 * 256 here), d >= 1
-        const unsigned invA = (unsigned)((0x100000000ull + (unsigned)rA - 1) / (unsigned)rA);
         const unsigned invB = (unsigned)((0x100000000ull + (unsigned)rB - 1) / (unsigned)rB);
-        // SNMF_XROW_A = 0 only: the extra row (F = 32*nf + 1) of a tile as the LOADERS' work, done right after the tile is
-        // staged (it needs the whole staged tile, hence the waits for every loader's arrival).  Default: the A team's.
         const int lw = w - (NA + NB);
-        auto xrow_of = [&](int j) {
-            if (!a.xr || SNMF_XROW_A) return;
-            rp_await(ready, (unsigned)(j + 1), a.stop);
-            rp_await(vready, (unsigned)(j + 1), a.stop);
-            float* bH = lds + (j & 1) * bufsz;
-            hstep_p1_xrow<NL, 1, BM_KL, OBJ>(a, bH, bH + Tt * ldh, wxs, tile_of(j) * Tt, lw, lane, true, acc_div);
-            rp_post(xdone, lw, (unsigned)(j + 1), lane);
-        };
-#if SNMF_LEAN_LOADER
         // Beside two waves that issue MFMAs back to back a loader wave gets an instruction in only where they stall
         // (scripts/mfma_valu_overlap.hip), so the time from p2done(j) to ready(j+2) -- which the A team waits for -- is
         // set by the NUMBER of instructions between them.  That was ~390 (index arithmetic per cell and tile, 64-bit
@@ -1416,7 +1469,6 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             loB[b] = Tt * ldh + t * ldr + 4 * k4;
             asm volatile("" : "+v"(loB[b]));
         }
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         auto ldA = [&](__amdgpu_buffer_rsrc_t rs, int i) {
             return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, hv, (lw + NL * i) * rp * 4, 0));
         };
@@ -1424,29 +1476,20 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             if (b == PB - 1) return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gbB, 0, 0));
             return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gv, b < nfB ? b * NLT * 16 : 0, 0));
         };
-        // (s_nop: a buffer_store_dwordx4 with a REGISTER scalar offset still reads its data registers after it has
-        //  issued -- the compiler reused the first of them for an LDS address in the very next instruction and, in a few
-        //  lanes of a few stores, that address went to memory instead of H (found by scripts/rp_shape_probe.py; LLVM's
-        //  hazard recogniser only pads the store when the scalar offset is NOT a register))
-        auto stA = [&](__amdgpu_buffer_rsrc_t rs, int i, const f32x4& x) {
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), rs, hv, (lw + NL * i) * rp * 4, 0);
-            asm volatile("s_nop 2" ::: "memory");
-        };
+        auto stA = [&](__amdgpu_buffer_rsrc_t rs, int i, const f32x4& x) { buf_store_b128(rs, hv, (lw + NL * i) * rp * 4, x); };
         auto rsrc_of = [&](const float* base, int n_cells) {
             return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, n_cells * 16, 0x00020000);
         };
-#endif
-        for (int j = 0; j < 2 && j < nmy; ++j) {
+        for (int j = 0; j < 2 && j < nst; ++j) {
             float* bH = lds + j * bufsz;
             stage_in2<NLT, PA, PB>(a.Hin + (size_t)tile_of(j) * Tt * rp, bH, Tt, rp, ldh, a.V + (size_t)tile_of(j) * Tt * Fp,
                                    bH + Tt * ldh, Tt, Fp, ldr, lt);
             rp_post(ready, lw, (unsigned)(j + 1), lane);
             rp_post(vready, lw, (unsigned)(j + 1), lane);
         }
-        for (int j = 0; j < 2 && j < nmy; ++j) xrow_of(j);
         for (int j = 0; j < nmy; ++j) {
             float* bH = lds + (j & 1) * bufsz;
-            const bool more = j + 2 < nmy;
+            const bool more = j + 2 < nst;  // (the workgroup's share of a split tile is staged like one more tile)
             // tile j+2 -> registers while tile j is still being worked on.  Every access below is UNCONDITIONAL: a slot past
             // the end of a block falls back onto the thread's OWN first cell (the same 16 bytes read and written again, by
             // the same thread, so program order keeps "copy out, then overwrite" intact -- a cell owned by another thread
@@ -1455,39 +1498,14 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             // accesses it fell back to vmcnt(0) in front of the first LDS write of the prefetched registers, i.e. it also
             // waited for the H stores issued just before to be acknowledged by HBM: 7 us of every 21 us tile period in
             // which neither team had a tile to work on (phase stamps of the diagnostic build).
-            // Row of cell i = i / r4 through a reciprocal multiply on an index the compiler cannot see through: hoisted out
-            // of the tile loop, the cell addresses cost more VGPRs than the role has (spills).
-            f32x4 xa[PA], xb[PB];
-            auto cell = [&](int b, int n) {
-                int l = lt;
-                asm volatile("" : "+v"(l));  // opaque: keeps the clamped indices from being hoisted out of the tile loop
-                const int i = l + b * NLT;
-                return i < n ? i : l;        // l < n: a block has at least 32 * 32 / 4 = 256 cells
-            };
+            f32x4 xa[PR], xb[PB];
             if (more && fits) {
                 const float* srcA = a.Hin + (size_t)tile_of(j + 2) * Tt * rp;
                 const float* srcB = a.V + (size_t)tile_of(j + 2) * Tt * Fp;
-#if SNMF_LEAN_LOADER
-                if (SNMF_LEAN_H) {
 #pragma unroll
-                    for (int b = 0; b < PR; ++b) xa[b] = ldA(rsrc_of(srcA, nA), b);
-                } else {
+                for (int b = 0; b < PR; ++b) xa[b] = ldA(rsrc_of(srcA, nA), b);
 #pragma unroll
-                    for (int b = 0; b < PA; ++b) xa[b] = *reinterpret_cast<const f32x4*>(srcA + 4 * (size_t)cell(b, nA));
-                }
-                if (SNMF_LEAN_V) {
-#pragma unroll
-                    for (int b = 0; b < PB; ++b) xb[b] = ldB(rsrc_of(srcB, nB), b);
-                } else {
-#pragma unroll
-                    for (int b = 0; b < PB; ++b) xb[b] = *reinterpret_cast<const f32x4*>(srcB + 4 * (size_t)cell(b, nB));
-                }
-#else
-#pragma unroll
-                for (int b = 0; b < PA; ++b) xa[b] = *reinterpret_cast<const f32x4*>(srcA + 4 * (size_t)cell(b, nA));
-#pragma unroll
-                for (int b = 0; b < PB; ++b) xb[b] = *reinterpret_cast<const f32x4*>(srcB + 4 * (size_t)cell(b, nB));
-#endif
+                for (int b = 0; b < PB; ++b) xb[b] = ldB(rsrc_of(srcB, nB), b);
             }
             SNMF_PIN();
             rp_await(p2done, (unsigned)(j + 1), a.stop);
@@ -1499,88 +1517,31 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     stage_in<NLT>(a.V + (size_t)tile_of(j + 2) * Tt * Fp, bH + Tt * ldh, Tt, Fp, ldr, lt);
                     rp_post(ready, lw, (unsigned)(j + 3), lane);
                     rp_post(vready, lw, (unsigned)(j + 3), lane);
-                    xrow_of(j + 2);
                 }
                 continue;
             }
             // the updated H tile leaves (LDS -> registers -> HBM; the stores are only ISSUED here) ...
-#if SNMF_LEAN_LOADER
+            // (four LDS reads in flight at a time: one read, one wait, one store at a time put eight LDS latencies between
+            //  p2done and ready)
             const char* const bHl = reinterpret_cast<const char*>(bH) + hv;  // this lane's column of the H image
-            if (SNMF_LEAN_H) {
-                // (four LDS reads in flight at a time: one read, one wait, one store at a time put eight LDS latencies
-                //  between p2done and ready)
 #pragma unroll
-                for (int b0 = 0; b0 < PR; b0 += 4) {
-                    f32x4 ho[4];
+            for (int b0 = 0; b0 < PR; b0 += 4) {
+                f32x4 ho[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) ho[u] = *reinterpret_cast<const f32x4*>(bHl + (lw + NL * (b0 + u)) * ldh * 4);
+                for (int u = 0; u < 4; ++u) ho[u] = *reinterpret_cast<const f32x4*>(bHl + (lw + NL * (b0 + u)) * ldh * 4);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) stA(rsrc_of(dstH, nA), b0 + u, ho[u]);
-                }
-            } else {
-#pragma unroll
-                for (int b = 0; b < PA; ++b) {
-                    const int i = cell(b, nA);
-                    const int t = (int)__umulhi((unsigned)i, invA), k4 = i - t * rA;
-                    const f32x4 ho = *reinterpret_cast<const f32x4*>(bH + t * ldh + 4 * k4);
-                    *reinterpret_cast<f32x4*>(dstH + 4 * (size_t)i) = ho;
-                }
+                for (int u = 0; u < 4; ++u) stA(rsrc_of(dstH, nA), b0 + u, ho[u]);
             }
-            if (more) {
-                if (SNMF_LEAN_H) {
-#pragma unroll
-                    for (int b = 0; b < PR; ++b)
-                        *reinterpret_cast<f32x4*>(const_cast<char*>(bHl) + (lw + NL * b) * ldh * 4) = xa[b];
-                } else {
-#pragma unroll
-                    for (int b = 0; b < PA; ++b) {
-                        const int i = cell(b, nA);
-                        const int t = (int)__umulhi((unsigned)i, invA), k4 = i - t * rA;
-                        *reinterpret_cast<f32x4*>(bH + t * ldh + 4 * k4) = xa[b];
-                    }
-                }
-                rp_post(ready, lw, (unsigned)(j + 3), lane);
-                if (SNMF_LEAN_V) {
-#pragma unroll
-                    for (int b = 0; b < PB; ++b) *reinterpret_cast<f32x4*>(bH + loB[b]) = xb[b];
-                } else {
-#pragma unroll
-                    for (int b = 0; b < PB; ++b) {
-                        const int i = cell(b, nB);
-                        const int t = (int)__umulhi((unsigned)i, invB), k4 = i - t * rB;
-                        *reinterpret_cast<f32x4*>(bH + Tt * ldh + t * ldr + 4 * k4) = xb[b];
-                    }
-                }
-                rp_post(vready, lw, (unsigned)(j + 3), lane);
-                xrow_of(j + 2);
-            }
-            continue;
-#endif
-#pragma unroll
-            for (int b = 0; b < PA; ++b) {
-                const int i = cell(b, nA);
-                const int t = (int)__umulhi((unsigned)i, invA), k4 = i - t * rA;
-                const f32x4 ho = *reinterpret_cast<const f32x4*>(bH + t * ldh + 4 * k4);
-                *reinterpret_cast<f32x4*>(dstH + 4 * (size_t)i) = ho;
-            }
-            // ... and the prefetched tile takes its place (its loads completed long ago; the wait in front of the first
-            // write is for "all but the newest PA stores")
+            // ... and the prefetched tile takes its place (its loads completed long ago): the H block first, so that `ready`
+            // does not wait for the V commit
             if (more) {
 #pragma unroll
-                for (int b = 0; b < PA; ++b) {
-                    const int i = cell(b, nA);
-                    const int t = (int)__umulhi((unsigned)i, invA), k4 = i - t * rA;
-                    *reinterpret_cast<f32x4*>(bH + t * ldh + 4 * k4) = xa[b];
-                }
-#pragma unroll
-                for (int b = 0; b < PB; ++b) {
-                    const int i = cell(b, nB);
-                    const int t = (int)__umulhi((unsigned)i, invB), k4 = i - t * rB;
-                    *reinterpret_cast<f32x4*>(bH + Tt * ldh + t * ldr + 4 * k4) = xb[b];
-                }
+                for (int b = 0; b < PR; ++b)
+                    *reinterpret_cast<f32x4*>(const_cast<char*>(bHl) + (lw + NL * b) * ldh * 4) = xa[b];
                 rp_post(ready, lw, (unsigned)(j + 3), lane);
+#pragma unroll
+                for (int b = 0; b < PB; ++b) *reinterpret_cast<f32x4*>(bH + loB[b]) = xb[b];
                 rp_post(vready, lw, (unsigned)(j + 3), lane);
-                xrow_of(j + 2);
             }
         }
     } else if (w < NA) {
@@ -1607,14 +1568,8 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             for (int phi = w; phi < a.nf; phi += 2 * NA) {
                 if (phi + NA < a.nf) {
                     f32x16 acc[2] = {zero16(), zero16()};
-#if SNMF_BUFW
                     const int so[2] = {phi * rp * 128, (phi + NA) * rp * 128};
                     contract_shared_buf<2>(acc, wimage_rsrc(a.Wt4, (size_t)a.nf * rp * 32), lane * 16, so, sp, rp / 8, gate_ready);
-#else
-                    const f32x4* const wp[2] = {reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)phi * rp * 32) + lane,
-                                                reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)(phi + NA) * rp * 32) + lane};
-                    contract_shared<2>(acc, wp, sp, rp / 8, xw, xs, gate_ready);
-#endif
                     SNMF_STAMP(4);
                     gate_v();
                     rp_p1_epilogue<OBJ>(a, acc[0], Rs, phi, t0, lane, dsum);
@@ -1623,13 +1578,8 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     SNMF_STAMP(5);
                 } else {
                     f32x16 acc[1] = {zero16()};
-#if SNMF_BUFW
                     const int so[1] = {phi * rp * 128};
                     contract_shared_buf<1>(acc, wimage_rsrc(a.Wt4, (size_t)a.nf * rp * 32), lane * 16, so, sp, rp / 8, gate_ready);
-#else
-                    const f32x4* const wp[1] = {reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)phi * rp * 32) + lane};
-                    contract_shared<1>(acc, wp, sp, rp / 8, xw, xs, gate_ready);
-#endif
                     gate_v();
                     rp_p1_epilogue<OBJ>(a, acc[0], Rs, phi, t0, lane, dsum);
                     if (phi == w) rp_post(p1a, w, (unsigned)(j + 1), lane);
@@ -1641,7 +1591,6 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             if (OBJ) acc_div += (double)dsum;
             SNMF_STAMP(6);
             rp_post(p1b, w, (unsigned)(j + 1), lane);
-#if SNMF_XROW_A
             // The extra row (F = 32n+1): 8 frames per A wave, AFTER p1b -- the B team's P2 needs it for its very last
             // k-block only (xdone), so it is off every critical path, and on an MFMA wave its ~80 instructions cost their
             // issue cycles; on the loader waves, which only get an instruction in where the MFMA waves stall, they cost
@@ -1650,8 +1599,8 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                 hstep_p1_xrow<NA, 1, BM_KL, OBJ>(a, Hs, Rs, wxs, t0, w, lane, true, acc_div);
                 rp_post(xdone, w, (unsigned)(j + 1), lane);
             }
-#endif
         }
+        if (has_part) acc_div += rp_part_p1<OBJ>(a, lds + (nmy & 1) * bufsz, wxs, cnt, nmy, ptile, w, lane);
         SNMF_STAMP_OUT(a.prof + ((size_t)blockIdx.x * (NA + NB) + w) * 12, 12);
         SNMF_STAMP_CLK(a.prof, (size_t)blockIdx.x * (NA + NB) + w);
     } else {
@@ -1676,23 +1625,16 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             float shsum = 0.f;
             // k-blocks over the ratio rows of the row tiles 0..NA-1 (never the extra row's block) / the rest
             const int nq = a.Fq / 8, nq1 = 4 * (a.nf < NA ? a.nf : NA);
-            constexpr bool XLAST = SNMF_XROW_A && SNMF_BUFW;  // the extra row's k-block is a phase of its own, gated by xdone
-            const int nqm = (XLAST && a.xr) ? nq - 1 : nq;       // k-blocks over the ratio rows proper
-            auto gate_p1b = [&]() {
-                rp_await(p1b, (unsigned)(j + 1), a.stop);
-                if (a.xr && !XLAST) rp_await(xdone, (unsigned)(j + 1), a.stop);
-            };
+            const int nqm = a.xr ? nq - 1 : nq;  // k-blocks over the ratio rows proper; the extra row's is a phase of its own, gated by xdone
+            auto gate_p1b = [&]() { rp_await(p1b, (unsigned)(j + 1), a.stop); };
             auto gate_x = [&]() { rp_await(xdone, (unsigned)(j + 1), a.stop); };
             for (int kap = wb; kap < a.nk; kap += 2 * NB) {
                 if (kap + NB < a.nk) {
                     f32x16 acc[2] = {zero16(), zero16()};
-                    const f32x4* const wp[2] = {reinterpret_cast<const f32x4*>(a.Wk4 + (size_t)kap * a.Fq * 32) + lane,
-                                                reinterpret_cast<const f32x4*>(a.Wk4 + (size_t)(kap + NB) * a.Fq * 32) + lane};
                     if (!one_group) {
                         rp_p2_consts(a, kap, lane, dp0);
                         rp_p2_consts(a, kap + NB, lane, dp1);
                     }
-#if SNMF_BUFW
                     {
                         const __amdgpu_buffer_rsrc_t rsk = wimage_rsrc(a.Wk4, (size_t)a.nk * a.Fq * 32);
                         const int so[2] = {kap * a.Fq * 128, (kap + NB) * a.Fq * 128};
@@ -1708,24 +1650,13 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                             contract_shared_buf<2>(acc, rsk, lane * 16, so3, sp + 8 * nqm, nq - nqm, gate_x);
                         }
                     }
-#else
-                    contract_shared<2>(acc, wp, sp, nq1, xw, xs, gate_p1a);
-                    if (nq > nq1) {
-                        const f32x4* const wp2[2] = {wp[0] + (size_t)nq1 * 64, wp[1] + (size_t)nq1 * 64};
-                        contract_shared<2>(acc, wp2, sp + 8 * nq1, nq - nq1, xw, xs, gate_p1b);
-                    } else {
-                        gate_p1b();
-                    }
-#endif
                     SNMF_STAMP(9);
                     rp_p2_epilogue<OBJ>(a, acc[0], Hs, kap, t0, lane, dp0, shsum);
                     rp_p2_epilogue<OBJ>(a, acc[1], Hs, kap + NB, t0, lane, dp1, shsum);
                     SNMF_STAMP(10);
                 } else {
                     f32x16 acc[1] = {zero16()};
-                    const f32x4* const wp[1] = {reinterpret_cast<const f32x4*>(a.Wk4 + (size_t)kap * a.Fq * 32) + lane};
                     if (!one_group) rp_p2_consts(a, kap, lane, dp0);
-#if SNMF_BUFW
                     {
                         const __amdgpu_buffer_rsrc_t rsk = wimage_rsrc(a.Wk4, (size_t)a.nk * a.Fq * 32);
                         const int so[1] = {kap * a.Fq * 128};
@@ -1741,15 +1672,6 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                             contract_shared_buf<1>(acc, rsk, lane * 16, so3, sp + 8 * nqm, nq - nqm, gate_x);
                         }
                     }
-#else
-                    contract_shared<1>(acc, wp, sp, nq1, xw, xs, gate_p1a);
-                    if (nq > nq1) {
-                        const f32x4* const wp2[1] = {wp[0] + (size_t)nq1 * 64};
-                        contract_shared<1>(acc, wp2, sp + 8 * nq1, nq - nq1, xw, xs, gate_p1b);
-                    } else {
-                        gate_p1b();
-                    }
-#endif
                     rp_p2_epilogue<OBJ>(a, acc[0], Hs, kap, t0, lane, dp0, shsum);
                 }
             }
@@ -1761,9 +1683,12 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             if (a.xr) gate_x();
             rp_post(p2done, wb, (unsigned)(j + 1), lane);
         }
+        if (has_part) rp_part_p2(a, lds + (nmy & 1) * bufsz + Tt * ldh, cnt, nmy, wb, lane);
         SNMF_STAMP_OUT(a.prof + ((size_t)blockIdx.x * (NA + NB) + w) * 12, 12);
         SNMF_STAMP_CLK(a.prof, (size_t)blockIdx.x * (NA + NB) + w);
     }
+
+    if (has_part) acc_sh += rp_part_finish<OBJ>(a, lds + (nmy & 1) * bufsz, cnt + 24, ptile, n_full);
 
     if (OBJ) {
         // deterministic workgroup reduction of the two fp64 partial sums (as k_hstep)
@@ -2339,7 +2264,6 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
                 }
             }
     };
-#if SNMF_WSTATS_DMA
     // ================================ loader role, LDS-DMA =====================================
     // Beside a wave that issues v_mfma_f32_32x32x2_f32 back to back a second wave of the SIMD gets an instruction in only
     // where the MFMA wave stalls (scripts/mfma_valu_overlap.hip), so how long a loader takes to stage a tile is set by
@@ -2407,38 +2331,6 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
             rp_post(ready, lw, (unsigned)(it + 2), lane);
         }
     }
-#else
-    if (is_loader) {
-        // ================================ loader role, through registers (SNMF_WSTATS_DMA = 0) ==
-        if (tb < te) {
-            stage_in<NST>(a.Hin + (size_t)tb * TT * rp, lds, TT, rp, ldh, sid);
-            stage_in<NST>(a.V + (size_t)tb * TT * Fp, lds + TT * ldh, TT, Fp, Fp, sid);
-            rp_post(ready, w - NWB, 1u, lane);
-        }
-        for (int tile = tb, it = 0; tile < te; ++tile, ++it) {
-            const float* cH = lds + (it & 1) * bufsz;
-            float* nH = lds + ((it & 1) ^ 1) * bufsz;
-            rp_await(ready, (unsigned)(it + 1), a.stop);  // tile `tile` is complete in buffer it&1 (every loader wave's part)
-            if (do_s) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int k = sid + j * NST;
-                    if (k < rp) {
-                        float sacc = 0.f;
-                        for (int t = 0; t < TT; ++t) sacc += cH[t * ldh + k];
-                        ssum[j] += sacc;
-                    }
-                }
-            }
-            if (tile + 1 < te) {
-                rp_await(done, (unsigned)it, a.stop);  // every consumer has finished tile-1, which lives in nH
-                stage_in2<NST, 10, 10>(a.Hin + (size_t)(tile + 1) * TT * rp, nH, TT, rp, ldh,
-                                       a.V + (size_t)(tile + 1) * TT * Fp, nH + TT * ldh, TT, Fp, Fp, sid);
-                rp_post(ready, w - NWB, (unsigned)(it + 2), lane);
-            }
-        }
-    }
-#endif
 
     SNMF_STAMP_DECL
     for (int tile = tb, it = 0; tile < te && !is_loader; ++tile, ++it) {
@@ -2467,7 +2359,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
                 }
             }
         }
-        if (do_x) xrow_tile(Hs, Vs, t0, w, (NL > 0 && SNMF_WSTATS_DMA) ? vx + (it & 1) * 32 : nullptr);
+        if (do_x) xrow_tile(Hs, Vs, t0, w, NL > 0 ? vx + (it & 1) * 32 : nullptr);
         SNMF_STAMP(2);
         if (!active) {
             if (NL > 0) rp_post(done, w, (unsigned)(it + 1), lane);
@@ -2479,19 +2371,12 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
             // ---- P3: Lam'^T[t, f] = sum_k H[k,t] W[f,k]  (A = H from LDS, B = W from L2) -----
             f32x16 acc1[1] = {zero16()};
             const f32x4* wp = reinterpret_cast<const f32x4*>(a.Wt4 + (size_t)phi * rp * 32) + lane;
-#ifndef SNMF_WSTATS_DUAL
-#define SNMF_WSTATS_DUAL 0  // measured on C2: 0.2488 ms with the two chains against 0.2475 without -- the dependent chain is not what P3 waits for
-#endif
-#if SNMF_BUFW
             {
                 const __amdgpu_buffer_rsrc_t rsw = wimage_rsrc(a.Wt4, (size_t)a.nf * rp * 32);
                 const float* spl = Hs + (fl & (TT - 1)) * ldh + 4 * h;
                 if (rp == 256) contract_p3_buf<true>(acc1[0], rsw, lane * 16, phi * rp * 128, spl, 32, NoGate());
                 else contract_p3_buf<false>(acc1[0], rsw, lane * 16, phi * rp * 128, spl, rp / 8, NoGate());
             }
-#else
-            contract_sb<1, true, 2, SNMF_WSTATS_DUAL != 0>(acc1, wp, Hs + (fl & (TT - 1)) * ldh + 4 * h, 0, rp / 8);
-#endif
             SNMF_STAMP(3);
             const f32x16 acc = acc1[0];
             // lane (f = fl, h), reg -> t = t0 + drow(reg,h)
@@ -2593,7 +2478,6 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
             }
         }
     }
-#if SNMF_WSTATS_DMA
     if (NL > 0) {
         if (do_s) {  // fixed-order sum of the loader waves' partial row sums, through LDS
             __syncthreads();
@@ -2616,7 +2500,6 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
             __syncthreads();
         }
     } else
-#endif
     if (do_s && sid >= 0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -2836,19 +2719,8 @@ struct ApplyArgs {
 // reference's doubles it stays positive and comes back as soon as V./Lam is large there -- which the
 // noise-dictionary adaptation (src/bnmf_sep_event_RT_IS16.m:296-336) does all the time.  W is
 // F x r: keeping it in fp64 costs nothing measurable.
-// Q / P: this column of the reduced statistics (global memory in k_wapply, LDS in k_wfused); P == nullptr: KL, the
+// Q / P: this column of the reduced statistics; P == nullptr: KL, the
 // "P" of every row is the row sum sk of H.
-// fixed-order sum over the 256 threads of a workgroup: xor butterfly inside each wave (the same tree on every rank), then
-// the four wave sums in wave order.  One workgroup barrier per call instead of the eight of an LDS tree.
-__device__ __forceinline__ double wg_sum_256(double v, double* scratch /*[4]*/, int tid) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    __syncthreads();  // scratch of the previous call has been read
-    if ((tid & 63) == 0) scratch[tid >> 6] = v;
-    __syncthreads();
-    return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
-}
-
 __device__ __forceinline__ void wapply_column(const ApplyArgs& a, int k, int tid, const double* Q, const double* P,
                                               double sk, double (&red)[3][256]) {
     double* wc = a.Wc + (size_t)k * a.Fp;
@@ -2966,124 +2838,6 @@ __global__ __launch_bounds__(256) void k_wapply(ApplyArgs a) {
     wapply_column(a, k, tid, Q, P, sk, red);
 }
 
-// ============================================================================================
-// k_wfused = k_reduce + k_wapply in ONE launch (single-rank solves: nothing has to be exchanged between the two).
-// The workgroup of column k sums ITS column of the split-T slabs (and its row sum of H, and the objective partials) in
-// exactly the order k_reduce uses -- eight groups of consecutive chunks, ascending inside a group, then the eight
-// group sums in group order, all in fp64 -- so W comes out bit-identical to the two-launch path (the multi-rank step
-// API, where the reduced statistics cross the all-reduce), and applies the epilogue from LDS.  One launch, one pass
-// over the slabs, no fp64 statistics round trip through HBM.
-// NP = f32x4 positions per thread (ceil(Fp/4 / 32)); all NP positions of a chunk batch are in flight together.
-// ============================================================================================
-template <int NP>
-__global__ __launch_bounds__(256) void k_wfused(ReduceArgs ra, ApplyArgs a) {
-    __shared__ double red[3][256];
-    __shared__ double part[8][NP][32][4];
-    extern __shared__ __attribute__((aligned(16))) double cols[];  // [n_mat][Fp4*4] reduced column(s)
-    if (a.st->stop) return;
-    const int k = blockIdx.x, tid = threadIdx.x;
-    const int e = tid & 31, g = tid >> 5;
-    // objective partials -> (div, sum S.*H), folded by EVERY workgroup in k_reduce's order (strided, then a tree)
-    double sc[2] = {0.0, 0.0};
-    if (a.check_it > 0) {
-        double d = 0.0, h = 0.0;
-        if (ra.do_obj) {
-            for (int c = tid; c < ra.n_part; c += 256) {
-                d += ra.part[2 * c];
-                h += ra.part[2 * c + 1];
-            }
-        }
-        red[0][tid] = d;
-        red[1][tid] = h;
-        __syncthreads();
-        for (int st = 128; st > 0; st >>= 1) {
-            if (tid < st) {
-                red[0][tid] += red[0][tid + st];
-                red[1][tid] += red[1][tid + st];
-            }
-            __syncthreads();
-        }
-        sc[0] = ra.do_obj ? red[0][0] : 0.0;
-        sc[1] = ra.do_obj ? (ra.use_sh_const ? ra.sh_const : red[1][0]) : 0.0;
-        __syncthreads();
-        if (conv_test(sc, a.divh, a.costh, a.st, a.check_it, a.conv_eps, k == 0 && tid == 0)) return;
-    }
-    if (!a.do_update) return;
-    if (k >= a.r) return;
-    const int Fp4 = a.Fp / 4;
-    const size_t nel = (size_t)a.rp * a.Fp, cstride = nel * ra.n_mat;
-    const int cb = (int)(((long long)ra.n_chunks * g) / 8), ce = (int)(((long long)ra.n_chunks * (g + 1)) / 8);
-    for (int m = 0; m < ra.n_mat; ++m) {
-        const float* base = ra.slabs + (size_t)m * nel + (size_t)k * a.Fp;
-        double s[NP][4];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) s[p][0] = s[p][1] = s[p][2] = s[p][3] = 0.0;
-        constexpr int CB = NP <= 3 ? 8 : 4;  // chunks per batch: CB * NP f32x4 in flight
-        int c = cb;
-        for (; c + CB <= ce; c += CB) {
-            f32x4 x[CB][NP];
-#pragma unroll
-            for (int j = 0; j < CB; ++j)
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    const int f4 = p * 32 + e;
-                    x[j][p] = f4 < Fp4 ? *reinterpret_cast<const f32x4*>(base + (size_t)(c + j) * cstride + 4 * f4)
-                                       : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-#pragma unroll
-            for (int j = 0; j < CB; ++j)
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    s[p][0] += (double)x[j][p][0];
-                    s[p][1] += (double)x[j][p][1];
-                    s[p][2] += (double)x[j][p][2];
-                    s[p][3] += (double)x[j][p][3];
-                }
-        }
-        for (; c < ce; ++c) {
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                const int f4 = p * 32 + e;
-                if (f4 < Fp4) {
-                    const f32x4 x = *reinterpret_cast<const f32x4*>(base + (size_t)c * cstride + 4 * f4);
-                    s[p][0] += (double)x[0];
-                    s[p][1] += (double)x[1];
-                    s[p][2] += (double)x[2];
-                    s[p][3] += (double)x[3];
-                }
-            }
-        }
-        __syncthreads();  // part[] of the previous matrix has been read
-#pragma unroll
-        for (int p = 0; p < NP; ++p)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) part[g][p][e][j] = s[p][j];
-        __syncthreads();
-        for (int i = tid; i < NP * 128; i += 256) {
-            const int p = i >> 7, ee = (i >> 2) & 31, j = i & 3;
-            double t = 0.0;
-#pragma unroll
-            for (int gg = 0; gg < 8; ++gg) t += part[gg][p][ee][j];
-            const int f = 4 * (p * 32 + ee) + j;
-            if (f < a.Fp) cols[(size_t)m * a.Fp + f] = t;
-        }
-    }
-    // row sum of H for this column (KL; zero otherwise), same two-level order as k_reduce
-    double sk = 0.0;
-    if (ra.n_mat == 1) {
-        double sp = 0.0;
-        if (e == 0)
-            for (int c = cb; c < ce; ++c) sp += (double)ra.spart[(size_t)c * a.rp + k];
-        __syncthreads();
-        if (e == 0) part[g][0][0][0] = sp;
-        __syncthreads();
-#pragma unroll
-        for (int gg = 0; gg < 8; ++gg) sk += part[gg][0][0][0];
-    }
-    __syncthreads();
-    // M0 = Q (or G), M1 = P: as in the statistics buffer
-    wapply_column(a, k, tid, cols, ra.n_mat == 2 ? cols + a.Fp : nullptr, sk, red);
-}
 
 // Convergence check alone (H-only mode and the final objective pass): one thread.
 __global__ void k_check(const double* stats, size_t sc_off, double* divh, double* costh, DevState* st, int it,

@@ -1,15 +1,22 @@
-"""The pipelined kernels of the headline path against the plain ones, bit for bit, through the product path.
+"""The pipelined kernels of the headline path against the plain ones through the product path.
 
 k_hstep_rp (role pipeline: loader waves with buffer loads / stores and scalar offsets, progress-slot signalling) and
 k_wstats with LDS-DMA loader waves compute exactly what the barrier-phased k_hstep and the synchronously staging
-k_wstats compute (same MFMA order per tile), so H after H-only iterations must agree in every bit and W after full
-iterations to the summation order of the row sums.  This is the check that found the two synchronisation bugs and the
-buffer-store hazard of round 2 (profiles/r02_experiments.md): the shapes are the ones that showed them -- few row
-tiles with several tiles per workgroup, short H rows (rp < 256: lanes past the row duplicate lane 0), a V block whose
-last cell straddles the end.  SNMF_HSTEP_RP / SNMF_WSTATS_NL are read when a plan is created, so both variants run in
-this one process.  (src/sparse_nmf.m:189-208 and :215-239 are the updates both variants implement.)
+k_wstats compute (same MFMA order per tile), so with every tile in the pipeline (SNMF_HSTEP_SPLIT=0) H after H-only
+iterations must agree in every bit and W after full iterations to the summation order of the row sums.  This is the
+check that found the two synchronisation bugs and the buffer-store hazard of round 2 (profiles/r02_experiments.md): the
+shapes are the ones that showed them -- few row tiles with several tiles per workgroup, short H rows (rp < 256: lanes
+past the row duplicate lane 0), a V block whose last cell straddles the end.
+
+Round 3: the tiles of the last PARTIAL round of k_hstep_rp are split by rows over the workgroups that would idle through
+it (rp_part_phase + k_hfinish in csrc/snmf_kernels.h).  A split tile sums Lam in k ranges and the numerator in row
+parts, i.e. in another fp32 order than the one-workgroup tiles: the default path must equal the plain kernels BIT FOR
+BIT on every pipelined tile and to the stated summation-order tolerance (2e-5 relative per element after two
+iterations) on the split ones.  The shapes cover 4-way and 2-way splits, no split, and problems smaller than one round
+(every tile split).  SNMF_HSTEP_RP / SNMF_HSTEP_SPLIT / SNMF_WSTATS_NL are read when a plan is created, so all variants
+run in this one process.  (src/sparse_nmf.m:189-208 and :215-239 are the updates all variants implement.)
 """
-import os
+import re
 
 import numpy as np
 import pytest
@@ -17,7 +24,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 SHAPES = [(65, 70, 12000), (129, 70, 12000), (65, 32, 12000), (64, 70, 12000), (97, 96, 20000), (257, 40, 20000),
-          (33, 8, 30000), (161, 200, 9000), (257, 256, 30000), (225, 100, 17000), (513, 64, 12000), (385, 100, 12000)]  # (the last two: four / four row groups in k_wstats)
+          (33, 8, 30000), (161, 200, 9000), (257, 256, 30000), (225, 100, 17000), (513, 64, 12000), (385, 100, 12000),  # (the last two: four / four row groups in k_wstats)
+          (257, 40, 1000), (65, 70, 3000), (257, 256, 9000), (129, 24, 40)]  # fewer tiles than workgroups: every tile split
 
 
 def _run(ctx, V, W0, H0, r, *, h_only, iters):
@@ -26,7 +34,7 @@ def _run(ctx, V, W0, H0, r, *, h_only, iters):
     kw = dict(w_update_ind=np.zeros(r, bool)) if h_only else {}
     pl = Plan(ctx, F, T, r, beta=1.0, max_iter=iters, conv_eps=0.0, cost_check=True, sparsity=1.0, **kw)
     pl.set_v(V); pl.set_w(W0); pl.set_h(H0); pl.init(); pl.run()
-    out = (pl.get_h(np.float32), pl.get_w(), pl.describe())
+    out = (pl.get_h(np.float32), pl.get_w(), pl.describe(), pl.get_objective()[1])
     pl.close()
     return out
 
@@ -38,15 +46,33 @@ def test_pipelined_kernels_equal_plain_kernels(gpu_ctx, shape, monkeypatch):
     V = (rs.gamma(0.5, 1.0, (F, 16)) @ rs.gamma(0.3, 1.0, (16, T)) + 1e-3).astype(np.float32)
     W0 = rs.random((F, r))
     H0 = rs.random((r, T)).astype(np.float32)
-    monkeypatch.delenv("SNMF_HSTEP_RP", raising=False)
-    monkeypatch.delenv("SNMF_WSTATS_NL", raising=False)
-    h_new, _, geo = _run(gpu_ctx, V, W0, H0, r, h_only=True, iters=2)
-    _, w_new, _ = _run(gpu_ctx, V, W0, H0, r, h_only=False, iters=3)
+    for k in ("SNMF_HSTEP_RP", "SNMF_HSTEP_SPLIT", "SNMF_WSTATS_NL"):
+        monkeypatch.delenv(k, raising=False)
+    h_new, _, geo, obj_new = _run(gpu_ctx, V, W0, H0, r, h_only=True, iters=2)
+    _, w_new, _, _ = _run(gpu_ctx, V, W0, H0, r, h_only=False, iters=3)
     assert "k_hstep_rp" in geo  # the pipelined path is what ran
+    m = re.search(r"(\d+) of (\d+) tiles pipelined, last round split (\d+) ways", geo)
+    n_full, n_tiles, S = (int(x) for x in m.groups())
+    monkeypatch.setenv("SNMF_HSTEP_SPLIT", "0")
+    h_ns, _, geo_ns, _ = _run(gpu_ctx, V, W0, H0, r, h_only=True, iters=2)
+    _, w_ns, _, _ = _run(gpu_ctx, V, W0, H0, r, h_only=False, iters=3)
+    assert "split 0 ways" in geo_ns
     monkeypatch.setenv("SNMF_HSTEP_RP", "0")
     monkeypatch.setenv("SNMF_WSTATS_NL", "0")
-    h_old, _, geo_old = _run(gpu_ctx, V, W0, H0, r, h_only=True, iters=2)
-    _, w_old, _ = _run(gpu_ctx, V, W0, H0, r, h_only=False, iters=3)
+    h_old, _, geo_old, obj_old = _run(gpu_ctx, V, W0, H0, r, h_only=True, iters=2)
+    _, w_old, _, _ = _run(gpu_ctx, V, W0, H0, r, h_only=False, iters=3)
     assert "k_hstep_rp" not in geo_old
-    assert np.array_equal(h_new, h_old)
-    assert np.abs(w_new - w_old).max() <= 1e-6 * np.abs(w_old).max()
+    # every tile in the pipeline: the plain kernels bit for bit
+    assert np.array_equal(h_ns, h_old)
+    assert np.abs(w_ns - w_old).max() <= 1e-6 * np.abs(w_old).max()
+    # default path: pipelined tiles bit for bit, split tiles to the summation-order tolerance
+    t_split = 32 * n_full if S else T
+    assert np.array_equal(h_new[:, :t_split], h_old[:, :t_split])
+    if S:
+        assert n_full < n_tiles
+        d = np.abs(h_new[:, t_split:] - h_old[:, t_split:])
+        assert (d <= 2e-5 * np.abs(h_old[:, t_split:]) + 1e-30).all(), d.max()
+        assert not np.array_equal(h_new[:, t_split:], h_old[:, t_split:]) or T - t_split < 64  # (another order: not the same bits)
+    assert np.abs(w_new - w_old).max() <= 2e-6 * np.abs(w_old).max()
+    for a, b in zip(obj_new, obj_old):
+        assert abs(a - b) <= 1e-6 * abs(b)
