@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""The reference's own geometry (F = 513: settings/initial_setting_SNMF_NAT.m:21-29,48-49) and BASELINE C4 / C5 at full size,
+per kernel: ms per launch from HIP events on the engine's stream, algorithmic TFLOP/s and fraction of the 157.3 TFLOP/s
+f32-MFMA peak.  One JSON line per shape; `python scripts/bench_f513.py [a11 c4h c4w c5] [--iters K]`.
+  a11  513 x 72000, r = 100, KL, full update      run_basis_train.m:88 (12 min of audio at the shipped settings)
+  c4h  513 x 100000, r = 200, KL, H-only          run_basis_DNMF.m:40 (solve 1 of the 3-solve loop)
+  c4w  513 x 100000, r = 100, KL, W-only          run_basis_DNMF.m:47,53 (solves 2 and 3)
+  c5   513 x 500000, r = 512, beta = 2, lambda 50 BASELINE configs[4]
+Under rocprofv3 this is the command the profiles/r03_f513_* summaries come from."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+from se_snmf_nat_amd import Context, Plan  # noqa: E402
+
+PEAK = 157.3
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+which = args or ["a11", "c4h", "c4w", "c5"]
+K = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 0
+ctx = Context(0)
+
+SHAPES = {
+    "a11": dict(F=513, T=72000, r=100, beta=1.0, sparsity=5.0, mode="full", iters=100, settle=150),
+    "c4h": dict(F=513, T=100000, r=200, beta=1.0, sparsity=5.0, mode="h", iters=100, settle=150),
+    "c4w": dict(F=513, T=100000, r=100, beta=1.0, sparsity=5.0, mode="w", iters=100, settle=150),
+    "c5": dict(F=513, T=500000, r=512, beta=2.0, sparsity=50.0, mode="full", iters=10, settle=4),
+}
+
+
+def synth(F, T, r, seed=0):
+    rd = np.random.default_rng(seed)
+    Wt = rd.gamma(0.5, 1.0, size=(F, r)).astype(np.float32)
+    V = np.empty((F, T), np.float32, order="F")
+    H0 = np.empty((r, T), np.float32, order="F")
+    for t0 in range(0, T, 50000):  # in blocks: the host box has little memory to spare at C5
+        t1 = min(T, t0 + 50000)
+        V[:, t0:t1] = Wt @ rd.gamma(0.3, 1.0, size=(r, t1 - t0)).astype(np.float32) + 1e-9
+        H0[:, t0:t1] = rd.random((r, t1 - t0), dtype=np.float32)
+    return V, rd.random((F, r)), H0
+
+
+for name in which:
+    c = SHAPES[name]
+    F, T, r = c["F"], c["T"], c["r"]
+    iters = K or c["iters"]
+    V, W0, H0 = synth(F, T, r)
+    kw = {}
+    if c["mode"] == "h":
+        kw["w_update_ind"] = np.zeros(r, bool)
+    if c["mode"] == "w":
+        kw["h_update_ind"] = np.zeros(r, bool)
+    plan = Plan(ctx, F, T, r, beta=c["beta"], max_iter=2 * c["settle"] + 2 * iters + 2, conv_eps=0.0, cost_check=True,
+                sparsity=c["sparsity"], **kw)
+    plan.set_v(V); plan.set_w(W0); plan.set_h(H0); plan.init()
+    del V, H0
+    plan.run_async(c["settle"]); ctx.sync()
+    t = time.perf_counter(); plan.run_async(iters); ctx.sync(); dt = time.perf_counter() - t
+    ctx.timing(True); plan.run_async(iters); ctx.sync()
+    fam = {f: ctx.timing_get(f) for f in ("hstep", "wstats", "reduce", "wapply")}
+    ctx.timing(False)
+    ms = dt / iters * 1e3
+    half = 4.0 * F * T * r  # flop of one Lam + one contraction pass over the whole problem
+    # launches per iteration and their algorithmic work: KL: hstep = wstats = 4FTr; beta = 2: hstep 2 x (Lam | contraction) = 6FTr
+    # (den pass + num pass share Lam: P1 once, P2 twice), wstats P (Lam' + contraction = 4FTr) + Q (contraction only = 2FTr)
+    kl = c["beta"] == 1.0
+    work = {"hstep": half if kl else 1.5 * half, "wstats": half if kl else 1.5 * half}
+    per_it = (work["hstep"] if c["mode"] != "w" else 0.0) + (work["wstats"] if c["mode"] != "h" else 0.0)
+    if c["mode"] == "w" and kl:
+        per_it = half
+    out = {"shape": name, "F": F, "T": T, "r": r, "beta": c["beta"], "mode": c["mode"], "iterations_per_s": iters / dt,
+           "ms_per_iteration": ms, "whole_iteration_TFLOPs": per_it / (ms * 1e-3) / 1e12,
+           "whole_iteration_frac": per_it / (ms * 1e-3) / 1e12 / PEAK, "kernel_ms": {}, "kernel_frac": {}, "geometry": plan.describe()}
+    for f, (avg, n) in fam.items():
+        if n:
+            per_launch_groups = n / iters  # event pairs per iteration (a beta != 1 W step is two launches under one pair)
+            out["kernel_ms"][f] = avg
+            if f in work and avg > 0:
+                out["kernel_frac"][f] = work[f] / (avg * 1e-3) / 1e12 / PEAK
+    plan.close()
+    print(json.dumps(out), flush=True)

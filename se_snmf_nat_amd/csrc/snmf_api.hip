@@ -222,6 +222,8 @@ struct snmf_plan {
     // k_hstep_rp launch geometry: tiles [0, rp_full) through the pipeline on rp_grid workgroups, the tiles of the last
     // partial round [rp_full, rp_tiles) cut into rp_S row parts, one workgroup each (rp_S = 0: no split)
     int rp_tiles = 0, rp_full = 0, rp_S = 0, rp_grid = 1;
+    bool rh = false;               // KL update launches run k_hstep_rh (9..16 row tiles, e.g. F = 513: one ratio image, pipelined by half tiles)
+    size_t lds_rh = 0;
     float* part_buf = nullptr;     // partial numerators of the split tiles [rp_grid][32][rp]
     unsigned* part_cnt = nullptr;  // arrivals per split tile (monotonic)
     int NKT = 8, NWB = 4, WPS = 2, NLW = 0;  // k_wstats template geometry (NLW loader waves)
@@ -372,6 +374,10 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
                     lds_cap, lds_cap / 64 - 16);
     }
     if (const char* e = getenv("SNMF_HSTEP_RP")) pl->hstep_rp = atoi(e) != 0;
+    // F = 513 (9..16 row tiles): two whole tile buffers do not fit, but two H blocks + ONE ratio image do -- k_hstep_rh
+    // pipelines on half tiles.  One pair of column tiles per wave of its P2 team: rp <= 256.
+    pl->lds_rh = std::max<size_t>(((size_t)2 * 32 * pl->ldh + (size_t)32 * pl->ldr + pl->rp) * 4 + 96, 2 * kMaxNW * 64 * sizeof(double));
+    pl->rh = pl->hstep_rp && pl->NLH != 4 && pl->bm == BM_KL && pl->nf >= 9 && pl->nf <= 16 && pl->rp <= 256 && pl->lds_rh <= lds_cap;
     pl->lds_h = std::max<size_t>(pl->NLH ? 2 * lds1 - lds_extra : (pl->NT == 1 ? (size_t)pl->TTH * per_col + lds_extra : lds2),
                                  2 * kMaxNW * 64 * sizeof(double));
     pl->lds_mdi = std::max<size_t>(lds1, 2 * kMaxNW * 64 * sizeof(double));  // MDI pass: (NW=8, NT=1, NL=0)
@@ -388,7 +394,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         const int G = ctx->n_cu;
         pl->rp_tiles = (T + 31) / 32;
         pl->rp_full = pl->rp_tiles;
-        pl->rp_grid = std::max(1, std::min(pl->rp_tiles, G));
+        pl->rp_grid = std::max(1, std::min(pl->rp_tiles, G));  // (k_hstep_rh launches on the same grid, never split)
         pl->rp_S = 0;
         const char* e = getenv("SNMF_HSTEP_SPLIT");
         if (pl->NLH == 4 && !(e && atoi(e) == 0)) {
@@ -407,7 +413,8 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     if (pl->nk <= 4) { pl->NKT = 4; pl->WPS = 2; }
     else if (pl->nk <= 8) { pl->NKT = 8; pl->WPS = 2; }
     else { pl->NKT = 16; pl->WPS = 1; }
-    pl->NWB = 4;
+    // (eight consumer waves, two per SIMD, for narrow statistics over at least eight row tiles: see the kernel)
+    pl->NWB = (pl->NKT == 4 && pl->nf >= 8) ? 8 : 4;
     pl->n_kg = (pl->nk + pl->NKT - 1) / pl->NKT;
     pl->n_fg = (pl->nf + pl->NWB - 1) / pl->NWB;
     // H image of k_wstats: rows padded to whole NKT-tile groups (branch-free P4, see the kernel)
@@ -416,11 +423,19 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         pl->TTW = 16;  // large r: 16-frame tiles (the 32-frame H + V images do not fit the LDS)
     const int n_tiles_w = pl->Tp / pl->TTW;
     {
+        // loaders + double buffering when the accumulators allow 2 waves per SIMD and LDS has room; the loader waves
+        // stage only the row group's 32 * NWB columns of V (the kernel's ldv), so F = 513 fits as well
+        const size_t buf_ld = ((size_t)pl->TTW * pl->ldhw + (size_t)pl->TTW * 32 * pl->NWB) * 4;
         const size_t buf = ((size_t)pl->TTW * pl->ldhw + (size_t)pl->TTW * pl->Fp) * 4;
-        // loaders + double buffering when the accumulators allow 2 waves per SIMD and LDS has room
-        pl->NLW = (pl->WPS == 2 && 2 * buf + (size_t)pl->rp * 4 + 288 <= lds_cap) ? 4 : 0;
+        pl->NLW = (pl->WPS == 2 && 2 * buf_ld + (size_t)pl->rp * 4 + 320 <= lds_cap) ? 4 : 0;
         if (const char* e = getenv("SNMF_WSTATS_NL")) pl->NLW = (atoi(e) == 4 && pl->NLW == 4) ? 4 : 0;
-        pl->lds_w = std::max<size_t>((pl->NLW ? 2 : 1) * buf + (size_t)pl->rp * 4 + 288,  // + ready/done slots + the extra row's V values [2][32]
+        if (!pl->NLW && pl->NWB == 8) {  // the eight-consumer geometry exists with loader waves only
+            pl->NWB = 4;
+            pl->n_fg = (pl->nf + pl->NWB - 1) / pl->NWB;
+        }
+        // (the fixed-order sums at the end of the kernel use [4][rp] floats / one double per thread of the same memory)
+        pl->lds_w = std::max<size_t>(std::max<size_t>((pl->NLW ? 2 * buf_ld : buf) + (size_t)pl->rp * 4 + 320,  // + ready/done slots + the extra row's V values [2][32]
+                                                      (size_t)std::max(4, pl->NWB) * pl->rp * 4),
                                      (size_t)(pl->NWB + pl->NLW) * 64 * sizeof(double));
     }
     const int wg_w = pl->NLW ? 1 : pl->WPS;  // workgroups per CU
@@ -428,21 +443,20 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     // Two row groups, only group 0 carries the extra row: deal the workgroups out so that both finish together.
     // Relative cost x of the extra row per tile: ~2.1 k cycles at rp = 256 against 21 k for the two MFMA loops (phase
     // stamps; a sweep of the split point on C2 had its optimum where this x puts it: 131..135 chunks for group 0,
-    // k_wstats 0.2573 -> 0.2481 ms, profiles/r02_experiments.md).  Only for launches without the objective pass (full updates: the objective
-    // rides on k_hstep).
+    // k_wstats 0.2573 -> 0.2481 ms, profiles/r02_experiments.md).
     pl->n_ch1 = 0;
-    if (pl->xr && pl->n_fg == 2 && pl->n_kg == 1 && pl->NLW && pl->upd_h && pl->upd_w && n_tiles_w >= 4 * pl->n_chunks) {
-        const int tot = 2 * pl->n_chunks;
-        const double x = (600.0 + 6.0 * pl->rp) / (82.0 * (pl->rp / 2 + 16 * pl->nk));
+    if (pl->xr && pl->n_fg >= 2 && pl->n_kg == 1 && pl->NLW && pl->upd_w && n_tiles_w >= 4 * pl->n_chunks) {
+        const int tot = pl->n_fg * pl->n_chunks, ng1 = pl->n_fg - 1;  // group 0: n0 workgroups, every other group n1
+        const double x = (600.0 + 6.0 * pl->rp) / (82.0 * (pl->rp / 2 + 16 * pl->nk)) * 4.0 / pl->NWB;  // (the row is shared by the group's NWB waves)
+        auto n1_of = [&](int n0) { return (tot - n0) / ng1; };
         auto cost = [&](int n0) {
-            const int n1 = tot - n0;
-            return std::max(std::ceil((double)n_tiles_w / n0) * (1.0 + x), std::ceil((double)n_tiles_w / n1));
+            return std::max(std::ceil((double)n_tiles_w / n0) * (1.0 + x), std::ceil((double)n_tiles_w / n1_of(n0)));
         };
         int best = pl->n_chunks;
-        for (int n0 = pl->n_chunks + 1; n0 <= pl->n_chunks + pl->n_chunks / 4; ++n0)
+        for (int n0 = pl->n_chunks + 1; n0 <= pl->n_chunks + pl->n_chunks / 4 && n1_of(n0) >= 1; ++n0)
             if (cost(n0) < cost(best) - 1e-9) best = n0;
         if (best != pl->n_chunks) {
-            pl->n_ch1 = tot - best;
+            pl->n_ch1 = n1_of(best);
             pl->n_chunks = best;
         }
     }
@@ -576,7 +590,11 @@ extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
     if (!pl || !buf) return fail(SNMF_ERR_INVALID, "NULL argument");
     const bool kl_pipe = pl->NWH == 8 && pl->NLH == 4 && pl->bm == BM_KL && pl->upd_h && !pl->M && pl->hstep_rp;
     char hs[160];
-    if (kl_pipe)
+    const bool rh_pipe = pl->rh && pl->upd_h && !pl->M;
+    if (rh_pipe)
+        snprintf(hs, sizeof hs, "k_hstep_rh (4 P1 + 4 P2 + 4 loader waves on half tiles; %d of %d tiles pipelined, last round split 0 ways, grid %d)",
+                 pl->rp_tiles, pl->rp_tiles, pl->rp_grid);
+    else if (kl_pipe)
         snprintf(hs, sizeof hs, "k_hstep_rp (4 P1 + 4 P2 + 4 loader waves; %d of %d tiles pipelined, last round split %d ways, grid %d)",
                  pl->rp_full, pl->rp_tiles, pl->rp_S, pl->rp_grid);
     else
@@ -585,8 +603,8 @@ extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
              "F=%d T=%d r=%d beta=%g | Fm=%d(+%d VALU row) rp=%d Tp=%d | hstep: %s, tile=%d frames, grid=%d x %d thr, lds=%zu B | "
              "wstats: NK=%d waves=%d+%d grid=(%d chunks,%d fgroups,%d kgroups; group-1 chunks %d) lds=%zu B | n_cu=%d",
              pl->p.F, pl->p.T, pl->p.r, pl->p.beta, pl->Fm, pl->xr, pl->rp, pl->Tp, hs, pl->TTH * pl->NT,
-             kl_pipe ? pl->rp_grid : pl->grid_h, (pl->NWH + pl->NLH) * 64,
-             pl->lds_h, pl->NKT, pl->NWB, pl->NLW, pl->n_chunks, pl->n_fg, pl->n_kg, pl->n_ch1 ? pl->n_ch1 : pl->n_chunks, pl->lds_w,
+             (kl_pipe || rh_pipe) ? pl->rp_grid : pl->grid_h, rh_pipe ? 768 : (pl->NWH + pl->NLH) * 64,
+             rh_pipe ? pl->lds_rh : pl->lds_h, pl->NKT, pl->NWB, pl->NLW, pl->n_chunks, pl->n_fg, pl->n_kg, pl->n_ch1 ? pl->n_ch1 : pl->n_chunks, pl->lds_w,
              pl->ctx->n_cu);
     return SNMF_OK;
 }
@@ -843,6 +861,12 @@ static int launch_hstep(snmf_plan* pl, bool obj, bool upd) {
         if (pl->bm == BM_EUC) return launch_hstep_mdi_b<BM_EUC>(pl, a, obj, upd);
         return launch_hstep_mdi_b<BM_GEN>(pl, a, obj, upd);
     }
+    if (pl->rh && upd) {  // KL update launches of the 9..16-row-tile geometry: the half-tile role pipeline (k_hstep_rh)
+        dim3 g(pl->rp_grid), b(768);
+        a.n_tiles = pl->rp_tiles;
+        return obj ? launch_big(k_hstep_rh<true>, g, b, pl->lds_rh, pl->ctx->stream, a)
+                   : launch_big(k_hstep_rh<false>, g, b, pl->lds_rh, pl->ctx->stream, a);
+    }
     if (pl->NWH == 8 && pl->NLH == 4) {
         if (pl->hstep_rp && pl->bm == BM_KL && upd) {  // KL update launches: the role pipeline (k_hstep_rp)
             dim3 g(pl->rp_grid), b(768);
@@ -865,8 +889,8 @@ static int launch_hstep(snmf_plan* pl, bool obj, bool upd) {
 // k_wstats dispatch
 template <int NK, int NWB, int NL, int WPS, int WM, int BM, bool OBJ, int TT = 32>
 static int launch_wstats_one(snmf_plan* pl, const StepArgs& a, int mat_index) {
-    const bool split = pl->n_ch1 > 0 && !OBJ;  // uneven row-group split: 1-D grid, group 0's chunks first
-    dim3 g(split ? pl->n_chunks + pl->n_ch1 : pl->n_chunks, split ? 1 : pl->n_fg, pl->n_kg), b((NWB + NL) * 64);
+    const bool split = pl->n_ch1 > 0;  // uneven row-group split: 1-D grid, group 0's chunks first
+    dim3 g(split ? pl->n_chunks + (pl->n_fg - 1) * pl->n_ch1 : pl->n_chunks, split ? 1 : pl->n_fg, pl->n_kg), b((NWB + NL) * 64);
     StepArgs as = a;
     as.n_ch1 = split ? pl->n_ch1 : 0;
     auto kern = k_wstats<NK, NWB, NL, WPS, WM, BM, OBJ, TT>;
@@ -896,6 +920,7 @@ static int launch_wstats(snmf_plan* pl, bool obj) {
     a.ldh = pl->ldhw;
     a.stagger = pl->stagger_w;
     ScopedTimer tm(pl->ctx, FAM_WSTATS);
+    if (pl->NKT == 4 && pl->NWB == 8) return launch_wstats_geo<4, 8, 4, 3>(pl, a, obj);
     if (pl->NKT == 4) return pl->NLW ? launch_wstats_geo<4, 4, 4, 2>(pl, a, obj) : launch_wstats_geo<4, 4, 0, 2>(pl, a, obj);
     if (pl->NKT == 8) return pl->NLW ? launch_wstats_geo<8, 4, 4, 2>(pl, a, obj) : launch_wstats_geo<8, 4, 0, 2>(pl, a, obj);
     if (pl->TTW == 16) return launch_wstats_geo<16, 4, 0, 1, 16>(pl, a, obj);
@@ -1031,8 +1056,12 @@ extern "C" int snmf_plan_init(snmf_plan* pl) {
 // iterate j-1 is produced by the first pass of iteration j that forms Lam = W_{j-1} * H_{j-1}.
 static bool want_obj(const snmf_plan* pl, int j) { return pl->p.cost_check && j > 1; }
 // objective partials written by an H-UPDATE launch of k_hstep* (= its grid; the objective-only launches use grid_h)
+// objective partials written by a k_wstats launch with the objective (W-only solves) = its workgroups
+static int wstats_parts(const snmf_plan* pl) {
+    return pl->n_ch1 ? pl->n_chunks + (pl->n_fg - 1) * pl->n_ch1 : pl->n_chunks * pl->n_fg;
+}
 static bool hupd_is_rp(const snmf_plan* pl) {
-    return !pl->M && pl->NWH == 8 && pl->NLH == 4 && pl->hstep_rp && pl->bm == BM_KL;
+    return !pl->M && (pl->rh || (pl->NWH == 8 && pl->NLH == 4 && pl->hstep_rp && pl->bm == BM_KL));
 }
 static int hupd_parts(const snmf_plan* pl) {
     if (pl->M) return pl->grid_mdi;
@@ -1070,7 +1099,7 @@ extern "C" int snmf_plan_wstats(snmf_plan* pl, double* stats) {
         // W-only mode: the divergence of iterate j-1 comes from this pass (Lam' = W_{j-1} * H)
         SN_TRY(launch_wstats(pl, obj && !pl->upd_h && !mdi_wonly));
     }
-    const int n_part = pl->upd_h ? hupd_parts(pl) : pl->M ? pl->grid_mdi : pl->n_chunks * pl->n_fg;
+    const int n_part = pl->upd_h ? hupd_parts(pl) : pl->M ? pl->grid_mdi : wstats_parts(pl);
     if (!pl->upd_h && !pl->upd_w && obj) {
         // neither factor is updated: the loop only re-evaluates the objective
         SN_TRY(launch_hstep(pl, true, false));

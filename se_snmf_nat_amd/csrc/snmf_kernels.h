@@ -1717,6 +1717,277 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
 }
 
 // ============================================================================================
+// k_hstep_rh: the role pipeline for spectrograms of 9..16 row tiles -- F = 513, the geometry the reference ships
+// (settings/initial_setting_SNMF_NAT.m:21-29: 40 ms window -> 1024-point FFT -> 513 rows; run_basis_train.m:88 at
+// r = 100, run_basis_DNMF.m:40 at r = 200) -- whose two tile buffers do not fit the 160 KiB LDS (a 32-frame ratio image
+// of 513 rows alone is 67 KB).  Same arithmetic and MFMA order per tile as k_hstep_rp / k_hstep<8,1,4,KL>, but the
+// pipeline runs on HALF tiles: the H block is double-buffered as before, the ratio image exists ONCE and its two row
+// halves (row tiles 0-7 | 8-15 + the extra row) are the pipeline's buffers:
+//     unit u = (tile j, half hf).   A team: P1 of the half's row tiles (two per wave) -> ratio rows in place over the
+//     staged V half;   B team: the half's k-blocks of W^T*ratio, accumulating over both halves of a tile in registers,
+//     then the H update;   loaders: V half (j+1, hf) -> registers while the B team still reads ratio half (j, hf),
+//     committed when the B team is through with it (bdone), H block j+2 as in k_hstep_rp.
+// While the B team contracts half (j, hf) the A team runs the loop of the unit after the next one (its MFMA loop needs
+// only the H block; the V half is needed by its epilogue), so a V commit has one A loop of slack.  Signals, each four
+// per-wave progress words as in k_hstep_rp: ready (H block of tile j), vready (V half of unit u), p1 (ratio half of unit
+// u whole), xdone (extra row of tile j), bdone (B team through with ratio half u), p2done (H_j updated).
+// Needs rp <= 256 (one pair of column tiles per B wave: the ratio halves are read once per tile).
+// ============================================================================================
+template <int NACC, bool OBJ, typename G0, typename G1, typename GX>
+__device__ __forceinline__ void rh_p2_tile(const StepArgs& a, float* Hs, const float* Rs, int kap, int t0, int lane, int wb, int j,
+                                           unsigned* bdone, const f32x4 (&dp0)[4], const f32x4 (&dp1)[4], float& shsum, G0 g0, G1 g1,
+                                           GX gx) {
+    constexpr int NB = 4;
+    const int fl = lane & 31, h = lane >> 5;
+    const float* sp = Rs + fl * a.ldr + 4 * h;
+    const int nq1 = 4 * (a.nf - 8);  // k-blocks of the second half's row tiles
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = zero16();
+    const __amdgpu_buffer_rsrc_t rsk = wimage_rsrc(a.Wk4, (size_t)a.nk * a.Fq * 32);
+    int so[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) so[i] = (kap + i * NB) * a.Fq * 128;
+    contract_shared_buf<NACC>(acc, rsk, lane * 16, so, sp, 32, g0);
+    rp_post(bdone, wb, (unsigned)(2 * j + 1), lane);
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) so[i] += 32 * 1024;
+    contract_shared_buf<NACC>(acc, rsk, lane * 16, so, sp + 256, nq1, g1);
+    if (a.xr) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) so[i] += nq1 * 1024;
+        contract_shared_buf<NACC>(acc, rsk, lane * 16, so, sp + 256 + 8 * nq1, 1, gx);
+    }
+    rp_post(bdone, wb, (unsigned)(2 * j + 2), lane);
+    rp_p2_epilogue<OBJ>(a, acc[0], Hs, kap, t0, lane, dp0, shsum);
+    if (NACC == 2) rp_p2_epilogue<OBJ>(a, acc[NACC - 1], Hs, kap + NB, t0, lane, dp1, shsum);
+}
+
+template <bool OBJ>
+__global__ __launch_bounds__(768, 3) void k_hstep_rh(StepArgs a) {
+    constexpr int NA = 4, NB = 4, NL = 4, NTHR = (NA + NB + NL) * 64, Tt = 32, PR = Tt / NL;
+    if (a.stop && *a.stop) return;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, w = wave_index();
+    const int rp = a.rp, Fp = a.Fp, ldh = a.ldh, ldr = a.ldr;
+    const int hsz = Tt * ldh;          // floats per H buffer [Tt][ldh]
+    float* Rs = lds + 2 * hsz;         // [Tt][ldr] the one ratio image (V staged into it by halves)
+    float* wxs = Rs + Tt * ldr;        // [rp] extra row of W
+    unsigned* cnt = reinterpret_cast<unsigned*>(wxs + rp);
+    unsigned *ready = cnt, *vready = cnt + 4, *p1 = cnt + 8, *xdone = cnt + 12, *bdone = cnt + 16, *p2done = cnt + 20;
+    double acc_div = 0.0, acc_sh = 0.0;
+    if (a.xr) {
+        for (int k = threadIdx.x; k < rp; k += NTHR) wxs[k] = a.wx[k];
+        // the unused cells of the extra 8-deep k-block stay zero for the whole kernel (the V commits write Fm .. Fm+3)
+        for (int i = threadIdx.x; i < Tt * 8; i += NTHR) Rs[(i >> 3) * ldr + a.Fm + (i & 7)] = 0.f;
+    }
+    if (threadIdx.x < 24) cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    const int nmy = (int)blockIdx.x < a.n_tiles ? (a.n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    auto tile_of = [&](int j) { return (int)blockIdx.x + j * (int)gridDim.x; };
+
+    if (w >= NA + NB) {
+        // ================================ loaders ===================================================
+        // As k_hstep_rp's: buffer instructions with scalar offsets, one lane offset per block, every access unconditional.
+        //  * H block by rows: wave lw takes rows lw, lw+4, ..., one 1 KiB piece each (lanes past a short row duplicate lane 0);
+        //  * V half hf by rows as well: columns [256 hf, 256 hf + 256) of a frame row are 64 16-byte cells, lane <-> cell; the
+        //    second half ends at Fp (its last cell carries the extra row's value): lanes past it duplicate lane 0.
+        const int lw = w - (NA + NB);
+        const int hv = lane * 4 < rp ? lane * 16 : 0;
+        const int nc1 = (Fp - 256) / 4;  // cells per frame row of the second half
+        const int vv1 = lane < nc1 ? lane * 16 : 0;
+        // F = 513: the second half has 65 cells a row -- the 65th (columns 512..515: the extra row's value) of this wave's
+        // eight rows is one more load, eight lanes wide (the others duplicate them)
+        const bool xcell = nc1 > 64;
+        const int xoff_g = ((lw + NL * (lane & 7)) * Fp + 512) * 4, xoff_l = ((lw + NL * (lane & 7)) * ldr + 512) * 4;
+        auto rsrc_of = [&](const float* base, int bytes) {
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+        };
+        auto ldA = [&](__amdgpu_buffer_rsrc_t rs, int i) {
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, hv, (lw + NL * i) * rp * 4, 0));
+        };
+        auto ldV = [&](__amdgpu_buffer_rsrc_t rs, int hf, int i) {
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, hf ? vv1 : lane * 16, ((lw + NL * i) * Fp + 256 * hf) * 4, 0));
+        };
+        auto stageH = [&](int tile, float* dst) {  // start-up only: straight through registers
+            const __amdgpu_buffer_rsrc_t rs = rsrc_of(a.Hin + (size_t)tile * Tt * rp, Tt * rp * 4);
+            f32x4 x[PR];
+#pragma unroll
+            for (int i = 0; i < PR; ++i) x[i] = ldA(rs, i);
+#pragma unroll
+            for (int i = 0; i < PR; ++i) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(dst) + hv + (lw + NL * i) * ldh * 4) = x[i];
+        };
+        auto commitV = [&](int hf, const f32x4 (&x)[PR]) {
+            char* base = reinterpret_cast<char*>(Rs) + (hf ? vv1 + 1024 : lane * 16);
+#pragma unroll
+            for (int i = 0; i < PR; ++i) *reinterpret_cast<f32x4*>(base + (lw + NL * i) * ldr * 4) = x[i];
+        };
+        auto ldX = [&](__amdgpu_buffer_rsrc_t rs) {
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, xoff_g, 0, 0));
+        };
+        auto commitX = [&](const f32x4& x) { *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(Rs) + xoff_l) = x; };
+        for (int j = 0; j < 2 && j < nmy; ++j) {
+            stageH(tile_of(j), lds + j * hsz);
+            rp_post(ready, lw, (unsigned)(j + 1), lane);
+        }
+        if (nmy > 0) {
+            const __amdgpu_buffer_rsrc_t rv = rsrc_of(a.V + (size_t)tile_of(0) * Tt * Fp, Tt * Fp * 4);
+            for (int hf = 0; hf < 2; ++hf) {
+                f32x4 x[PR];
+#pragma unroll
+                for (int i = 0; i < PR; ++i) x[i] = ldV(rv, hf, i);
+                commitV(hf, x);
+                if (hf && xcell) commitX(ldX(rv));
+                rp_post(vready, lw, (unsigned)(hf + 1), lane);
+            }
+        }
+        for (int j = 0; j < nmy; ++j) {
+            float* bH = lds + (j & 1) * hsz;
+            const bool more_v = j + 1 < nmy, more_h = j + 2 < nmy;
+            const __amdgpu_buffer_rsrc_t rv = rsrc_of(a.V + (size_t)tile_of(more_v ? j + 1 : j) * Tt * Fp, Tt * Fp * 4);
+            f32x4 xv[PR], xa[PR], xx;
+            // unit (j, 0): V half (j+1, 0) and the H block of tile j+2 -> registers, then wait for the B team to leave half 0
+            if (more_v) {
+#pragma unroll
+                for (int i = 0; i < PR; ++i) xv[i] = ldV(rv, 0, i);
+            }
+            if (more_h) {
+                const __amdgpu_buffer_rsrc_t rh = rsrc_of(a.Hin + (size_t)tile_of(j + 2) * Tt * rp, Tt * rp * 4);
+#pragma unroll
+                for (int i = 0; i < PR; ++i) xa[i] = ldA(rh, i);
+            }
+            SNMF_PIN();
+            rp_await(bdone, (unsigned)(2 * j + 1), a.stop);
+            if (more_v) {
+                commitV(0, xv);
+                rp_post(vready, lw, (unsigned)(2 * j + 3), lane);
+#pragma unroll
+                for (int i = 0; i < PR; ++i) xv[i] = ldV(rv, 1, i);
+                if (xcell) xx = ldX(rv);
+            }
+            SNMF_PIN();
+            rp_await(bdone, (unsigned)(2 * j + 2), a.stop);
+            if (more_v) {
+                commitV(1, xv);
+                if (xcell) commitX(xx);
+                rp_post(vready, lw, (unsigned)(2 * j + 4), lane);
+            }
+            rp_await(p2done, (unsigned)(j + 1), a.stop);
+            // the updated H tile leaves (LDS -> registers -> HBM; four LDS reads in flight at a time) ...
+            const __amdgpu_buffer_rsrc_t ro = rsrc_of(a.Hout + (size_t)tile_of(j) * Tt * rp, Tt * rp * 4);
+            const char* const bHl = reinterpret_cast<const char*>(bH) + hv;
+#pragma unroll
+            for (int b0 = 0; b0 < PR; b0 += 4) {
+                f32x4 ho[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ho[u] = *reinterpret_cast<const f32x4*>(bHl + (lw + NL * (b0 + u)) * ldh * 4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) buf_store_b128(ro, hv, (lw + NL * (b0 + u)) * rp * 4, ho[u]);
+            }
+            // ... and the H block of tile j+2 takes its place
+            if (more_h) {
+#pragma unroll
+                for (int i = 0; i < PR; ++i) *reinterpret_cast<f32x4*>(const_cast<char*>(bHl) + (lw + NL * i) * ldh * 4) = xa[i];
+                rp_post(ready, lw, (unsigned)(j + 3), lane);
+            }
+        }
+    } else if (w < NA) {
+        // ================================ A team: P1, two units per tile ==============================
+        const __amdgpu_buffer_rsrc_t rsw = wimage_rsrc(a.Wt4, (size_t)a.nf * rp * 32);
+        for (int j = 0; j < nmy; ++j) {
+            const int t0 = tile_of(j) * Tt;
+            float* Hs = lds + (j & 1) * hsz;
+            const int fl = lane & 31, h = lane >> 5;
+            const float* sp = Hs + fl * ldh + 4 * h;
+            float dsum = 0.f;
+            bool waited = false;
+            auto gate_ready = [&]() {  // the tile's H block: waited for once, behind the first W fragments of the tile
+                if (!waited) rp_await(ready, (unsigned)(j + 1), a.stop);
+                waited = true;
+            };
+            for (int hf = 0; hf < 2; ++hf) {
+                const int u = 2 * j + hf, phi = 8 * hf + w;
+                if (phi + NA < a.nf) {
+                    f32x16 acc[2] = {zero16(), zero16()};
+                    const int so[2] = {phi * rp * 128, (phi + NA) * rp * 128};
+                    contract_shared_buf<2>(acc, rsw, lane * 16, so, sp, rp / 8, gate_ready);
+                    rp_await(vready, (unsigned)(u + 1), a.stop);  // the V half, and with it: the B team is through with ratio half u-2
+                    rp_p1_epilogue<OBJ>(a, acc[0], Rs, phi, t0, lane, dsum);
+                    rp_p1_epilogue<OBJ>(a, acc[1], Rs, phi + NA, t0, lane, dsum);
+                } else if (phi < a.nf) {
+                    f32x16 acc[1] = {zero16()};
+                    const int so[1] = {phi * rp * 128};
+                    contract_shared_buf<1>(acc, rsw, lane * 16, so, sp, rp / 8, gate_ready);
+                    rp_await(vready, (unsigned)(u + 1), a.stop);
+                    rp_p1_epilogue<OBJ>(a, acc[0], Rs, phi, t0, lane, dsum);
+                } else {
+                    gate_ready();
+                    rp_await(vready, (unsigned)(u + 1), a.stop);
+                }
+                rp_post(p1, w, (unsigned)(u + 1), lane);
+            }
+            if (OBJ) acc_div += (double)dsum;
+            if (a.xr) {  // the extra row: after the last epilogue, the B team needs it for its very last k-block only
+                hstep_p1_xrow<NA, 1, BM_KL, OBJ>(a, Hs, Rs, wxs, t0, w, lane, true, acc_div);
+                rp_post(xdone, w, (unsigned)(j + 1), lane);
+            }
+        }
+    } else {
+        // ================================ B team: P2 =================================================
+        const int wb = w - NA;
+        f32x4 dp0[4], dp1[4];
+        if (wb < a.nk) {
+            rp_p2_consts(a, wb, lane, dp0);
+            if (wb + NB < a.nk) rp_p2_consts(a, wb + NB, lane, dp1);
+        }
+        for (int j = 0; j < nmy; ++j) {
+            const int t0 = tile_of(j) * Tt;
+            float* Hs = lds + (j & 1) * hsz;
+            float shsum = 0.f;
+            auto g0 = [&]() { rp_await(p1, (unsigned)(2 * j + 1), a.stop); };
+            auto g1 = [&]() { rp_await(p1, (unsigned)(2 * j + 2), a.stop); };
+            auto gx = [&]() { rp_await(xdone, (unsigned)(j + 1), a.stop); };
+            if (wb + NB < a.nk) rh_p2_tile<2, OBJ>(a, Hs, Rs, wb, t0, lane, wb, j, bdone, dp0, dp1, shsum, g0, g1, gx);
+            else if (wb < a.nk) rh_p2_tile<1, OBJ>(a, Hs, Rs, wb, t0, lane, wb, j, bdone, dp0, dp1, shsum, g0, g1, gx);
+            else {  // a wave without a column tile keeps step (the slots are progress numbers)
+                g0();
+                rp_post(bdone, wb, (unsigned)(2 * j + 1), lane);
+                g1();
+                if (a.xr) gx();
+                rp_post(bdone, wb, (unsigned)(2 * j + 2), lane);
+            }
+            if (OBJ) acc_sh += (double)shsum;
+            rp_post(p2done, wb, (unsigned)(j + 1), lane);
+        }
+    }
+
+    if (OBJ) {
+        // deterministic workgroup reduction of the two fp64 partial sums (as k_hstep)
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(lds);  // [2][NTHR]
+        red[threadIdx.x] = acc_div;
+        red[NTHR + threadIdx.x] = acc_sh;
+        __syncthreads();
+        if ((int)threadIdx.x + 512 < NTHR) {
+            red[threadIdx.x] += red[threadIdx.x + 512];
+            red[NTHR + threadIdx.x] += red[NTHR + threadIdx.x + 512];
+        }
+        __syncthreads();
+        for (int s = 256; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) {
+                red[threadIdx.x] += red[threadIdx.x + s];
+                red[NTHR + threadIdx.x] += red[NTHR + threadIdx.x + s];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            a.part[2 * blockIdx.x] = red[0];
+            a.part[2 * blockIdx.x + 1] = red[NTHR];
+        }
+    }
+}
+
+// ============================================================================================
 // k_hsolve_small: the WHOLE H-only solve of src/sparse_nmf.m:186-286 for T <= 32 frames in ONE
 // launch by ONE workgroup: the online separation call (src/bnmf_sep_event_RT_IS16.m:138-154,
 // T = 1, W = [B_x, B_d] fixed) is latency-bound -- ~27 iterations of two GEMV-sized products --
@@ -2152,33 +2423,41 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     constexpr int NBUF = NL > 0 ? 2 : 1;
     if (a.stop && *a.stop) return;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int bufsz = TT * (a.ldh + a.Fp);  // floats per buffer: Hs [TT][ldh] then Vs [TT][Fp]
+    // V image: with loader waves only the columns of this workgroup's row group are staged, so it is [TT][32 * NWB]
+    // (F = 513, four row groups: 16 KiB instead of 64 -- what lets two tile buffers fit); without them the whole V tile
+    const int ldv = NL > 0 ? 32 * NWB : a.Fp;
+    const int bufsz = TT * (a.ldh + ldv);   // floats per buffer: Hs [TT][ldh] then Vs [TT][ldv]
     float* wxs = lds + NBUF * bufsz;        // [rp] extra row of W
     const int lane = threadIdx.x & 63, w = wave_index();
     const bool is_loader = NL > 0 && w >= NWB;
     const int fl = lane & 31, h = lane >> 5;
     const int rp = a.rp, Fp = a.Fp, ldh = a.ldh;
-    // Row group and frame chunk of this workgroup.  Two row groups of which only group 0 carries the extra row are
-    // not equally expensive per tile (the VALU row costs ~14 % of a tile on the MFMA-issuing waves), so the host may
-    // give them DIFFERENT numbers of frame chunks: a 1-D grid of n_chunks workgroups of group 0 followed by a.n_ch1
-    // of group 1.  The slabs of the chunks group 1 does not have stay zero (set once at plan creation).
+    // Row group and frame chunk of this workgroup.  Row groups of which only group 0 carries the extra row are not
+    // equally expensive per tile (the VALU row costs ~14 % of a tile on the MFMA-issuing waves), so the host may give
+    // them DIFFERENT numbers of frame chunks: a 1-D grid of n_chunks workgroups of group 0 followed by a.n_ch1 for each
+    // further group.  The slabs of the chunks those groups do not have stay zero (set once at plan creation).
     int chunk = blockIdx.x, by = blockIdx.y, nch = n_chunks;
     if (a.n_ch1 > 0) {
-        by = chunk >= n_chunks ? 1 : 0;
-        if (by) {
-            chunk -= n_chunks;
+        by = 0;
+        if (chunk >= n_chunks) {
+            const int c1 = chunk - n_chunks;
+            by = 1 + c1 / a.n_ch1;
+            chunk = c1 - (by - 1) * a.n_ch1;
             nch = a.n_ch1;
         }
     }
     const bool do_x = a.xr && by == 0 && blockIdx.z == 0;  // extra row: one f-group only
     constexpr int CPW = TT / NWB;  // columns of the extra-row dot product per wave
     static_assert(CPW % 4 == 0, "the extra row takes 4 frames x 16 lanes at a time");
-    float gx[16];                  // extra row of the slab: lane <-> k = 256*(i/4) + 4*lane + i%4  (rp <= 1024)
+    // 256-column pieces of an H row this geometry can have: NK <= 8 is rp <= 256 (one kappa-group, n_kg = 1 on the host)
+    constexpr int NPC = NK <= 8 ? 1 : 4;
+    float gx[4 * NPC];             // extra row of the slab: lane <-> k = 256*(i/4) + 4*lane + i%4  (rp <= 256 * NPC)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) gx[i] = 0.f;
+    for (int i = 0; i < 4 * NPC; ++i) gx[i] = 0.f;
     if (do_x && WM != 3)
         for (int k = threadIdx.x; k < rp; k += NTHR) wxs[k] = a.wx[k];
     const int phi = by * NWB + w;
+    const int fc = NL > 0 ? w * 32 + fl : phi * 32 + fl;  // this lane's column of the staged V image
     const bool active = !is_loader && phi < a.nf;
     const int kap_base = blockIdx.z * NK;  // kappa-group (r > 32*NK: P3 is recomputed per group)
     const bool do_obj = OBJ && blockIdx.z == 0;
@@ -2204,12 +2483,15 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     // Per-wave progress slots (rp_post / rp_await): a single counter bumped by all four waves is a TOTAL, and a consumer
     // that drifts a tile ahead of a slow team-mate (nothing synchronises the consumers with each other) could have stood
     // in for it and let the loaders refill a buffer that wave was still reading.
-    static_assert(NL == 0 || (NL == 4 && NWB == 4), "four progress slots per role");
+    // NWB = 8 (narrow statistics, NK = 4: 64 accumulator VGPRs): TWO consumer waves per SIMD, each with its own row tile --
+    // one wave's epilogue, extra row and wait for the tile then run beside the other's MFMA loops, which at rp <= 128 are
+    // too short (128 MFMAs per tile) to amortise them, and the H tile is staged once per eight row tiles instead of four.
+    static_assert(NL == 0 || (NL == 4 && (NWB == 4 || NWB == 8)), "progress slots: four per loader role, NWB consumers");
     unsigned* ready = reinterpret_cast<unsigned*>(wxs + rp);  // [4] loader waves: tiles staged
-    unsigned* done = ready + 4;                               // [4] consumer waves: tiles finished
-    float* vx = reinterpret_cast<float*>(done + 4);           // [2][32] V of the extra row, one value per frame (DMA loaders)
+    unsigned* done = ready + 4;                               // [NWB] consumer waves: tiles finished
+    float* vx = reinterpret_cast<float*>(done + NWB);         // [2][32] V of the extra row, one value per frame (DMA loaders)
     if (NL > 0) {
-        if (threadIdx.x < 8) ready[threadIdx.x] = 0u;
+        if (threadIdx.x < 4 + NWB) ready[threadIdx.x] = 0u;
         __syncthreads();  // slots and wxs are set
     }
 
@@ -2252,7 +2534,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
             if (OBJ) acc_div += (double)dsum;
             // (one ds_read_b128 per column and 256 rows of H: beside its own MFMAs every instruction of this wave counts)
 #pragma unroll
-            for (int pc = 0; pc < 4; ++pc) {
+            for (int pc = 0; pc < NPC; ++pc) {
                 const int k0 = 256 * pc + 4 * lane;
                 if (k0 < rp) {
 #pragma unroll
@@ -2272,9 +2554,9 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     // for it, and any cycle their loops saved went into that wait).  Here a tile is ~17 buffer_load ... lds per wave
     // (scalar addressing: one 1 KiB piece per padded H row, one piece per frame row for this row group's columns of V) and the row sums are taken
     // over the wave's OWN rows (complete as soon as its own DMA has landed) with one ds_read_b128 per row and 256 columns.
-    float rs4[4][4];  // row sums of H over this wave's rows: k = 256 p + 4 lane + e   (rp <= 1024)
+    float rs4[NPC][4];  // row sums of H over this wave's rows: k = 256 p + 4 lane + e   (rp <= 256 * NPC)
 #pragma unroll
-    for (int pp = 0; pp < 4; ++pp)
+    for (int pp = 0; pp < NPC; ++pp)
 #pragma unroll
         for (int e = 0; e < 4; ++e) rs4[pp][e] = 0.f;
     if (is_loader) {
@@ -2300,7 +2582,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
             for (int t = lw; t < TT; t += NL)
                 for (int pc = 0; pc * 256 < cw; ++pc)
                     if (pc * 256 + lane * 4 < cw)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(dst + TT * ldh + t * Fp + c0 + pc * 256), 16, lane * 16,
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(dst + TT * ldh + t * ldv + pc * 256), 16, lane * 16,
                                                                  (t * Fp + c0 + pc * 256) * 4, 0, 0);
             if (do_x && lw == 0 && lane < TT)  // one dword per frame: V[Fm, t] -> vx[buffer][t]
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(vx + (dst == lds ? 0 : 32)), 4, lane * Fp * 4, a.Fm * 4, 0, 0);
@@ -2309,7 +2591,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
             if (!do_s) return;
             for (int t = lw; t < TT; t += NL)
 #pragma unroll
-                for (int pc = 0; pc < 4; ++pc)
+                for (int pc = 0; pc < NPC; ++pc)
                     if (pc < npc && pc * 256 + lane * 4 < rp) {
                         const f32x4 hv = *reinterpret_cast<const f32x4*>(H + t * ldh + pc * 256 + lane * 4);
 #pragma unroll
@@ -2325,6 +2607,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         for (int tile = tb, it = 0; tile + 1 < te; ++tile, ++it) {
             float* nH = lds + ((it & 1) ^ 1) * bufsz;
             rp_await(done, (unsigned)it, a.stop);  // every consumer has finished tile-1, which lives in nH
+            if (NWB == 8) rp_await(done + 4, (unsigned)it, a.stop);
             dma_tile(tile + 1, nH);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             sums_of(nH);
@@ -2337,7 +2620,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         const int t0 = tile * TT;
         SNMF_STAMP(0);
         float* Hs = lds + (NL > 0 ? (it & 1) * bufsz : 0);  // [32][ldh]
-        float* Vs = Hs + TT * ldh;                            // [TT][Fp]  (no HBM access in the MFMA loops)
+        float* Vs = Hs + TT * ldh;                            // [TT][ldv]  (no HBM access in the MFMA loops)
         if (NL == 0) {
             __syncthreads();
             stage_in<NST>(a.Hin + (size_t)t0 * rp, Hs, TT, rp, ldh, sid);
@@ -2389,7 +2672,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
                     continue;
                 }
                 const int t = t0 + drow(i, h);
-                const float v = Vs[drow(i, h) * Fp + f];
+                const float v = Vs[drow(i, h) * ldv + fc];
                 float lam = fmaxf(acc[i], kFlr);
                 if (OBJ) {
                     if (do_obj) {
@@ -2405,7 +2688,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         } else {
             const int f = phi * 32 + fl;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) R[i] = (TT < 32 && i >= TT / 2) ? 0.f : Vs[drow(i, h) * Fp + f];
+            for (int i = 0; i < 16; ++i) R[i] = (TT < 32 && i >= TT / 2) ? 0.f : Vs[drow(i, h) * ldv + fc];
         }
         // ---- P4: G[phi, kap] += ratio[f, t] * H[k, t]  (A = ratio registers, B = H from LDS)
         // B fragments (one ds_read_b32 per MFMA) are fetched a whole kappa-tile (16 reads) ahead.
@@ -2484,7 +2767,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
             float* red = lds;  // [NL][rp]
             if (is_loader) {
 #pragma unroll
-                for (int pc = 0; pc < 4; ++pc)
+                for (int pc = 0; pc < NPC; ++pc)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int k = pc * 256 + lane * 4 + e;
@@ -2513,7 +2796,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         float* red = lds;  // [NWB][rp]  (NWB*rp <= 32*ldh)
         if (!is_loader) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < 4 * NPC; ++i) {
                 const int k = 256 * (i >> 2) + 4 * lane + (i & 3);
                 if (k < rp) red[w * rp + k] = gx[i];
             }
@@ -2532,13 +2815,19 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         double* red = reinterpret_cast<double*>(lds);
         red[threadIdx.x] = acc_div;
         __syncthreads();
-        for (int s = NTHR / 2; s > 0; s >>= 1) {  // NTHR is 256 or 512
+        // NTHR is 256, 512 or 768: fold the tail above the largest power of two first
+        constexpr int P2 = NTHR >= 512 ? 512 : 256;
+        if ((int)threadIdx.x + P2 < NTHR) red[threadIdx.x] += red[threadIdx.x + P2];
+        __syncthreads();
+        for (int s = P2 / 2; s > 0; s >>= 1) {
             if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
             __syncthreads();
         }
         if (threadIdx.x == 0 && blockIdx.z == 0) {
-            a.part[2 * (by * n_chunks + chunk)] = red[0];
-            a.part[2 * (by * n_chunks + chunk) + 1] = 0.0;
+            // (uneven row-group split: a 1-D grid, one slot per workgroup; n_chunks * n_fg slots are reduced, the unused ones stay 0)
+            const int slot = a.n_ch1 > 0 ? (int)blockIdx.x : by * n_chunks + chunk;
+            a.part[2 * slot] = red[0];
+            a.part[2 * slot + 1] = 0.0;
         }
     }
 }

@@ -24,8 +24,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 SHAPES = [(65, 70, 12000), (129, 70, 12000), (65, 32, 12000), (64, 70, 12000), (97, 96, 20000), (257, 40, 20000),
-          (33, 8, 30000), (161, 200, 9000), (257, 256, 30000), (225, 100, 17000), (513, 64, 12000), (385, 100, 12000),  # (the last two: four / four row groups in k_wstats)
-          (257, 40, 1000), (65, 70, 3000), (257, 256, 9000), (129, 24, 40)]  # fewer tiles than workgroups: every tile split
+          (33, 8, 30000), (161, 200, 9000), (257, 256, 30000), (225, 100, 17000), (513, 64, 12000),
+          (257, 40, 1000), (65, 70, 3000), (257, 256, 9000), (129, 24, 40),  # fewer tiles than workgroups: every tile split
+          # 9..16 row tiles: k_hstep_rh (one ratio image, pipelined by half tiles) and k_wstats with loader waves on a
+          # compact V image -- the reference's shipped F = 513 at R = 100 / 200 (settings/initial_setting_SNMF_NAT.m:21-29,48-49)
+          (513, 100, 12000), (513, 200, 9000), (513, 256, 5000), (385, 100, 12000), (449, 250, 9000), (512, 128, 8000),
+          (289, 40, 20000), (513, 200, 100)]
 
 
 def _run(ctx, V, W0, H0, r, *, h_only, iters):
@@ -50,7 +54,7 @@ def test_pipelined_kernels_equal_plain_kernels(gpu_ctx, shape, monkeypatch):
         monkeypatch.delenv(k, raising=False)
     h_new, _, geo, obj_new = _run(gpu_ctx, V, W0, H0, r, h_only=True, iters=2)
     _, w_new, _, _ = _run(gpu_ctx, V, W0, H0, r, h_only=False, iters=3)
-    assert "k_hstep_rp" in geo  # the pipelined path is what ran
+    assert "k_hstep_rp" in geo or "k_hstep_rh" in geo  # the pipelined path is what ran
     m = re.search(r"(\d+) of (\d+) tiles pipelined, last round split (\d+) ways", geo)
     n_full, n_tiles, S = (int(x) for x in m.groups())
     monkeypatch.setenv("SNMF_HSTEP_SPLIT", "0")
@@ -61,7 +65,7 @@ def test_pipelined_kernels_equal_plain_kernels(gpu_ctx, shape, monkeypatch):
     monkeypatch.setenv("SNMF_WSTATS_NL", "0")
     h_old, _, geo_old, obj_old = _run(gpu_ctx, V, W0, H0, r, h_only=True, iters=2)
     _, w_old, _, _ = _run(gpu_ctx, V, W0, H0, r, h_only=False, iters=3)
-    assert "k_hstep_rp" not in geo_old
+    assert "k_hstep_rp" not in geo_old and "k_hstep_rh" not in geo_old
     # every tile in the pipeline: the plain kernels bit for bit
     assert np.array_equal(h_ns, h_old)
     assert np.abs(w_ns - w_old).max() <= 1e-6 * np.abs(w_old).max()
