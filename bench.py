@@ -74,16 +74,27 @@ def cpu_baseline(F, T, r, budget_iters=8, repeats=3):
     V, W0, H0 = make_problem(F, T, r)
     p = dict(cf="kl", sparsity=SPARSITY, max_iter=budget_iters, conv_eps=0, init_w=W0, init_h=H0, cost_check=1)
     dts = []
+    ncpu = os.cpu_count()
+    cap_note = ""
+    try:  # "all host cores" -- ask the BLAS for every logical CPU and report what it grants
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=ncpu, user_api="blas")
+    except Exception:  # noqa: BLE001
+        limiter = None
+    nthr = blas_threads()
+    if nthr < ncpu:
+        cap_note = f" (asked for {ncpu}: the OpenBLAS bundled with NumPy is built for at most {nthr} threads)"
     for _ in range(repeats):
         t = time.perf_counter()
         oracle_nmf(V, p, mimic_matlab_flops=True)
         dts.append(time.perf_counter() - t)
+    if limiter is not None:
+        limiter.restore_original_limits()
     dt = min(dts)
-    nthr, ncpu = blas_threads(), os.cpu_count()
     return {"value": budget_iters / dt, "unit": "iterations/s", "cores": nthr, "kind": "port",
             "sample": f"best of {repeats} runs of {budget_iters} iterations of the same {F}x{T} r={r} KL workload, fp64 "
                       f"NumPy/OpenBLAS oracle (stand-in for MATLAB sparse_nmf.m, not MATLAB itself); {nthr} BLAS threads "
-                      f"of {ncpu} logical CPUs (element-wise passes are single-threaded NumPy); runs took "
+                      f"of {ncpu} logical CPUs{cap_note} (element-wise passes are single-threaded NumPy); runs took "
                       + ", ".join(f"{x:.1f}" for x in dts) + " s"}
 
 
@@ -131,12 +142,92 @@ def self_launch(args):
     print(line)
 
 
+def oneshot_child(args):
+    """The SAME sharded problem through the one-process multi-GPU entry of the C ABI (snmf_multi_*: one host thread per
+    device, the one-shot peer-store all-reduce of csrc/snmf_multi.h) -- the exchange SURVEY.md section 5 / 8e asks to be
+    reported next to RCCL.  Runs in a process of its own that rank 0 starts BEFORE it touches HIP and releases (one line
+    on stdin) after the RCCL leg; prints one JSON object."""
+    if sys.stdin.readline().strip() != "go":  # wait for rank 0's go (a closed pipe = rank 0 is gone: nothing to do)
+        return
+    out = {}
+    try:
+        import ctypes as C
+        from se_snmf_nat_amd import _lib
+        from se_snmf_nat_amd.api import _make_params
+        lib = _lib.load()
+        N, K, Wm = args.gpus, args.steps, args.warmup
+        F, T, r = args.F, args.T, args.r
+        if "SNMF_FORCE_DEVICE" in os.environ:
+            devs = np.full(N, int(os.environ["SNMF_FORCE_DEVICE"]), np.int32)  # single-GPU dry run: the ranks share it
+        else:
+            devs = np.arange(N, dtype=np.int32)
+        V, W0, H0 = make_problem(F, T, r)
+        Vf, Hf, Wf = np.asfortranarray(V, np.float32), np.asfortranarray(H0, np.float32), np.asfortranarray(W0)
+        n_pre = SETTLE + 2 * Wm  # as many untimed iterations as the RCCL leg runs ahead of its timed region
+        sp = _make_params(F, T, r, 1.0, n_pre + K + 1, 0.0, 1, True, 0, SPARSITY, None, None)
+        h = C.c_void_p()
+        _lib.check(lib.snmf_multi_create(C.c_void_p(devs.ctypes.data), N, C.byref(sp), None, C.byref(h)))
+        try:
+            _lib.check(lib.snmf_multi_set_v_f32(h, C.c_void_p(Vf.ctypes.data), F))
+            _lib.check(lib.snmf_multi_set_w_f64(h, C.c_void_p(Wf.ctypes.data), F))
+            _lib.check(lib.snmf_multi_set_h_f32(h, C.c_void_p(Hf.ctypes.data), r))
+            _lib.check(lib.snmf_multi_init(h))
+            done = C.c_int32()
+            _lib.check(lib.snmf_multi_run(h, n_pre, C.byref(done)))
+            t = time.perf_counter()
+            _lib.check(lib.snmf_multi_run(h, K, C.byref(done)))  # returns after every rank's stream has drained
+            dt = time.perf_counter() - t
+            div, cost = np.zeros(n_pre + K + 1), np.zeros(n_pre + K + 1)
+            n = C.c_int32()
+            _lib.check(lib.snmf_multi_get_objective(h, C.c_void_p(div.ctypes.data), C.c_void_p(cost.ctypes.data), C.byref(n)))
+        finally:
+            lib.snmf_multi_destroy(h)
+        last = [c for c in cost if c != 0.0]
+        out = {"ms_per_step": dt / K * 1e3, "value": K / dt, "unit": "iterations/s", "devices": [int(d) for d in devs],
+               "ordering": "device-side arrival flags" if len(set(int(d) for d in devs)) == N else "hipEvents + host barrier (ranks share a device)",
+               "entry": "snmf_multi_* (one process, one host thread per device, peer-store all-reduce)",
+               "steps": K, "final_cost": float(last[-1]) if last else None}
+        out["cost_vs_oracle"] = cost_vs_oracle(F, T, r, len(last), out["final_cost"])
+    except Exception as e:  # noqa: BLE001 -- the extra leg must never fail the bench
+        out = {"error": f"{type(e).__name__}: {e}"}
+    print("ONESHOT " + json.dumps(out), flush=True)
+
+
+def start_oneshot_child(args):
+    """Started by rank 0 before anything in it touches HIP (a process that has initialised the GPU must not fork + exec)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--oneshot-child", "--gpus", str(args.gpus), "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--dim-F", str(args.F), "--dim-T", str(args.T), "--dim-r", str(args.r)]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    try:
+        return subprocess.Popen(cmd, env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def finish_oneshot_child(proc, limit_s=420):
+    if proc is None:
+        return {"error": "the one-shot child process could not be started"}
+    try:
+        outs, errs = proc.communicate("go\n", timeout=limit_s)
+    except Exception as e:  # noqa: BLE001
+        proc.kill()
+        return {"error": f"one-shot leg: {type(e).__name__}: {e}"}
+    for ln in outs.splitlines():
+        if ln.startswith("ONESHOT "):
+            return json.loads(ln[len("ONESHOT "):])
+    return {"error": f"one-shot leg exited with code {proc.returncode}: {errs.strip()[-400:]}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--oneshot-child", action="store_true", help=argparse.SUPPRESS)
     # --dim-*: the spellings self_launch() passes on (torch.distributed.run's own parser prefix-matches a bare --r)
     ap.add_argument("--F", "--dim-F", dest="F", type=int, default=F_)
     ap.add_argument("--T", "--dim-T", dest="T", type=int, default=T_)
@@ -144,6 +235,8 @@ def main():
     args = ap.parse_args()
     F, T, r = args.F, args.T, args.r
     K, W = args.steps, args.warmup
+    if args.oneshot_child:
+        return oneshot_child(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -185,7 +278,7 @@ def main():
         # HBM bytes per launch of the dominant kernel: from the SEPARATE rocprofv3 --pmc passes of the
         # same command (scripts/prof.sh -> scripts/summarize_prof.py -> profiles/*_traffic.json);
         # a profiler cannot run inside this process, so the committed measurement is quoted.
-        traffic = None
+        traffic, traffic_source = None, None
         if (F, T, r) == (F_, T_, R_):
             import glob
             for fn in sorted(glob.glob(os.path.join(_ROOT, "profiles", "r*_traffic.json")))[-1:]:
@@ -195,8 +288,17 @@ def main():
                 pref = [k for k in keys if k.startswith("k_hstep_rp<true") or "true, true" in k] or keys
                 if pref:
                     traffic = tj[pref[0]]["total_bytes"]
+                    traffic_source = {"file": "profiles/" + os.path.basename(fn), "kernel": pref[0],
+                                      "commit": tj.get("_source_commit"),
+                                      "note": "quoted from the committed rocprofv3 --pmc passes of this command (a profiler cannot run "
+                                              "inside bench.py); stale if the kernel changed after that commit"}
         last_cost = [c for c in cost if c != 0.0]
         ach = flops_half / (fam[dom][0] * 1e-3) / 1e12 if fam[dom][0] > 0 else 0.0
+        # the kernel(s) actually launched for the dominant half-step (from the plan's own description)
+        if dom == "hstep":
+            kname = "k_hstep_rh" if "k_hstep_rh" in desc else ("k_hstep_rp" if "k_hstep_rp" in desc else "k_hstep")
+        else:
+            kname = "k_wstats"
         out = {
             "metric": "NMF multiplicative-update iterations/sec (FxTxr)", "value": K / dt, "unit": "iterations/s",
             "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
@@ -204,11 +306,15 @@ def main():
             "config": {"workload": f"single-MI355X sparse NMF basis train (BASELINE configs[1]): {F}x{T} frames, "
                                    f"r={r}, KL, sparsity={SPARSITY}, full W+H update + objective per step",
                        "F": F, "T": T, "r": r, "beta": 1, "settle_steps": SETTLE, "geometry": desc},
-            "roofline": {"bound": "mfma", "kernel": f"k_{dom}", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE/WRITE_SIZE passes)",
+                         "traffic_source": traffic_source,
                          "algorithmic_flops_per_launch": flops_half,
                          "kernel_ms": {f: fam[f][0] for f in fam}, "launches": {f: fam[f][1] for f in fam},
+                         "kernel_ms_note": "HIP events on the engine's stream around every launch of a family, from a SEPARATE "
+                                           "event-instrumented pass of the same loop (the events add host work, so the four "
+                                           "averages need not sum to ms_per_step, which comes from the un-instrumented pass)",
                          "whole_iteration_TFLOPs": 2 * flops_half / (ms * 1e-3) / 1e12},
             "final_cost": float(last_cost[-1]) if last_cost else None,
         }
@@ -219,6 +325,7 @@ def main():
         return
 
     # ---- multi-GPU: one rank per GPU, frames sharded, RCCL all-reduce of the W statistics ----
+    oneshot = start_oneshot_child(args) if (rank == 0 and world > 1) else None  # (before this process touches HIP)
     import torch
     import torch.distributed as dist
     from se_snmf_nat_amd.dist import ShardedTrainer, shard_bounds
@@ -289,9 +396,17 @@ def main():
         }
         out["cost_vs_oracle"] = cost_vs_oracle(F, T, r, len(last_cost), out["final_cost"])
         # the contract times the CPU baseline on rank 0 at N = 1 only
-        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if world > 1:
+            # the same problem through the one-shot peer-store exchange behind the C ABI, AFTER the timed RCCL leg (the
+            # other ranks are gone or idle by now); reported beside `value`, never instead of it
+            del tr
+            torch.cuda.empty_cache()
+            out["exchange_oneshot"] = finish_oneshot_child(oneshot)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

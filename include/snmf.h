@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SNMF_ABI_VERSION 1
+#define SNMF_ABI_VERSION 2  /* 2: snmf_multi_* family, snmf_multi_set_exchange, snmf_online_trace is a ring of the newest frames */
 
 typedef enum snmf_status {
     SNMF_OK = 0,
@@ -312,16 +312,26 @@ void snmf_online_destroy(snmf_online* o);
  * W, src/sparse_nmf.m:189-208), rank g on devices[g] (a device may appear more than once: the ranks then share it --
  * single-GPU testing); W is replicated.  Per iteration ONE exchange of the fp64 statistics
  *     [ G or Q | P (beta != 1) | rowsum(H) | div | sum(S.*H) ]        (src/sparse_nmf.m:215-239, :248-261)
- * as a one-shot all-reduce over peer-mapped memory: every rank stores its buffer into its slot on every peer, every
- * rank sums the slots in rank order, so the W replicas and the stop decision (:272-284) are bit-identical everywhere.
+ * as a one-shot all-reduce over peer-mapped (fine-grained) memory: every rank stores its buffer into its slot on every
+ * peer, every rank sums the slots in rank order, so the W replicas and the stop decision (:272-284) are bit-identical everywhere.
  * H-only solves exchange only the two cost scalars.  Call order as for a plan: create -> set_v / set_w / set_h
  * [/ set_sparsity] -> init -> run -> get_*.  Matrices are HOST buffers of the WHOLE problem (V: F x T, H: r x T,
- * column-major); params->T is the total frame count.
+ * column-major); params->T is the total frame count.  snmf_multi_run creates its rank threads per call and restores
+ * the calling thread's current HIP device before it returns; the one-shot entries use min(n_dev, T) ranks.
  *   col_begin: n_dev + 1 ascending column offsets (col_begin[0] = 0, col_begin[n_dev] = T), or NULL = balanced. */
 typedef struct snmf_multi snmf_multi;
 int snmf_multi_create(const int32_t* devices, int32_t n_dev, const snmf_params* params, const int64_t* col_begin,
                       snmf_multi** out);
 void snmf_multi_destroy(snmf_multi* m);
+/* How push and sum of the per-iteration exchange are ordered (csrc/snmf_multi.h).  FLAGS: on the devices (arrival words
+ * polled by the summing kernel; a rank's host thread only enqueues) -- AUTO picks it when every rank has a device of its
+ * own.  EVENTS: hipEvents + a host barrier per iteration -- AUTO picks it when ranks share a device (single-GPU testing),
+ * where FLAGS can stall on a shared hardware queue until its 5 s device-side time-out.  FLAGS across two PHYSICAL devices
+ * has only been exercised where tests/test_gpu_multi_abi.py finds two devices.  Between init and the first run only. */
+#define SNMF_EXCHANGE_AUTO 0
+#define SNMF_EXCHANGE_FLAGS 1
+#define SNMF_EXCHANGE_EVENTS 2
+int snmf_multi_set_exchange(snmf_multi* m, int32_t mode);
 int snmf_multi_set_v_f64(snmf_multi* m, const double* V, int64_t ld);
 int snmf_multi_set_v_f32(snmf_multi* m, const float* V, int64_t ld);
 int snmf_multi_set_w_f64(snmf_multi* m, const double* W, int64_t ld);

@@ -51,6 +51,8 @@ static std::vector<float> to_float(const mxArray* a, const char* what) {
 }
 
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    if (snmf_abi_version() != SNMF_ABI_VERSION)  // a stale libsnmf_hip.so must not be driven through newer prototypes
+        mexErrMsgIdAndTxt("snmf:abi", "libsnmf_hip.so has ABI version %d, this MEX file was built against %d", snmf_abi_version(), SNMF_ABI_VERSION);
     if (nrhs < 1 || !mxIsChar(prhs[0])) mexErrMsgIdAndTxt("snmf:nargin", "usage: snmf_frontend_mex('stft'|'mel', ...)");
     if (nlhs > 1) mexErrMsgIdAndTxt("snmf:nargout", "one output");
     char cmd[16];

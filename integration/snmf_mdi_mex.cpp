@@ -51,6 +51,8 @@ static void fill_mask(const mxArray* opts, const char* name, size_t r, std::vect
 }
 
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    if (snmf_abi_version() != SNMF_ABI_VERSION)  // a stale libsnmf_hip.so must not be driven through newer prototypes
+        mexErrMsgIdAndTxt("snmf:abi", "libsnmf_hip.so has ABI version %d, this MEX file was built against %d", snmf_abi_version(), SNMF_ABI_VERSION);
     if (nrhs != 6) mexErrMsgIdAndTxt("snmf:nargin", "usage: [v_mdi,w,h,div,cost,n_iter] = snmf_mdi_mex(v,mask,w0,h0,sparsity,opts)");
     if (nlhs > 6) mexErrMsgIdAndTxt("snmf:nargout", "too many outputs");
     const mxArray *v = prhs[0], *mk = prhs[1], *w0 = prhs[2], *h0 = prhs[3], *sp = prhs[4], *opts = prhs[5];

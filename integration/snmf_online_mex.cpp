@@ -63,6 +63,8 @@ static snmf_online* handle_of(const mxArray* a) {
 }
 
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    if (snmf_abi_version() != SNMF_ABI_VERSION)  // a stale libsnmf_hip.so must not be driven through newer prototypes
+        mexErrMsgIdAndTxt("snmf:abi", "libsnmf_hip.so has ABI version %d, this MEX file was built against %d", snmf_abi_version(), SNMF_ABI_VERSION);
     if (nrhs < 1 || !mxIsChar(prhs[0])) mexErrMsgIdAndTxt("snmf:usage", "first argument: 'create' | 'process' | 'destroy'");
     char cmd[16];
     mxGetString(prhs[0], cmd, sizeof cmd);

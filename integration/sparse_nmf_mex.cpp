@@ -64,6 +64,8 @@ static void fill_mask(const mxArray* opts, const char* name, size_t r, std::vect
 }
 
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    if (snmf_abi_version() != SNMF_ABI_VERSION)  // a stale libsnmf_hip.so must not be driven through newer prototypes
+        mexErrMsgIdAndTxt("snmf:abi", "libsnmf_hip.so has ABI version %d, this MEX file was built against %d", snmf_abi_version(), SNMF_ABI_VERSION);
     if (nrhs != 5) mexErrMsgIdAndTxt("snmf:nargin", "usage: [w,h,div,cost,n_iter] = sparse_nmf_mex(v,w0,h0,sparsity,opts)");
     if (nlhs > 5) mexErrMsgIdAndTxt("snmf:nargout", "too many outputs");
     const mxArray *v = prhs[0], *w0 = prhs[1], *h0 = prhs[2], *sp = prhs[3], *opts = prhs[4];

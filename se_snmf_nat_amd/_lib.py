@@ -41,8 +41,10 @@ SYMBOLS = [
     "snmf_multi_set_w_f32", "snmf_multi_set_h_f64", "snmf_multi_set_h_f32", "snmf_multi_set_sparsity_f64",
     "snmf_multi_set_sparsity_f32", "snmf_multi_init", "snmf_multi_run", "snmf_multi_get_w_f64", "snmf_multi_get_w_f32",
     "snmf_multi_get_w_rank_f64", "snmf_multi_get_h_f64", "snmf_multi_get_h_f32", "snmf_multi_get_objective",
-    "snmf_sparse_nmf_multi_f64", "snmf_sparse_nmf_multi_f32",
+    "snmf_sparse_nmf_multi_f64", "snmf_sparse_nmf_multi_f32", "snmf_multi_set_exchange",
 ]
+ABI_VERSION = 2  # include/snmf.h: SNMF_ABI_VERSION this binding was written against
+EXCHANGE_AUTO, EXCHANGE_FLAGS, EXCHANGE_EVENTS = 0, 1, 2
 
 SNMF_OK = 0
 STATUS_NAMES = {
@@ -218,9 +220,13 @@ def load():
         sig[f"snmf_multi_get_h_{ty}"] = (C.c_int, [vp, vp, i64])
         sig[f"snmf_sparse_nmf_multi_{ty}"] = (C.c_int, [vp, i32, PP, vp, i64, vp, vp, vp, vp, vp, C.POINTER(i32)])
     sig["snmf_multi_init"] = (C.c_int, [vp])
+    sig["snmf_multi_set_exchange"] = (C.c_int, [vp, i32])
     sig["snmf_multi_run"] = (C.c_int, [vp, i32, C.POINTER(i32)])
     sig["snmf_multi_get_w_rank_f64"] = (C.c_int, [vp, i32, vp, i64])
     sig["snmf_multi_get_objective"] = (C.c_int, [vp, vp, vp, C.POINTER(i32)])
+    lib.snmf_abi_version.restype = C.c_int
+    if lib.snmf_abi_version() != ABI_VERSION:  # a stale library must not be driven through newer prototypes
+        raise ImportError(f"{path} has ABI version {lib.snmf_abi_version()}, this binding needs {ABI_VERSION}: rebuild the library")
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
         fn.restype = res

@@ -11,12 +11,25 @@
 // asks for instead of a ring (the message is ~0.5 MB: latency, not bytes, is the enemy on the fully connected xGMI
 // mesh):
 //     k_push_stats  every rank writes its fp64 statistics into slot g of EVERY rank's gather buffer (peer stores)
-//     event record / cross-stream event waits (no host synchronisation of the device work)
+//     ordering      (see below)
 //     k_sum_ranks   every rank adds the n slots of its own gather buffer in rank order
 // so all ranks hold bit-identical sums, run the identical deterministic W epilogue and take identical stop decisions.
-// Gather buffers and events are double-buffered by iteration parity: rank g can only push iteration j+2 after it has
-// seen every peer's push of j+1, which each peer issued after its own sum of iteration j.
+// Gather buffers (and events / flags) are double-buffered by iteration parity: rank g can only push iteration j+2 after
+// it has seen every peer's push of j+1, which each peer issued after its own sum of iteration j.
 // H-only solves exchange just the two cost scalars at the tail of the buffer.
+//
+// Ordering of push and sum, two modes (snmf_multi_set_exchange):
+//   FLAGS  (round 3; the default when every rank has a device of its own): ordered ON THE DEVICES.  The last workgroup
+//          of k_push_stats -- after a system-scope fence behind everybody's stores -- writes the exchange's sequence
+//          number into this rank's arrival word on every peer; k_sum_ranks polls its n arrival words (system-scope
+//          acquire loads, bounded by wall time: a lost peer raises the plan's fault word, never a hang) and only then
+//          reads the slots.  Gather buffers and arrival words are fine-grained device memory, so a peer's stores are
+//          visible without relying on what an L2 does at a kernel boundary.  A rank's host thread only ENQUEUES: two
+//          launches per exchange, no host barrier, no event calls.
+//   EVENTS (round 2; the default when ranks share a device, i.e. single-GPU testing): an event per rank and parity, a
+//          host barrier so that every peer has ISSUED its record before anybody waits on it, n-1 cross-stream waits.
+//          On a shared device FLAGS could deadlock until its time-out: streams beyond the runtime's hardware-queue count
+//          share a queue, and a polling kernel would then sit in front of the push it polls for.
 #pragma once
 
 #include <atomic>
@@ -27,17 +40,49 @@ namespace snmf {
 struct PushArgs {
     const double* src;
     double* dst[16];
+    unsigned* flag[16];   // FLAGS mode: this rank's arrival word on every peer (nullptr: EVENTS mode)
+    unsigned* done_ctr;   // FLAGS mode: workgroups of this launch that have finished (on this rank's device, zero at launch)
     size_t len;
     int n;
+    unsigned seq;         // sequence number of the exchange (>= 1)
 };
 __global__ __launch_bounds__(256) void k_push_stats(PushArgs a) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.len; i += (size_t)gridDim.x * 256) {
         const double v = a.src[i];
         for (int q = 0; q < a.n; ++q) a.dst[q][i] = v;
     }
+    if (a.done_ctr) {
+        __threadfence_system();  // this thread's peer stores are performed before it reports
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned old = __hip_atomic_fetch_add(a.done_ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == gridDim.x - 1) {  // the last workgroup: every store of the launch is out -> announce on every peer
+                __hip_atomic_store(a.done_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __threadfence_system();
+                for (int q = 0; q < a.n; ++q) __hip_atomic_store(a.flag[q], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 }
-// out[i] = slot_0[i] + slot_1[i] + ... in rank order (identical on every rank)
-__global__ __launch_bounds__(256) void k_sum_ranks(const double* __restrict__ slots, int n, size_t len, double* __restrict__ out) {
+// out[i] = slot_0[i] + slot_1[i] + ... in rank order (identical on every rank).
+// flags != nullptr (FLAGS mode): first wait until every rank's arrival word has reached `seq`.  The wait is bounded by
+// WALL time (s_memrealtime, 100 MHz): a peer that never arrives raises *fault and the sums are garbage the host rejects.
+__global__ __launch_bounds__(256) void k_sum_ranks(const double* __restrict__ slots, int n, size_t len, double* __restrict__ out,
+                                                   const unsigned* flags, unsigned seq, int* fault) {
+    if (flags) {
+        if ((int)threadIdx.x < n) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while ((int)(__hip_atomic_load(flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) {  // 5 s
+                    atomicExch(fault, 1);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(32);
+            }
+        }
+        __syncthreads();
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);  // (system scope: nothing read below may come from a line cached before the arrival)
+    }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (size_t)gridDim.x * 256) {
         double s = slots[i];
         for (int q = 1; q < n; ++q) s += slots[(size_t)q * len + i];
@@ -55,8 +100,11 @@ struct snmf_multi {
     std::vector<snmf_ctx*> ctx;
     std::vector<snmf_plan*> plan;
     std::vector<double*> stats;       // [n] device statistics buffer of each rank
-    std::vector<double*> slots;       // [n] gather buffers: [2 parities][n ranks][xlen]
-    std::vector<hipEvent_t> ev[2];    // ev[parity][rank]: "rank has pushed"
+    std::vector<double*> slots;       // [n] gather buffers: [2 parities][n ranks][xlen]  (fine-grained device memory)
+    std::vector<unsigned*> flags;     // [n] arrival words: [2 parities][n ranks], then the push launch's workgroup counter
+    std::vector<hipEvent_t> ev[2];    // ev[parity][rank]: "rank has pushed"  (EVENTS mode)
+    int mode = 0;                     // SNMF_EXCHANGE_FLAGS / _EVENTS (resolved from AUTO at creation)
+    unsigned xseq = 0;                // exchanges issued so far (the next one is number xseq + 1)
     std::vector<uint8_t> w_ind, h_ind;
     size_t len = 0, xoff = 0, xlen = 0;  // statistics length; the exchanged part [xoff, xoff + xlen)
     bool upd_w = true, can_stop = false;
@@ -106,6 +154,7 @@ extern "C" void snmf_multi_destroy(snmf_multi* m) {
             if (g < (int)m->ev[q].size() && m->ev[q][g]) hipEventDestroy(m->ev[q][g]);
         if (g < (int)m->stats.size() && m->stats[g]) hipFree(m->stats[g]);
         if (g < (int)m->slots.size() && m->slots[g]) hipFree(m->slots[g]);
+        if (g < (int)m->flags.size() && m->flags[g]) hipFree(m->flags[g]);
         if (m->plan[g]) snmf_plan_destroy(m->plan[g]);
     }
     for (snmf_ctx* c : m->ctx)
@@ -120,6 +169,12 @@ extern "C" int snmf_multi_create(const int32_t* devices, int32_t n_dev, const sn
     if (n_dev < 1 || n_dev > 16) return fail(SNMF_ERR_INVALID, "n_dev = %d outside [1, 16]", n_dev);
     SN_TRY(validate_params(p));
     if (p->T < n_dev) return fail(SNMF_ERR_INVALID, "fewer frames (%d) than ranks (%d)", p->T, n_dev);
+    int dev_before = -1;
+    (void)hipGetDevice(&dev_before);  // the calling thread's current device is restored on the way out (torch / gpuArray callers)
+    struct Restore {
+        int d;
+        ~Restore() { if (d >= 0) (void)hipSetDevice(d); }
+    } restore{dev_before};
     snmf_multi* m = new snmf_multi();
     m->n = n_dev;
     m->p = *p;
@@ -143,6 +198,13 @@ extern "C" int snmf_multi_create(const int32_t* devices, int32_t n_dev, const sn
     m->plan.assign(n_dev, nullptr);
     m->stats.assign(n_dev, nullptr);
     m->slots.assign(n_dev, nullptr);
+    m->flags.assign(n_dev, nullptr);
+    {   // AUTO: device-side ordering when every rank has a device of its own
+        bool distinct = true;
+        for (int g = 0; g < n_dev; ++g)
+            for (int q = 0; q < g; ++q) distinct = distinct && devices[g] != devices[q];
+        m->mode = distinct ? SNMF_EXCHANGE_FLAGS : SNMF_EXCHANGE_EVENTS;
+    }
     m->ev[0].assign(n_dev, nullptr);
     m->ev[1].assign(n_dev, nullptr);
     m->rc.assign(n_dev, SNMF_OK);
@@ -165,7 +227,20 @@ extern "C" int snmf_multi_create(const int32_t* devices, int32_t n_dev, const sn
     for (int g = 0; g < n_dev && s == SNMF_OK; ++g) {
         if (hipSetDevice(m->dev[g]) != hipSuccess) s = fail(SNMF_ERR_NO_DEVICE, "hipSetDevice(%d)", m->dev[g]);
         if (s == SNMF_OK) s = dalloc(&m->stats[g], m->len);
-        if (s == SNMF_OK) s = dalloc(&m->slots[g], (size_t)2 * n_dev * m->xlen);
+        // gather buffer and arrival words are written by PEERS while this device may hold lines of them: fine-grained
+        // (coherent) device memory; plain hipMalloc only if the runtime refuses (then kernel boundaries must do)
+        if (s == SNMF_OK) {
+            const size_t sb = (size_t)2 * n_dev * m->xlen * sizeof(double), fb = ((size_t)2 * n_dev + 1) * sizeof(unsigned);
+            if (hipExtMallocWithFlags((void**)&m->slots[g], sb, hipDeviceMallocFinegrained) != hipSuccess) {
+                (void)hipGetLastError();
+                s = dalloc(&m->slots[g], (size_t)2 * n_dev * m->xlen);
+            }
+            if (s == SNMF_OK && hipExtMallocWithFlags((void**)&m->flags[g], fb, hipDeviceMallocFinegrained) != hipSuccess) {
+                (void)hipGetLastError();
+                s = dalloc(&m->flags[g], (size_t)2 * n_dev + 1);
+            }
+            if (s == SNMF_OK) hipMemset(m->flags[g], 0, fb);
+        }
         if (s == SNMF_OK) {
             hipMemset(m->stats[g], 0, m->len * sizeof(double));
             for (int q = 0; q < 2 && s == SNMF_OK; ++q)
@@ -194,6 +269,21 @@ extern "C" int snmf_multi_create(const int32_t* devices, int32_t n_dev, const sn
         return s;
     }
     *out = m;
+    return SNMF_OK;
+}
+
+extern "C" int snmf_multi_set_exchange(snmf_multi* m, int32_t mode) {
+    if (!m) return fail(SNMF_ERR_INVALID, "multi handle is NULL");
+    if (mode != SNMF_EXCHANGE_AUTO && mode != SNMF_EXCHANGE_FLAGS && mode != SNMF_EXCHANGE_EVENTS)
+        return fail(SNMF_ERR_INVALID, "unknown exchange mode %d", mode);
+    if (m->it != 0 && m->inited) return fail(SNMF_ERR_STATE, "the exchange mode can only change between solves (before snmf_multi_run)");
+    if (mode == SNMF_EXCHANGE_AUTO) {
+        bool distinct = true;
+        for (int g = 0; g < m->n; ++g)
+            for (int q = 0; q < g; ++q) distinct = distinct && m->dev[g] != m->dev[q];
+        mode = distinct ? SNMF_EXCHANGE_FLAGS : SNMF_EXCHANGE_EVENTS;
+    }
+    m->mode = mode;
     return SNMF_OK;
 }
 
@@ -251,10 +341,13 @@ extern "C" int snmf_multi_init(snmf_multi* m) {
     return SNMF_OK;
 }
 
-// One exchange on rank g (device work only; the host barrier makes sure every peer has ISSUED its event record before
-// anybody waits on it, and that nobody re-records an event a peer has not yet waited on).  `rc` is the rank's status so
-// far: a failed rank still takes part in the barrier.  Returns false when the ranks agreed to stop (some rank failed).
-static bool multi_exchange(snmf_multi* m, int g, int par, int& seq, int& rc, std::string& err) {
+// One exchange on rank g, number `xs` (>= 1), parity `par`.  `rc` is the rank's status so far.
+// FLAGS mode: two launches, nothing else -- the devices order push and sum among themselves.
+// EVENTS mode: the host barrier makes sure every peer has ISSUED its event record before anybody waits on it, and that
+// nobody re-records an event a peer has not yet waited on; a failed rank still takes part in the barrier.
+// Returns false when the ranks agreed to stop (some rank failed; EVENTS mode only -- in FLAGS mode a failed rank is
+// found at the barrier behind the loop, and its peers' polls time out on the device).
+static bool multi_exchange(snmf_multi* m, int g, int par, unsigned xs, int& seq, int& rc, std::string& err) {
     hipStream_t st = m->ctx[g]->stream;
     auto note = [&](int s) {
         if (rc == SNMF_OK && s != SNMF_OK) {
@@ -262,24 +355,32 @@ static bool multi_exchange(snmf_multi* m, int g, int par, int& seq, int& rc, std
             err = g_err;
         }
     };
+    const bool flags = m->mode == SNMF_EXCHANGE_FLAGS;
     const int grid = (int)std::max<size_t>(1, std::min<size_t>((m->xlen + 255) / 256, 512));
     if (m->n > 1 && rc == SNMF_OK) {
         PushArgs pa{};
         pa.src = m->stats[g] + m->xoff;
         pa.len = m->xlen;
         pa.n = m->n;
-        for (int q = 0; q < m->n; ++q) pa.dst[q] = m->slots[q] + ((size_t)par * m->n + g) * m->xlen;
+        pa.seq = xs;
+        for (int q = 0; q < m->n; ++q) {
+            pa.dst[q] = m->slots[q] + ((size_t)par * m->n + g) * m->xlen;
+            pa.flag[q] = flags ? m->flags[q] + (size_t)par * m->n + g : nullptr;
+        }
+        pa.done_ctr = flags ? m->flags[g] + (size_t)2 * m->n : nullptr;
         hipLaunchKernelGGL(k_push_stats, dim3(grid), dim3(256), 0, st, pa);
         if (hipGetLastError() != hipSuccess) note(fail(SNMF_ERR_NO_DEVICE, "k_push_stats launch failed"));
-        else if (hipEventRecord(m->ev[par][g], st) != hipSuccess) note(fail(SNMF_ERR_NO_DEVICE, "hipEventRecord failed"));
+        else if (!flags && hipEventRecord(m->ev[par][g], st) != hipSuccess) note(fail(SNMF_ERR_NO_DEVICE, "hipEventRecord failed"));
     }
-    if (!multi_barrier(m, seq++, rc != SNMF_OK)) return false;  // every rank has recorded -- or somebody failed: all leave
+    if (!flags && !multi_barrier(m, seq++, rc != SNMF_OK)) return false;  // every rank has recorded -- or somebody failed: all leave
     if (m->n > 1) {
-        for (int q = 0; q < m->n; ++q)
-            if (q != g && hipStreamWaitEvent(st, m->ev[par][q], 0) != hipSuccess) note(fail(SNMF_ERR_NO_DEVICE, "hipStreamWaitEvent failed"));
+        if (!flags)
+            for (int q = 0; q < m->n; ++q)
+                if (q != g && hipStreamWaitEvent(st, m->ev[par][q], 0) != hipSuccess) note(fail(SNMF_ERR_NO_DEVICE, "hipStreamWaitEvent failed"));
         if (rc == SNMF_OK) {
             hipLaunchKernelGGL(k_sum_ranks, dim3(grid), dim3(256), 0, st, (const double*)(m->slots[g] + (size_t)par * m->n * m->xlen),
-                               m->n, m->xlen, m->stats[g] + m->xoff);
+                               m->n, m->xlen, m->stats[g] + m->xoff, flags ? (const unsigned*)(m->flags[g] + (size_t)par * m->n) : nullptr,
+                               xs, &m->plan[g]->st->fault);
             if (hipGetLastError() != hipSuccess) note(fail(SNMF_ERR_NO_DEVICE, "k_sum_ranks launch failed"));
         }
     }
@@ -298,11 +399,13 @@ static void multi_rank_loop(snmf_multi* m, int g, int it0, int target, bool fina
     };
     step(hipSetDevice(m->dev[g]) == hipSuccess ? SNMF_OK : fail(SNMF_ERR_NO_DEVICE, "hipSetDevice(%d) failed", m->dev[g]));
     int par = m->par, since = 0, stopped = 0;
+    unsigned xs = m->xseq;
+    const bool flags = m->mode == SNMF_EXCHANGE_FLAGS;
     bool all_ok = true;
     for (int it = it0; it < target && all_ok; ++it) {
         if (rc == SNMF_OK) step(snmf_plan_hstep(m->plan[g]));
         if (rc == SNMF_OK) step(snmf_plan_wstats(m->plan[g], m->stats[g]));
-        all_ok = multi_exchange(m, g, par, seq, rc, err);
+        all_ok = multi_exchange(m, g, par, ++xs, seq, rc, err);
         if (!all_ok) break;
         par ^= 1;
         if (rc == SNMF_OK) step(snmf_plan_wapply(m->plan[g], m->stats[g]));
@@ -310,7 +413,9 @@ static void multi_rank_loop(snmf_multi* m, int g, int it0, int target, bool fina
             since = 0;
             int32_t sflag = 0;
             if (rc == SNMF_OK) step(snmf_plan_stopped(m->plan[g], &sflag));
-            all_ok = multi_barrier(m, seq++, rc != SNMF_OK);
+            // (FLAGS mode: no rendezvous -- every rank reads the same flag value: the statistics are bit-identical)
+            if (!flags) all_ok = multi_barrier(m, seq++, rc != SNMF_OK);
+            else if (rc != SNMF_OK) break;
             if (all_ok && sflag) {
                 stopped = 1;
                 break;
@@ -320,7 +425,7 @@ static void multi_rank_loop(snmf_multi* m, int g, int it0, int target, bool fina
     if (all_ok) all_ok = multi_barrier(m, seq++, rc != SNMF_OK);  // agree on the state the loop was left in
     if (all_ok && finalize && !stopped) {
         if (rc == SNMF_OK) step(snmf_plan_objstats(m->plan[g], m->stats[g]));
-        all_ok = multi_exchange(m, g, par, seq, rc, err);
+        all_ok = multi_exchange(m, g, par, ++xs, seq, rc, err);
         if (all_ok) {
             par ^= 1;
             if (rc == SNMF_OK) step(snmf_plan_objapply(m->plan[g], m->stats[g]));
@@ -331,6 +436,7 @@ static void multi_rank_loop(snmf_multi* m, int g, int it0, int target, bool fina
     m->err[g] = err;
     if (g == 0) {
         m->par = par;
+        m->xseq = xs;
         *stopped_out = stopped;
     }
 }
@@ -340,7 +446,8 @@ extern "C" int snmf_multi_run(snmf_multi* m, int32_t n_iters, int32_t* iters_don
     if (!m->inited) return fail(SNMF_ERR_STATE, "snmf_multi_init must precede snmf_multi_run");
     const int target = std::min(m->p.max_iter, m->it + std::max(0, n_iters));
     const bool finalize = target >= m->p.max_iter && m->p.cost_check && !m->finalized && target > 0;
-    int stopped = 0;
+    int stopped = 0, dev_before = -1;
+    (void)hipGetDevice(&dev_before);  // rank 0's loop runs on the calling thread and moves its current device
     if (!m->stopped && (m->it < target || finalize)) {
         m->failed_at.store(0x7fffffff);
         m->bar_count.store(0);
@@ -348,6 +455,7 @@ extern "C" int snmf_multi_run(snmf_multi* m, int32_t n_iters, int32_t* iters_don
         for (int g = 1; g < m->n; ++g) th.emplace_back(multi_rank_loop, m, g, m->it, target, finalize, &stopped);
         multi_rank_loop(m, 0, m->it, target, finalize, &stopped);
         for (auto& t : th) t.join();
+        if (dev_before >= 0) (void)hipSetDevice(dev_before);
         for (int g = 0; g < m->n; ++g)
             if (m->rc[g] != SNMF_OK) return fail(m->rc[g], "rank %d (device %d): %s", g, m->dev[g], m->err[g].c_str());
         if (m->failed_at.load() != 0x7fffffff) return fail(SNMF_ERR_INTERNAL, "a rank failed");
@@ -396,6 +504,7 @@ template <typename T>
 static int sparse_nmf_multi_impl(const int32_t* devices, int32_t n_dev, const snmf_params* p, const T* V, int64_t ldV, T* W,
                                  T* H, const T* sparsity, double* div_out, double* cost_out, int32_t* n_iter_out) {
     if (!V || !W || !H) return fail(SNMF_ERR_INVALID, "V, W and H must be non-NULL");
+    if (p && p->T >= 1 && n_dev > p->T) n_dev = p->T;  // a short clip on a long device list: use as many ranks as there are frames
     snmf_multi* m = nullptr;
     SN_TRY(snmf_multi_create(devices, n_dev, p, nullptr, &m));
     int s = SNMF_OK;

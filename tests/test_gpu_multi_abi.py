@@ -60,13 +60,20 @@ def test_device_list_solve_matches_oracle_and_unsharded(gpu_ctx, case):
     assert rel(w, w1) < 1e-5 and rel(h, h1) < 1e-5  # only the summation order of the statistics differs
 
 
-def test_handle_api_replicas_are_bit_identical_and_equal_the_step_api(gpu_ctx, lib):
-    """snmf_multi_* with 2 ranks on device 0 against a hand-driven pair of plans over the step API (hstep -> wstats ->
-    host-side fp64 sum in rank order -> wapply): the one-shot exchange adds the slots in rank order too, so W, H and
-    every cost must agree BIT FOR BIT; and the two W replicas of the multi handle must be identical."""
+@pytest.mark.parametrize("mode,two_devices", [("events", False), ("flags", False), ("flags", True), ("events", True)],
+                         ids=["events-one-device", "flags-one-device", "flags-two-devices", "events-two-devices"])
+def test_handle_api_replicas_are_bit_identical_and_equal_the_step_api(gpu_ctx, lib, mode, two_devices):
+    """snmf_multi_* with 2 ranks against a hand-driven pair of plans over the step API (hstep -> wstats -> host-side fp64
+    sum in rank order -> wapply): the one-shot exchange adds the slots in rank order too, so W, H and every cost must
+    agree BIT FOR BIT; and the two W replicas of the multi handle must be identical.  Both orderings of the exchange
+    (EVENTS: hipEvents + host barrier; FLAGS: arrival words polled on the device, the host only enqueues), on device 0
+    twice (peer stores degenerate to local ones) and -- where the box has them -- on two PHYSICAL devices: peer-mapped
+    fine-grained gather buffers, cross-device arrival words; the only check of the path on real peers."""
     import torch
     from se_snmf_nat_amd import Plan, _lib
     from se_snmf_nat_amd.api import _make_params
+    if two_devices and lib.snmf_device_count() < 2:
+        pytest.skip("needs two HIP devices")
     F, T, r, iters = 257, 1300, 48, 9
     V, W0, H0 = synth_problem(F, T, r)
     V32, H32 = V.astype(np.float32), H0.astype(np.float32)
@@ -74,9 +81,10 @@ def test_handle_api_replicas_are_bit_identical_and_equal_the_step_api(gpu_ctx, l
     # ---- multi handle
     sp = _make_params(F, T, r, 1.0, iters, 0.0, 1, True, 0, 5.0, None, None)
     h = C.c_void_p()
-    devs = np.zeros(2, np.int32)
+    devs = np.asarray([0, 1 if two_devices else 0], np.int32)
     cb = np.asarray(cols, np.int64)
     _lib.check(lib.snmf_multi_create(C.c_void_p(devs.ctypes.data), 2, C.byref(sp), C.c_void_p(cb.ctypes.data), C.byref(h)))
+    _lib.check(lib.snmf_multi_set_exchange(h, _lib.EXCHANGE_FLAGS if mode == "flags" else _lib.EXCHANGE_EVENTS))
     try:
         Vf, Hf, Wf = np.asfortranarray(V32), np.asfortranarray(H32), np.asfortranarray(W0)
         _lib.check(lib.snmf_multi_set_v_f32(h, C.c_void_p(Vf.ctypes.data), F))

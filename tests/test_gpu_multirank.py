@@ -161,6 +161,12 @@ def test_bench_launches_its_own_ranks():
     assert d["scaling"] == "strong" and "frames/2" in d["config"]["parallelism"]
     assert len(d["roofline"]["kernel_ms_per_rank"]) == 2 and all(k["hstep"] > 0 for k in d["roofline"]["kernel_ms_per_rank"])
     assert d["final_cost"] and d["final_cost"] > 0
+    # the same sharded problem through the one-shot peer-store exchange behind the C ABI, reported beside the RCCL leg
+    # (here: two ranks on the one device, hipEvents ordering); a failure of this leg would be an "error" string, not a crash
+    one = d["exchange_oneshot"]
+    assert "error" not in one, one
+    assert one["ms_per_step"] > 0 and one["devices"] == [0, 0] and one["steps"] == 4
+    assert abs(one["final_cost"] - d["final_cost"]) <= 1e-6 * d["final_cost"]
 
 
 def test_bench_single_gpu_line_keeps_the_contract():
@@ -187,5 +193,7 @@ def test_bench_single_gpu_line_keeps_the_contract():
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == pytest.approx(157.3)
     assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"]) and 0 < rf["frac"] < 1 and "traffic" in rf
     assert rf["kernel_ms"]["hstep"] > 0 and rf["kernel_ms"]["wstats"] > 0
+    assert rf["kernel"] in ("k_hstep_rp", "k_hstep_rh", "k_hstep", "k_wstats") and rf["kernel"] in d["config"]["geometry"] + " k_wstats"
+    assert "separate" in rf["kernel_ms_note"].lower() and "traffic_source" in rf
     cb = d["cpu_baseline"]
     assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("port", "reference") and cb["sample"]
