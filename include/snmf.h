@@ -214,6 +214,11 @@ int snmf_plan_set_v_from_audio_f32(snmf_plan* plan, const snmf_stft_params* sp, 
  * mel: M x n ROW-major host matrix (mel_matrix(...)'), V / out host or device (both the same side). */
 int snmf_mel_features_f32(snmf_ctx* ctx, const float* mel, int32_t M, int32_t n, int32_t K, const float* V,
                           int64_t ldv, int32_t T, float* out, int64_t ldo, int on_device);
+/* TF_DD of src/TF_DD.m:1-9 (run_basis_train.m:64-67, p.domain_DD): recursive average along the frames, row by row,
+ * X_DD(:,1) = X(:,1), X_DD(:,l) = alpha_eta X_DD(:,l-1) + (1 - alpha_eta) X(:,l).  X / out: F x T column-major, host or
+ * device (both the same side); out may be X. */
+int snmf_tf_dd_f32(snmf_ctx* ctx, double alpha_eta, int32_t F, int32_t T, const float* X, int64_t ldx, float* out,
+                   int64_t ldo, int on_device);
 
 /* ---- missing-data imputation variants --------------------------------
  * [v_MDI, h, objective] = snmf_mdi(v, Dm, p)     src/snmf_mdi.m:1      (binary observed mask)

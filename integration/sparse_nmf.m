@@ -9,6 +9,14 @@ function [w, h, objective] = sparse_nmf(v, p)
 %   function sparse_nmf_mex (integration/sparse_nmf_mex.cpp).
 %
 %   To emulate src/sparse_nmf_GPU.m set p.snmf_gpu_variant = 1 (no V floor, objective left zero).
+%
+%   The parameter defaulting and the rand() draws below (down to the call of sparse_nmf_mex) repeat, in the reference's
+%   order so that MATLAB's generator yields the same initial factors, lines 75-148 of src/sparse_nmf.m of
+%   lordet01/SE_SNMF_NAT, which is
+%     Copyright (C) 2015 Mitsubishi Electric Research Labs (Jonathan Le Roux, Felix Weninger, John R. Hershey)
+%     Licensed under the Apache License, Version 2.0 (http://www.apache.org/licenses/LICENSE-2.0)
+%   (J. Le Roux, J. R. Hershey, F. Weninger, "Sparse NMF - half-baked or well done?", MERL TR2015-023, March 2015).
+%   This file is a modified version of that block; the solver behind sparse_nmf_mex is new code.
 m = size(v, 1);
 n = size(v, 2);
 if ~exist('p', 'var'), p = struct; end
@@ -47,6 +55,7 @@ elseif ischar(p.init_h) && strcmp(p.init_h, 'ones')
 else
     h = p.init_h;
 end
+if ~isfield(p, 'display'), p.display = 0; end
 if ~isfield(p, 'w_update_ind'), p.w_update_ind = true(r, 1); end
 if ~isfield(p, 'h_update_ind'), p.h_update_ind = true(r, 1); end
 gpu_variant = isfield(p, 'snmf_gpu_variant') && p.snmf_gpu_variant;
@@ -74,5 +83,28 @@ elseif n_iter < p.max_iter
 else
     objective.div = div(1:p.max_iter);
     objective.cost = cost(1:p.max_iter);
+end
+if p.display ~= 0
+    % what src/sparse_nmf.m:181-183,266-270,276-278,288-290 print, from the objective vectors the engine recorded (the
+    % whole solve is one MEX call, so the lines appear after it instead of during it)
+    stopped = n_iter < p.max_iter;
+    if gpu_variant   % src/sparse_nmf_GPU.m:266-268,274
+        for it = 1:n_iter
+            fprintf('iteration %d div = %.3e cost = %.3e\n', it, div(it), cost(it));
+        end
+        if stopped && p.conv_eps > 0, disp('Convergence reached, aborting iteration'); end
+    else
+        fprintf(1, 'Performing sparse NMF with beta-divergence, beta=%.1f\n', p.beta);
+        if opts.cost_check
+            str = [];
+            for it = 1:n_iter
+                fprintf(repmat('\b', 1, length(str)));
+                str = sprintf('iteration %d div = %.3e cost = %.3e', it, div(it), cost(it));
+                fprintf('%s', str);
+            end
+            if stopped && p.conv_eps > 0, disp('Convergence reached, aborting iteration'); end
+        end
+        disp('\nMax Iteration reached, aborting iteration\n');
+    end
 end
 end

@@ -118,11 +118,23 @@ def mel_features(TF_mag, p):
     return out
 
 
+def tf_dd(X, p):
+    """src/TF_DD.m:1-9, fp64, column by column exactly as written."""
+    X = np.asarray(X, dtype=np.float64)
+    X_DD = X.copy()  # :5
+    a = float(p["alpha_eta"])
+    for l in range(1, X.shape[1]):  # :6  (l = 2:L)
+        X_DD[:, l] = a * X_DD[:, l - 1] + (1 - a) * X[:, l]  # :7
+    return X_DD
+
+
 def run_basis_train_signal(s_full, R, p, sample_idx):
     """run_basis_train.m:58-116 for one event class, cluster_buff = 1, on an assembled signal.
     sample_idx: 1-based exemplar columns (:81).  Uses the solver oracle for :88,:91."""
     from oracle.sparse_nmf_oracle import sparse_nmf
     TF_mag = dft_features(s_full, p)
+    if p.get("domain_DD", 0):
+        TF_mag = tf_dd(TF_mag, p)  # :64-67
     TF_Mel = mel_features(TF_mag, p)
     idx = np.asarray(sample_idx, dtype=int) - 1
     q = {k: p[k] for k in ("cf", "beta", "sparsity", "max_iter", "conv_eps", "cost_check") if k in p}

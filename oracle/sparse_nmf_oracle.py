@@ -168,6 +168,14 @@ def sparse_nmf(v, p=None, *, rng=None, gpu_variant=False, mimic_matlab_flops=Fal
         raise OracleError("Reference to non-existent field 'cost_check'.")
     cost_check = True if gpu_variant else bool(p["cost_check"])
 
+    # p.display (:162-164 default 0): the console output, written where the reference writes it
+    import sys
+    display = p.get("display", 0) != 0
+    put = sys.stdout.write
+    pstr = ""  # :70 str = []
+    if display and not gpu_variant:
+        put("Performing sparse NMF with beta-divergence, beta=%.1f\n" % beta)  # :181-183
+
     n_iter = max_iter
     for it in range(1, max_iter + 1):  # :186
         # ---- H updates :189-208
@@ -232,10 +240,19 @@ def sparse_nmf(v, p=None, *, rng=None, gpu_variant=False, mimic_matlab_flops=Fal
             if not gpu_variant:
                 div_hist[it - 1] = div  # :263-264
                 cost_hist[it - 1] = cost
+            if display:
+                if gpu_variant:
+                    put("iteration %d div = %.3e cost = %.3e\n" % (it, div, cost))  # sparse_nmf_GPU.m:266-268
+                else:
+                    put("\b" * len(pstr))  # :267
+                    pstr = "iteration %d div = %.3e cost = %.3e" % (it, div, cost)  # :268
+                    put(pstr)  # :269
             if it > 1 and conv_eps > 0:  # :273
                 with np.errstate(divide="ignore", invalid="ignore"):  # MATLAB: x/0 = Inf, 0/0 = NaN (NaN < eps is false)
                     e = np.float64(abs(cost - last_cost)) / np.float64(last_cost)  # :274
                 if e < conv_eps:  # :275
+                    if display:  # :276-278 (sparse_nmf_GPU.m:274 prints it unconditionally; not restated)
+                        put("Convergence reached, aborting iteration\n")
                     if not gpu_variant:
                         div_hist = div_hist[:it]  # :279-280
                         cost_hist = cost_hist[:it]
@@ -243,6 +260,8 @@ def sparse_nmf(v, p=None, *, rng=None, gpu_variant=False, mimic_matlab_flops=Fal
                     break
             last_cost = cost  # :284
 
+    if display and not gpu_variant:
+        put("\\nMax Iteration reached, aborting iteration\\n\n")  # :288-290: disp of a single-quoted string, after a stop too
     objective = {"div": div_hist, "cost": cost_hist, "n_iter": n_iter}
     return w, h, objective
 

@@ -33,7 +33,7 @@ SYMBOLS = [
     "snmf_plan_get_w_f64", "snmf_plan_get_w_f32", "snmf_plan_get_h_f64", "snmf_plan_get_h_f32",
     "snmf_plan_get_objective", "snmf_plan_solve_frames_f64", "snmf_plan_solve_frames_f32",
     "snmf_ctx_timing", "snmf_ctx_timing_get", "snmf_plan_describe",
-    "snmf_stft_num_frames", "snmf_stft_features_f32", "snmf_plan_set_v_from_audio_f32", "snmf_mel_features_f32",
+    "snmf_stft_num_frames", "snmf_stft_features_f32", "snmf_plan_set_v_from_audio_f32", "snmf_mel_features_f32", "snmf_tf_dd_f32",
     "snmf_plan_set_mask_f64", "snmf_plan_set_mask_f32", "snmf_plan_get_v_mdi_f64", "snmf_plan_get_v_mdi_f32",
     "snmf_online_create", "snmf_online_set_mel", "snmf_online_get_mel_basis_f32", "snmf_online_process_f32", "snmf_online_get_basis_f32", "snmf_online_trace",
     "snmf_online_destroy",
@@ -189,6 +189,7 @@ def load():
     sig["snmf_stft_features_f32"] = (C.c_int, [vp, SP, vp, i64, C.c_int, vp, i64, C.c_int, C.POINTER(i32)])
     sig["snmf_plan_set_v_from_audio_f32"] = (C.c_int, [vp, SP, vp, i64, C.c_int])
     sig["snmf_mel_features_f32"] = (C.c_int, [vp, vp, i32, i32, i32, vp, i64, i32, vp, i64, C.c_int])
+    sig["snmf_tf_dd_f32"] = (C.c_int, [vp, dbl, i32, i32, vp, i64, vp, i64, C.c_int])
     OP = C.POINTER(SnmfOnlineParams)
     sig["snmf_online_create"] = (C.c_int, [vp, OP, vp, vp, vp, vp, vp, vp, C.POINTER(vp)])
     sig["snmf_online_set_mel"] = (C.c_int, [vp, i32, i32, vp, vp, vp])

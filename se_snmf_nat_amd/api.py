@@ -165,6 +165,7 @@ def _solve(v, p, *, gpu_variant, ctx, dtype, rng, devices=None):
     if ih is None:
         h0 = rng.random_sample((r, n))
     elif isinstance(ih, str) and ih == "ones":
+        print("sup_nmf: Initalizing H with ones.")  # :135 (unconditional in the reference)
         h0 = np.ones((r, n))
     else:
         h0 = np.asarray(ih, dtype=np.float64)
@@ -204,6 +205,8 @@ def _solve(v, p, *, gpu_variant, ctx, dtype, rng, devices=None):
         _lib.check(fn(ctx._h, C.byref(sp), _ptr(vv), ldv, _ptr(W), _ptr(H),
                       _ptr(sarr) if sarr is not None else None, _ptr(div), _ptr(cost), C.byref(n_iter)))
     ni = n_iter.value
+    if p.get("display", 0) != 0:  # :162-164 default 0
+        _display(beta, div, cost, ni, max_iter, cost_check, conv_eps, gpu_variant)
     if gpu_variant:
         # sparse_nmf_GPU.m:263-264 never fills the vectors: zeros(1, max_iter) are returned
         objective = {"div": np.zeros(max_iter), "cost": np.zeros(max_iter), "n_iter": ni}
@@ -215,6 +218,34 @@ def _solve(v, p, *, gpu_variant, ctx, dtype, rng, devices=None):
     else:
         objective = {"div": np.zeros(max_iter), "cost": np.zeros(max_iter), "n_iter": ni}
     return W, H, objective
+
+
+def _display(beta, div, cost, n_iter, max_iter, cost_check, conv_eps, gpu_variant, out=None):
+    """p.display ~= 0: what the reference writes to the console, in its format, reproduced from the objective vectors the
+    engine recorded (the whole solve is ONE call across the C boundary, so the lines appear after it instead of during it).
+    src/sparse_nmf.m:181-183 (header), :266-270 (per iteration, only inside `if p.cost_check`: the previous line is erased
+    with backspaces), :276-278 (convergence), :288-290 -- disp of a SINGLE-quoted string: the backslash-n are printed
+    literally, and the line comes after a convergence stop as well.  src/sparse_nmf_GPU.m:266-268,:274: one line per
+    iteration, no erasing; its unconditional console chatter (:162,:186,:283, toc) is not reproduced."""
+    import sys
+    w = (out or sys.stdout).write
+    stopped = n_iter < max_iter
+    if gpu_variant:
+        for it in range(1, n_iter + 1):
+            w("iteration %d div = %.3e cost = %.3e\n" % (it, div[it - 1], cost[it - 1]))
+        if stopped and conv_eps > 0:
+            w("Convergence reached, aborting iteration\n")
+        return
+    w("Performing sparse NMF with beta-divergence, beta=%.1f\n" % beta)
+    if cost_check:
+        prev = ""
+        for it in range(1, n_iter + 1):
+            w("\b" * len(prev))
+            prev = "iteration %d div = %.3e cost = %.3e" % (it, div[it - 1], cost[it - 1])
+            w(prev)
+        if stopped and conv_eps > 0:
+            w("Convergence reached, aborting iteration\n")
+    w("\\nMax Iteration reached, aborting iteration\\n\n")
 
 
 def sparse_nmf(v, p=None, *, ctx=None, dtype=np.float64, rng=None, devices=None):

@@ -1655,6 +1655,45 @@ extern "C" int snmf_mel_features_f32(snmf_ctx* ctx, const float* mel, int32_t M,
     return rc;
 }
 
+// TF_DD feature transform (src/TF_DD.m, run_basis_train.m:64-67): see snmf_frontend.h.  X / out: F x T column-major,
+// host or device (both the same side); out may alias X.
+extern "C" int snmf_tf_dd_f32(snmf_ctx* ctx, double alpha_eta, int32_t F, int32_t T, const float* X, int64_t ldx, float* out,
+                              int64_t ldo, int on_device) {
+    if (!ctx || !X || !out) return fail(SNMF_ERR_INVALID, "NULL argument");
+    if (F < 1 || T < 1 || ldx < F || ldo < F) return fail(SNMF_ERR_INVALID, "bad TF_DD sizes");
+    if (!(alpha_eta == alpha_eta)) return fail(SNMF_ERR_INVALID, "alpha_eta is NaN");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int nch = (T + kDdChunk - 1) / kDdChunk;
+    float *d_x = nullptr, *d_o = nullptr;
+    double* d_c = nullptr;
+    int rc = SNMF_OK;
+    if (hipMalloc((void**)&d_c, (size_t)nch * F * sizeof(double)) != hipSuccess) return fail(SNMF_ERR_NOMEM, "hipMalloc failed");
+    if (on_device) {
+        d_x = const_cast<float*>(X);
+        d_o = out;
+    } else if (hipMalloc((void**)&d_x, (size_t)ldx * T * 4) != hipSuccess || hipMalloc((void**)&d_o, (size_t)ldo * T * 4) != hipSuccess) {
+        rc = fail(SNMF_ERR_NOMEM, "hipMalloc failed");
+    } else {
+        hipMemcpyAsync(d_x, X, (size_t)ldx * T * 4, hipMemcpyHostToDevice, st);
+    }
+    if (rc == SNMF_OK) {
+        const dim3 g(nch, (F + 255) / 256);
+        hipLaunchKernelGGL(k_tfdd_carry, g, dim3(256), 0, st, (const float*)d_x, ldx, (int)F, (int)T, alpha_eta, d_c);
+        hipLaunchKernelGGL(k_tfdd_state, dim3((F + 255) / 256), dim3(256), 0, st, (const float*)d_x, (int)F, (int)T, alpha_eta, d_c);
+        hipLaunchKernelGGL(k_tfdd_apply, g, dim3(256), 0, st, (const float*)d_x, ldx, (int)F, (int)T, alpha_eta, (const double*)d_c, d_o, ldo);
+        if (hipGetLastError() != hipSuccess) rc = fail(SNMF_ERR_NO_DEVICE, "TF_DD launch failed");
+        if (!on_device && rc == SNMF_OK) hipMemcpyAsync(out, d_o, (size_t)ldo * T * 4, hipMemcpyDeviceToHost, st);
+    }
+    hipStreamSynchronize(st);
+    hipFree(d_c);
+    if (!on_device) {
+        if (d_x) hipFree(d_x);
+        if (d_o) hipFree(d_o);
+    }
+    return rc;
+}
+
 // ---- online separation loop (include/snmf.h: snmf_online_*) -------------------------------------
 // Host side of src/bnmf_sep_event_RT_IS16.m + the frame loop of src/NTF_sep_event_RT.m:54-135.  The
 // host only sequences launches: per frame it reads one 32-byte status (did the adaptation condition

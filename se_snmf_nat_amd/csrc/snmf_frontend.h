@@ -119,4 +119,46 @@ __global__ void k_floor_real(float* V, int Fp, int F, int T, float flr) {
         if ((int)(i % Fp) < F) V[i] = fmaxf(V[i], flr);
 }
 
+// ---- TF_DD (src/TF_DD.m:1-9, called by run_basis_train.m:64-67 when p.domain_DD is set): a one-tap recursive average
+// along the frame axis, row by row:  X_DD(:,1) = X(:,1);  X_DD(:,l) = a X_DD(:,l-1) + (1-a) X(:,l).
+// Rows are independent and the matrix is column-major, so thread <-> row gives coalesced frame-by-frame accesses; the
+// frame axis is cut into chunks of kDdChunk frames scanned in parallel:
+//   k_tfdd_carry : every (chunk, row) runs the recursion over its chunk from state 0 -> its carry c
+//   k_tfdd_state : per row, the states at the chunk starts: S_{j+1} = a^len_j S_j + c_j  (sequential over the few chunks);
+//                  S_0 = X(:,1), which makes the first column come out as itself
+//   k_tfdd_apply : every (chunk, row) re-runs its chunk from the true start state and writes the result
+// State and coefficients in fp64 (the features are fp32; the recursion then adds no error of its own).
+constexpr int kDdChunk = 256;
+__global__ __launch_bounds__(256) void k_tfdd_carry(const float* __restrict__ X, int64_t ld, int F, int T, double a, double* __restrict__ carry) {
+    const int f = blockIdx.y * 256 + threadIdx.x, j = blockIdx.x;
+    if (f >= F) return;
+    const int t0 = j * kDdChunk, t1 = min(T, t0 + kDdChunk);
+    double s = 0.0;
+    for (int t = t0; t < t1; ++t) s = a * s + (1.0 - a) * (double)X[(int64_t)t * ld + f];
+    carry[(int64_t)j * F + f] = s;
+}
+__global__ __launch_bounds__(256) void k_tfdd_state(const float* __restrict__ X, int F, int T, double a, double* __restrict__ carry /* in: carries, out: start states */) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= F) return;
+    const int nch = (T + kDdChunk - 1) / kDdChunk;
+    double s = (double)X[f];  // state "before" column 1: a x + (1-a) x = x
+    for (int j = 0; j < nch; ++j) {
+        const int len = min(T, (j + 1) * kDdChunk) - j * kDdChunk;
+        const double c = carry[(int64_t)j * F + f];
+        carry[(int64_t)j * F + f] = s;
+        s = pow(a, (double)len) * s + c;
+    }
+}
+__global__ __launch_bounds__(256) void k_tfdd_apply(const float* __restrict__ X, int64_t ld, int F, int T, double a, const double* __restrict__ state,
+                                                    float* __restrict__ out, int64_t ldo) {
+    const int f = blockIdx.y * 256 + threadIdx.x, j = blockIdx.x;
+    if (f >= F) return;
+    const int t0 = j * kDdChunk, t1 = min(T, t0 + kDdChunk);
+    double s = state[(int64_t)j * F + f];
+    for (int t = t0; t < t1; ++t) {
+        s = a * s + (1.0 - a) * (double)X[(int64_t)t * ld + f];
+        out[(int64_t)t * ldo + f] = (float)s;
+    }
+}
+
 }  // namespace snmf

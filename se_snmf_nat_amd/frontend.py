@@ -2,6 +2,7 @@
 
     stft_features(s, p)       <->  src/stft_fft.m + run_basis_train.m:60-63  (TF_mag, on the GPU)
     mel_features(TF_mag, p)   <->  run_basis_train.m:70-78                   (Mel projection, on the GPU)
+    tf_dd(TF_mag, p)          <->  src/TF_DD.m (run_basis_train.m:64-67)     (recursive average along frames, on the GPU)
     mel_matrix(...)           <->  src/mel_matrix.m   (a parameter TABLE, built on the host like the window)
     default_params()          <->  settings/initial_setting_SNMF_NAT.m:17,21-37,53,88-90
 
@@ -106,4 +107,21 @@ def mel_features(TF_mag, p, *, ctx=None):
     out = np.zeros((K * M, T), dtype=np.float32, order="F")
     _lib.check(_lib.load().snmf_mel_features_f32(ctx._h, C.c_void_p(mel.ctypes.data), M, n, K, C.c_void_p(V.ctypes.data),
                                                   K * n, T, C.c_void_p(out.ctypes.data), K * M, 0))
+    return out
+
+
+def tf_dd(X, p, *, ctx=None):
+    """[X_DD] = TF_DD(X, p), src/TF_DD.m:1-9: X_DD(:,l) = p.alpha_eta * X_DD(:,l-1) + (1 - p.alpha_eta) * X(:,l), on the GPU."""
+    ctx = ctx or default_context()
+    if "alpha_eta" not in p:
+        raise SnmfError(4, "Reference to non-existent field 'alpha_eta'.")
+    X = np.asfortranarray(X, dtype=np.float32)
+    if X.ndim != 2:
+        raise SnmfError(3, "TF_DD: X must be a matrix")
+    F, T = X.shape
+    out = np.zeros((F, T), dtype=np.float32, order="F")
+    if T == 0:
+        return out
+    _lib.check(_lib.load().snmf_tf_dd_f32(ctx._h, float(p["alpha_eta"]), F, T, C.c_void_p(X.ctypes.data), F,
+                                           C.c_void_p(out.ctypes.data), F, 0))
     return out

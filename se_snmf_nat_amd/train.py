@@ -27,14 +27,12 @@ def run_basis_train_signal(s_full, R, p, *, DC_bin=None, sample_idx=None, ctx=No
     if cluster_buff > 1 and p.get("train_Exemplar", 0):
         # :125-126 index the activation matrices, which :95-96 set to the scalar 0 in exemplar mode: MATLAB stops there too
         raise SnmfError(3, "cluster_buff > 1 needs train_Exemplar = 0 (run_basis_train.m:125-126 index A_*_init, a scalar otherwise)")
-    if p.get("domain_DD", 0):
-        # run_basis_train.m:64-67 replaces the features by TF_DD(TF_mag, p); that transform is not part of this path
-        # (the shipped settings leave domain_DD = 0), and silently training on the wrong features would be worse
-        raise SnmfError(8, "domain_DD != 0 (TF_DD feature transform, run_basis_train.m:64-67) is not implemented")
     fp = dict(p)
     if DC_bin is not None:
         fp["DCbin"] = int(DC_bin)
     TF_mag = frontend.stft_features(s_full, fp, ctx=ctx)  # :60-63 (all-zero columns never produced)
+    if p.get("domain_DD", 0):
+        TF_mag = frontend.tf_dd(TF_mag, p, ctx=ctx)  # :64-67 (src/TF_DD.m)
     TF_Mel = frontend.mel_features(TF_mag, fp, ctx=ctx)  # :70-78
     n_ex = cluster_buff * int(R)
     T = TF_mag.shape[1]

@@ -161,6 +161,60 @@ def test_basis_training_caller_end_to_end(gpu_ctx, tmp_path):
     np.testing.assert_array_equal(back["B_DFT_sub"], out["B_DFT_sub"])
 
 
+def test_tf_dd_oracle_is_the_recursive_average():
+    """oracle/frontend_oracle.py::tf_dd against two independent statements of src/TF_DD.m:1-9: scipy's IIR filter run
+    with the first column as its initial state, and the closed form X_DD(:,l) = a^(l-1) X(:,1) + (1-a) sum_j a^(l-j) X(:,j)."""
+    from scipy.signal import lfilter, lfiltic
+    rs = np.random.RandomState(2)
+    X = rs.gamma(0.5, 1.0, (7, 300))
+    for a in (0.4, 0.95, 0.0):  # 0.4: settings/initial_setting_SNMF_NAT.m:119
+        ref = np.empty_like(X)
+        for f in range(X.shape[0]):
+            zi = lfiltic([1 - a], [1, -a], y=[X[f, 0]])
+            ref[f, 0] = X[f, 0]
+            ref[f, 1:] = lfilter([1 - a], [1, -a], X[f, 1:], zi=zi)[0]
+        got = fo.tf_dd(X, {"alpha_eta": a})
+        np.testing.assert_allclose(got, ref, rtol=1e-12, atol=0)
+        l = 37
+        closed = a ** l * X[:, 0] + (1 - a) * sum(a ** (l - j) * X[:, j] for j in range(1, l + 1))
+        np.testing.assert_allclose(got[:, l], closed, rtol=1e-10)
+    np.testing.assert_array_equal(fo.tf_dd(X[:, :1], {"alpha_eta": 0.4}), X[:, :1])  # one frame: X_DD = X
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,alpha", [((513, 3000), 0.4), ((64, 257), 0.95), ((513, 256), 0.4), ((1, 1000), 0.7), ((700, 1), 0.4),
+                                         ((257, 100000), 0.98)])
+def test_tf_dd_on_device_against_oracle(gpu_ctx, shape, alpha):
+    """src/TF_DD.m on the GPU (chunked scan, csrc/snmf_frontend.h) against the fp64 oracle: fp32 in and out, fp64 state --
+    within fp32 rounding of the result (tolerance 2e-7 relative + a hair of the row scale), including chunk boundaries
+    (multiples of 256 frames), one row, one frame and a slowly forgetting average over 100 000 frames."""
+    from se_snmf_nat_amd import frontend as fe
+    rs = np.random.RandomState(shape[0] + shape[1])
+    X = (rs.gamma(0.5, 1.0, shape) * 10.0 ** rs.uniform(-3, 3, (shape[0], 1))).astype(np.float32)
+    got = fe.tf_dd(X, {"alpha_eta": alpha}, ctx=gpu_ctx)
+    ref = fo.tf_dd(X.astype(np.float64), {"alpha_eta": alpha})
+    assert got.dtype == np.float32 and got.shape == X.shape
+    assert (np.abs(got - ref) <= 2e-7 * np.abs(ref) + 1e-7 * np.abs(ref).max(axis=1, keepdims=True)).all()
+    np.testing.assert_array_equal(got[:, 0], X[:, 0])
+
+
+@pytest.mark.gpu
+def test_basis_training_with_domain_dd(gpu_ctx):
+    """run_basis_train.m:64-67: with p.domain_DD the features are replaced by TF_DD(TF_mag, p) BEFORE the Mel projection
+    and both solves; against the oracle chain with the same flag, and different from the run without it."""
+    from se_snmf_nat_amd import train
+    s = np.load(os.path.join(GOLD, "frontend_audio.npz"))["samples"].astype(np.float64)
+    p = dict(fo.default_params(), cf="kl", sparsity=5, max_iter=20, conv_eps=0, cost_check=1, cluster_buff=1,
+             train_Exemplar=0, domain_DD=1, alpha_eta=0.4)
+    idx = np.random.RandomState(5).choice(114, size=16, replace=False) + 1
+    out = train.run_basis_train_signal(s, 16, p, sample_idx=idx, ctx=gpu_ctx)
+    ref = fo.run_basis_train_signal(s, 16, p, idx)
+    plain = fo.run_basis_train_signal(s, 16, dict(p, domain_DD=0), idx)
+    for k in ("B_DFT_sub", "B_Mel_sub", "A_DFT_sub", "A_Mel_sub"):
+        assert np.linalg.norm(out[k] - ref[k]) / np.linalg.norm(ref[k]) < 2e-4, k
+    assert np.linalg.norm(ref["B_DFT_sub"] - plain["B_DFT_sub"]) / np.linalg.norm(plain["B_DFT_sub"]) > 1e-2
+
+
 @pytest.mark.gpu
 def test_basis_training_with_kmeans_rank_reduction(gpu_ctx):
     """run_basis_train.m:118-129 (cluster_buff > 1): the dictionary is trained with cluster_buff*R atoms and reduced to

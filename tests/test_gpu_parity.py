@@ -166,6 +166,37 @@ def test_gpu_variant_entry_point(gpu_ctx):
     assert rel(w, wr) < REL_WH and rel(h, hr) < REL_WH
 
 
+def test_display_prints_the_reference_lines(gpu_ctx, capsys):
+    """p.display (src/sparse_nmf.m:181-183,266-270,276-278,288-290): the drop-in writes what the reference writes -- here
+    compared with the oracle's console output on the same problem: every character outside the %.3e numbers equal (so
+    also the count of backspaces, i.e. the printed widths), the numbers within one unit of their last printed digit
+    (full update with early stop, no cost_check, the default display = 0, the _GPU file's per-iteration lines, and
+    init_h = 'ones' with its unconditional notice :135)."""
+    import re
+    from se_snmf_nat_amd import sparse_nmf, sparse_nmf_GPU
+    num = re.compile(r"\d\.\d{3}e[+-]\d{2}")
+    V, W0, H0 = synth_problem(65, 200, 12)
+    base = dict(cf="kl", sparsity=1, max_iter=200, conv_eps=1e-3, init_w=W0, init_h=H0, cost_check=1)
+    for extra, gpu in ((dict(display=1), False), (dict(display=1, cost_check=0, max_iter=4), False), (dict(), False),
+                       (dict(display=2, conv_eps=0, max_iter=5), False), (dict(display=1, max_iter=6, conv_eps=0), True),
+                       (dict(display=1, init_h="ones", max_iter=3), False)):
+        p = dict(base, **extra)
+        (sparse_nmf_GPU if gpu else sparse_nmf)(V, p, ctx=gpu_ctx)
+        got = capsys.readouterr().out
+        oracle_nmf(V, p, gpu_variant=gpu)
+        want = capsys.readouterr().out
+        if isinstance(p["init_h"], str):
+            assert got.startswith("sup_nmf: Initalizing H with ones.\n")
+            got = got[len("sup_nmf: Initalizing H with ones.\n"):]
+        assert num.sub("#", got) == num.sub("#", want), (extra, got[:200], want[:200])
+        for a, b in zip(num.findall(got), num.findall(want)):
+            assert abs(float(a) - float(b)) <= 1.01e-3 * abs(float(b)), (a, b)
+        if p.get("display", 0) == 0:
+            assert got == ""
+        elif not gpu:
+            assert got.endswith("\\nMax Iteration reached, aborting iteration\\n\n")
+
+
 def test_inputs_are_not_mutated_and_random_init_path(gpu_ctx):
     from se_snmf_nat_amd import sparse_nmf
     V, W0, H0 = synth_problem(40, 60, 6)
@@ -311,12 +342,15 @@ def test_persistent_small_solve_matches_generic_path_and_oracle(gpu_ctx, monkeyp
         ref = oracle_nmf(V, p)
         monkeypatch.delenv("SNMF_NO_SMALL", raising=False)
         small = sparse_nmf(V, p, ctx=gpu_ctx)
-        monkeypatch.setenv("SNMF_NO_SMALL", "1")
+        monkeypatch.setenv("SNMF_NO_SMALL", "1")  # no persistent kernel: the per-iteration plan loop
         generic = sparse_nmf(V, p, ctx=gpu_ctx)
+        monkeypatch.setenv("SNMF_NO_SMALL", "2")  # no register-resident frame kernel: k_hsolve_small (MFMA, H in LDS) also at T = 1
+        lds_small = sparse_nmf(V, p, ctx=gpu_ctx)
         monkeypatch.delenv("SNMF_NO_SMALL")
         check(small, ref, vsum=float(V.sum()))
         check(generic, ref, vsum=float(V.sum()))
-        assert small[2]["n_iter"] == generic[2]["n_iter"]
+        check(lds_small, ref, vsum=float(V.sum()))
+        assert small[2]["n_iter"] == generic[2]["n_iter"] == lds_small[2]["n_iter"]
         assert rel(small[1], generic[1]) < 1e-5
         # no cost_check: fixed iteration count, zero objective vectors
         p2 = dict(p, cost_check=0, max_iter=9)

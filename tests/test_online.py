@@ -128,6 +128,24 @@ def test_device_run_matches_the_golden_run(gpu_ctx):
     np.testing.assert_allclose([t["beta"] for t in tr], g["beta"], rtol=1e-3)
 
 
+@pytest.mark.gpu
+def test_adaptation_solve_cooperative_kernel_equals_the_plan_path(gpu_ctx, monkeypatch):
+    """The noise-dictionary adaptation (src/bnmf_sep_event_RT_IS16.m:296-336, a W-only sparse_nmf of 513 x 100, rank <= 50)
+    runs as ONE cooperative launch (k_wadapt) by default and through the ordinary three-launch plan path with
+    SNMF_NO_WADAPT=1 (read when the separator is created): both must take every decision of the golden run -- frame
+    iterations, triggers, atoms updated, iterations of each adaptation solve -- and give the same signal and dictionary."""
+    g = np.load(os.path.join(GOLD, "online_is16_124frames.npz"))
+    s, Bx, Bd, H0, Ad0 = fixture_inputs()
+    monkeypatch.delenv("SNMF_NO_WADAPT", raising=False)
+    out_c, tr_c, Bn_c = _device(s, Bx, Bd, default_params(), H0, Ad0, ctx=gpu_ctx)
+    monkeypatch.setenv("SNMF_NO_WADAPT", "1")
+    out_p, tr_p, Bn_p = _device(s, Bx, Bd, default_params(), H0, Ad0, ctx=gpu_ctx)
+    for tr in (tr_c, tr_p):
+        _check_trace(tr, g["n_iter"], g["trig"], g["n_up"], g["adapt_iters"])
+    assert np.linalg.norm(out_c["x_tilde_f"] - out_p["x_tilde_f"]) / np.linalg.norm(out_p["x_tilde_f"]) < REL_OUT
+    assert np.linalg.norm(Bn_c - Bn_p) / np.linalg.norm(Bn_p) < 1e-3
+
+
 VARIANTS = [
     dict(ENHANCE_METHOD="Wiener"),
     dict(blk_sparse=0),

@@ -157,6 +157,34 @@ def test_reference_error_behaviour():
     assert h.shape == (3, 12)
 
 
+def test_display_lines_have_the_reference_format(capsys):
+    """p.display ~= 0 (src/sparse_nmf.m:162-164 default 0): header :181-183, one erased-and-rewritten line per iteration
+    inside `if p.cost_check` :266-270, the convergence line :276-278, and the closing disp of a SINGLE-quoted string
+    :288-290 whose backslash-n stay literal and which is printed after a convergence stop as well."""
+    import re
+    V, W0, H0 = synth_problem(33, 80, 5)
+    p = dict(cf="kl", sparsity=1, max_iter=300, conv_eps=1e-2, init_w=W0, init_h=H0, cost_check=1, display=1)
+    _, _, o = sparse_nmf(V, p)
+    out = capsys.readouterr().out
+    assert 2 < o["n_iter"] < 300
+    assert out.startswith("Performing sparse NMF with beta-divergence, beta=1.0\n")
+    lines = re.findall(r"iteration (\d+) div = (\d\.\d{3}e[+-]\d{2}) cost = (\d\.\d{3}e[+-]\d{2})", out)
+    assert [int(x[0]) for x in lines] == list(range(1, o["n_iter"] + 1))
+    assert float(lines[-1][2]) == pytest.approx(o["cost"][-1], rel=1e-3)
+    first = "iteration 1 div = %.3e cost = %.3e" % (o["div"][0], o["cost"][0])
+    assert first + "\b" * len(first) + "iteration 2" in out  # the previous line is erased with backspaces
+    assert out.endswith("Convergence reached, aborting iteration\n\\nMax Iteration reached, aborting iteration\\n\n")
+    # without cost_check: header and closing line only; display = 0 (the default): nothing
+    sparse_nmf(V, dict(p, cost_check=0, max_iter=3))
+    assert capsys.readouterr().out == "Performing sparse NMF with beta-divergence, beta=1.0\n\\nMax Iteration reached, aborting iteration\\n\n"
+    sparse_nmf(V, dict(p, display=0, max_iter=3))
+    assert capsys.readouterr().out == ""
+    # src/sparse_nmf_GPU.m:266-268: one plain line per iteration
+    sparse_nmf(V, dict(p, max_iter=2, conv_eps=0), gpu_variant=True)
+    g = capsys.readouterr().out.splitlines()
+    assert len(g) == 2 and g[0].startswith("iteration 1 div = ") and g[1].startswith("iteration 2 div = ")
+
+
 def test_gpu_variant_deltas():
     V, W0, H0 = synth_problem(20, 30, 4)
     p = dict(sparsity=1, max_iter=6, init_w=W0, init_h=H0)
