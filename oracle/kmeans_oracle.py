@@ -24,7 +24,7 @@ def _batch(X, C, max_iter):
         counts = [new.count(j) for j in range(k)]
         for j in range(k):
             if counts[j] == 0:
-                far = max(range(n), key=lambda i: (own[i], -i))
+                far = max(range(n), key=lambda i: (own[i] if counts[new[i]] > 1 else -1.0, -i))  # donor keeps a member
                 counts[new[far]] -= 1
                 new[far] = j
                 counts[j] = 1

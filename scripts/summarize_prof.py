@@ -16,6 +16,7 @@ import os
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+cmd = sys.argv[2] if len(sys.argv) > 2 else "bench.py --steps 20 --warmup 3 --no-cpu-baseline"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 
@@ -28,7 +29,7 @@ def short(name):
 stats = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")[0]
 rows = list(csv.DictReader(open(stats)))
 with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline\n")
+    f.write(f"# rocprofv3 --kernel-trace --stats -- python3 {cmd}\n")
     f.write("kernel,calls,total_ns,avg_ns,pct,min_ns,max_ns\n")
     for r in rows:
         f.write(f"\"{short(r['Name'])}\",{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},"
@@ -46,18 +47,26 @@ with open(f"profiles/{tag}_pmc.csv", "w") as f:
     cols = sorted({c for d in avg.values() for c in d})
     f.write("kernel," + ",".join(cols) + ",hbm_read_bytes(2*FETCH*1024),hbm_write_bytes(WRITE*1024)\n")
     for k, d in sorted(avg.items()):
-        if not any(x in k for x in ("k_hstep", "k_wstats", "k_reduce", "k_wapply")):
+        if not any(x in k for x in ("k_hstep", "k_wstats", "k_reduce", "k_wapply", "k_hsolve", "k_wadapt", "k_o")):
             continue
         rd = 2 * d.get("FETCH_SIZE", 0) * 1024
         wr = d.get("WRITE_SIZE", 0) * 1024
         traffic[k] = {"read_bytes": rd, "write_bytes": wr, "total_bytes": rd + wr}
         f.write(f"\"{k}\"," + ",".join(f"{d.get(c, float('nan')):.6g}" for c in cols) + f",{rd:.6g},{wr:.6g}\n")
+traffic["_command"] = cmd
+if os.environ.get("SNMF_SOURCE_COMMIT"):
+    traffic["_source_commit"] = os.environ["SNMF_SOURCE_COMMIT"]
 json.dump(traffic, open(f"profiles/{tag}_traffic.json", "w"), indent=1)
 for fn in ("bench_trace.json",):
     if os.path.exists(f"{src}/{fn}"):
         open(f"profiles/{tag}_{fn}", "w").write(open(f"{src}/{fn}").read())
 print(open(f"profiles/{tag}_kernel_stats.csv").read())
 print(json.dumps(traffic, indent=1))
+with open(f"profiles/{tag}_mfma_util.txt", "w") as fu:
+    for k, d in avg.items():
+        if ("k_hstep" in k or "k_wstats" in k) and "SQ_VALU_MFMA_BUSY_CYCLES" in d and "GRBM_GUI_ACTIVE" in d:
+            fu.write("%s MFMA pipe utilisation %.1f%% (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs)\n"
+                     % (k, 100 * d["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (d["GRBM_GUI_ACTIVE"] / 8)))
 for k, d in avg.items():
     if "k_hstep" in k or "k_wstats" in k:
         if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "GRBM_GUI_ACTIVE" in d:

@@ -421,7 +421,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     pl->ldhw = std::max(pl->rp, 32 * pl->NKT * pl->n_kg) + 4;
     if (((size_t)32 * pl->ldhw + (size_t)32 * pl->Fp) * 4 + (size_t)pl->rp * 4 + 288 > lds_cap && pl->NKT == 16)
         pl->TTW = 16;  // large r: 16-frame tiles (the 32-frame H + V images do not fit the LDS)
-    const int n_tiles_w = pl->Tp / pl->TTW;
+    const int n_tiles_w = (T + pl->TTW - 1) / pl->TTW;  // tiles that hold a frame (an all-padding tile adds exact zeros: skipped)
     {
         // loaders + double buffering when the accumulators allow 2 waves per SIMD and LDS has room; the loader waves
         // stage only the row group's 32 * NWB columns of V (the kernel's ldv), so F = 513 fits as well
@@ -916,7 +916,7 @@ static int launch_wstats_geo(snmf_plan* pl, const StepArgs& a, bool obj) {
 }
 static int launch_wstats(snmf_plan* pl, bool obj) {
     StepArgs a = make_args(pl);
-    a.n_tiles = pl->Tp / pl->TTW;
+    a.n_tiles = (pl->p.T + pl->TTW - 1) / pl->TTW;
     a.ldh = pl->ldhw;
     a.stagger = pl->stagger_w;
     ScopedTimer tm(pl->ctx, FAM_WSTATS);

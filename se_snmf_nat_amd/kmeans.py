@@ -44,8 +44,11 @@ def _batch_phase(X, C, max_iter):
         own = D[np.arange(n), new]
         # 'singleton': every empty cluster takes the observation that is furthest from its own centroid
         counts = np.bincount(new, minlength=k)
+        # -- taken from a cluster that keeps at least one member (n >= k: while a cluster is empty another holds two), so
+        # the repair can never empty its donor (duplicate observations make every own-distance 0 and argmax would then
+        # pick a singleton's only member: a NaN centroid)
         for j in np.flatnonzero(counts == 0):
-            far = int(own.argmax())
+            far = int(np.where(counts[new] > 1, own, -1.0).argmax())
             counts[new[far]] -= 1
             new[far] = j
             counts[j] = 1
@@ -83,6 +86,8 @@ def kmeans_cityblock(X, k, *, seed=1, max_iter=100):
 def reduce_rank(B_Mel, B_DFT, A_DFT, A_Mel, R, *, seed=1):
     """run_basis_train.m:118-129: keep, for each of R clusters of the Mel basis vectors, the vector nearest to the
     cluster's centroid -- the same columns of both dictionaries and the same rows of both activation matrices."""
-    _, _, _, D = kmeans_cityblock(np.asarray(B_Mel).T, R, seed=seed)  # :120-123 (observations = basis vectors)
+    _, C, _, D = kmeans_cityblock(np.asarray(B_Mel).T, R, seed=seed)  # :120-123 (observations = basis vectors)
+    if not (np.isfinite(C).all() and np.isfinite(D).all()):
+        raise ValueError("kmeans: non-finite centroid (empty cluster)")
     keep = D.argmin(0)                                                # :124  [~, Dmin_idx] = min(D)
     return B_Mel[:, keep], B_DFT[:, keep], A_DFT[keep, :], A_Mel[keep, :], keep

@@ -50,3 +50,20 @@ def test_reduce_rank_picks_the_same_atoms_everywhere():
     assert len(set(keep.tolist())) == R                                               # distinct atoms for distinct clusters here
     with pytest.raises(ValueError):
         kmeans.kmeans_cityblock(B_Mel.T, n_ex + 1)
+
+
+def test_duplicate_observations_never_leave_a_cluster_empty():
+    """'emptyaction','singleton' with repeated rows: every own-distance can be 0, and a repair that took the only member of
+    another cluster left that one empty (NaN centroid, 31 of 400 runs of such a fuzz).  The donor must keep a member."""
+    from oracle import kmeans_oracle
+    from se_snmf_nat_amd.kmeans import kmeans_cityblock
+    rs = np.random.RandomState(0)
+    for trial in range(150):
+        base = rs.gamma(0.5, 1.0, (rs.randint(2, 5), 4))
+        X = base[rs.randint(0, len(base), rs.randint(6, 14))]  # many duplicates
+        k = rs.randint(2, min(6, len(X)) + 1)
+        idx, C, sumd, D = kmeans_cityblock(X, k, seed=trial)
+        assert np.isfinite(C).all() and np.isfinite(D).all()
+        assert np.bincount(idx, minlength=k).min() >= 1
+        i2, C2, D2 = kmeans_oracle.kmeans_cityblock(X, k, seed=trial)
+        assert np.array_equal(idx, i2) and np.allclose(C, C2)
