@@ -19,9 +19,8 @@ import numpy as np  # noqa: E402
 from se_snmf_nat_amd import Context, Plan  # noqa: E402
 
 PEAK = 157.3
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
-which = args or ["a11", "c4h", "c4w", "c5"]
 K = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 0
+which = [a for a in sys.argv[1:] if a in ("a11", "c4h", "c4w", "c5")] or ["a11", "c4h", "c4w", "c5"]
 ctx = Context(0)
 
 SHAPES = {

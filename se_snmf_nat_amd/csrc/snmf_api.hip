@@ -229,6 +229,10 @@ struct snmf_plan {
     int NKT = 8, NWB = 4, WPS = 2, NLW = 0;  // k_wstats template geometry (NLW loader waves)
     int n_fg = 1, n_kg = 1, n_chunks = 1;
     int n_ch1 = 0;  // k_wstats: chunks of row group 1 when the two row groups are split unevenly (else 0)
+    // beta = 2, r > 256: the V*H^T launch (needs no Lam') runs the loader-wave geometry <8,4,4,2> once per 256-column
+    // kappa-group, each staging only its own columns of H (kq_chunks frame chunks, kq_kg kappa-groups; 0 = off)
+    int kq_chunks = 0, kq_kg = 0;
+    size_t kq_lds = 0;
     int grid_h = 1;
     int ldh = 0, ldr = 0, ldhw = 0;
     int stagger_h = 0, stagger_w = 0;
@@ -419,19 +423,20 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     pl->n_fg = (pl->nf + pl->NWB - 1) / pl->NWB;
     // H image of k_wstats: rows padded to whole NKT-tile groups (branch-free P4, see the kernel)
     pl->ldhw = std::max(pl->rp, 32 * pl->NKT * pl->n_kg) + 4;
-    if (((size_t)32 * pl->ldhw + (size_t)32 * pl->Fp) * 4 + (size_t)pl->rp * 4 + 288 > lds_cap && pl->NKT == 16)
+    if (((size_t)32 * pl->ldhw + (size_t)32 * 32 * pl->NWB) * 4 + (size_t)pl->rp * 4 + 320 > lds_cap && pl->NKT == 16)
         pl->TTW = 16;  // large r: 16-frame tiles (the 32-frame H + V images do not fit the LDS)
     const int n_tiles_w = (T + pl->TTW - 1) / pl->TTW;  // tiles that hold a frame (an all-padding tile adds exact zeros: skipped)
     {
         // loaders + double buffering when the accumulators allow 2 waves per SIMD and LDS has room; the loader waves
         // stage only the row group's 32 * NWB columns of V (the kernel's ldv), so F = 513 fits as well
         const size_t buf_ld = ((size_t)pl->TTW * pl->ldhw + (size_t)pl->TTW * 32 * pl->NWB) * 4;
-        const size_t buf = ((size_t)pl->TTW * pl->ldhw + (size_t)pl->TTW * pl->Fp) * 4;
         pl->NLW = (pl->WPS == 2 && 2 * buf_ld + (size_t)pl->rp * 4 + 320 <= lds_cap) ? 4 : 0;
         if (const char* e = getenv("SNMF_WSTATS_NL")) pl->NLW = (atoi(e) == 4 && pl->NLW == 4) ? 4 : 0;
+        size_t buf = buf_ld;
         if (!pl->NLW && pl->NWB == 8) {  // the eight-consumer geometry exists with loader waves only
             pl->NWB = 4;
             pl->n_fg = (pl->nf + pl->NWB - 1) / pl->NWB;
+            buf = ((size_t)pl->TTW * pl->ldhw + (size_t)pl->TTW * 32 * pl->NWB) * 4;
         }
         // (the fixed-order sums at the end of the kernel use [4][rp] floats / one double per thread of the same memory)
         pl->lds_w = std::max<size_t>(std::max<size_t>((pl->NLW ? 2 * buf_ld : buf) + (size_t)pl->rp * 4 + 320,  // + ready/done slots + the extra row's V values [2][32]
@@ -473,6 +478,14 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     if (pl->lds_w > lds_cap) {
         delete pl;
         return fail(SNMF_ERR_UNSUPPORTED, "r = %d too large for the LDS H tile", r);
+    }
+    if (pl->bm == BM_EUC && pl->NKT == 16 && pl->TTW == 32 && pl->upd_w) {
+        // Q = V * H^T of the Euclidean W step needs no Lam', so nothing is recomputed when the statistics' columns are cut
+        // into 256-wide kappa-groups: the NK = 16 geometry (256 accumulator registers, no room for loader waves, 116
+        // spilled VGPRs) is replaced for this launch by <8,4,4,2> with double-buffered LDS-DMA staging
+        pl->kq_kg = (pl->nk + 7) / 8;
+        pl->kq_chunks = std::max(1, std::min(std::min(n_tiles_w, pl->n_chunks), ctx->n_cu / std::max(1, pl->n_fg * pl->kq_kg)));
+        pl->kq_lds = (size_t)2 * 32 * (260 + 32 * 4) * 4 + (size_t)pl->rp * 4 + 320;
     }
     if (pl->rp > 4 * pl->NWB * 64 && pl->upd_w && (pl->bm == BM_KL || pl->xr)) {
         // k_wstats keeps the row sums of H (KL) and the extra row of the slab (F = 32n+1) in per-thread registers: 1024 columns
@@ -908,6 +921,18 @@ static int launch_wstats_geo(snmf_plan* pl, const StepArgs& a, bool obj) {
     if (pl->bm == BM_EUC) {
         SN_TRY(obj ? (launch_wstats_one<NK, NWB, NL, WPS, 1, BM_EUC, true, TT>(pl, a, 1))
                    : (launch_wstats_one<NK, NWB, NL, WPS, 1, BM_EUC, false, TT>(pl, a, 1)));
+        if (pl->kq_kg) {  // V * H^T by 256-column kappa-groups on the loader-wave geometry (see snmf_plan_create)
+            StepArgs aq = a;
+            aq.ldh = 260;
+            aq.kc = 1;
+            aq.n_ch1 = 0;
+            auto kern = k_wstats<8, 4, 4, 2, 3, BM_EUC, false, 32>;
+            SN_TRY(ensure_dyn_lds(pl->ctx->device, (const void*)kern, pl->kq_lds));
+            hipLaunchKernelGGL(kern, dim3(pl->kq_chunks, pl->n_fg, pl->kq_kg), dim3(512), pl->kq_lds, pl->ctx->stream, aq, pl->kq_chunks, 0,
+                               pl->n_mat);
+            HIP_TRY(hipGetLastError());
+            return SNMF_OK;
+        }
         return launch_wstats_one<NK, NWB, NL, WPS, 3, BM_EUC, false, TT>(pl, a, 0);
     }
     SN_TRY(obj ? (launch_wstats_one<NK, NWB, NL, WPS, 1, BM_GEN, true, TT>(pl, a, 1))

@@ -142,6 +142,7 @@ struct StepArgs {
     float* Vw;            // MDI: V, writable (re-imputed in place by the Lam pass)
     int impute;           // MDI: this pass carries the re-imputation of the previous iteration (:251-254)
     int n_ch1;            // k_wstats: > 0 = row group 1 has its own, smaller, number of frame chunks (1-D grid)
+    int kc;               // k_wstats, WM = 3 (V * H^T needs no Lam'): each kappa-group stages only ITS 32*NK columns of H
     int F, T, Fp, rp, Tp, nf, nk;
     int Fm;               // rows covered by MFMA tiles = 32*nf
     int Fq;               // contraction length of W^T*ratio = Fm + 8*xr
@@ -2423,9 +2424,10 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     constexpr int NBUF = NL > 0 ? 2 : 1;
     if (a.stop && *a.stop) return;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    // V image: with loader waves only the columns of this workgroup's row group are staged, so it is [TT][32 * NWB]
-    // (F = 513, four row groups: 16 KiB instead of 64 -- what lets two tile buffers fit); without them the whole V tile
-    const int ldv = NL > 0 ? 32 * NWB : a.Fp;
+    // V image: only the columns of this workgroup's row group are staged, so it is [TT][32 * NWB] (F = 513, four row
+    // groups: 16 KiB instead of 64 -- what lets two tile buffers fit -- and the V block crosses L2 once per iteration, not
+    // once per row group); the extra row's V values go to a small array of their own (vx)
+    const int ldv = 32 * NWB;
     const int bufsz = TT * (a.ldh + ldv);   // floats per buffer: Hs [TT][ldh] then Vs [TT][ldv]
     float* wxs = lds + NBUF * bufsz;        // [rp] extra row of W
     const int lane = threadIdx.x & 63, w = wave_index();
@@ -2446,7 +2448,8 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
             nch = a.n_ch1;
         }
     }
-    const bool do_x = a.xr && by == 0 && blockIdx.z == 0;  // extra row: one f-group only
+    const bool kc = WM == 3 && NK == 8 && a.kc != 0;  // kappa-compact H image (columns [256 z, 256 z + 256) at offset 0)
+    const bool do_x = a.xr && by == 0 && (blockIdx.z == 0 || kc);  // extra row: one f-group only (its k range: see kc)
     constexpr int CPW = TT / NWB;  // columns of the extra-row dot product per wave
     static_assert(CPW % 4 == 0, "the extra row takes 4 frames x 16 lanes at a time");
     // 256-column pieces of an H row this geometry can have: NK <= 8 is rp <= 256 (one kappa-group, n_kg = 1 on the host)
@@ -2457,7 +2460,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     if (do_x && WM != 3)
         for (int k = threadIdx.x; k < rp; k += NTHR) wxs[k] = a.wx[k];
     const int phi = by * NWB + w;
-    const int fc = NL > 0 ? w * 32 + fl : phi * 32 + fl;  // this lane's column of the staged V image
+    const int fc = w * 32 + fl;  // this lane's column of the staged V image
     const bool active = !is_loader && phi < a.nf;
     const int kap_base = blockIdx.z * NK;  // kappa-group (r > 32*NK: P3 is recomputed per group)
     const bool do_obj = OBJ && blockIdx.z == 0;
@@ -2498,7 +2501,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     // The extra row of one tile (row group 0 only): ratio_x[t] for this wave's CPW columns, then gx[k] += ratio_x[t] * H[k,t].
     // It stays on the CONSUMER waves: moved to the loader waves -- which only get an instruction in where their SIMD's
     // MFMA wave stalls -- it delayed the staging of the next tile (k_wstats 0.249 -> 0.277 ms on C2).
-    auto xrow_tile = [&](const float* xH, const float* xV, int xt0, int xw, const float* vxc = nullptr) {
+    auto xrow_tile = [&](const float* xH, int xt0, int xw, const float* vxc) {
             // extra row: ratio_x[t] for this wave's CPW columns, then gx[k] += ratio_x[t] * H[k,t]
             float rxv[CPW];
             float dsum = 0.f;
@@ -2508,7 +2511,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
                 const int kl = lane & 15;
                 const float* hrow = xH + tl * ldh;
                 const int t = xt0 + tl;
-                const float v = vxc ? vxc[tl] : xV[tl * Fp + a.Fm];  // (DMA loaders keep the extra row's V values in a compact array)
+                const float v = vxc[tl];  // (the extra row's V values are staged into a compact array)
                 float rv;
                 if (WM != 3) {
                     float s0 = 0.f, s1 = 0.f;
@@ -2536,7 +2539,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
 #pragma unroll
             for (int pc = 0; pc < NPC; ++pc) {
                 const int k0 = 256 * pc + 4 * lane;
-                if (k0 < rp) {
+                if (k0 + (kc ? kap_base * 32 : 0) < rp) {
 #pragma unroll
                     for (int c = 0; c < CPW; ++c) {
                         const f32x4 hv = *reinterpret_cast<const f32x4*>(xH + (xw * CPW + c) * ldh + k0);
@@ -2572,11 +2575,12 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         auto dma_tile = [&](int tile, float* dst) {
             const __amdgpu_buffer_rsrc_t rh =
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Hin + (size_t)tile * TT * rp), 0, TT * rp * 4, 0x00020000);
+            const int pc0 = kc ? (int)blockIdx.z : 0, pcn = kc ? 1 : npc;  // kc: only this kappa-group's 1 KiB piece of every row
             for (int t = lw; t < TT; t += NL)
-                for (int pc = 0; pc < npc; ++pc)
-                    if (pc * 256 + lane * 4 < rp)
+                for (int pc = 0; pc < pcn; ++pc)
+                    if ((pc0 + pc) * 256 + lane * 4 < rp)
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, (lds_ptr_t)(dst + t * ldh + pc * 256), 16, lane * 16,
-                                                                 (t * rp + pc * 256) * 4, 0, 0);
+                                                                 (t * rp + (pc0 + pc) * 256) * 4, 0, 0);
             const __amdgpu_buffer_rsrc_t rv =
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.V + (size_t)tile * TT * Fp), 0, nVb, 0x00020000);
             for (int t = lw; t < TT; t += NL)
@@ -2624,7 +2628,25 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         if (NL == 0) {
             __syncthreads();
             stage_in<NST>(a.Hin + (size_t)t0 * rp, Hs, TT, rp, ldh, sid);
-            stage_in<NST>(a.V + (size_t)t0 * Fp, Vs, TT, Fp, Fp, sid);
+            {   // this row group's columns of the V tile: cw4 16-byte cells per frame row, all loads of a batch in flight
+                const int c0 = by * NWB * 32, cw4 = (a.Fm - c0 < NWB * 32 ? a.Fm - c0 : NWB * 32) / 4, n4 = TT * cw4;
+                const float* vsrc = a.V + (size_t)t0 * Fp + c0;
+                constexpr int B = 8;
+                for (int i0 = sid; i0 < n4; i0 += B * NST) {
+                    f32x4 x[B];
+#pragma unroll
+                    for (int b = 0; b < B; ++b) {
+                        const int i = i0 + b * NST;
+                        if (i < n4) x[b] = *reinterpret_cast<const f32x4*>(vsrc + (size_t)(i / cw4) * Fp + 4 * (i % cw4));
+                    }
+#pragma unroll
+                    for (int b = 0; b < B; ++b) {
+                        const int i = i0 + b * NST;
+                        if (i < n4) *reinterpret_cast<f32x4*>(Vs + (i / cw4) * ldv + 4 * (i % cw4)) = x[b];
+                    }
+                }
+                if (do_x && sid < TT) vx[sid] = a.V[(size_t)(t0 + sid) * Fp + a.Fm];
+            }
             __syncthreads();
         }
         // NL > 0: the wait for the staged tile.  (Taken behind P3's first W loads instead, as k_hstep_rp does with its
@@ -2642,7 +2664,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
                 }
             }
         }
-        if (do_x) xrow_tile(Hs, Vs, t0, w, NL > 0 ? vx + (it & 1) * 32 : nullptr);
+        if (do_x) xrow_tile(Hs, t0, w, vx + (NL > 0 ? (it & 1) * 32 : 0));
         SNMF_STAMP(2);
         if (!active) {
             if (NL > 0) rp_post(done, w, (unsigned)(it + 1), lane);
@@ -2698,7 +2720,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         // The H image of this kernel is padded to 32*NK columns per kappa-group (host: ldh), so tiles
         // beyond nk read finite padding into accumulators that are never stored -- no clamps, and
         // every read is (one of 16 row bases) + an immediate offset.
-        const float* hb = Hs + (4 * h) * ldh + fl + kap_base * 32;
+        const float* hb = Hs + (4 * h) * ldh + fl + (kc ? 0 : kap_base * 32);
         const float* hrow[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) hrow[i] = hb + ((i & 3) + 8 * (i >> 2)) * ldh;
@@ -2803,10 +2825,11 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         }
         __syncthreads();
         float* slab = a.slabs + ((size_t)chunk * n_mat + mat_index) * rp * Fp;
-        for (int k = threadIdx.x; k < rp; k += NTHR) {
+        const int koff = kc ? kap_base * 32 : 0, kn = kc ? 32 * NK : rp;  // kc: this kappa-group's columns only
+        for (int k = threadIdx.x; k < kn && koff + k < rp; k += NTHR) {
             float s = 0.f;
             for (int ww = 0; ww < NWB; ++ww) s += red[ww * rp + k];
-            slab[(size_t)k * Fp + a.Fm] = s;
+            slab[(size_t)(koff + k) * Fp + a.Fm] = s;
         }
         __syncthreads();
     }
