@@ -402,13 +402,16 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         pl->rp_S = 0;
         const char* e = getenv("SNMF_HSTEP_SPLIT");
         if (pl->NLH == 4 && !(e && atoi(e) == 0)) {
-            const int full = pl->rp_tiles >= G ? (pl->rp_tiles / G) * G : 0, R = pl->rp_tiles - full;
-            int S = R > 0 ? (4 * R <= G ? 4 : (2 * R <= G ? 2 : 0)) : 0;
+            // (only a partial round BEHIND whole ones: a problem of fewer tiles than workgroups is latency-bound, and there
+            //  the split's extra steps -- partial stores, the arrival counter, the finishing pass -- cost more than the
+            //  shorter MFMA loops save: C1, 257 x 2000 r = 40, ran 23.3 k iterations/s split against 26.7 k whole)
+            const int full = (pl->rp_tiles / G) * G, R = pl->rp_tiles - full;
+            int S = (full > 0 && R > 0) ? (4 * R <= G ? 4 : (2 * R <= G ? 2 : 0)) : 0;
             while (S > pl->nf) S >>= 1;
             if (S >= 2) {
                 pl->rp_S = S;
                 pl->rp_full = full;
-                pl->rp_grid = full ? G : R * S;
+                pl->rp_grid = G;
             }
         }
     }

@@ -13,7 +13,7 @@ it (rp_part_phase + k_hfinish in csrc/snmf_kernels.h).  A split tile sums Lam in
 parts, i.e. in another fp32 order than the one-workgroup tiles: the default path must equal the plain kernels BIT FOR
 BIT on every pipelined tile and to the stated summation-order tolerance (2e-5 relative per element after two
 iterations) on the split ones.  The shapes cover 4-way and 2-way splits, no split, and problems smaller than one round
-(every tile split).  SNMF_HSTEP_RP / SNMF_HSTEP_SPLIT / SNMF_WSTATS_NL are read when a plan is created, so all variants
+(never split).  SNMF_HSTEP_RP / SNMF_HSTEP_SPLIT / SNMF_WSTATS_NL are read when a plan is created, so all variants
 run in this one process.  (src/sparse_nmf.m:189-208 and :215-239 are the updates all variants implement.)
 """
 import re
@@ -25,7 +25,7 @@ pytestmark = pytest.mark.gpu
 
 SHAPES = [(65, 70, 12000), (129, 70, 12000), (65, 32, 12000), (64, 70, 12000), (97, 96, 20000), (257, 40, 20000),
           (33, 8, 30000), (161, 200, 9000), (257, 256, 30000), (225, 100, 17000), (513, 64, 12000),
-          (257, 40, 1000), (65, 70, 3000), (257, 256, 9000), (129, 24, 40),  # fewer tiles than workgroups: every tile split
+          (257, 40, 1000), (65, 70, 3000), (257, 256, 9000), (129, 24, 40),  # fewer tiles than workgroups (never split: latency-bound) / a short partial round
           # 9..16 row tiles: k_hstep_rh (one ratio image, pipelined by half tiles) and k_wstats with loader waves on a
           # compact V image -- the reference's shipped F = 513 at R = 100 / 200 (settings/initial_setting_SNMF_NAT.m:21-29,48-49)
           (513, 100, 12000), (513, 200, 9000), (513, 256, 5000), (385, 100, 12000), (449, 250, 9000), (512, 128, 8000),
