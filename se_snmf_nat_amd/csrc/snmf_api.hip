@@ -378,6 +378,9 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
                     lds_cap, lds_cap / 64 - 16);
     }
     if (const char* e = getenv("SNMF_HSTEP_RP")) pl->hstep_rp = atoi(e) != 0;
+    // A workgroup with a single tile has nothing to pipeline: the role pipelines' hand-offs then only add latency (C1,
+    // 257 x 2000 r = 40, 63 tiles: k_hstep 16.9 us against k_hstep_rp 18.5), so such problems take the barrier-phased kernel
+    if ((T + 31) / 32 <= ctx->n_cu) pl->hstep_rp = false;
     // F = 513 (9..16 row tiles): two whole tile buffers do not fit, but two H blocks + ONE ratio image do -- k_hstep_rh
     // pipelines on half tiles.  One pair of column tiles per wave of its P2 team: rp <= 256.
     pl->lds_rh = std::max<size_t>(((size_t)2 * 32 * pl->ldh + (size_t)32 * pl->ldr + pl->rp) * 4 + 96, 2 * kMaxNW * 64 * sizeof(double));
@@ -434,6 +437,9 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         // stage only the row group's 32 * NWB columns of V (the kernel's ldv), so F = 513 fits as well
         const size_t buf_ld = ((size_t)pl->TTW * pl->ldhw + (size_t)pl->TTW * 32 * pl->NWB) * 4;
         pl->NLW = (pl->WPS == 2 && 2 * buf_ld + (size_t)pl->rp * 4 + 320 <= lds_cap) ? 4 : 0;
+        // (loader waves pay from the second tile of a workgroup on; with one tile each -- C1: 63 tiles -- the synchronous
+        //  4-wave geometry is faster: 12.7 us against 16.4)
+        if (n_tiles_w <= ctx->n_cu / std::max(1, ((pl->nf + 3) / 4) * pl->n_kg)) pl->NLW = 0;
         if (const char* e = getenv("SNMF_WSTATS_NL")) pl->NLW = (atoi(e) == 4 && pl->NLW == 4) ? 4 : 0;
         size_t buf = buf_ld;
         if (!pl->NLW && pl->NWB == 8) {  // the eight-consumer geometry exists with loader waves only
