@@ -807,6 +807,7 @@ static StepArgs make_args(snmf_plan* pl) {
     a.Tp = pl->Tp;
     a.nf = pl->nf;
     a.nk = pl->nk;
+    a.nqk = (pl->p.r + 7) / 8;
     a.ldh = pl->ldh;
     a.ldr = pl->ldr;
     a.lam_is_u = pl->p.sparsity_kind == SNMF_SPARSITY_SCALAR ? 1 : 0;

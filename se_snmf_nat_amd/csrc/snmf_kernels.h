@@ -144,6 +144,8 @@ struct StepArgs {
     int n_ch1;            // k_wstats: > 0 = row group 1 has its own, smaller, number of frame chunks (1-D grid)
     int kc;               // k_wstats, WM = 3 (V * H^T needs no Lam'): each kappa-group stages only ITS 32*NK columns of H
     int F, T, Fp, rp, Tp, nf, nk;
+    int nqk;              // 8-deep k-blocks of the contractions over the components = ceil(r / 8): W's columns / H's rows
+                          // r .. rp-1 are zero padding, so the blocks past it (r = 100: 3 of 16) only add zeros and are skipped
     int Fm;               // rows covered by MFMA tiles = 32*nf
     int Fq;               // contraction length of W^T*ratio = Fm + 8*xr
     int xr;               // 1: F = Fm + 1, the last row ("Nyquist bin") is handled on the VALU
@@ -512,7 +514,7 @@ __device__ __forceinline__ void hstep_p1_tiles(const StepArgs& a, float* Hs, flo
                 }
         }
         contract_buf<NT, false>(acc, wimage_rsrc(a.Wt4, (size_t)a.nf * rp * 32), lane * 16, phi * rp * 128, Hs + flt * ldh + 4 * h,
-                                32 * ldh, rp / 8);
+                                32 * ldh, a.nqk);
         // epilogue: lane (t = fl, h), reg -> f = 32*phi + drow(reg,h)
         float dsum = 0.f;
 #pragma unroll
@@ -1224,7 +1226,7 @@ __device__ __forceinline__ double rp_part_p1(const StepArgs& a, float* Hs, const
             const int phi = pp + i * pS;
             f32x16 acc[1] = {zero16()};
             const int so[1] = {phi * rp * 128};
-            contract_shared_buf<1>(acc, rsw, lane * 16, so, sp, rp / 8, gate_ready);
+            contract_shared_buf<1>(acc, rsw, lane * 16, so, sp, a.nqk, gate_ready);
             gate_v();
             rp_p1_epilogue<OBJ>(a, acc[0], Rs, phi, t0, lane, dsum);
         }
@@ -1233,11 +1235,12 @@ __device__ __forceinline__ double rp_part_p1(const StepArgs& a, float* Hs, const
         rp_post(p1a, w, (unsigned)(j + 1), lane);
     } else {
         // item w = (row tile w >> 1, k half w & 1): partial Lam -> the cells of a row tile the part does not own
-        const int nqs = rp / 16, it_i = w >> 1, it_k = w & 1;
+        const int it_i = w >> 1, it_k = w & 1;
+        const int nq0 = (a.nqk + 1) / 2, qb = it_k ? nq0 : 0, nqs = it_k ? a.nqk - nq0 : nq0;  // this item's k-blocks [qb, qb + nqs)
         if (w < 2 * pnrt) {
             f32x16 acc[1] = {zero16()};
-            const int so[1] = {(pp + it_i * pS) * rp * 128 + it_k * nqs * 1024};
-            contract_shared_buf<1>(acc, rsw, lane * 16, so, sp + 8 * it_k * nqs, nqs, gate_ready);
+            const int so[1] = {(pp + it_i * pS) * rp * 128 + qb * 1024};
+            contract_shared_buf<1>(acc, rsw, lane * 16, so, sp + 8 * qb, nqs, gate_ready);
             gate_v();  // (the V commit of the loaders must not land on top of the scratch cells)
             float* d = Rs + fl * ldr + part_scratch_tile(w, pp, pS) * 32 + 4 * h;
 #pragma unroll
@@ -1570,7 +1573,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                 if (phi + NA < a.nf) {
                     f32x16 acc[2] = {zero16(), zero16()};
                     const int so[2] = {phi * rp * 128, (phi + NA) * rp * 128};
-                    contract_shared_buf<2>(acc, wimage_rsrc(a.Wt4, (size_t)a.nf * rp * 32), lane * 16, so, sp, rp / 8, gate_ready);
+                    contract_shared_buf<2>(acc, wimage_rsrc(a.Wt4, (size_t)a.nf * rp * 32), lane * 16, so, sp, a.nqk, gate_ready);
                     SNMF_STAMP(4);
                     gate_v();
                     rp_p1_epilogue<OBJ>(a, acc[0], Rs, phi, t0, lane, dsum);
@@ -1580,7 +1583,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                 } else {
                     f32x16 acc[1] = {zero16()};
                     const int so[1] = {phi * rp * 128};
-                    contract_shared_buf<1>(acc, wimage_rsrc(a.Wt4, (size_t)a.nf * rp * 32), lane * 16, so, sp, rp / 8, gate_ready);
+                    contract_shared_buf<1>(acc, wimage_rsrc(a.Wt4, (size_t)a.nf * rp * 32), lane * 16, so, sp, a.nqk, gate_ready);
                     gate_v();
                     rp_p1_epilogue<OBJ>(a, acc[0], Rs, phi, t0, lane, dsum);
                     if (phi == w) rp_post(p1a, w, (unsigned)(j + 1), lane);
@@ -1911,14 +1914,14 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rh(StepArgs a) {
                 if (phi + NA < a.nf) {
                     f32x16 acc[2] = {zero16(), zero16()};
                     const int so[2] = {phi * rp * 128, (phi + NA) * rp * 128};
-                    contract_shared_buf<2>(acc, rsw, lane * 16, so, sp, rp / 8, gate_ready);
+                    contract_shared_buf<2>(acc, rsw, lane * 16, so, sp, a.nqk, gate_ready);
                     rp_await(vready, (unsigned)(u + 1), a.stop);  // the V half, and with it: the B team is through with ratio half u-2
                     rp_p1_epilogue<OBJ>(a, acc[0], Rs, phi, t0, lane, dsum);
                     rp_p1_epilogue<OBJ>(a, acc[1], Rs, phi + NA, t0, lane, dsum);
                 } else if (phi < a.nf) {
                     f32x16 acc[1] = {zero16()};
                     const int so[1] = {phi * rp * 128};
-                    contract_shared_buf<1>(acc, rsw, lane * 16, so, sp, rp / 8, gate_ready);
+                    contract_shared_buf<1>(acc, rsw, lane * 16, so, sp, a.nqk, gate_ready);
                     rp_await(vready, (unsigned)(u + 1), a.stop);
                     rp_p1_epilogue<OBJ>(a, acc[0], Rs, phi, t0, lane, dsum);
                 } else {
@@ -2679,8 +2682,8 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
             {
                 const __amdgpu_buffer_rsrc_t rsw = wimage_rsrc(a.Wt4, (size_t)a.nf * rp * 32);
                 const float* spl = Hs + (fl & (TT - 1)) * ldh + 4 * h;
-                if (rp == 256) contract_p3_buf<true>(acc1[0], rsw, lane * 16, phi * rp * 128, spl, 32, NoGate());
-                else contract_p3_buf<false>(acc1[0], rsw, lane * 16, phi * rp * 128, spl, rp / 8, NoGate());
+                if (a.nqk == 32) contract_p3_buf<true>(acc1[0], rsw, lane * 16, phi * rp * 128, spl, 32, NoGate());
+                else contract_p3_buf<false>(acc1[0], rsw, lane * 16, phi * rp * 128, spl, a.nqk, NoGate());
             }
             SNMF_STAMP(3);
             const f32x16 acc = acc1[0];
@@ -2714,12 +2717,10 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         }
         // ---- P4: G[phi, kap] += ratio[f, t] * H[k, t]  (A = ratio registers, B = H from LDS)
         // B fragments (one ds_read_b32 per MFMA) are fetched a whole kappa-tile (16 reads) ahead.
-        // kappa-tiles beyond nk (NK is a template bound) are clamped: they recompute the last real
-        // tile into an accumulator that is never stored, which keeps the loop branch-free.
+        // kappa-tiles beyond nk (NK is a template bound) are skipped by a scalar test.
         SNMF_STAMP(4);
-        // The H image of this kernel is padded to 32*NK columns per kappa-group (host: ldh), so tiles
-        // beyond nk read finite padding into accumulators that are never stored -- no clamps, and
-        // every read is (one of 16 row bases) + an immediate offset.
+        // The H image of this kernel is padded to 32*NK columns per kappa-group (host: ldh), so the prefetch of a tile
+        // beyond nk reads finite padding -- no clamps, and every read is (one of 16 row bases) + an immediate offset.
         const float* hb = Hs + (4 * h) * ldh + fl + (kc ? 0 : kap_base * 32);
         const float* hrow[16];
 #pragma unroll
@@ -2733,9 +2734,11 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         // the tile index is a compile-time constant so that G[] is never indexed dynamically
 #define SNMF_KTILE(KP, CUR, NXT)                                                  \
     if constexpr ((KP) < NK) {                                                    \
-        if constexpr ((KP) + 1 < NK) ldb(NXT, (KP) + 1);                          \
-        SNMF_PIN();                                                               \
-        _Pragma("unroll") for (int i = 0; i < TT / 2; ++i) G[KP] = mfma32(R[i], CUR[i], G[KP]); \
+        if (kap_base + (KP) < a.nk) { /* (scalar test: tiles past nk -- r = 200: the 8th of NK = 8 -- hold padding only) */ \
+            if constexpr ((KP) + 1 < NK) ldb(NXT, (KP) + 1);                      \
+            SNMF_PIN();                                                           \
+            _Pragma("unroll") for (int i = 0; i < TT / 2; ++i) G[KP] = mfma32(R[i], CUR[i], G[KP]); \
+        }                                                                         \
     }
         ldb(b0, 0);
         SNMF_KTILE(0, b0, b1)
