@@ -910,13 +910,13 @@ static int launch_hstep(snmf_plan* pl, bool obj, bool upd) {
 }
 
 // k_wstats dispatch
-template <int NK, int NWB, int NL, int WPS, int WM, int BM, bool OBJ, int TT = 32>
+template <int NK, int NWB, int NL, int WPS, int WM, int BM, bool OBJ, int TT = 32, int LX = 0>
 static int launch_wstats_one(snmf_plan* pl, const StepArgs& a, int mat_index) {
     const bool split = pl->n_ch1 > 0;  // uneven row-group split: 1-D grid, group 0's chunks first
     dim3 g(split ? pl->n_chunks + (pl->n_fg - 1) * pl->n_ch1 : pl->n_chunks, split ? 1 : pl->n_fg, pl->n_kg), b((NWB + NL) * 64);
     StepArgs as = a;
     as.n_ch1 = split ? pl->n_ch1 : 0;
-    auto kern = k_wstats<NK, NWB, NL, WPS, WM, BM, OBJ, TT>;
+    auto kern = k_wstats<NK, NWB, NL, WPS, WM, BM, OBJ, TT, LX>;
     SN_TRY(ensure_dyn_lds(pl->ctx->device, (const void*)kern, pl->lds_w));
     hipLaunchKernelGGL(kern, g, b, pl->lds_w, pl->ctx->stream, as, pl->n_chunks, mat_index, pl->n_mat);
     HIP_TRY(hipGetLastError());
@@ -925,6 +925,17 @@ static int launch_wstats_one(snmf_plan* pl, const StepArgs& a, int mat_index) {
 template <int NK, int NWB, int NL, int WPS, int TT = 32>
 static int launch_wstats_geo(snmf_plan* pl, const StepArgs& a, bool obj) {
     if (pl->bm == BM_KL) {
+        // statistics columns past the last full 32-column tile: up to 8 go through the VALU (k_wstats<..., LX>; loader
+        // geometries only: r = 100 at the reference's settings)
+        const int left = pl->p.r - 32 * (pl->nk - 1);
+        const int lx = (pl->nk >= 2 && pl->n_kg == 1 && left <= 8) ? (left + 3) / 4 : 0;
+        // (NK = 4 geometries only: at NK = 8 -- 128 accumulator registers -- the extra code spills: 69 VGPRs at LX = 2)
+        if constexpr (NL > 0 && TT == 32 && NK == 4) {
+            if (lx == 1) return obj ? launch_wstats_one<NK, NWB, NL, WPS, 0, BM_KL, true, TT, 1>(pl, a, 0)
+                                    : launch_wstats_one<NK, NWB, NL, WPS, 0, BM_KL, false, TT, 1>(pl, a, 0);
+            if (lx == 2) return obj ? launch_wstats_one<NK, NWB, NL, WPS, 0, BM_KL, true, TT, 2>(pl, a, 0)
+                                    : launch_wstats_one<NK, NWB, NL, WPS, 0, BM_KL, false, TT, 2>(pl, a, 0);
+        }
         return obj ? launch_wstats_one<NK, NWB, NL, WPS, 0, BM_KL, true, TT>(pl, a, 0)
                    : launch_wstats_one<NK, NWB, NL, WPS, 0, BM_KL, false, TT>(pl, a, 0);
     }
@@ -954,6 +965,7 @@ static int launch_wstats(snmf_plan* pl, bool obj) {
     a.n_tiles = (pl->p.T + pl->TTW - 1) / pl->TTW;
     a.ldh = pl->ldhw;
     a.stagger = pl->stagger_w;
+
     ScopedTimer tm(pl->ctx, FAM_WSTATS);
     if (pl->NKT == 4 && pl->NWB == 8) return launch_wstats_geo<4, 8, 4, 3>(pl, a, obj);
     if (pl->NKT == 4) return pl->NLW ? launch_wstats_geo<4, 4, 4, 2>(pl, a, obj) : launch_wstats_geo<4, 4, 0, 2>(pl, a, obj);

@@ -2419,7 +2419,10 @@ __global__ __launch_bounds__(512, 2) void k_hsolve_frame(StepArgs a, SmallArgs s
 // CU when the accumulators leave room).
 // TT = frames per tile (32; 16 = narrow tiles for shapes whose 32-frame H image does not fit the LDS: lanes / rows past
 // the tile carry duplicates that are masked out of the ratio, P4 contracts over TT frames only, P3 wastes half its MFMAs).
-template <int NK, int NWB, int NL, int WPS, int WM, int BM, bool OBJ, int TT = 32>
+// LX: 16-byte groups (1 or 2) of statistics columns past the last FULL 32-column tile that are accumulated on the VALU
+// instead of a nearly empty MFMA tile (r = 100: 4 columns, r = 200: 8); 0 = every column tile through the MFMAs.  A template
+// parameter: as a run-time branch the extra code cost the 8+4-wave geometry 113 spilled VGPRs.
+template <int NK, int NWB, int NL, int WPS, int WM, int BM, bool OBJ, int TT = 32, int LX = 0>
 __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int n_chunks, int mat_index,
                                                                  int n_mat) {
     static_assert(TT == 32 || (TT == 16 && NL == 0), "narrow tiles: 16 frames, synchronous staging");
@@ -2474,6 +2477,14 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     f32x16 G[NK];
 #pragma unroll
     for (int k = 0; k < NK; ++k) G[k] = zero16();
+    // Leftover columns (LX): r = 100 is three full 32-column tiles + 4 columns, r = 200 six + 8 -- the reference's own
+    // ranks (settings/initial_setting_SNMF_NAT.m:48-49).  A fourth / seventh MFMA tile would be 87 % / 75 % padding; the
+    // few columns are accumulated here instead: this lane holds ratio[f, t] for its 16 frames, so
+    // gl[j] += sum_i R[i] * H[k0 + j, t_i]  (one broadcast ds_read_b128 per frame), the two lane halves are added at the end.
+    const int nkm = LX ? a.nk - 1 : a.nk;  // column tiles that go through the MFMAs
+    float gl[LX ? 4 * LX : 1];
+#pragma unroll
+    for (int j = 0; j < (LX ? 4 * LX : 1); ++j) gl[j] = 0.f;
     // row sums of H: kept by the staging threads (loaders, or everybody when NL = 0);
     // thread <-> k = sid + j*NST, j < 4 (rp <= 4*NST checked on the host)
     constexpr int NST = NL > 0 ? NL * 64 : NWB * 64;
@@ -2734,7 +2745,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         // the tile index is a compile-time constant so that G[] is never indexed dynamically
 #define SNMF_KTILE(KP, CUR, NXT)                                                  \
     if constexpr ((KP) < NK) {                                                    \
-        if (kap_base + (KP) < a.nk) { /* (scalar test: tiles past nk -- r = 200: the 8th of NK = 8 -- hold padding only) */ \
+        if (kap_base + (KP) < nkm) { /* (scalar test: tiles past the last one that goes through the MFMAs are skipped) */ \
             if constexpr ((KP) + 1 < NK) ldb(NXT, (KP) + 1);                      \
             SNMF_PIN();                                                           \
             _Pragma("unroll") for (int i = 0; i < TT / 2; ++i) G[KP] = mfma32(R[i], CUR[i], G[KP]); \
@@ -2758,6 +2769,28 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         SNMF_KTILE(14, b0, b1)
         SNMF_KTILE(15, b1, b0)
 #undef SNMF_KTILE
+        if constexpr (LX > 0) {  // the leftover columns, on the VALU
+            const int koff = (a.nk - 1) * 32 - fl;  // hrow[i] points at column fl of frame t_i
+            // (four frames at a time, fenced: left alone the compiler hoists all 16 / 32 reads -- 64+ live registers, spills)
+#pragma unroll
+            for (int i0 = 0; i0 < TT / 2; i0 += 4) {
+#pragma unroll
+                for (int i = i0; i < i0 + 4; ++i) {
+                    const f32x4 h0 = *reinterpret_cast<const f32x4*>(hrow[i] + koff);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) gl[e] += R[i] * h0[e];
+                }
+                if constexpr (LX > 1) {
+#pragma unroll
+                    for (int i = i0; i < i0 + 4; ++i) {
+                        const f32x4 h1 = *reinterpret_cast<const f32x4*>(hrow[i] + koff + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) gl[4 + e] += R[i] * h1[e];
+                    }
+                }
+                SNMF_PIN();
+            }
+        }
         if (NL > 0) rp_post(done, w, (unsigned)(it + 1), lane);  // this wave's last LDS read of the tile fed the MFMAs above
         SNMF_STAMP(5);
     }
@@ -2776,7 +2809,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         float* slab = a.slabs + ((size_t)chunk * n_mat + mat_index) * rp * Fp;
 #pragma unroll
         for (int kap = 0; kap < NK; ++kap) {
-            if (kap_base + kap < a.nk) {
+            if (kap_base + kap < nkm) {
                 float* dst = slab + (size_t)((kap_base + kap) * 32 + fl) * Fp + phi * 32 + 4 * h;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -2784,6 +2817,15 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
                     *reinterpret_cast<f32x4*>(dst + 8 * g) = o;
                 }
             }
+        }
+    }
+    if (active && LX > 0) {  // leftover columns: slab[k0 + j][f] = the two lane halves' partial sums (fixed order: h = 0, then h = 1)
+        float* slab = a.slabs + ((size_t)chunk * n_mat + mat_index) * rp * Fp;
+        const int k0 = (a.nk - 1) * 32;
+#pragma unroll
+        for (int j = 0; j < 4 * LX; ++j) {
+            const float other = __shfl_xor(gl[j], 32, 64);
+            if (h == 0 && k0 + j < rp) slab[(size_t)(k0 + j) * Fp + phi * 32 + fl] = gl[j] + other;
         }
     }
     if (NL > 0) {
