@@ -254,7 +254,7 @@ def sparse_nmf(v, p=None, *, ctx=None, dtype=np.float64, rng=None, devices=None)
     `dtype` selects the host-buffer type handed over the C ABI (the device arithmetic is fp32
     MFMA + fp64 objective either way).  `devices`: list of device ordinals -> the frame axis is sharded over
     that many ranks inside this one process (snmf_sparse_nmf_multi_*), same results up to the fp64 summation order
-    of the W statistics."""
+    of the W statistics; the multi-device entry creates a context per rank itself, so `ctx` is not used then."""
     return _solve(v, p, gpu_variant=False, ctx=ctx, dtype=dtype, rng=rng, devices=devices)
 
 
