@@ -1154,15 +1154,17 @@ __device__ __forceinline__ void rp_p2_consts(const StepArgs& a, int kap, int lan
 // W and V (and the whole H tile), and P2 is linear in the ratio rows, so part p of S forms the ratio rows of its own
 // 32-row tiles phi = p, p + S, ... and contracts W^T*ratio over exactly those rows -- a PARTIAL numerator [rp x 32].
 // The tiles of the last partial round are dealt out S parts each over the workgroups that would otherwise idle, and a
-// workgroup's part is simply one more tile of its list (staged by the loaders like any other, index nmy):
-//   A team: P1 of the part's row tiles, under the B team's P2 of the last whole tile (the pipeline's drain).  A part with
-//       at most two row tiles (F = 257, S = 4) is ALSO cut in two over k so that all four A waves have an item; the two
-//       partial Lam tiles of a row tile meet in the ratio image's cells of row tiles the part does not own;
+// workgroup's part is one more item of its list, staged by the loaders like any tile, in the SECOND TO LAST place:
+//   A team: P1 of the part's row tiles.  A part with at most two row tiles (F = 257, S = 4) is ALSO cut in two over k so
+//       that all four A waves have an item; the two partial Lam tiles of a row tile meet in the ratio image's cells of
+//       row tiles the part does not own;
 //   B team: W^T*ratio over the part's k-blocks (4 per own row tile, + the extra row's for the last part) -> partial
 //       numerator to HBM in MFMA fragment order, through agent-scope (sc1, write-through) stores;
-//   the LAST of a tile's S workgroups to arrive (one agent-scope counter per tile; nobody waits for anybody) adds the S
+//   loaders: when every B wave has seen its stores acknowledged, bump the tile's agent-scope arrival counter (all of this
+//       runs under the workgroup's last whole tile);
+//   at the end of the kernel the LAST of a tile's S workgroups to have arrived (nobody waits for anybody) adds the S
 //       partials in part order -- sc1 loads, so no stale L2 line of its XCD can answer -- and applies the H update from
-//       the H tile it has in LDS anyway, exactly as rp_p2_epilogue forms it (+ the tile's share of sum(S .* H)).
+//       the H block it still has in LDS, exactly as rp_p2_epilogue forms it (+ the tile's share of sum(S .* H)).
 // Summation order of a split tile: Lam possibly in two k ranges, the numerator in S row parts -- fp32, a few ulp from
 // the one-workgroup order of the pipelined tiles (tests/test_gpu_pipelined_vs_plain.py states the tolerance).
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -1196,9 +1198,10 @@ __device__ __forceinline__ PartGeo part_geo(const StepArgs& a) {
     g.own_x = a.xr && g.pp == g.S - 1;
     return g;
 }
-// The three steps of a split tile run AFTER the tile loops of their role, not as a branch inside them: the loops sit at
-// the 168-VGPR limit of three waves per SIMD, and with the part's code in the loop body the pipelined tiles got 5 % slower
-// (22 spilled VGPRs); as real (not inlined) functions they need scratch for their arguments and are slower still.
+// The steps of a split tile are NOT a branch inside the tile loops of their role: the loops sit at the 168-VGPR limit of
+// three waves per SIMD, and with the part's code in the loop body the pipelined tiles got 5 % slower (22 spilled VGPRs);
+// as real (not inlined) functions they need scratch for their arguments and are slower still.  The loops are peeled
+// instead: the part and the workgroup's last whole tile are straight-line code behind them.
 // A team, wave w: P1 of the part's row tiles; returns the divergence terms (OBJ).  cnt: the kernel's progress slots.
 template <bool OBJ>
 __device__ __forceinline__ double rp_part_p1(const StepArgs& a, float* Hs, const float* wxs, unsigned* cnt, int j, int ptile, int w, int lane) {
@@ -1341,56 +1344,67 @@ __device__ __forceinline__ void rp_part_p2(const StepArgs& a, const float* Rs, u
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partial is at the coherence point before this wave reports
+    rp_post(cnt + 12, wb, (unsigned)(j + 1), lane);     // p2done of the part's place in the list: the loaders bump the arrival counter
 }
-// All waves: whoever bumps the tile's counter to a multiple of S is the last of its S workgroups and finishes the tile:
+// All waves, at the very end of the kernel: the workgroup that bumped the tile's counter to a multiple of S (loader wave 0,
+// right after the part's P2, a whole tile period ago) was the last of the tile's S workgroups and finishes the tile:
 // numerator = the S partials in part order, then H <- H .* dmh ./ dph as rp_p2_epilogue forms it; returns the tile's
 // share of sum(S .* H) of the previous iterate (OBJ).  Hs: the split tile's H block, staged for P1.
 template <bool OBJ>
-__device__ __forceinline__ double rp_part_finish(const StepArgs& a, const float* Hs, unsigned* plast, int ptile, int n_full) {
+__device__ __forceinline__ double rp_part_finish(const StepArgs& a, const float* Hs, const unsigned* plast, int ptile) {
     constexpr int NTHR = 768, Tt = 32;
     const PartGeo pg = part_geo(a);
     const int rp = a.rp, ldh = a.ldh, pS = pg.S;
-    __syncthreads();  // every wave of the B team has waited for its partial stores
-    if (threadIdx.x == 0) {
-        const unsigned old = __hip_atomic_fetch_add(a.part_cnt + (ptile - n_full), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *plast = (old % (unsigned)pS == (unsigned)pS - 1u) ? 1u : 0u;
-    }
-    __syncthreads();
+    __syncthreads();  // every role is through its list; loader wave 0 wrote *plast when it bumped the tile's arrival counter
     if (!*plast) return 0.0;
     const int u0 = (int)blockIdx.x - pg.pp;  // first of the tile's S units
     const __amdgpu_buffer_rsrc_t rsp_ = __builtin_amdgcn_make_buffer_rsrc(a.part_buf + (size_t)u0 * Tt * rp, 0, pS * Tt * rp * 4, 0x00020000);
     float shsum = 0.f;
-    for (int idx = threadIdx.x; idx < a.nk * 256; idx += NTHR) {
-        const int kap = idx >> 8, g = (idx >> 6) & 3, ln = idx & 63, fl = ln & 31, h = ln >> 5;
-        f32x4 x[8];
+    // The partials come from memory (sc1: ~2 us a round trip): all loads of a batch of three elements per thread are issued
+    // before the first is used (one element at a time it was three dependent round trips for rp = 256: the most
+    // expensive part of the whole split)
+    constexpr int NB3 = 3;
+    for (int idx0 = threadIdx.x; idx0 < a.nk * 256; idx0 += NB3 * NTHR) {
+        f32x4 x[NB3][4];  // S <= 4 here (8-way splits do not exist yet)
 #pragma unroll
-        for (int p = 0; p < 8; ++p)
-            if (p < pS) x[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsp_, idx * 16, p * Tt * rp * 4, kAuxSC1));
-        const int t = ptile * Tt + fl, k0 = kap * 32 + 8 * g + 4 * h;
-        const f32x4 ho = *reinterpret_cast<const f32x4*>(Hs + fl * ldh + k0);
-        f32x4 spv = {0.f, 0.f, 0.f, 0.f}, o, den;
-        if (a.S) {
-            spv = *reinterpret_cast<const f32x4*>(a.S + (size_t)t * rp + k0);
-            const f32x4 cs = *reinterpret_cast<const f32x4*>(a.colsum + k0);
+        for (int b = 0; b < NB3; ++b) {
+            const int idx = idx0 + b * NTHR;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) den[jj] = fmaxf(cs[jj] + spv[jj], kFlr);
-        } else {
-            if (OBJ && !a.lam_is_u) spv = *reinterpret_cast<const f32x4*>(a.lamk + k0);
-            den = *reinterpret_cast<const f32x4*>(a.dphv + k0);
+            for (int p = 0; p < 4; ++p)
+                if (p < pS && idx < a.nk * 256)
+                    x[b][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsp_, idx * 16, p * Tt * rp * 4, kAuxSC1));
         }
-        f32x4 num = x[0];
 #pragma unroll
-        for (int p = 1; p < 8; ++p)
-            if (p < pS) {
+        for (int b = 0; b < NB3; ++b) {
+            const int idx = idx0 + b * NTHR;
+            if (idx >= a.nk * 256) break;
+            const int kap = idx >> 8, g = (idx >> 6) & 3, ln = idx & 63, fl = ln & 31, h = ln >> 5;
+            const int t = ptile * Tt + fl, k0 = kap * 32 + 8 * g + 4 * h;
+            const f32x4 ho = *reinterpret_cast<const f32x4*>(Hs + fl * ldh + k0);
+            f32x4 spv = {0.f, 0.f, 0.f, 0.f}, o, den;
+            if (a.S) {
+                spv = *reinterpret_cast<const f32x4*>(a.S + (size_t)t * rp + k0);
+                const f32x4 cs = *reinterpret_cast<const f32x4*>(a.colsum + k0);
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) num[jj] += x[p][jj];
+                for (int jj = 0; jj < 4; ++jj) den[jj] = fmaxf(cs[jj] + spv[jj], kFlr);
+            } else {
+                if (OBJ && !a.lam_is_u) spv = *reinterpret_cast<const f32x4*>(a.lamk + k0);
+                den = *reinterpret_cast<const f32x4*>(a.dphv + k0);
             }
+            f32x4 num = x[b][0];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) o[jj] = ho[jj] * num[jj] * fast_rcp(den[jj]);
-        *reinterpret_cast<f32x4*>(a.Hout + (size_t)t * rp + k0) = o;
-        if (OBJ) {
-            if (a.lam_is_u && !a.S) shsum += a.lam_u * ((ho[0] + ho[1]) + (ho[2] + ho[3]));
-            else shsum += (spv[0] * ho[0] + spv[1] * ho[1]) + (spv[2] * ho[2] + spv[3] * ho[3]);
+            for (int p = 1; p < 4; ++p)
+                if (p < pS) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) num[jj] += x[b][p][jj];
+                }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) o[jj] = ho[jj] * num[jj] * fast_rcp(den[jj]);
+            *reinterpret_cast<f32x4*>(a.Hout + (size_t)t * rp + k0) = o;
+            if (OBJ) {
+                if (a.lam_is_u && !a.S) shsum += a.lam_u * ((ho[0] + ho[1]) + (ho[2] + ho[3]));
+                else shsum += (spv[0] * ho[0] + spv[1] * ho[1]) + (spv[2] * ho[2] + spv[3] * ho[3]);
+            }
         }
     }
     return (double)shsum;
@@ -1436,8 +1450,13 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
     const int nmy = (int)blockIdx.x < n_full ? (n_full - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     const bool has_part = a.part_S > 0 && (int)blockIdx.x < (a.n_tiles - n_full) * a.part_S;
     const int ptile = has_part ? n_full + (int)blockIdx.x / a.part_S : 0;
-    const int nst = nmy + (has_part ? 1 : 0);  // tiles the loaders stage and the teams work on
-    auto tile_of = [&](int j) { return j < nmy ? (int)blockIdx.x + j * (int)gridDim.x : ptile; };
+    // A workgroup's list of nst items: its nmy pipelined tiles with, when it has one, its part of a split tile in the
+    // SECOND TO LAST place -- so that the part's tail (partial stores acknowledged, the arrival counter) runs under the
+    // last whole tile instead of at the end of the kernel, where only the last arriver's finishing pass is left.
+    const int nst = nmy + (has_part ? 1 : 0);
+    const int ppos = has_part ? nmy - 1 : 0x7fffffff;  // (has_part: n_full >= gridDim.x, so nmy >= 1)
+    auto tile_of = [&](int j) { return j < ppos ? (int)blockIdx.x + j * (int)gridDim.x : (j == ppos ? ptile : (int)blockIdx.x + (j - 1) * (int)gridDim.x); };
+    unsigned* const plast = cnt + 24;  // 1: this workgroup was the last of its split tile's to arrive (set by loader wave 0)
 
     if (w >= NA + NB) {
         // ================================ loaders ===================================================
@@ -1491,7 +1510,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             rp_post(ready, lw, (unsigned)(j + 1), lane);
             rp_post(vready, lw, (unsigned)(j + 1), lane);
         }
-        for (int j = 0; j < nmy; ++j) {
+        for (int j = 0; j < nst; ++j) {
             float* bH = lds + (j & 1) * bufsz;
             const bool more = j + 2 < nst;  // (the workgroup's share of a split tile is staged like one more tile)
             // tile j+2 -> registers while tile j is still being worked on.  Every access below is UNCONDITIONAL: a slot past
@@ -1513,6 +1532,16 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             }
             SNMF_PIN();
             rp_await(p2done, (unsigned)(j + 1), a.stop);
+            if (j == ppos) {
+                // the part: nothing to copy out (its H block stays for the finishing pass: no later item takes this buffer).
+                // Every B wave has waited for its partial stores: bump the tile's arrival counter; whoever brings it to a
+                // multiple of S is the last of the tile's S workgroups and will finish it at the end of the kernel
+                if (lw == 0 && lane == 0) {
+                    const unsigned old = __hip_atomic_fetch_add(a.part_cnt + (ptile - n_full), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *plast = (old % (unsigned)a.part_S == (unsigned)a.part_S - 1u) ? 1u : 0u;
+                }
+                continue;
+            }
             float* const dstH = a.Hout + (size_t)tile_of(j) * Tt * rp;
             if (!fits) {  // shape too big for the register path: plain copy-out, then a plain (latency-exposed) refill
                 stage_out<NLT>(dstH, bH, Tt, rp, ldh, lt);
@@ -1551,7 +1580,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
     } else if (w < NA) {
         // ================================ A team: P1 ================================================
         SNMF_STAMP_DECL
-        for (int j = 0; j < nmy; ++j) {
+        auto a_item = [&](const int j) {  // P1 of the whole tile in place j of the list
             const int t0 = tile_of(j) * Tt;
             float* Hs = lds + (j & 1) * bufsz;
             float* Rs = Hs + Tt * ldh;
@@ -1603,8 +1632,13 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                 hstep_p1_xrow<NA, 1, BM_KL, OBJ>(a, Hs, Rs, wxs, t0, w, lane, true, acc_div);
                 rp_post(xdone, w, (unsigned)(j + 1), lane);
             }
+        };
+        // (the part and the last tile come after the loop, not as a branch inside it: the loop sits at the register limit)
+        for (int j = 0; j < (has_part ? nmy - 1 : nmy); ++j) a_item(j);
+        if (has_part) {
+            acc_div += rp_part_p1<OBJ>(a, lds + (ppos & 1) * bufsz, wxs, cnt, ppos, ptile, w, lane);
+            a_item(nmy);
         }
-        if (has_part) acc_div += rp_part_p1<OBJ>(a, lds + (nmy & 1) * bufsz, wxs, cnt, nmy, ptile, w, lane);
         SNMF_STAMP_OUT(a.prof + ((size_t)blockIdx.x * (NA + NB) + w) * 12, 12);
         SNMF_STAMP_CLK(a.prof, (size_t)blockIdx.x * (NA + NB) + w);
     } else {
@@ -1618,7 +1652,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             rp_p2_consts(a, wb, lane, dp0);
             if (wb + NB < a.nk) rp_p2_consts(a, wb + NB, lane, dp1);
         }
-        for (int j = 0; j < nmy; ++j) {
+        auto b_item = [&](const int j) {  // P2 of the whole tile in place j of the list
             const int t0 = tile_of(j) * Tt;
             float* Hs = lds + (j & 1) * bufsz;
             const float* Rs = Hs + Tt * ldh;
@@ -1686,13 +1720,17 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             gate_p1b();
             if (a.xr) gate_x();
             rp_post(p2done, wb, (unsigned)(j + 1), lane);
+        };
+        for (int j = 0; j < (has_part ? nmy - 1 : nmy); ++j) b_item(j);
+        if (has_part) {
+            rp_part_p2(a, lds + (ppos & 1) * bufsz + Tt * ldh, cnt, ppos, wb, lane);
+            b_item(nmy);
         }
-        if (has_part) rp_part_p2(a, lds + (nmy & 1) * bufsz + Tt * ldh, cnt, nmy, wb, lane);
         SNMF_STAMP_OUT(a.prof + ((size_t)blockIdx.x * (NA + NB) + w) * 12, 12);
         SNMF_STAMP_CLK(a.prof, (size_t)blockIdx.x * (NA + NB) + w);
     }
 
-    if (has_part) acc_sh += rp_part_finish<OBJ>(a, lds + (nmy & 1) * bufsz, cnt + 24, ptile, n_full);
+    if (has_part) acc_sh += rp_part_finish<OBJ>(a, lds + (ppos & 1) * bufsz, plast, ptile);
 
     if (OBJ) {
         // deterministic workgroup reduction of the two fp64 partial sums (as k_hstep)

@@ -51,6 +51,23 @@ static void snmf_prof_report(snmf_plan* pl) {
                     st.push_back((double)(hs0[i] - t0) * 0.01);
                     en.push_back((double)(hs0[i] - t0 + hc[2 * i + 1]) * 0.01);
                 }
+            if (!wlast && !st.empty()) {
+                // where do the stragglers sit?  mean end time of the workgroups by blockIdx % 8 (the XCD a workgroup lands
+                // on with round-robin dispatch) and by blockIdx / 32 (position in the grid)
+                const int wpg = nw / std::max(1, pl->hstep_rp ? pl->rp_grid : pl->grid_h);  // stamped waves per workgroup
+                double sx[8] = {0}, nx[8] = {0}, sg[8] = {0}, ng[8] = {0};
+                for (int i = 0; i < nw; ++i)
+                    if (hs0[i] && wpg > 0) {
+                        const int wg = i / wpg;
+                        const double e = (double)(hs0[i] - t0 + hc[2 * i + 1]) * 0.01;
+                        sx[wg % 8] += e; nx[wg % 8] += 1;
+                        sg[(wg / 32) % 8] += e; ng[(wg / 32) % 8] += 1;
+                    }
+                fprintf(stderr, " | mean wave end us by blockIdx%%8:");
+                for (int x = 0; x < 8; ++x) fprintf(stderr, " %.1f", nx[x] ? sx[x] / nx[x] : 0.0);
+                fprintf(stderr, " ; by blockIdx/32:");
+                for (int x = 0; x < 8; ++x) fprintf(stderr, " %.1f", ng[x] ? sg[x] / ng[x] : 0.0);
+            }
             if (!st.empty()) {
                 std::sort(st.begin(), st.end());
                 std::sort(en.begin(), en.end());
