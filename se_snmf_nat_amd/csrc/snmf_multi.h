@@ -70,7 +70,9 @@ __global__ __launch_bounds__(256) void k_push_stats(PushArgs a) {
 __global__ __launch_bounds__(256) void k_sum_ranks(const double* __restrict__ slots, int n, size_t len, double* __restrict__ out,
                                                    const unsigned* flags, unsigned seq, int* fault) {
     if (flags) {
-        if ((int)threadIdx.x < n) {
+        // (a time-out is sticky: once the fault word is up nobody waits again, so a lost peer costs one time-out, not one
+        //  per remaining iteration, and the host finds the fault at its next look at the plan's state)
+        if ((int)threadIdx.x < n && !__hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             while ((int)(__hip_atomic_load(flags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
                 if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) {  // 5 s
@@ -459,6 +461,13 @@ extern "C" int snmf_multi_run(snmf_multi* m, int32_t n_iters, int32_t* iters_don
         for (int g = 0; g < m->n; ++g)
             if (m->rc[g] != SNMF_OK) return fail(m->rc[g], "rank %d (device %d): %s", g, m->dev[g], m->err[g].c_str());
         if (m->failed_at.load() != 0x7fffffff) return fail(SNMF_ERR_INTERNAL, "a rank failed");
+        for (int g = 0; g < m->n; ++g) {  // a device-side wait that gave up (FLAGS mode: a peer never arrived) invalidates the run
+            DevState hs{};
+            if (hipSetDevice(m->dev[g]) != hipSuccess) return fail(SNMF_ERR_NO_DEVICE, "hipSetDevice(%d) failed", m->dev[g]);
+            const int rs = read_state(m->plan[g], &hs);
+            if (dev_before >= 0) (void)hipSetDevice(dev_before);
+            if (rs != SNMF_OK) return fail(rs, "rank %d (device %d): %s", g, m->dev[g], g_err.c_str());
+        }
         m->it = m->plan[0]->it_done;
         if (stopped) m->stopped = true;
         else if (finalize) m->finalized = true;
