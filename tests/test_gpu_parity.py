@@ -116,6 +116,14 @@ CASES = [
     ("kl_r1000_wonly", 513, 200, 1000, dict(cf="kl", sparsity=5, max_iter=4), None, "none"),
     ("ed_r1000_full", 513, 200, 1000, dict(cf="ed", sparsity=1, max_iter=3), None, None),
     ("b05_r800_513", 513, 150, 800, dict(cf="beta", beta=0.5, sparsity=1, max_iter=3), None, None),
+    # the reference's shipped geometry (513 rows, R = 100 / 200) with more than one tile per workgroup (T > 256 x 32), so
+    # that the half-tile role pipeline k_hstep_rh, k_wstats on eight consumer waves with the leftover columns on the VALU,
+    # its objective-carrying W-only launch and the trimmed contraction depth (13 / 25 k-blocks) are what runs
+    ("kl_f513_r100_T8400_full", 513, 8400, 100, dict(cf="kl", sparsity=5, max_iter=6), None, None),
+    ("kl_f513_r200_T8400_honly_stop", 513, 8400, 200, dict(cf="kl", sparsity=5, max_iter=60, conv_eps=2e-3), "none", None),
+    ("kl_f513_r100_T8400_wonly", 513, 8400, 100, dict(cf="kl", sparsity=5, max_iter=6), None, "none"),
+    ("kl_f513_r104_T8400_full", 513, 8400, 104, dict(cf="kl", sparsity=5, max_iter=4), None, None),  # 8 leftover columns
+    ("kl_f385_r36_T9000_full", 385, 9000, 36, dict(cf="kl", sparsity=1, max_iter=4), None, None),   # 12 row tiles, 4 leftover columns
 ]
 
 
@@ -151,6 +159,19 @@ def test_sparsity_argument_forms(gpu_ctx):
     for sp in (np.linspace(0, 9, 24).reshape(-1, 1), np.abs(rs.randn(24, 300)) * 4, np.full((24, 300), 2.0)):
         for cf in ("kl", "ed"):
             p = dict(cf=cf, sparsity=sp, max_iter=15, init_w=W0, init_h=H0, cost_check=1)
+            check(sparse_nmf(V, p, ctx=gpu_ctx), oracle_nmf(V, p))
+
+
+def test_sparsity_forms_on_the_pipelined_kernels(gpu_ctx):
+    """r x 1 and full r x n sparsity (src/sparse_nmf.m:150-155) through the pipelined KL kernels: a shape whose last
+    partial round is split 4 ways (282 tiles on 256 workgroups: the last-arriver finishing pass forms dph from S) and the
+    reference's F = 513 at R = 100 (k_hstep_rh)."""
+    from se_snmf_nat_amd import sparse_nmf
+    for F, T, r in ((257, 9000, 40), (513, 8400, 100)):
+        V, W0, H0 = synth_problem(F, T, r)
+        rs = np.random.RandomState(F)
+        for sp in (np.linspace(0, 9, r).reshape(-1, 1), np.abs(rs.randn(r, T)) * 4):
+            p = dict(cf="kl", sparsity=sp, max_iter=4, init_w=W0, init_h=H0, cost_check=1)
             check(sparse_nmf(V, p, ctx=gpu_ctx), oracle_nmf(V, p))
 
 
