@@ -9,7 +9,7 @@ shapes are the ones that showed them -- few row tiles with several tiles per wor
 past the row duplicate lane 0), a V block whose last cell straddles the end.
 
 Round 3: the tiles of the last PARTIAL round of k_hstep_rp are split by rows over the workgroups that would idle through
-it (rp_part_phase + k_hfinish in csrc/snmf_kernels.h).  A split tile sums Lam in k ranges and the numerator in row
+it ("the split last round" in csrc/snmf_kernels.h: rp_part_p1 / rp_part_p2 / rp_part_finish).  A split tile sums Lam in k ranges and the numerator in row
 parts, i.e. in another fp32 order than the one-workgroup tiles: the default path must equal the plain kernels BIT FOR
 BIT on every pipelined tile and to the stated summation-order tolerance (2e-5 relative per element after two
 iterations) on the split ones.  The shapes cover 4-way and 2-way splits, no split, and problems smaller than one round
