@@ -985,6 +985,7 @@ static ReduceArgs make_reduce_args(snmf_plan* pl, double* stats, bool do_mats, b
     ra.n_mat = pl->n_mat;
     ra.n_part = n_part;
     ra.rp = pl->rp;
+    ra.r = pl->p.r;
     ra.Fp = pl->Fp;
     ra.do_mats = do_mats;
     ra.do_obj = do_obj;
@@ -994,7 +995,7 @@ static ReduceArgs make_reduce_args(snmf_plan* pl, double* stats, bool do_mats, b
 }
 static int launch_reduce(snmf_plan* pl, double* stats, bool do_mats, bool do_obj, int n_part, bool sh_const) {
     const ReduceArgs ra = make_reduce_args(pl, stats, do_mats, do_obj, n_part, sh_const);
-    const size_t tot = do_mats ? ((size_t)pl->n_mat * pl->rp * pl->Fp) / 4 : 1;
+    const size_t tot = do_mats ? ((size_t)pl->n_mat * pl->p.r * pl->Fp) / 4 : 1;
     ScopedTimer tm(pl->ctx, FAM_REDUCE);
     hipLaunchKernelGGL(k_reduce, dim3((int)std::max<size_t>(1, std::min<size_t>((tot + 31) / 32, 4096))), dim3(256),
                        0, pl->ctx->stream, ra);
