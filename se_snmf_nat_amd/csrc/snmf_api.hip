@@ -383,7 +383,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     if ((T + 31) / 32 <= ctx->n_cu) pl->hstep_rp = false;
     // F = 513 (9..16 row tiles): two whole tile buffers do not fit, but two H blocks + ONE ratio image do -- k_hstep_rh
     // pipelines on half tiles.  One pair of column tiles per wave of its P2 team: rp <= 256.
-    pl->lds_rh = std::max<size_t>(((size_t)2 * 32 * pl->ldh + (size_t)32 * pl->ldr + pl->rp) * 4 + 96, 2 * kMaxNW * 64 * sizeof(double));
+    pl->lds_rh = std::max<size_t>(((size_t)2 * 32 * pl->ldh + (size_t)32 * pl->ldr + pl->rp) * 4 + 128, 2 * kMaxNW * 64 * sizeof(double));
     pl->rh = pl->hstep_rp && pl->NLH != 4 && pl->bm == BM_KL && pl->nf >= 9 && pl->nf <= 16 && pl->rp <= 256 && pl->lds_rh <= lds_cap;
     pl->lds_h = std::max<size_t>(pl->NLH ? 2 * lds1 - lds_extra : (pl->NT == 1 ? (size_t)pl->TTH * per_col + lds_extra : lds2),
                                  2 * kMaxNW * 64 * sizeof(double));
@@ -401,10 +401,11 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         const int G = ctx->n_cu;
         pl->rp_tiles = (T + 31) / 32;
         pl->rp_full = pl->rp_tiles;
-        pl->rp_grid = std::max(1, std::min(pl->rp_tiles, G));  // (k_hstep_rh launches on the same grid, never split)
+        pl->rp_grid = std::max(1, std::min(pl->rp_tiles, G));  // (k_hstep_rh launches on the same grid)
         pl->rp_S = 0;
         const char* e = getenv("SNMF_HSTEP_SPLIT");
-        if (pl->NLH == 4 && !(e && atoi(e) == 0)) {
+        // (k_hstep_rh splits by CONTIGUOUS row tiles within a half: 16 row tiles only, F = 505..513)
+        if ((pl->NLH == 4 || (pl->rh && pl->nf == 16)) && !(e && atoi(e) == 0)) {
             // (only a partial round BEHIND whole ones: a problem of fewer tiles than workgroups is latency-bound, and there
             //  the split's extra steps -- partial stores, the arrival counter, the finishing pass -- cost more than the
             //  shorter MFMA loops save: C1, 257 x 2000 r = 40, ran 23.3 k iterations/s split against 26.7 k whole)
@@ -614,8 +615,8 @@ extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
     char hs[160];
     const bool rh_pipe = pl->rh && pl->upd_h && !pl->M;
     if (rh_pipe)
-        snprintf(hs, sizeof hs, "k_hstep_rh (4 P1 + 4 P2 + 4 loader waves on half tiles; %d of %d tiles pipelined, last round split 0 ways, grid %d)",
-                 pl->rp_tiles, pl->rp_tiles, pl->rp_grid);
+        snprintf(hs, sizeof hs, "k_hstep_rh (4 P1 + 4 P2 + 4 loader waves on half tiles; %d of %d tiles pipelined, last round split %d ways, grid %d)",
+                 pl->rp_full, pl->rp_tiles, pl->rp_S, pl->rp_grid);
     else if (kl_pipe)
         snprintf(hs, sizeof hs, "k_hstep_rp (4 P1 + 4 P2 + 4 loader waves; %d of %d tiles pipelined, last round split %d ways, grid %d)",
                  pl->rp_full, pl->rp_tiles, pl->rp_S, pl->rp_grid);
@@ -887,6 +888,10 @@ static int launch_hstep(snmf_plan* pl, bool obj, bool upd) {
     if (pl->rh && upd) {  // KL update launches of the 9..16-row-tile geometry: the half-tile role pipeline (k_hstep_rh)
         dim3 g(pl->rp_grid), b(768);
         a.n_tiles = pl->rp_tiles;
+        a.n_full = pl->rp_full;
+        a.part_S = pl->rp_S;
+        a.part_buf = pl->part_buf;
+        a.part_cnt = pl->part_cnt;
         return obj ? launch_big(k_hstep_rh<true>, g, b, pl->lds_rh, pl->ctx->stream, a)
                    : launch_big(k_hstep_rh<false>, g, b, pl->lds_rh, pl->ctx->stream, a);
     }

@@ -1823,10 +1823,22 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rh(StepArgs a) {
         // the unused cells of the extra 8-deep k-block stay zero for the whole kernel (the V commits write Fm .. Fm+3)
         for (int i = threadIdx.x; i < Tt * 8; i += NTHR) Rs[(i >> 3) * ldr + a.Fm + (i & 7)] = 0.f;
     }
-    if (threadIdx.x < 24) cnt[threadIdx.x] = 0u;
+    if (threadIdx.x < 25) cnt[threadIdx.x] = 0u;
     __syncthreads();
-    const int nmy = (int)blockIdx.x < a.n_tiles ? (a.n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-    auto tile_of = [&](int j) { return (int)blockIdx.x + j * (int)gridDim.x; };
+    // The split last round as in k_hstep_rp ("the split last round" above), with 16 row tiles: part p of S owns the
+    // CONTIGUOUS row tiles [p nfp, (p+1) nfp), nfp = 16 / S -- half a half (S = 4: one row tile per A wave) or a whole
+    // half (S = 2: the ordinary pairs), so a part has work in ONE unit of its place and its k-blocks are one range.
+    const int n_full = a.part_S > 0 ? a.n_full : a.n_tiles;
+    const int nmy = (int)blockIdx.x < n_full ? (n_full - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const bool has_part = a.part_S > 0 && (int)blockIdx.x < (a.n_tiles - n_full) * a.part_S;
+    const int pS = a.part_S > 0 ? a.part_S : 1, unit = (int)blockIdx.x, pp = unit % pS;
+    const int ptile = has_part ? n_full + unit / pS : 0;
+    const int nfp = a.nf / pS, php = (pp * nfp) / 8;  // row tiles per part; the half its row tiles are in
+    const bool own_x = a.xr && pp == pS - 1;
+    const int nst = nmy + (has_part ? 1 : 0);
+    const int ppos = has_part ? nmy - 1 : 0x7fffffff;  // the part: second to last in the list (has_part: nmy >= 1)
+    auto tile_of = [&](int j) { return j < ppos ? (int)blockIdx.x + j * (int)gridDim.x : (j == ppos ? ptile : (int)blockIdx.x + (j - 1) * (int)gridDim.x); };
+    unsigned* const plast = cnt + 24;  // 1: this workgroup was the last of its split tile's to arrive (set by loader wave 0)
 
     if (w >= NA + NB) {
         // ================================ loaders ===================================================
@@ -1868,11 +1880,11 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rh(StepArgs a) {
             return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, xoff_g, 0, 0));
         };
         auto commitX = [&](const f32x4& x) { *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(Rs) + xoff_l) = x; };
-        for (int j = 0; j < 2 && j < nmy; ++j) {
+        for (int j = 0; j < 2 && j < nst; ++j) {
             stageH(tile_of(j), lds + j * hsz);
             rp_post(ready, lw, (unsigned)(j + 1), lane);
         }
-        if (nmy > 0) {
+        if (nst > 0) {
             const __amdgpu_buffer_rsrc_t rv = rsrc_of(a.V + (size_t)tile_of(0) * Tt * Fp, Tt * Fp * 4);
             for (int hf = 0; hf < 2; ++hf) {
                 f32x4 x[PR];
@@ -1883,9 +1895,9 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rh(StepArgs a) {
                 rp_post(vready, lw, (unsigned)(hf + 1), lane);
             }
         }
-        for (int j = 0; j < nmy; ++j) {
+        for (int j = 0; j < nst; ++j) {
             float* bH = lds + (j & 1) * hsz;
-            const bool more_v = j + 1 < nmy, more_h = j + 2 < nmy;
+            const bool more_v = j + 1 < nst, more_h = j + 2 < nst;
             const __amdgpu_buffer_rsrc_t rv = rsrc_of(a.V + (size_t)tile_of(more_v ? j + 1 : j) * Tt * Fp, Tt * Fp * 4);
             f32x4 xv[PR], xa[PR], xx;
             // unit (j, 0): V half (j+1, 0) and the H block of tile j+2 -> registers, then wait for the B team to leave half 0
@@ -1915,6 +1927,13 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rh(StepArgs a) {
                 rp_post(vready, lw, (unsigned)(2 * j + 4), lane);
             }
             rp_await(p2done, (unsigned)(j + 1), a.stop);
+            if (j == ppos) {  // the part: no H to copy out (its H block stays for the finishing pass); bump the tile's arrival counter
+                if (lw == 0 && lane == 0) {
+                    const unsigned old = __hip_atomic_fetch_add(a.part_cnt + (ptile - n_full), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *plast = (old % (unsigned)pS == (unsigned)pS - 1u) ? 1u : 0u;
+                }
+                continue;
+            }
             // the updated H tile leaves (LDS -> registers -> HBM; four LDS reads in flight at a time) ...
             const __amdgpu_buffer_rsrc_t ro = rsrc_of(a.Hout + (size_t)tile_of(j) * Tt * rp, Tt * rp * 4);
             const char* const bHl = reinterpret_cast<const char*>(bH) + hv;
@@ -1936,7 +1955,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rh(StepArgs a) {
     } else if (w < NA) {
         // ================================ A team: P1, two units per tile ==============================
         const __amdgpu_buffer_rsrc_t rsw = wimage_rsrc(a.Wt4, (size_t)a.nf * rp * 32);
-        for (int j = 0; j < nmy; ++j) {
+        auto a_item = [&](const int j) {  // P1 of the whole tile in place j of the list
             const int t0 = tile_of(j) * Tt;
             float* Hs = lds + (j & 1) * hsz;
             const int fl = lane & 31, h = lane >> 5;
@@ -1973,6 +1992,48 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rh(StepArgs a) {
                 hstep_p1_xrow<NA, 1, BM_KL, OBJ>(a, Hs, Rs, wxs, t0, w, lane, true, acc_div);
                 rp_post(xdone, w, (unsigned)(j + 1), lane);
             }
+        };
+        for (int j = 0; j < (has_part ? nmy - 1 : nmy); ++j) a_item(j);
+        if (has_part) {
+            // the part (place ppos): its nfp row tiles sit in half php -- S = 4: row tile 4 pp + w, one per wave; S = 2: the
+            // half's ordinary pairs (w, w + 4)
+            const int j = ppos, t0 = ptile * Tt;
+            float* Hs = lds + (j & 1) * hsz;
+            const int fl = lane & 31, h = lane >> 5;
+            const float* sp = Hs + fl * ldh + 4 * h;
+            float dsum = 0.f;
+            bool waited = false;
+            auto gate_ready = [&]() {
+                if (!waited) rp_await(ready, (unsigned)(j + 1), a.stop);
+                waited = true;
+            };
+            for (int hf = 0; hf < 2; ++hf) {
+                const int u = 2 * j + hf;
+                if (hf == php && nfp == 8) {
+                    const int phi = 8 * hf + w;
+                    f32x16 acc[2] = {zero16(), zero16()};
+                    const int so[2] = {phi * rp * 128, (phi + NA) * rp * 128};
+                    contract_shared_buf<2>(acc, rsw, lane * 16, so, sp, a.nqk, gate_ready);
+                    rp_await(vready, (unsigned)(u + 1), a.stop);
+                    rp_p1_epilogue<OBJ>(a, acc[0], Rs, phi, t0, lane, dsum);
+                    rp_p1_epilogue<OBJ>(a, acc[1], Rs, phi + NA, t0, lane, dsum);
+                } else if (hf == php) {
+                    const int phi = pp * nfp + w;
+                    f32x16 acc[1] = {zero16()};
+                    const int so[1] = {phi * rp * 128};
+                    contract_shared_buf<1>(acc, rsw, lane * 16, so, sp, a.nqk, gate_ready);
+                    rp_await(vready, (unsigned)(u + 1), a.stop);
+                    rp_p1_epilogue<OBJ>(a, acc[0], Rs, phi, t0, lane, dsum);
+                } else {
+                    gate_ready();
+                    rp_await(vready, (unsigned)(u + 1), a.stop);
+                }
+                rp_post(p1, w, (unsigned)(u + 1), lane);
+            }
+            if (OBJ) acc_div += (double)dsum;
+            if (own_x) hstep_p1_xrow<NA, 1, BM_KL, OBJ>(a, Hs, Rs, wxs, t0, w, lane, true, acc_div);
+            if (a.xr) rp_post(xdone, w, (unsigned)(j + 1), lane);  // (every place posts it: the slots are progress numbers)
+            a_item(nmy);
         }
     } else {
         // ================================ B team: P2 =================================================
@@ -1982,7 +2043,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rh(StepArgs a) {
             rp_p2_consts(a, wb, lane, dp0);
             if (wb + NB < a.nk) rp_p2_consts(a, wb + NB, lane, dp1);
         }
-        for (int j = 0; j < nmy; ++j) {
+        auto b_item = [&](const int j) {  // P2 of the whole tile in place j of the list
             const int t0 = tile_of(j) * Tt;
             float* Hs = lds + (j & 1) * hsz;
             float shsum = 0.f;
@@ -2000,8 +2061,55 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rh(StepArgs a) {
             }
             if (OBJ) acc_sh += (double)shsum;
             rp_post(p2done, wb, (unsigned)(j + 1), lane);
+        };
+        for (int j = 0; j < (has_part ? nmy - 1 : nmy); ++j) b_item(j);
+        if (has_part) {
+            // the part: W^T*ratio over its own k-blocks [4 pp nfp, 4 (pp+1) nfp) (+ the extra row's for the last part) ->
+            // partial numerator, fragment order, agent-scope stores (as rp_part_p2)
+            const int j = ppos, fl = lane & 31, h = lane >> 5;
+            const float* sp = Rs + fl * ldr + 4 * h;
+            const int qb = 4 * pp * nfp, nqp = 4 * nfp;
+            auto gp = [&]() { rp_await(p1, (unsigned)(2 * j + php + 1), a.stop); };
+            auto gx = [&]() { rp_await(xdone, (unsigned)(j + 1), a.stop); };
+            const __amdgpu_buffer_rsrc_t rsk = wimage_rsrc(a.Wk4, (size_t)a.nk * a.Fq * 32);
+            const __amdgpu_buffer_rsrc_t rsp_ = __builtin_amdgcn_make_buffer_rsrc(a.part_buf + (size_t)unit * Tt * rp, 0, Tt * rp * 4, 0x00020000);
+            if (php == 1) rp_post(bdone, wb, (unsigned)(2 * j + 1), lane);  // (nobody reads the part's other ratio half)
+            if (wb < a.nk) {
+                const bool two = wb + NB < a.nk;
+                const int kap1 = two ? wb + NB : wb;
+                f32x16 acc[2] = {zero16(), zero16()};
+                int so[2] = {wb * a.Fq * 128 + qb * 1024, kap1 * a.Fq * 128 + qb * 1024};
+                contract_shared_buf<2>(acc, rsk, lane * 16, so, sp + 8 * qb, nqp, gp);
+                if (own_x) {
+                    so[0] = wb * a.Fq * 128 + (a.Fm / 8) * 1024;
+                    so[1] = kap1 * a.Fq * 128 + (a.Fm / 8) * 1024;
+                    contract_shared_buf<2>(acc, rsk, lane * 16, so, sp + a.Fm, 1, gx);
+                }
+                rp_await(p1, (unsigned)(2 * j + 2), a.stop);  // (the A team is through with both units of the place)
+                if (a.xr) gx();
+                if (php == 0) rp_post(bdone, wb, (unsigned)(2 * j + 1), lane);
+                rp_post(bdone, wb, (unsigned)(2 * j + 2), lane);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    if (c == 1 && !two) break;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 o = {acc[c][4 * g], acc[c][4 * g + 1], acc[c][4 * g + 2], acc[c][4 * g + 3]};
+                        buf_store_b128<kAuxSC1>(rsp_, lane * 16, ((c ? kap1 : wb) * 1024 + g * 256) * 4, o);
+                    }
+                }
+            } else {
+                rp_await(p1, (unsigned)(2 * j + 2), a.stop);
+                if (a.xr) gx();
+                if (php == 0) rp_post(bdone, wb, (unsigned)(2 * j + 1), lane);
+                rp_post(bdone, wb, (unsigned)(2 * j + 2), lane);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partial is at the coherence point before this wave reports
+            rp_post(p2done, wb, (unsigned)(j + 1), lane);
+            b_item(nmy);
         }
     }
+    if (has_part) acc_sh += rp_part_finish<OBJ>(a, lds + (ppos & 1) * hsz, plast, ptile);
 
     if (OBJ) {
         // deterministic workgroup reduction of the two fp64 partial sums (as k_hstep)

@@ -29,7 +29,7 @@ SHAPES = [(65, 70, 12000), (129, 70, 12000), (65, 32, 12000), (64, 70, 12000), (
           # 9..16 row tiles: k_hstep_rh (one ratio image, pipelined by half tiles) and k_wstats with loader waves on a
           # compact V image -- the reference's shipped F = 513 at R = 100 / 200 (settings/initial_setting_SNMF_NAT.m:21-29,48-49)
           (513, 100, 12000), (513, 200, 9000), (513, 256, 5000), (385, 100, 12000), (449, 250, 9000), (512, 128, 8000),
-          (289, 40, 20000), (513, 200, 100)]
+          (289, 40, 20000), (513, 200, 100), (513, 100, 9000), (512, 256, 10000)]
 
 
 def _run(ctx, V, W0, H0, r, *, h_only, iters):
