@@ -264,7 +264,7 @@ def main():
         ctx.timing(True)
         plan.run_async(K)
         ctx.sync()
-        fam = {f: ctx.timing_get(f) for f in ("hstep", "wstats", "reduce", "wapply")}
+        fam = {f: ctx.timing_get(f) for f in ("hstep", "wstats", "reduce", "wapply", "wfin")}
         ctx.timing(False)
         plan2.run_async(SETTLE + W)
         ctx.sync()
@@ -353,7 +353,7 @@ def main():
     tr.ctx.timing(True)
     tr.run(W)
     tr.sync()
-    fam = {f: tr.ctx.timing_get(f)[0] for f in ("hstep", "wstats", "reduce", "wapply")}
+    fam = {f: tr.ctx.timing_get(f)[0] for f in ("hstep", "wstats", "reduce", "wapply", "wfin")}
     tr.ctx.timing(False)
     tr.run(W)  # the contract's W warm-up steps, directly ahead of the timed region
     tr.sync()

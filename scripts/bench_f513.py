@@ -60,7 +60,7 @@ for name in which:
     plan.run_async(c["settle"]); ctx.sync()
     t = time.perf_counter(); plan.run_async(iters); ctx.sync(); dt = time.perf_counter() - t
     ctx.timing(True); plan.run_async(iters); ctx.sync()
-    fam = {f: ctx.timing_get(f) for f in ("hstep", "wstats", "reduce", "wapply")}
+    fam = {f: ctx.timing_get(f) for f in ("hstep", "wstats", "reduce", "wapply", "wfin")}
     ctx.timing(False)
     ms = dt / iters * 1e3
     half = 4.0 * F * T * r  # flop of one Lam + one contraction pass over the whole problem

@@ -34,7 +34,7 @@ def main():
         plan.run_async(W); ctx.sync()
         t = time.perf_counter(); plan.run_async(K); ctx.sync(); a = (time.perf_counter() - t) / K * 1e3
         ctx.timing(True); plan.run_async(20); ctx.sync()
-        fam = {f: round(ctx.timing_get(f)[0] * 1e3, 1) for f in ("hstep", "wstats", "reduce", "wapply")}
+        fam = {f: round(ctx.timing_get(f)[0] * 1e3, 1) for f in ("hstep", "wstats", "reduce", "wapply", "wfin")}
         ctx.timing(False)
         geo = plan.describe()
         plan.close()

@@ -59,8 +59,8 @@ struct TimerPair {
     hipEvent_t a, b;
     int fam;
 };
-enum { FAM_HSTEP = 0, FAM_WSTATS, FAM_WAPPLY, FAM_REDUCE, FAM_N };
-static const char* kFamNames[FAM_N] = {"hstep", "wstats", "wapply", "reduce"};
+enum { FAM_HSTEP = 0, FAM_WSTATS, FAM_WAPPLY, FAM_REDUCE, FAM_WFIN, FAM_N };
+static const char* kFamNames[FAM_N] = {"hstep", "wstats", "wapply", "reduce", "wfin"};
 
 struct snmf_ctx {
     int device = 0;
@@ -70,8 +70,8 @@ struct snmf_ctx {
     size_t lds_max = 160 * 1024;
     bool timing = false;
     std::vector<TimerPair> pending;
-    double fam_ms[FAM_N] = {0, 0, 0, 0};
-    int64_t fam_n[FAM_N] = {0, 0, 0, 0};
+    double fam_ms[FAM_N] = {0, 0, 0, 0, 0};
+    int64_t fam_n[FAM_N] = {0, 0, 0, 0, 0};
 };
 
 struct ScopedTimer {
@@ -232,6 +232,9 @@ struct snmf_plan {
     // beta = 2, r > 256: the V*H^T launch (needs no Lam') runs the loader-wave geometry <8,4,4,2> once per 256-column
     // kappa-group, each staging only its own columns of H (kq_chunks frame chunks, kq_kg kappa-groups; 0 = off)
     int kq_chunks = 0, kq_kg = 0;
+    // snmf_plan_run: k_reduce + k_wapply as one launch (k_wfin) when a column's chunk-group sums fit the LDS
+    bool wfin = false;
+    size_t lds_wfin = 0;
     size_t kq_lds = 0;
     int grid_h = 1;
     int ldh = 0, ldr = 0, ldhw = 0;
@@ -504,6 +507,9 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
                     pl->bm == BM_KL ? "the KL divergence" : "F = 32n+1 rows");
     }
 
+    pl->lds_wfin = (size_t)9 * pl->n_mat * pl->Fp * sizeof(double);
+    pl->wfin = pl->upd_w && pl->lds_wfin + 12 * 1024 <= lds_cap;
+
     // persistent single-launch path for the online shape (H-only, at most one 32-frame tile)
     {
         const size_t need = ((size_t)32 * (pl->ldh + pl->ldr) + ((pl->rp + 3) & ~3)) * 4 + 2 * 512 * sizeof(double);
@@ -624,11 +630,11 @@ extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
         snprintf(hs, sizeof hs, "k_hstep");
     snprintf(buf, n,
              "F=%d T=%d r=%d beta=%g | Fm=%d(+%d VALU row) rp=%d Tp=%d | hstep: %s, tile=%d frames, grid=%d x %d thr, lds=%zu B | "
-             "wstats: NK=%d waves=%d+%d grid=(%d chunks,%d fgroups,%d kgroups; group-1 chunks %d) lds=%zu B | n_cu=%d",
+             "wstats: NK=%d waves=%d+%d grid=(%d chunks,%d fgroups,%d kgroups; group-1 chunks %d) lds=%zu B | W finish (run loop): %s | n_cu=%d",
              pl->p.F, pl->p.T, pl->p.r, pl->p.beta, pl->Fm, pl->xr, pl->rp, pl->Tp, hs, pl->TTH * pl->NT,
              (kl_pipe || rh_pipe) ? pl->rp_grid : pl->grid_h, rh_pipe ? 768 : (pl->NWH + pl->NLH) * 64,
              rh_pipe ? pl->lds_rh : pl->lds_h, pl->NKT, pl->NWB, pl->NLW, pl->n_chunks, pl->n_fg, pl->n_kg, pl->n_ch1 ? pl->n_ch1 : pl->n_chunks, pl->lds_w,
-             pl->ctx->n_cu);
+             pl->wfin ? "k_wfin" : (pl->upd_w ? "k_reduce + k_wapply" : "none"), pl->ctx->n_cu);
     return SNMF_OK;
 }
 
@@ -1046,6 +1052,20 @@ static int launch_wapply(snmf_plan* pl, const double* stats, int check_it, bool 
     return SNMF_OK;
 }
 
+// k_reduce + k_wapply in one launch (the loop of snmf_plan_run; see k_wfin)
+static int launch_wfin(snmf_plan* pl, double* stats, bool do_obj, int n_part, bool sh_const, int check_it) {
+    const ReduceArgs ra = make_reduce_args(pl, stats, true, do_obj, n_part, sh_const);
+    const ApplyArgs aa = make_apply_args(pl, stats, check_it, true, false);
+    ScopedTimer tm(pl->ctx, FAM_WFIN);
+    auto launch = [&](auto kern) -> int {
+        SN_TRY(ensure_dyn_lds(pl->ctx->device, (const void*)kern, pl->lds_wfin));
+        hipLaunchKernelGGL(kern, dim3(pl->p.r), dim3(768), pl->lds_wfin, pl->ctx->stream, ra, aa);
+        HIP_TRY(hipGetLastError());
+        return SNMF_OK;
+    };
+    return pl->n_mat == 2 ? launch(k_wfin<2>) : launch(k_wfin<1>);
+}
+
 static int launch_check(snmf_plan* pl, const double* stats, int it) {
     const size_t off = (size_t)pl->n_mat * pl->rp * pl->Fp + pl->rp;
     hipLaunchKernelGGL(k_check, dim3(1), dim3(64), 0, pl->ctx->stream, stats, off, pl->divh, pl->costh, pl->st, it,
@@ -1309,8 +1329,18 @@ extern "C" int snmf_plan_run(snmf_plan* pl, int32_t n_iters, int32_t* iters_done
     bool stopped = false;
     while (pl->it_done < target) {
         SN_TRY(snmf_plan_hstep(pl));
-        SN_TRY(snmf_plan_wstats(pl, pl->stats));
-        SN_TRY(snmf_plan_wapply(pl, pl->stats));
+        if (pl->wfin) {
+            // (what snmf_plan_wstats + snmf_plan_wapply do for a W update, the reduction and the update in one launch)
+            const int j = pl->it_done + 1;
+            const bool obj = want_obj(pl, j), mdi_wonly = pl->M && !pl->upd_h;
+            SN_TRY(launch_wstats(pl, obj && !pl->upd_h && !mdi_wonly));
+            const int n_part = pl->upd_h ? hupd_parts(pl) : pl->M ? pl->grid_mdi : wstats_parts(pl);
+            SN_TRY(launch_wfin(pl, pl->stats, obj, n_part, !pl->upd_h, obj ? j - 1 : 0));
+            pl->it_done = j;
+        } else {
+            SN_TRY(snmf_plan_wstats(pl, pl->stats));
+            SN_TRY(snmf_plan_wapply(pl, pl->stats));
+        }
         if (can_stop && ++since_poll >= 4) {
             since_poll = 0;
             DevState hs{};

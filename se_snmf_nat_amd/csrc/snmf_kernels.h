@@ -3347,6 +3347,133 @@ __global__ __launch_bounds__(256) void k_wapply(ApplyArgs a) {
     wapply_column(a, k, tid, Q, P, sk, red);
 }
 
+// ============================================================================================
+// k_wfin: k_reduce and k_wapply in ONE launch, for the loop of a single device (snmf_plan_run): nothing is exchanged
+// between the two there, and as two launches they were 21 us of every iteration that do not shrink with T (the chunk
+// slabs cross HBM once, 34 MB at C2; the rest was a second launch and the fp64 statistics' round trip through memory).
+// One workgroup per column k of W: it adds the column's n_chunks slab pieces in k_reduce's order (eight contiguous chunk
+// groups, then the eight partial sums in group order: the same doubles, bit for bit), keeps the sums in LDS and runs
+// wapply_column on them.  Every workgroup folds the objective partials itself (k_reduce's order again) and evaluates the
+// convergence test on its own copy.  The step API (snmf_plan_wstats / snmf_plan_wapply: the statistics leave the device
+// or are summed over ranks in between) keeps the two kernels; tests compare the two paths bit for bit.
+// Dynamic LDS: (8 + 1) * n_mat * Fp doubles.
+// ============================================================================================
+template <int NMAT>
+__global__ __launch_bounds__(768) void k_wfin(ReduceArgs ra, ApplyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double wfin_lds[];
+    __shared__ double red[3][256];
+    __shared__ double red2[2][256];
+    __shared__ double skp[8];
+    if (a.st->stop) return;
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const size_t nel = (size_t)a.rp * a.Fp;
+    const int nE = a.Fp / 4, nI = NMAT * nE;  // f32x4 of a column (of both matrices)
+    double* part = wfin_lds;                  // [8][nI][4]
+    double* QP = wfin_lds + (size_t)8 * nI * 4;  // [NMAT][Fp]
+    const size_t cstride = nel * NMAT;
+    // The column's slab pieces: item (g, e) = chunk group g, f32x4 e.  768 threads for this phase only (sixteen loads of
+    // a thread in flight: one memory round trip for a column of C2, where 256 threads needed four); the W update behind
+    // it is wapply_column's 256 threads, the other waves end at the barrier.
+    for (int i = tid; i < 8 * nI; i += 768) {
+        const int g = i / nI, e = i - g * nI, m = e / nE, e4 = e - m * nE;
+        const int cb = (int)(((long long)ra.n_chunks * g) / 8), ce = (int)(((long long)ra.n_chunks * (g + 1)) / 8);
+        const float* p = ra.slabs + (size_t)m * nel + (size_t)k * a.Fp + 4 * e4;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int c = cb;
+        for (; c + 16 <= ce; c += 16) {
+            f32x4 x[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) x[j] = *reinterpret_cast<const f32x4*>(p + (size_t)(c + j) * cstride);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                s0 += (double)x[j][0];
+                s1 += (double)x[j][1];
+                s2 += (double)x[j][2];
+                s3 += (double)x[j][3];
+            }
+        }
+        if (c < ce) {  // the rest of the group (up to 15 chunks), again all loads first
+            f32x4 x[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (c + j < ce) x[j] = *reinterpret_cast<const f32x4*>(p + (size_t)(c + j) * cstride);
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (c + j < ce) {
+                    s0 += (double)x[j][0];
+                    s1 += (double)x[j][1];
+                    s2 += (double)x[j][2];
+                    s3 += (double)x[j][3];
+                }
+        }
+        part[(size_t)i * 4 + 0] = s0;
+        part[(size_t)i * 4 + 1] = s1;
+        part[(size_t)i * 4 + 2] = s2;
+        part[(size_t)i * 4 + 3] = s3;
+    }
+    // row sum of H (KL): eight chunk groups as well
+    if (NMAT == 1 && tid >= 760) {  // (threads of the last wave: it has the fewest items above)
+        const int g = tid - 760;
+        const int cb = (int)(((long long)ra.n_chunks * g) / 8), ce = (int)(((long long)ra.n_chunks * (g + 1)) / 8);
+        double sk = 0.0;
+        int c = cb;
+        for (; c + 8 <= ce; c += 8) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = ra.spart[(size_t)(c + j) * a.rp + k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sk += (double)x[j];
+        }
+        for (; c < ce; ++c) sk += (double)ra.spart[(size_t)c * a.rp + k];
+        skp[g] = sk;
+    }
+    // objective partials (k_reduce's last block: strided, then a tree)
+    if (tid < 256) {
+        double d = 0.0, h = 0.0;
+        if (ra.do_obj) {
+            for (int c = tid; c < ra.n_part; c += 256) {
+                d += ra.part[2 * c];
+                h += ra.part[2 * c + 1];
+            }
+        }
+        red2[0][tid] = d;
+        red2[1][tid] = h;
+    }
+    __syncthreads();
+    if (tid >= 256) return;  // (ended waves do not count at later barriers)
+    for (int idx = tid; idx < nI * 4; idx += 256) {  // (nE * 4 = Fp: element idx of [NMAT][Fp])
+        double t = 0.0;
+#pragma unroll
+        for (int gg = 0; gg < 8; ++gg) t += part[((size_t)gg * nI) * 4 + idx];
+        QP[idx] = t;
+    }
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) {
+            red2[0][tid] += red2[0][tid + st];
+            red2[1][tid] += red2[1][tid + st];
+        }
+        __syncthreads();
+    }
+    double sc[2];
+    sc[0] = ra.do_obj ? red2[0][0] : 0.0;
+    sc[1] = ra.do_obj ? (ra.use_sh_const ? ra.sh_const : red2[1][0]) : 0.0;
+    if (k == 0 && tid == 0) {
+        double* scg = ra.stats + cstride + a.rp;
+        scg[0] = sc[0];
+        scg[1] = sc[1];
+    }
+    if (a.check_it > 0) {
+        const bool stopnow = conv_test(sc, a.divh, a.costh, a.st, a.check_it, a.conv_eps, k == 0 && tid == 0);
+        if (stopnow) return;
+    }
+    double sk = 0.0;
+    if (NMAT == 1) {
+#pragma unroll
+        for (int gg = 0; gg < 8; ++gg) sk += skp[gg];
+    }
+    wapply_column(a, k, tid, QP, NMAT == 2 ? QP + a.Fp : nullptr, sk, red);
+}
+
 
 // Convergence check alone (H-only mode and the final objective pass): one thread.
 __global__ void k_check(const double* stats, size_t sc_off, double* divh, double* costh, DevState* st, int it,

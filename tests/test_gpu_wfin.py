@@ -1,0 +1,69 @@
+"""snmf_plan_run's fused W finish (k_wfin: the chunk reduction and the W update in one launch) against the step API's two
+launches (k_reduce -> statistics in memory -> k_wapply), which is the path the statistics take when they are summed over
+ranks in between (se_snmf_nat_amd/dist.py, csrc/snmf_multi.h).  Both add the chunk slabs in the same fixed order, so W, H,
+the objective and the stop index must agree bit for bit -- this is what lets the sharded tests pin the sharding algebra
+against the single-device solve.  (src/sparse_nmf.m:215-244 is the update both implement.)
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "kl_full": dict(F=257, T=3000, r=40, beta=1.0, iters=12),
+    "kl_full_513_r100": dict(F=513, T=9000, r=100, beta=1.0, iters=6),
+    "kl_wonly": dict(F=129, T=2500, r=24, beta=1.0, iters=10, h_ind=False),
+    "kl_semi": dict(F=64, T=900, r=48, beta=1.0, iters=10, w_part=16),
+    "kl_early_stop": dict(F=129, T=2000, r=20, beta=1.0, iters=60, conv_eps=2e-3),
+    "ed_full": dict(F=257, T=3000, r=40, beta=2.0, iters=10),
+    "ed_r300": dict(F=200, T=2500, r=300, beta=2.0, iters=5),
+    "is_full": dict(F=129, T=2000, r=16, beta=0.0, iters=8),
+    "b05_nocost": dict(F=97, T=1500, r=12, beta=0.5, iters=8, cost_check=False),
+}
+
+
+def _mk(gpu_ctx, c):
+    from se_snmf_nat_amd import Plan
+    F, T, r = c["F"], c["T"], c["r"]
+    rs = np.random.default_rng(F + T + r)
+    V = (rs.gamma(0.5, 1.0, (F, 8)) @ rs.gamma(0.3, 1.0, (8, T)) + 1e-3).astype(np.float32)
+    W0 = rs.random((F, r))
+    H0 = rs.random((r, T)).astype(np.float32)
+    kw = {}
+    if c.get("h_ind") is False:
+        kw["h_update_ind"] = np.zeros(r, bool)
+    if "w_part" in c:
+        wi = np.zeros(r, bool); wi[c["w_part"]:] = True
+        kw["w_update_ind"] = wi
+    pl = Plan(gpu_ctx, F, T, r, beta=c["beta"], max_iter=c["iters"], conv_eps=c.get("conv_eps", 0.0),
+              cost_check=c.get("cost_check", True), sparsity=2.0, **kw)
+    pl.set_v(V); pl.set_w(W0); pl.set_h(H0); pl.init()
+    return pl
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_fused_w_finish_equals_reduce_then_apply(gpu_ctx, name):
+    import torch
+    c = CASES[name]
+    a = _mk(gpu_ctx, c)
+    assert "W finish (run loop): k_wfin" in a.describe()
+    a.run()
+    Wa, Ha = a.get_w(), a.get_h()
+    div_a, cost_a, n_a = a.get_objective()
+    a.close()
+    b = _mk(gpu_ctx, c)
+    stats = torch.zeros(b.stats_len(), dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    for _ in range(c["iters"]):
+        b.hstep(); b.wstats(stats.data_ptr()); b.wapply(stats.data_ptr())
+    if c.get("cost_check", True):
+        b.objstats(stats.data_ptr()); b.objapply(stats.data_ptr())
+    gpu_ctx.sync()
+    Wb, Hb = b.get_w(), b.get_h()
+    div_b, cost_b, n_b = b.get_objective()
+    b.close()
+    assert n_a == n_b
+    if "conv_eps" in c:
+        assert 1 < n_a < c["iters"]  # the case does stop early
+    assert np.array_equal(Wa, Wb) and np.array_equal(Ha, Hb)
+    assert np.array_equal(cost_a, cost_b) and np.array_equal(div_a, div_b)
