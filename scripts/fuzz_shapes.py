@@ -1,0 +1,85 @@
+"""Development helper: random shapes / modes through the product path against the fp64 oracle (GPU box).
+   python scripts/fuzz_shapes.py [seed] [n_cases] [time budget s]  -> one line per case, FAIL lines at the end.
+Shapes are drawn to land on the plan's geometry switches: tile counts around multiples of the CU count (the split last
+round), F on both sides of 32n+1, r around the 32-column tiles and the LX / NK limits, all divergences and update modes."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from oracle.sparse_nmf_oracle import sparse_nmf as onmf
+from se_snmf_nat_amd import SnmfError, sparse_nmf
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+budget = float(sys.argv[3]) if len(sys.argv) > 3 else 420.0
+rs = np.random.default_rng(seed)
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def draw():
+    F = int(rs.choice([257, 513, 129, 65, 64, 128, 512, 385, 97, int(rs.integers(8, 600)), int(rs.integers(8, 200))]))
+    r = int(rs.choice([int(rs.integers(1, 40)), int(rs.integers(90, 132)), int(rs.integers(190, 260)), 100, 200, 256, 40,
+                       int(rs.integers(257, 700)), int(rs.integers(1, 300))]))
+    kind = rs.integers(0, 4)
+    if kind == 0:
+        T = int(rs.integers(1, 400))
+    elif kind == 1:
+        T = int(8192 * rs.integers(1, 4) + rs.integers(-3000, 3000))
+    elif kind == 2:
+        T = int(rs.integers(400, 9000))
+    else:
+        T = int(8192 + 32 * rs.integers(1, 140) + rs.integers(-31, 1))
+    while F * T * r > 6e9 or (F + r) > 2400:
+        T = max(1, T // 2)
+        if (F + r) > 2400:
+            r = r // 2
+    beta = float(rs.choice([1.0, 1.0, 1.0, 2.0, 0.0, 0.5, 1.5]))
+    mode = str(rs.choice(["full", "full", "h", "w", "semi"]))
+    sp = str(rs.choice(["scalar", "scalar", "vec", "mat", "zero"]))
+    return F, T, r, beta, mode, sp
+
+
+fails = []
+t_start = time.time()
+for ci in range(n_cases):
+    if time.time() - t_start > budget:
+        print(f"(time budget reached after {ci} cases)")
+        break
+    F, T, r, beta, mode, sp = draw()
+    V = (rs.gamma(0.5, 1.0, (F, 12)) @ rs.gamma(0.3, 1.0, (12, T)) + 1e-3)
+    W0 = rs.random((F, r))
+    H0 = rs.random((r, T))
+    iters = int(rs.integers(2, 6))
+    p = dict(cf={1.0: "kl", 2.0: "ed", 0.0: "is"}.get(beta, "x"), beta=beta, max_iter=iters, conv_eps=0, cost_check=int(rs.integers(0, 4) > 0),
+             init_w=W0, init_h=H0)
+    p["sparsity"] = {"scalar": float(rs.choice([0.1, 1.0, 5.0])), "zero": 0.0, "vec": rs.random(r) * 4,
+                     "mat": rs.random((r, T)) * 3}[sp]
+    if mode == "h":
+        p["w_update_ind"] = np.zeros(r, bool)
+    elif mode == "w":
+        p["h_update_ind"] = np.zeros(r, bool)
+    elif mode == "semi":
+        p["w_update_ind"] = np.arange(r) >= r // 2
+    tag = f"F={F} T={T} r={r} beta={beta} {mode} sp={sp} it={iters} cc={p['cost_check']}"
+    try:
+        w, h, o = sparse_nmf(V, p)
+    except SnmfError as e:
+        print(f"{ci:3d} {tag}: REFUSED {str(e)[:90]}")
+        continue
+    wr, hr, orf = onmf(V, p)
+    n = min(len(o["cost"]), len(orf["cost"]))
+    ec = float(np.max(np.abs(o["cost"][:n] - orf["cost"][:n]) / np.abs(orf["cost"][:n]))) if n and p["cost_check"] else 0.0
+    ew, eh = rel(w, wr), rel(h, hr)
+    bad = (not np.isfinite(w).all()) or (not np.isfinite(h).all()) or ew > 2e-4 or eh > 2e-4 or ec > 2e-5
+    print(f"{ci:3d} {tag}: relW {ew:.1e} relH {eh:.1e} cost {ec:.1e}{'  <<< FAIL' if bad else ''}", flush=True)
+    if bad:
+        fails.append(tag)
+print(f"{len(fails)} failures")
+for f in fails:
+    print("FAIL", f)
