@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The reference's own geometry (F = 513: settings/initial_setting_SNMF_NAT.m:21-29,48-49) and BASELINE C4 / C5 at full size,
-per kernel: ms per launch from HIP events on the engine's stream, algorithmic TFLOP/s and fraction of the 157.3 TFLOP/s
+per kernel (`--no-cost`: without the objective): ms per launch from HIP events on the engine's stream, algorithmic TFLOP/s and fraction of the 157.3 TFLOP/s
 f32-MFMA peak.  One JSON line per shape; `python scripts/bench_f513.py [a11 c4h c4w c5] [--iters K]`.
   a11  513 x 72000, r = 100, KL, full update      run_basis_train.m:88 (12 min of audio at the shipped settings)
   c4h  513 x 100000, r = 200, KL, H-only          run_basis_DNMF.m:40 (solve 1 of the 3-solve loop)
@@ -53,7 +53,7 @@ for name in which:
         kw["w_update_ind"] = np.zeros(r, bool)
     if c["mode"] == "w":
         kw["h_update_ind"] = np.zeros(r, bool)
-    plan = Plan(ctx, F, T, r, beta=c["beta"], max_iter=2 * c["settle"] + 2 * iters + 2, conv_eps=0.0, cost_check=True,
+    plan = Plan(ctx, F, T, r, beta=c["beta"], max_iter=2 * c["settle"] + 2 * iters + 2, conv_eps=0.0, cost_check="--no-cost" not in sys.argv,
                 sparsity=c["sparsity"], **kw)
     plan.set_v(V); plan.set_w(W0); plan.set_h(H0); plan.init()
     del V, H0

@@ -2847,25 +2847,31 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
             // lane (f = fl, h), reg -> t = t0 + drow(reg,h)
             const int f = phi * 32 + fl;
             float dsum = 0.f;
+            // (the bounds masks of the objective only where a tile has padding: a wave-uniform test, as rp_p1_epilogue)
+            auto ratio_rows = [&](auto masked) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (TT < 32 && i >= TT / 2) {  // rows drow(i,h) >= TT: duplicates of the narrow tile
-                    R[i] = 0.f;
-                    continue;
-                }
-                const int t = t0 + drow(i, h);
-                const float v = Vs[drow(i, h) * ldv + fc];
-                float lam = fmaxf(acc[i], kFlr);
-                if (OBJ) {
-                    if (do_obj) {
-                        float d = div_term<BM>(v, lam, a.beta, a.inv_bb1);
-                        dsum += (f < a.F && t < a.T) ? d : 0.f;
+                for (int i = 0; i < 16; ++i) {
+                    if (TT < 32 && i >= TT / 2) {  // rows drow(i,h) >= TT: duplicates of the narrow tile
+                        R[i] = 0.f;
+                        continue;
                     }
+                    const int t = t0 + drow(i, h);
+                    const float v = Vs[drow(i, h) * ldv + fc];
+                    float lam = fmaxf(acc[i], kFlr);
+                    if (OBJ) {
+                        if (do_obj) {
+                            float d = div_term<BM>(v, lam, a.beta, a.inv_bb1);
+                            if (decltype(masked)::value) dsum += (f < a.F && t < a.T) ? d : 0.f;
+                            else dsum += d;
+                        }
+                    }
+                    if (WM == 0) R[i] = v * fast_rcp(lam);
+                    else if (WM == 1) R[i] = den_of_lam<BM>(lam, a.beta);
+                    else R[i] = v * numfac_of_lam<BM>(lam, a.beta);
                 }
-                if (WM == 0) R[i] = v * fast_rcp(lam);
-                else if (WM == 1) R[i] = den_of_lam<BM>(lam, a.beta);
-                else R[i] = v * numfac_of_lam<BM>(lam, a.beta);
-            }
+            };
+            if (OBJ && TT == 32 && phi * 32 + 32 <= a.F && t0 + 32 <= a.T) ratio_rows(std::false_type{});
+            else ratio_rows(std::true_type{});
             if (OBJ) acc_div += (double)dsum;
         } else {
             const int f = phi * 32 + fl;

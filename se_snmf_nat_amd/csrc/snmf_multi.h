@@ -28,8 +28,11 @@
 //          launches per exchange, no host barrier, no event calls.
 //   EVENTS (round 2; the default when ranks share a device, i.e. single-GPU testing): an event per rank and parity, a
 //          host barrier so that every peer has ISSUED its record before anybody waits on it, n-1 cross-stream waits.
-//          On a shared device FLAGS could deadlock until its time-out: streams beyond the runtime's hardware-queue count
-//          share a queue, and a polling kernel would then sit in front of the push it polls for.
+//          On a shared device FLAGS by itself could deadlock until its time-out: streams that land on the same hardware
+//          queue run in submission order, and a polling kernel would then sit in front of the push it polls for (seen
+//          once in round 3: the mapping of streams to queues changes from run to run).  FLAGS forced on a device list
+//          with repeats (the single-GPU tests of the flag path) therefore keeps ONE host barrier per exchange between
+//          the ranks' push and sum submissions: every push then precedes every sum in every queue.
 #pragma once
 
 #include <atomic>
@@ -106,6 +109,7 @@ struct snmf_multi {
     std::vector<unsigned*> flags;     // [n] arrival words: [2 parities][n ranks], then the push launch's workgroup counter
     std::vector<hipEvent_t> ev[2];    // ev[parity][rank]: "rank has pushed"  (EVENTS mode)
     int mode = 0;                     // SNMF_EXCHANGE_FLAGS / _EVENTS (resolved from AUTO at creation)
+    bool shared_dev = false;          // two ranks on one device: submissions of push and sum are ordered by the host in every mode
     unsigned xseq = 0;                // exchanges issued so far (the next one is number xseq + 1)
     std::vector<uint8_t> w_ind, h_ind;
     size_t len = 0, xoff = 0, xlen = 0;  // statistics length; the exchanged part [xoff, xoff + xlen)
@@ -206,6 +210,7 @@ extern "C" int snmf_multi_create(const int32_t* devices, int32_t n_dev, const sn
         for (int g = 0; g < n_dev; ++g)
             for (int q = 0; q < g; ++q) distinct = distinct && devices[g] != devices[q];
         m->mode = distinct ? SNMF_EXCHANGE_FLAGS : SNMF_EXCHANGE_EVENTS;
+        m->shared_dev = !distinct;
     }
     m->ev[0].assign(n_dev, nullptr);
     m->ev[1].assign(n_dev, nullptr);
@@ -374,7 +379,8 @@ static bool multi_exchange(snmf_multi* m, int g, int par, unsigned xs, int& seq,
         if (hipGetLastError() != hipSuccess) note(fail(SNMF_ERR_NO_DEVICE, "k_push_stats launch failed"));
         else if (!flags && hipEventRecord(m->ev[par][g], st) != hipSuccess) note(fail(SNMF_ERR_NO_DEVICE, "hipEventRecord failed"));
     }
-    if (!flags && !multi_barrier(m, seq++, rc != SNMF_OK)) return false;  // every rank has recorded -- or somebody failed: all leave
+    // every rank has recorded (EVENTS) / submitted its push (FLAGS on a shared device) -- or somebody failed: all leave
+    if ((!flags || m->shared_dev) && !multi_barrier(m, seq++, rc != SNMF_OK)) return false;
     if (m->n > 1) {
         if (!flags)
             for (int q = 0; q < m->n; ++q)
@@ -416,7 +422,7 @@ static void multi_rank_loop(snmf_multi* m, int g, int it0, int target, bool fina
             int32_t sflag = 0;
             if (rc == SNMF_OK) step(snmf_plan_stopped(m->plan[g], &sflag));
             // (FLAGS mode: no rendezvous -- every rank reads the same flag value: the statistics are bit-identical)
-            if (!flags) all_ok = multi_barrier(m, seq++, rc != SNMF_OK);
+            if (!flags || m->shared_dev) all_ok = multi_barrier(m, seq++, rc != SNMF_OK);
             else if (rc != SNMF_OK) break;
             if (all_ok && sflag) {
                 stopped = 1;
