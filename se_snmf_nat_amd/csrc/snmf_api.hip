@@ -452,7 +452,9 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
             buf = ((size_t)pl->TTW * pl->ldhw + (size_t)pl->TTW * 32 * pl->NWB) * 4;
         }
         // (the fixed-order sums at the end of the kernel use [4][rp] floats / one double per thread of the same memory)
-        pl->lds_w = std::max<size_t>(std::max<size_t>((pl->NLW ? 2 * buf_ld : buf) + (size_t)pl->rp * 4 + 320,  // + ready/done slots + the extra row's V values [2][32]
+        // (+ ready/done slots + the extra row's V values [2][32] + the consumers' partial extra rows of the slab, NK <= 8)
+        const size_t gxs = pl->NKT <= 8 ? (size_t)pl->NWB * std::min(pl->rp, 256) * 4 : 0;
+        pl->lds_w = std::max<size_t>(std::max<size_t>((pl->NLW ? 2 * buf_ld : buf) + (size_t)pl->rp * 4 + 320 + gxs,
                                                       (size_t)std::max(4, pl->NWB) * pl->rp * 4),
                                      (size_t)(pl->NWB + pl->NLW) * 64 * sizeof(double));
     }
@@ -498,7 +500,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         // spilled VGPRs) is replaced for this launch by <8,4,4,2> with double-buffered LDS-DMA staging
         pl->kq_kg = (pl->nk + 7) / 8;
         pl->kq_chunks = std::max(1, std::min(std::min(n_tiles_w, pl->n_chunks), ctx->n_cu / std::max(1, pl->n_fg * pl->kq_kg)));
-        pl->kq_lds = (size_t)2 * 32 * (260 + 32 * 4) * 4 + (size_t)pl->rp * 4 + 320;
+        pl->kq_lds = (size_t)2 * 32 * (260 + 32 * 4) * 4 + (size_t)pl->rp * 4 + 320 + (size_t)4 * 256 * 4;
     }
     if (pl->rp > 4 * pl->NWB * 64 && pl->upd_w && (pl->bm == BM_KL || pl->xr)) {
         // k_wstats keeps the row sums of H (KL) and the extra row of the slab (F = 32n+1) in per-thread registers: 1024 columns

@@ -2606,11 +2606,19 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     static_assert(CPW % 4 == 0, "the extra row takes 4 frames x 16 lanes at a time");
     // 256-column pieces of an H row this geometry can have: NK <= 8 is rp <= 256 (one kappa-group, n_kg = 1 on the host)
     constexpr int NPC = NK <= 8 ? 1 : 4;
-    float gx[4 * NPC];             // extra row of the slab: lane <-> k = 256*(i/4) + 4*lane + i%4  (rp <= 256 * NPC)
+    // extra row of the slab: lane <-> k = 256*(i/4) + 4*lane + i%4  (rp <= 256 * NPC).  One 256-column piece (NK <= 8):
+    // the four partial sums live in LDS, one row per consumer wave (gxs; a read-modify-write per tile) -- as registers
+    // they were what the 168-VGPR geometries spilled, and a scratch round trip per tile on the waves with the extra row
+    // paces the whole workgroup.  NK = 16: registers.
+    constexpr bool GXL = NPC == 1;
+    const int gxw = a.rp < 256 ? a.rp : 256;
+    float gx[4 * NPC];
 #pragma unroll
     for (int i = 0; i < 4 * NPC; ++i) gx[i] = 0.f;
     if (do_x && WM != 3)
         for (int k = threadIdx.x; k < rp; k += NTHR) wxs[k] = a.wx[k];
+    if (GXL && do_x)  // (the consumers' partial extra rows start at zero; a barrier separates this from their first use)
+        for (int k = threadIdx.x; k < NWB * gxw; k += NTHR) (lds + NBUF * TT * (a.ldh + 32 * NWB) + a.rp + 80)[k] = 0.f;
     const int phi = by * NWB + w;
     const int fc = w * 32 + fl;  // this lane's column of the staged V image
     const bool active = !is_loader && phi < a.nf;
@@ -2653,6 +2661,10 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     unsigned* ready = reinterpret_cast<unsigned*>(wxs + rp);  // [4] loader waves: tiles staged
     unsigned* done = ready + 4;                               // [NWB] consumer waves: tiles finished
     float* vx = reinterpret_cast<float*>(done + NWB);         // [2][32] V of the extra row, one value per frame (DMA loaders)
+    float* gxs = wxs + rp + 80;                               // [NWB][gxw] partial extra row of the slab per consumer wave (GXL)
+    // (the read-modify-write is inline assembly: as C++ stores into the LDS array inside the tile loop they alias every
+    //  tile read as far as the compiler knows, and the 168-VGPR geometries went from 16 to 211 spilled registers)
+    const unsigned gxa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(gxs + w * gxw + 4 * lane);
     if (NL > 0) {
         if (threadIdx.x < 4 + NWB) ready[threadIdx.x] = 0u;
         __syncthreads();  // slots and wxs are set
@@ -2700,12 +2712,18 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
             for (int pc = 0; pc < NPC; ++pc) {
                 const int k0 = 256 * pc + 4 * lane;
                 if (k0 + (kc ? kap_base * 32 : 0) < rp) {
+                    f32x4 g4;
+                    if (GXL) asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(g4) : "v"(gxa));
 #pragma unroll
                     for (int c = 0; c < CPW; ++c) {
                         const f32x4 hv = *reinterpret_cast<const f32x4*>(xH + (xw * CPW + c) * ldh + k0);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) gx[4 * pc + e] += rxv[c] * hv[e];
+                        for (int e = 0; e < 4; ++e) {
+                            if (GXL) g4[e] += rxv[c] * hv[e];
+                            else gx[4 * pc + e] += rxv[c] * hv[e];
+                        }
                     }
+                    if (GXL) asm volatile("ds_write_b128 %0, %1" ::"v"(gxa), "v"(g4));
                 }
             }
     };
@@ -2861,8 +2879,16 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
                     if (OBJ) {
                         if (do_obj) {
                             float d = div_term<BM>(v, lam, a.beta, a.inv_bb1);
-                            if (decltype(masked)::value) dsum += (f < a.F && t < a.T) ? d : 0.f;
-                            else dsum += d;
+                            // (the unmasked add must not be contracted with the term's last product into an fma: the masked
+                            //  form -- a select between product and add -- cannot be, the two would differ in the last bit,
+                            //  and the early-stop decisions in the online loop's Euclidean test hang on less.  __fadd_rn is
+                            //  a plain "+" to the compiler and does not stop it)
+                            if (decltype(masked)::value) {
+                                dsum += (f < a.F && t < a.T) ? d : 0.f;
+                            } else {
+#pragma clang fp contract(off)
+                                dsum = dsum + d;
+                            }
                         }
                     }
                     if (WM == 0) R[i] = v * fast_rcp(lam);
@@ -3011,13 +3037,15 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     }
     if (do_x) {
         // fixed-order sum of the consumers' partial extra rows, through LDS
+        if (GXL) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the assembly stores above are not the compiler's to wait for)
         __syncthreads();
-        float* red = lds;  // [NWB][rp]  (NWB*rp <= 32*ldh)
-        if (!is_loader) {
+        float* red = GXL ? gxs : lds;  // [NWB][rp]  (NWB*rp <= 32*ldh)
+        const int rw = GXL ? gxw : rp;
+        if (!GXL && !is_loader) {
 #pragma unroll
             for (int i = 0; i < 4 * NPC; ++i) {
                 const int k = 256 * (i >> 2) + 4 * lane + (i & 3);
-                if (k < rp) red[w * rp + k] = gx[i];
+                if (k < rp) red[w * rw + k] = gx[i];
             }
         }
         __syncthreads();
@@ -3025,7 +3053,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         const int koff = kc ? kap_base * 32 : 0, kn = kc ? 32 * NK : rp;  // kc: this kappa-group's columns only
         for (int k = threadIdx.x; k < kn && koff + k < rp; k += NTHR) {
             float s = 0.f;
-            for (int ww = 0; ww < NWB; ++ww) s += red[ww * rp + k];
+            for (int ww = 0; ww < NWB; ++ww) s += red[ww * rw + k];
             slab[(size_t)(koff + k) * Fp + a.Fm] = s;
         }
         __syncthreads();

@@ -19,6 +19,9 @@ CASES = {
     "ed_r300": dict(F=200, T=2500, r=300, beta=2.0, iters=5),
     "is_full": dict(F=129, T=2000, r=16, beta=0.0, iters=8),
     "b05_nocost": dict(F=97, T=1500, r=12, beta=0.5, iters=8, cost_check=False),
+    # the online adaptation's solve (src/bnmf_sep_event_RT_IS16.m:330-335): W-only, some columns fixed, m_a = 100 frames
+    "ed_adapt_513x100": dict(F=513, T=100, r=50, beta=2.0, iters=40, h_ind=False, w_part=10, conv_eps=1e-4),
+    "kl_adapt_513x100": dict(F=513, T=100, r=50, beta=1.0, iters=40, h_ind=False, w_part=10, conv_eps=1e-4),
 }
 
 
@@ -63,7 +66,7 @@ def test_fused_w_finish_equals_reduce_then_apply(gpu_ctx, name):
     div_b, cost_b, n_b = b.get_objective()
     b.close()
     assert n_a == n_b
-    if "conv_eps" in c:
+    if name == "kl_early_stop":
         assert 1 < n_a < c["iters"]  # the case does stop early
     assert np.array_equal(Wa, Wb) and np.array_equal(Ha, Hb)
     assert np.array_equal(cost_a, cost_b) and np.array_equal(div_a, div_b)
