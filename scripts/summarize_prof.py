@@ -47,7 +47,7 @@ with open(f"profiles/{tag}_pmc.csv", "w") as f:
     cols = sorted({c for d in avg.values() for c in d})
     f.write("kernel," + ",".join(cols) + ",hbm_read_bytes(2*FETCH*1024),hbm_write_bytes(WRITE*1024)\n")
     for k, d in sorted(avg.items()):
-        if not any(x in k for x in ("k_hstep", "k_wstats", "k_reduce", "k_wapply", "k_hsolve", "k_wadapt", "k_o")):
+        if not any(x in k for x in ("k_hstep", "k_wstats", "k_reduce", "k_wapply", "k_wfin", "k_hsolve", "k_wadapt", "k_o")):
             continue
         rd = 2 * d.get("FETCH_SIZE", 0) * 1024
         wr = d.get("WRITE_SIZE", 0) * 1024
