@@ -1006,8 +1006,13 @@ static ReduceArgs make_reduce_args(snmf_plan* pl, double* stats, bool do_mats, b
     ra.use_sh_const = sh_const;
     return ra;
 }
-static int launch_reduce(snmf_plan* pl, double* stats, bool do_mats, bool do_obj, int n_part, bool sh_const) {
-    const ReduceArgs ra = make_reduce_args(pl, stats, do_mats, do_obj, n_part, sh_const);
+static int launch_reduce(snmf_plan* pl, double* stats, bool do_mats, bool do_obj, int n_part, bool sh_const, int check_it = 0) {
+    ReduceArgs ra = make_reduce_args(pl, stats, do_mats, do_obj, n_part, sh_const);
+    ra.check_it = check_it;
+    ra.conv_eps = pl->p.conv_eps;
+    ra.divh = pl->divh;
+    ra.costh = pl->costh;
+    ra.st = pl->st;
     const size_t tot = do_mats ? ((size_t)pl->n_mat * pl->p.r * pl->Fp) / 4 : 1;
     ScopedTimer tm(pl->ctx, FAM_REDUCE);
     hipLaunchKernelGGL(k_reduce, dim3((int)std::max<size_t>(1, std::min<size_t>((tot + 31) / 32, 4096))), dim3(256),
@@ -1338,6 +1343,11 @@ extern "C" int snmf_plan_run(snmf_plan* pl, int32_t n_iters, int32_t* iters_done
             SN_TRY(launch_wstats(pl, obj && !pl->upd_h && !mdi_wonly));
             const int n_part = pl->upd_h ? hupd_parts(pl) : pl->M ? pl->grid_mdi : wstats_parts(pl);
             SN_TRY(launch_wfin(pl, pl->stats, obj, n_part, !pl->upd_h, obj ? j - 1 : 0));
+            pl->it_done = j;
+        } else if (pl->upd_h && !pl->upd_w && !pl->M) {
+            // H-only: the objective fold and the convergence test in one launch (the step API's k_reduce + k_check)
+            const int j = pl->it_done + 1;
+            if (want_obj(pl, j)) SN_TRY(launch_reduce(pl, pl->stats, false, true, hupd_parts(pl), false, j - 1));
             pl->it_done = j;
         } else {
             SN_TRY(snmf_plan_wstats(pl, pl->stats));

@@ -3080,6 +3080,28 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     }
 }
 
+// Convergence test of src/sparse_nmf.m:260-285 for iteration `it` (1-based) whose (div, sh) sit
+// in the reduced statistics.  Every workgroup evaluates it identically (no races: it reads only
+// the statistics and the cost of iteration it-1, written by an earlier launch); one thread
+// records.  Returns true when the loop must stop at `it`.
+__device__ __forceinline__ bool conv_test(const double* sc, double* divh, double* costh, DevState* st, int it,
+                                          double conv_eps, bool recorder) {
+    const double div = sc[0], cost = sc[0] + sc[1];
+    bool stopnow = false;
+    if (it > 1 && conv_eps > 0.0) {
+        const double last = costh[it - 2];
+        const double e = fabs(cost - last) / last;
+        stopnow = e < conv_eps;
+    }
+    if (recorder) {
+        divh[it - 1] = div;
+        costh[it - 1] = cost;
+        st->n_iter = it;
+        if (stopnow) st->stop = 1;
+    }
+    return stopnow;
+}
+
 // ============================================================================================
 // Statistics buffer (fp64, device), the unit that is all-reduced across ranks:
 //   [ M0 (rp*Fp) | M1 (rp*Fp, beta != 1) | s (rp) | div | sh ]
@@ -3097,6 +3119,13 @@ struct ReduceArgs {
     int do_obj;           // reduce objective partials
     double sh_const;      // W-only mode: sum(S.*H) is constant, added here
     int use_sh_const;
+    // > 0: the convergence test of that iteration runs behind the objective fold (H-only loop of snmf_plan_run: one
+    // launch instead of k_reduce + k_check)
+    int check_it;
+    double conv_eps;
+    double* divh;
+    double* costh;
+    DevState* st;
 };
 
 __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
@@ -3206,30 +3235,9 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
         if (threadIdx.x == 0) {
             sc[0] = a.do_obj ? red2[0][0] : 0.0;
             sc[1] = a.do_obj ? (a.use_sh_const ? a.sh_const : red2[1][0]) : 0.0;
+            if (a.check_it > 0) conv_test(sc, a.divh, a.costh, a.st, a.check_it, a.conv_eps, true);
         }
     }
-}
-
-// Convergence test of src/sparse_nmf.m:260-285 for iteration `it` (1-based) whose (div, sh) sit
-// in the reduced statistics.  Every workgroup evaluates it identically (no races: it reads only
-// the statistics and the cost of iteration it-1, written by an earlier launch); one thread
-// records.  Returns true when the loop must stop at `it`.
-__device__ __forceinline__ bool conv_test(const double* sc, double* divh, double* costh, DevState* st, int it,
-                                          double conv_eps, bool recorder) {
-    const double div = sc[0], cost = sc[0] + sc[1];
-    bool stopnow = false;
-    if (it > 1 && conv_eps > 0.0) {
-        const double last = costh[it - 2];
-        const double e = fabs(cost - last) / last;
-        stopnow = e < conv_eps;
-    }
-    if (recorder) {
-        divh[it - 1] = div;
-        costh[it - 1] = cost;
-        st->n_iter = it;
-        if (stopnow) st->stop = 1;
-    }
-    return stopnow;
 }
 
 struct ApplyArgs {

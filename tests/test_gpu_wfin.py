@@ -1,4 +1,4 @@
-"""snmf_plan_run's fused W finish (k_wfin: the chunk reduction and the W update in one launch) against the step API's two
+"""snmf_plan_run's fused launches: the W finish (k_wfin: the chunk reduction and the W update in one launch) against the step API's two
 launches (k_reduce -> statistics in memory -> k_wapply), which is the path the statistics take when they are summed over
 ranks in between (se_snmf_nat_amd/dist.py, csrc/snmf_multi.h).  Both add the chunk slabs in the same fixed order, so W, H,
 the objective and the stop index must agree bit for bit -- this is what lets the sharded tests pin the sharding algebra
@@ -19,6 +19,10 @@ CASES = {
     "ed_r300": dict(F=200, T=2500, r=300, beta=2.0, iters=5),
     "is_full": dict(F=129, T=2000, r=16, beta=0.0, iters=8),
     "b05_nocost": dict(F=97, T=1500, r=12, beta=0.5, iters=8, cost_check=False),
+    # H-only: the run loop folds the objective and tests convergence in one launch (step API: k_reduce + k_check)
+    "kl_honly_513": dict(F=513, T=9000, r=200, beta=1.0, iters=6, w_none=True),
+    "kl_honly_early_stop": dict(F=129, T=2000, r=20, beta=1.0, iters=80, w_none=True, conv_eps=2e-3),
+    "ed_honly": dict(F=257, T=3000, r=40, beta=2.0, iters=8, w_none=True),
     # the online adaptation's solve (src/bnmf_sep_event_RT_IS16.m:330-335): W-only, some columns fixed, m_a = 100 frames
     "ed_adapt_513x100": dict(F=513, T=100, r=50, beta=2.0, iters=40, h_ind=False, w_part=10, conv_eps=1e-4),
     "kl_adapt_513x100": dict(F=513, T=100, r=50, beta=1.0, iters=40, h_ind=False, w_part=10, conv_eps=1e-4),
@@ -35,6 +39,8 @@ def _mk(gpu_ctx, c):
     kw = {}
     if c.get("h_ind") is False:
         kw["h_update_ind"] = np.zeros(r, bool)
+    if c.get("w_none"):
+        kw["w_update_ind"] = np.zeros(r, bool)
     if "w_part" in c:
         wi = np.zeros(r, bool); wi[c["w_part"]:] = True
         kw["w_update_ind"] = wi
@@ -49,7 +55,7 @@ def test_fused_w_finish_equals_reduce_then_apply(gpu_ctx, name):
     import torch
     c = CASES[name]
     a = _mk(gpu_ctx, c)
-    assert "W finish (run loop): k_wfin" in a.describe()
+    assert ("W finish (run loop): none" if c.get("w_none") else "W finish (run loop): k_wfin") in a.describe()
     a.run()
     Wa, Ha = a.get_w(), a.get_h()
     div_a, cost_a, n_a = a.get_objective()
@@ -66,7 +72,7 @@ def test_fused_w_finish_equals_reduce_then_apply(gpu_ctx, name):
     div_b, cost_b, n_b = b.get_objective()
     b.close()
     assert n_a == n_b
-    if name == "kl_early_stop":
+    if name in ("kl_early_stop", "kl_honly_early_stop"):
         assert 1 < n_a < c["iters"]  # the case does stop early
     assert np.array_equal(Wa, Wb) and np.array_equal(Ha, Hb)
     assert np.array_equal(cost_a, cost_b) and np.array_equal(div_a, div_b)
