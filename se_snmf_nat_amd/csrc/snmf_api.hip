@@ -5,6 +5,7 @@
 // numeric step is a HIP kernel launch; without a device the entry points fail.
 #include "snmf_kernels.h"
 #include "snmf_frontend.h"
+#include "snmf_generic.h"
 
 #include <algorithm>
 #include <cmath>
@@ -235,6 +236,10 @@ struct snmf_plan {
     // snmf_plan_run: k_reduce + k_wapply as one launch (k_wfin) when a column's chunk-group sums fit the LDS
     bool wfin = false;
     size_t lds_wfin = 0;
+    // shapes beyond the fused kernels' LDS / register envelope: the same iteration with its intermediates in HBM
+    // (csrc/snmf_generic.h); Lam / ratio / denominator images [Tp][Fp], numerator / denominator of the H update [Tp][rp]
+    bool generic = false;
+    float *gLam = nullptr, *gR = nullptr, *gD = nullptr, *gNum = nullptr, *gDen = nullptr;
     size_t kq_lds = 0;
     int grid_h = 1;
     int ldh = 0, ldr = 0, ldhw = 0;
@@ -311,7 +316,8 @@ extern "C" void snmf_plan_destroy(snmf_plan* pl) {
 #endif
     void* ptrs[] = {pl->V,     pl->H[0],  pl->H[1], pl->Wc,   pl->Wt4,   pl->Wk4,  pl->dphv, pl->colsum, pl->lamk,
                     pl->S,     pl->slabs, pl->spart, pl->part, pl->stats, pl->divh, pl->costh, pl->wn,    pl->st,
-                    pl->w_ind, pl->staging, pl->wx, pl->Wcf, pl->M, pl->part_buf, pl->part_cnt};
+                    pl->w_ind, pl->staging, pl->wx, pl->Wcf, pl->M, pl->part_buf, pl->part_cnt,
+                    pl->gLam,  pl->gR,    pl->gD,   pl->gNum, pl->gDen};
     for (void* q : ptrs)
         if (q) hipFree(q);
     delete pl;
@@ -376,9 +382,9 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         // R_x = R_d = 500 at F = 513, settings/bak_IS16_results/initial_setting_Exemplar.m:47-48): 16-frame tiles
         pl->NWH = 8; pl->NT = 1; pl->TTH = 16;
     } else {
-        delete pl;
-        return fail(SNMF_ERR_UNSUPPORTED, "F + r = %d too large for the %zu-byte LDS tile (limit F+r <= %zu)", F + r,
-                    lds_cap, lds_cap / 64 - 16);
+        // F + r beyond what a 16-frame tile's H block + ratio image take of the LDS (~2540): the out-of-envelope path
+        pl->generic = true;
+        pl->NWH = 8; pl->NT = 1; pl->TTH = 16;
     }
     if (const char* e = getenv("SNMF_HSTEP_RP")) pl->hstep_rp = atoi(e) != 0;
     // A workgroup with a single tile has nothing to pipeline: the role pipelines' hand-offs then only add latency (C1,
@@ -490,10 +496,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         pl->stagger_w = 0;
         (void)mf_w;
     }
-    if (pl->lds_w > lds_cap) {
-        delete pl;
-        return fail(SNMF_ERR_UNSUPPORTED, "r = %d too large for the LDS H tile", r);
-    }
+    if (pl->lds_w > lds_cap && pl->upd_w) pl->generic = true;  // r too large for k_wstats' H image
     if (pl->bm == BM_EUC && pl->NKT == 16 && pl->TTW == 32 && pl->upd_w) {
         // Q = V * H^T of the Euclidean W step needs no Lam', so nothing is recomputed when the statistics' columns are cut
         // into 256-wide kappa-groups: the NK = 16 geometry (256 accumulator registers, no room for loader waves, 116
@@ -502,12 +505,8 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         pl->kq_chunks = std::max(1, std::min(std::min(n_tiles_w, pl->n_chunks), ctx->n_cu / std::max(1, pl->n_fg * pl->kq_kg)));
         pl->kq_lds = (size_t)2 * 32 * (260 + 32 * 4) * 4 + (size_t)pl->rp * 4 + 320 + (size_t)4 * 256 * 4;
     }
-    if (pl->rp > 4 * pl->NWB * 64 && pl->upd_w && (pl->bm == BM_KL || pl->xr)) {
-        // k_wstats keeps the row sums of H (KL) and the extra row of the slab (F = 32n+1) in per-thread registers: 1024 columns
-        delete pl;
-        return fail(SNMF_ERR_UNSUPPORTED, "r = %d > %d not supported for W updates with %s", r, 4 * pl->NWB * 64,
-                    pl->bm == BM_KL ? "the KL divergence" : "F = 32n+1 rows");
-    }
+    // k_wstats keeps the row sums of H (KL) and the extra row of the slab (F = 32n+1) in per-thread registers: 1024 columns
+    if (pl->rp > 4 * pl->NWB * 64 && pl->upd_w && (pl->bm == BM_KL || pl->xr)) pl->generic = true;
 
     pl->lds_wfin = (size_t)9 * pl->n_mat * pl->Fp * sizeof(double);
     pl->wfin = pl->upd_w && pl->lds_wfin + 12 * 1024 <= lds_cap;
@@ -537,6 +536,20 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
             }
         }
     }
+    if (pl->generic) {
+        // none of the fused geometries applies; contractions over the frames are split into chunks of kGChunkT frames,
+        // whose slabs k_reduce adds like the fast path's
+        pl->hstep_rp = pl->rh = false;
+        pl->rp_S = 0;
+        pl->kq_kg = 0;
+        pl->n_ch1 = 0;
+        pl->small_ok = pl->small = false;
+        pl->frame_fb = pl->frame_kb = 0;
+        pl->wfin = false;
+        pl->n_fg = pl->n_kg = 1;
+        pl->n_chunks = (T + kGChunkT - 1) / kGChunkT;
+        pl->grid_h = pl->grid_mdi = kGBlocks;
+    }
     // allocations
     const size_t nV = (size_t)pl->Fp * pl->Tp, nH = (size_t)pl->rp * pl->Tp, nW = (size_t)pl->Fp * pl->rp;
     const size_t nWt = (size_t)pl->Fm * pl->rp, nWk = (size_t)pl->Fq * pl->rp;
@@ -558,6 +571,15 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         A(dalloc(&pl->slabs, (size_t)pl->n_chunks * pl->n_mat * nW));
         A(dalloc(&pl->spart, (size_t)pl->n_chunks * pl->rp));
     }
+    if (pl->generic) {
+        A(dalloc(&pl->gLam, nV));
+        A(dalloc(&pl->gR, nV));
+        if (pl->bm != BM_KL) A(dalloc(&pl->gD, nV));
+        if (pl->upd_h) {
+            A(dalloc(&pl->gNum, nH));
+            if (pl->bm != BM_KL) A(dalloc(&pl->gDen, nH));
+        }
+    }
     if (pl->rp_S) {
         A(dalloc(&pl->part_buf, (size_t)pl->rp_grid * 32 * pl->rp));
         A(dalloc(&pl->part_cnt, (size_t)(pl->rp_tiles - pl->rp_full)));
@@ -565,6 +587,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     pl->n_part = std::max(std::max(pl->grid_h, pl->grid_mdi), pl->n_chunks * pl->n_fg);
     pl->n_part = std::max(pl->n_part, pl->rp_grid);
     pl->n_part = std::max(pl->n_part, 1024);
+    if (pl->generic) pl->n_part = kGBlocks + 256;  // (+ the slots of k_sum_sh behind the Lam pass's)
     A(dalloc(&pl->part, (size_t)2 * pl->n_part));
     A(dalloc(&pl->stats, (size_t)pl->n_mat * nW + pl->rp + 2));
     A(dalloc(&pl->divh, (size_t)std::max(1, p->max_iter)));
@@ -630,6 +653,11 @@ extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
                  pl->rp_full, pl->rp_tiles, pl->rp_S, pl->rp_grid);
     else
         snprintf(hs, sizeof hs, "k_hstep");
+    if (pl->generic) {
+        snprintf(buf, n, "F=%d T=%d r=%d beta=%g | out-of-envelope path (intermediates in HBM: k_g_gemm / k_g_ratio / k_g_hupd, %d frame splits) | n_cu=%d",
+                 pl->p.F, pl->p.T, pl->p.r, pl->p.beta, pl->n_chunks, pl->ctx->n_cu);
+        return SNMF_OK;
+    }
     snprintf(buf, n,
              "F=%d T=%d r=%d beta=%g | Fm=%d(+%d VALU row) rp=%d Tp=%d | hstep: %s, tile=%d frames, grid=%d x %d thr, lds=%zu B | "
              "wstats: NK=%d waves=%d+%d grid=(%d chunks,%d fgroups,%d kgroups; group-1 chunks %d) lds=%zu B | W finish (run loop): %s | n_cu=%d",
@@ -726,7 +754,7 @@ template <typename T>
 static int set_mask(snmf_plan* pl, const T* M, int64_t ld, int dev) {
     PLAN_CHECK(pl);
     if (!pl->upd_h && !pl->upd_w) return fail(SNMF_ERR_UNSUPPORTED, "MDI with neither factor updated is not implemented");
-    if (pl->TTH != 32 || pl->TTW != 32)
+    if (pl->TTH != 32 || pl->TTW != 32 || pl->generic)
         return fail(SNMF_ERR_UNSUPPORTED, "MDI needs the 32-frame tile images in LDS: F + r = %d is too large", pl->p.F + pl->p.r);
     if (!pl->M) {
         SN_TRY(dalloc(&pl->M, (size_t)pl->Fp * pl->Tp));
@@ -878,7 +906,83 @@ static int launch_hstep_mdi_b(snmf_plan* pl, const StepArgs& a, bool obj, bool u
                         : launch_big(k_hstep<8, 1, 0, BM, false, true, true>, g, b, pl->lds_mdi, st, a);
     return launch_big(k_hstep<8, 1, 0, BM, true, false, true>, g, b, pl->lds_mdi, st, a);  // imputation (+ objective)
 }
+// ---- the out-of-envelope path (csrc/snmf_generic.h) ---------------------------------------------
+static int g_gemm(snmf_plan* pl, const float* A, long long rsA, long long csA, const float* B, long long rsB, long long csB, float* C,
+                  long long rsC, long long csC, int M, int N, int K, int kchunk, long long zC) {
+    GemmArgs g{};
+    g.A = A; g.B = B; g.C = C;
+    g.M = M; g.N = N; g.K = K;
+    g.kchunk = kchunk > 0 ? kchunk : K;
+    g.rsA = rsA; g.csA = csA; g.rsB = rsB; g.csB = csB; g.rsC = rsC; g.csC = csC; g.zC = zC;
+    g.stop = &pl->st->stop;
+    const int nz = (K + g.kchunk - 1) / g.kchunk;
+    hipLaunchKernelGGL(k_g_gemm, dim3((M + 63) / 64, (N + 63) / 64, std::max(1, nz)), dim3(256), 0, pl->ctx->stream, g);
+    HIP_TRY(hipGetLastError());
+    return SNMF_OK;
+}
+// Lam = W * H (H = the current iterate), then the ratio images (+ the divergence terms of that iterate)
+template <int BM>
+static int g_lam_ratio(snmf_plan* pl, const float* H, bool obj) {
+    const int F = pl->p.F, T = pl->p.T, r = pl->p.r;
+    SN_TRY(g_gemm(pl, pl->Wcf, 1, pl->Fp, H, 1, pl->rp, pl->gLam, 1, pl->Fp, F, T, r, 0, 0));
+    const double bb1 = pl->p.beta * (pl->p.beta - 1.0);
+    const float inv_bb1 = bb1 != 0.0 ? (float)(1.0 / bb1) : 0.f;
+    if (obj)
+        hipLaunchKernelGGL((k_g_ratio<BM, true>), dim3(kGBlocks), dim3(256), 0, pl->ctx->stream, (const float*)pl->V, (const float*)pl->gLam,
+                           pl->gR, pl->gD, F, pl->Fp, T, (float)pl->p.beta, inv_bb1, pl->part, (const int*)&pl->st->stop);
+    else
+        hipLaunchKernelGGL((k_g_ratio<BM, false>), dim3(kGBlocks), dim3(256), 0, pl->ctx->stream, (const float*)pl->V, (const float*)pl->gLam,
+                           pl->gR, pl->gD, F, pl->Fp, T, (float)pl->p.beta, inv_bb1, pl->part, (const int*)&pl->st->stop);
+    HIP_TRY(hipGetLastError());
+    return SNMF_OK;
+}
+static int g_lam_ratio(snmf_plan* pl, const float* H, bool obj) {
+    if (pl->bm == BM_KL) return g_lam_ratio<BM_KL>(pl, H, obj);
+    if (pl->bm == BM_EUC) return g_lam_ratio<BM_EUC>(pl, H, obj);
+    return g_lam_ratio<BM_GEN>(pl, H, obj);
+}
+static int generic_hstep(snmf_plan* pl, bool obj, bool upd) {
+    const int F = pl->p.F, T = pl->p.T, r = pl->p.r;
+    const float* Hin = pl->H[pl->cur];
+    SN_TRY(g_lam_ratio(pl, Hin, obj));
+    if (!upd) return SNMF_OK;
+    // num = W' * R, den = W' * D (beta != 1)
+    SN_TRY(g_gemm(pl, pl->Wcf, pl->Fp, 1, pl->gR, 1, pl->Fp, pl->gNum, 1, pl->rp, r, T, F, 0, 0));
+    if (pl->bm != BM_KL) SN_TRY(g_gemm(pl, pl->Wcf, pl->Fp, 1, pl->gD, 1, pl->Fp, pl->gDen, 1, pl->rp, r, T, F, 0, 0));
+    float* Hout = pl->H[pl->cur ^ 1];
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(kGBlocks), dim3(256), 0, pl->ctx->stream, Hin, Hout, (const float*)pl->gNum, (const float*)pl->gDen,
+                           (const float*)pl->S, (const float*)pl->lamk, (const float*)pl->colsum, (const float*)pl->dphv, r, pl->rp, T, pl->part,
+                           (const int*)&pl->st->stop);
+    };
+    if (pl->bm == BM_KL) { if (obj) go(k_g_hupd<true, true>); else go(k_g_hupd<true, false>); }
+    else { if (obj) go(k_g_hupd<false, true>); else go(k_g_hupd<false, false>); }
+    HIP_TRY(hipGetLastError());
+    return SNMF_OK;
+}
+// W statistics of the current H as split-T slabs (+ the divergence of the previous iterate in W-only solves)
+static int generic_wstats(snmf_plan* pl, bool obj) {
+    const int F = pl->p.F, T = pl->p.T, r = pl->p.r;
+    const float* H = pl->H[pl->cur];
+    SN_TRY(g_lam_ratio(pl, H, obj));
+    const long long nW = (long long)pl->Fp * pl->rp, zC = nW * pl->n_mat;
+    // M0 = Q = R * H' (KL: G), M1 = P = D * H'; element (f, k) of a slab at k * Fp + f
+    SN_TRY(g_gemm(pl, pl->gR, 1, pl->Fp, H, pl->rp, 1, pl->slabs, 1, pl->Fp, F, r, T, kGChunkT, zC));
+    if (pl->bm != BM_KL) {
+        SN_TRY(g_gemm(pl, pl->gD, 1, pl->Fp, H, pl->rp, 1, pl->slabs + nW, 1, pl->Fp, F, r, T, kGChunkT, zC));
+    } else {
+        hipLaunchKernelGGL(k_g_rowsum, dim3((r + 255) / 256, pl->n_chunks), dim3(256), 0, pl->ctx->stream, H, pl->rp, r, T, kGChunkT,
+                           pl->spart, (const int*)&pl->st->stop);
+        HIP_TRY(hipGetLastError());
+    }
+    return SNMF_OK;
+}
+
 static int launch_hstep(snmf_plan* pl, bool obj, bool upd) {
+    if (pl->generic) {
+        ScopedTimer tm(pl->ctx, FAM_HSTEP);
+        return generic_hstep(pl, obj, upd);
+    }
     StepArgs a = make_args(pl);
     a.n_tiles = pl->Tp / (pl->TTH * pl->NT);
     a.stagger = pl->stagger_h;
@@ -974,6 +1078,10 @@ static int launch_wstats_geo(snmf_plan* pl, const StepArgs& a, bool obj) {
     return launch_wstats_one<NK, NWB, NL, WPS, 2, BM_GEN, false, TT>(pl, a, 0);
 }
 static int launch_wstats(snmf_plan* pl, bool obj) {
+    if (pl->generic) {
+        ScopedTimer tm(pl->ctx, FAM_WSTATS);
+        return generic_wstats(pl, obj);
+    }
     StepArgs a = make_args(pl);
     a.n_tiles = (pl->p.T + pl->TTW - 1) / pl->TTW;
     a.ldh = pl->ldhw;
@@ -1138,12 +1246,14 @@ static bool want_obj(const snmf_plan* pl, int j) { return pl->p.cost_check && j 
 // objective partials written by an H-UPDATE launch of k_hstep* (= its grid; the objective-only launches use grid_h)
 // objective partials written by a k_wstats launch with the objective (W-only solves) = its workgroups
 static int wstats_parts(const snmf_plan* pl) {
+    if (pl->generic) return kGBlocks;
     return pl->n_ch1 ? pl->n_chunks + (pl->n_fg - 1) * pl->n_ch1 : pl->n_chunks * pl->n_fg;
 }
 static bool hupd_is_rp(const snmf_plan* pl) {
     return !pl->M && (pl->rh || (pl->NWH == 8 && pl->NLH == 4 && pl->hstep_rp && pl->bm == BM_KL));
 }
 static int hupd_parts(const snmf_plan* pl) {
+    if (pl->generic) return kGBlocks;
     if (pl->M) return pl->grid_mdi;
     if (hupd_is_rp(pl)) return pl->rp_grid;
     return pl->grid_h;

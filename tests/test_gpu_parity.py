@@ -541,15 +541,16 @@ def test_dnmf_adapt_caller(gpu_ctx):
     assert B_a.shape == (129, 6) and rel(B_a, ref) < REL_WH
 
 
-def test_shape_limits_are_reported(gpu_ctx):
-    """What the engine cannot hold in LDS / registers is refused with SNMF_ERR_UNSUPPORTED and a message, never run
-    wrongly: F + r beyond the 16-frame tile images (~2540), and W updates with r > 1024 under KL or with F = 32n+1 rows
-    (src/sparse_nmf.m itself has no such limit; DESIGN.md section 7 lists them)."""
-    from se_snmf_nat_amd import Plan, SnmfError
-    with pytest.raises(SnmfError) as e:
-        Plan(gpu_ctx, 513, 64, 2100, beta=1.0, max_iter=2, cost_check=True)
-    assert e.value.status == 8 and "too large" in e.value.message
-    with pytest.raises(SnmfError) as e:
-        Plan(gpu_ctx, 512, 64, 1100, beta=1.0, max_iter=2, cost_check=True)
-    assert e.value.status == 8 and "W updates" in e.value.message
-    Plan(gpu_ctx, 512, 64, 1100, beta=1.0, max_iter=2, cost_check=True, w_update_ind=np.zeros(1100, bool)).close()  # H-only is fine
+def test_shapes_beyond_the_fused_kernels_take_the_out_of_envelope_path(gpu_ctx):
+    """What the fused kernels cannot hold in LDS / registers -- F + r beyond the 16-frame tile images (~2540), W updates
+    with r > 1024 under KL or with F = 32n+1 rows -- is no longer refused (src/sparse_nmf.m has no such limit): the plan
+    runs the iteration with its intermediates in HBM (csrc/snmf_generic.h; parity in tests/test_gpu_generic.py).  A shape
+    inside the envelope keeps the fused kernels."""
+    from se_snmf_nat_amd import Plan
+    for F, r, kw in ((513, 2100, {}), (512, 1100, {})):
+        pl = Plan(gpu_ctx, F, 64, r, beta=1.0, max_iter=2, cost_check=True, **kw)
+        assert "out-of-envelope path" in pl.describe()
+        pl.close()
+    pl = Plan(gpu_ctx, 512, 64, 1100, beta=1.0, max_iter=2, cost_check=True, w_update_ind=np.zeros(1100, bool))  # H-only: fused
+    assert "out-of-envelope" not in pl.describe() and "k_hstep" in pl.describe()
+    pl.close()
