@@ -35,7 +35,12 @@ def draw():
         T = int(rs.integers(400, 9000))
     else:
         T = int(8192 + 32 * rs.integers(1, 140) + rs.integers(-31, 1))
-    while F * T * r > 6e9 or (F + r) > 2400:
+    big = rs.integers(0, 12)  # now and then a shape beyond the fused kernels' envelope (csrc/snmf_generic.h)
+    if big == 0:
+        F, r, T = int(rs.integers(2500, 3200)), int(rs.integers(1, 80)), int(rs.integers(1, 700))
+    elif big == 1:
+        F, r, T = int(rs.choice([129, 200, 257, 64])), int(rs.integers(1030, 1300)), int(rs.integers(1, 5000))
+    while F * T * r > 6e9 or ((F + r) > 2400 and big > 1):
         T = max(1, T // 2)
         if (F + r) > 2400:
             r = r // 2
