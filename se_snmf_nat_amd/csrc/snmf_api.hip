@@ -916,7 +916,7 @@ static int g_gemm(snmf_plan* pl, const float* A, long long rsA, long long csA, c
     g.rsA = rsA; g.csA = csA; g.rsB = rsB; g.csB = csB; g.rsC = rsC; g.csC = csC; g.zC = zC;
     g.stop = &pl->st->stop;
     const int nz = (K + g.kchunk - 1) / g.kchunk;
-    hipLaunchKernelGGL(k_g_gemm, dim3((M + 63) / 64, (N + 63) / 64, std::max(1, nz)), dim3(256), 0, pl->ctx->stream, g);
+    hipLaunchKernelGGL(k_g_gemm, dim3((N + 63) / 64, (M + 63) / 64, std::max(1, nz)), dim3(256), 0, pl->ctx->stream, g);
     HIP_TRY(hipGetLastError());
     return SNMF_OK;
 }

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_g_gemm(GemmArgs g) {
     __shared__ float As[BK][BM + 4];
     __shared__ float Bs[BK][BN + 4];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;  // (x runs over N: the frames, the one dimension that can pass 65535 tiles)
     const int k_lo = blockIdx.z * g.kchunk, k_hi = min(g.K, k_lo + g.kchunk);
     float acc[4][4];
 #pragma unroll
