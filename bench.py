@@ -311,10 +311,12 @@ def main():
                          "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE/WRITE_SIZE passes)",
                          "traffic_source": traffic_source,
                          "algorithmic_flops_per_launch": flops_half,
-                         "kernel_ms": {f: fam[f][0] for f in fam}, "launches": {f: fam[f][1] for f in fam},
+                         "kernel_ms": {f: fam[f][0] for f in fam if fam[f][1]}, "launches": {f: fam[f][1] for f in fam if fam[f][1]},
                          "kernel_ms_note": "HIP events on the engine's stream around every launch of a family, from a SEPARATE "
-                                           "event-instrumented pass of the same loop (the events add host work, so the four "
-                                           "averages need not sum to ms_per_step, which comes from the un-instrumented pass)",
+                                           "event-instrumented pass of the same loop (the events add host work, so the "
+                                           "averages need not sum to ms_per_step, which comes from the un-instrumented pass); "
+                                           "wfin = k_wfin, the chunk reduction and the W update in one launch (the step API "
+                                           "and the multi-GPU loops run them as k_reduce + k_wapply)",
                          "whole_iteration_TFLOPs": 2 * flops_half / (ms * 1e-3) / 1e12},
             "final_cost": float(last_cost[-1]) if last_cost else None,
         }
