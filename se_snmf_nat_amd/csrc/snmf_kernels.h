@@ -517,6 +517,7 @@ __device__ __forceinline__ void hstep_p1_tiles(const StepArgs& a, float* Hs, flo
                                 32 * ldh, a.nqk);
         // epilogue: lane (t = fl, h), reg -> f = 32*phi + drow(reg,h)
         float dsum = 0.f;
+        const bool interior = OBJ && Tt >= 32 && phi * 32 + 32 <= a.F && t0 + Tt <= a.T;
 #pragma unroll
         for (int tau = 0; tau < NT; ++tau) {
             if (!fvalid) break;
@@ -541,7 +542,14 @@ __device__ __forceinline__ void hstep_p1_tiles(const StepArgs& a, float* Hs, flo
                     if (OBJ) {
                         const int f = phi * 32 + 8 * g + 4 * h + j;
                         float d = div_term<BM>(v[j], lam, a.beta, a.inv_bb1);
-                        dsum += (f < a.F && t < a.T) ? d : 0.f;
+                        // (bounds masks only where the tile has padding: a wave-uniform test; the unmasked add stays
+                        //  un-contracted so that both forms round alike, see k_wstats)
+                        if (interior) {
+#pragma clang fp contract(off)
+                            dsum = dsum + d;
+                        } else {
+                            dsum += (f < a.F && t < a.T) ? d : 0.f;
+                        }
                     }
                     if (BM == BM_KL) o[j] = v[j] * fast_rcp(lam);
                     else o[j] = den_of_lam<BM>(lam, a.beta);
