@@ -65,9 +65,13 @@ for name in which:
     ms = dt / iters * 1e3
     half = 4.0 * F * T * r  # flop of one Lam + one contraction pass over the whole problem
     # launches per iteration and their algorithmic work: KL: hstep = wstats = 4FTr; beta = 2: hstep 2 x (Lam | contraction) = 6FTr
-    # (den pass + num pass share Lam: P1 once, P2 twice), wstats P (Lam' + contraction = 4FTr) + Q (contraction only = 2FTr)
+    # (den pass + num pass share Lam: P1 once, P2 twice), wstats P (Lam' + contraction = 4FTr; or, r > 256 in a full update, the Gram
+    # formulation below) + Q (contraction only = 2FTr)
     kl = c["beta"] == 1.0
     work = {"hstep": half if kl else 1.5 * half, "wstats": half if kl else 1.5 * half}
+    if "Gram matrix" in plan.describe():
+        # beta = 2, r > 256, full update: P = W * (H*H') -- the Gram launch is 2 r^2 T flop (+ 2 F r^2 for W * Gram), Q stays 2 F T r
+        work["wstats"] = 2.0 * F * T * r + 2.0 * r * r * T + 2.0 * F * r * r
     per_it = (work["hstep"] if c["mode"] != "w" else 0.0) + (work["wstats"] if c["mode"] != "h" else 0.0)
     if c["mode"] == "w" and kl:
         per_it = half

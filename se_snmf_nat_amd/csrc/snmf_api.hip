@@ -238,6 +238,10 @@ struct snmf_plan {
     size_t lds_wfin = 0;
     // shapes beyond the fused kernels' LDS / register envelope: the same iteration with its intermediates in HBM
     // (csrc/snmf_generic.h); Lam / ratio / denominator images [Tp][Fp], numerator / denominator of the H update [Tp][rp]
+    // Euclidean W step, r > 256, full updates: P = max(W*H, flr) * H' is formed as W * (H*H') -- the r x r Gram matrix
+    // costs 2 r^2 T flop instead of the P launch's 4 F T r (C5: 4.75 -> ~2.5 ms); see launch_gram_p
+    bool gram_p = false;
+    float *gram_slabs = nullptr, *gram32 = nullptr;
     bool generic = false;
     float *gLam = nullptr, *gR = nullptr, *gD = nullptr, *gNum = nullptr, *gDen = nullptr;
     size_t kq_lds = 0;
@@ -317,7 +321,7 @@ extern "C" void snmf_plan_destroy(snmf_plan* pl) {
     void* ptrs[] = {pl->V,     pl->H[0],  pl->H[1], pl->Wc,   pl->Wt4,   pl->Wk4,  pl->dphv, pl->colsum, pl->lamk,
                     pl->S,     pl->slabs, pl->spart, pl->part, pl->stats, pl->divh, pl->costh, pl->wn,    pl->st,
                     pl->w_ind, pl->staging, pl->wx, pl->Wcf, pl->M, pl->part_buf, pl->part_cnt,
-                    pl->gLam,  pl->gR,    pl->gD,   pl->gNum, pl->gDen};
+                    pl->gLam,  pl->gR,    pl->gD,   pl->gNum, pl->gDen, pl->gram_slabs, pl->gram32};
     for (void* q : ptrs)
         if (q) hipFree(q);
     delete pl;
@@ -504,6 +508,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         pl->kq_kg = (pl->nk + 7) / 8;
         pl->kq_chunks = std::max(1, std::min(std::min(n_tiles_w, pl->n_chunks), ctx->n_cu / std::max(1, pl->n_fg * pl->kq_kg)));
         pl->kq_lds = (size_t)2 * 32 * (260 + 32 * 4) * 4 + (size_t)pl->rp * 4 + 320 + (size_t)4 * 256 * 4;
+        pl->gram_p = pl->upd_h && r < 2 * F;  // (W-only solves take their objective from the P launch's Lam')
     }
     // k_wstats keeps the row sums of H (KL) and the extra row of the slab (F = 32n+1) in per-thread registers: 1024 columns
     if (pl->rp > 4 * pl->NWB * 64 && pl->upd_w && (pl->bm == BM_KL || pl->xr)) pl->generic = true;
@@ -542,6 +547,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         pl->hstep_rp = pl->rh = false;
         pl->rp_S = 0;
         pl->kq_kg = 0;
+        pl->gram_p = false;
         pl->n_ch1 = 0;
         pl->small_ok = pl->small = false;
         pl->frame_fb = pl->frame_kb = 0;
@@ -570,6 +576,10 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     if (pl->upd_w) {
         A(dalloc(&pl->slabs, (size_t)pl->n_chunks * pl->n_mat * nW));
         A(dalloc(&pl->spart, (size_t)pl->n_chunks * pl->rp));
+    }
+    if (pl->gram_p) {
+        A(dalloc(&pl->gram_slabs, (size_t)pl->kq_chunks * pl->rp * pl->rp));
+        A(dalloc(&pl->gram32, (size_t)pl->rp * pl->rp));
     }
     if (pl->generic) {
         A(dalloc(&pl->gLam, nV));
@@ -660,11 +670,11 @@ extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
     }
     snprintf(buf, n,
              "F=%d T=%d r=%d beta=%g | Fm=%d(+%d VALU row) rp=%d Tp=%d | hstep: %s, tile=%d frames, grid=%d x %d thr, lds=%zu B | "
-             "wstats: NK=%d waves=%d+%d grid=(%d chunks,%d fgroups,%d kgroups; group-1 chunks %d) lds=%zu B | W finish (run loop): %s | n_cu=%d",
+             "wstats: NK=%d waves=%d+%d grid=(%d chunks,%d fgroups,%d kgroups; group-1 chunks %d) lds=%zu B%s | W finish (run loop): %s | n_cu=%d",
              pl->p.F, pl->p.T, pl->p.r, pl->p.beta, pl->Fm, pl->xr, pl->rp, pl->Tp, hs, pl->TTH * pl->NT,
              (kl_pipe || rh_pipe) ? pl->rp_grid : pl->grid_h, rh_pipe ? 768 : (pl->NWH + pl->NLH) * 64,
              rh_pipe ? pl->lds_rh : pl->lds_h, pl->NKT, pl->NWB, pl->NLW, pl->n_chunks, pl->n_fg, pl->n_kg, pl->n_ch1 ? pl->n_ch1 : pl->n_chunks, pl->lds_w,
-             pl->wfin ? "k_wfin" : (pl->upd_w ? "k_reduce + k_wapply" : "none"), pl->ctx->n_cu);
+             pl->gram_p ? ", P = W*(H*H') through the Gram matrix" : "", pl->wfin ? "k_wfin" : (pl->upd_w ? "k_reduce + k_wapply" : "none"), pl->ctx->n_cu);
     return SNMF_OK;
 }
 
@@ -1039,6 +1049,35 @@ static int launch_wstats_one(snmf_plan* pl, const StepArgs& a, int mat_index) {
     HIP_TRY(hipGetLastError());
     return SNMF_OK;
 }
+// The "P" statistics of a Euclidean W step without the Lam' pass: P = max(W*H, flr) * H' = W * (H*H') wherever W*H is above
+// the 1e-9 floor (everywhere that matters: an entry at the floor contributes < 1e-9 * sum(h) either way, far below the
+// engine's fp32 rounding of P).  H*H' is the V*H' launch with the H image as "V" (r rows, no extra row), by kappa-groups
+// like the Q launch; its chunk slabs are added in fp64, and W * Gram is one small GEMM into the P slab of chunk 0 (the P
+// slabs of the other chunks stay zero from plan creation), so k_reduce / k_wfin / k_wapply see an ordinary P.
+static int launch_gram_p(snmf_plan* pl, const StepArgs& a) {
+    StepArgs ag = a;
+    ag.V = a.Hin;
+    ag.F = pl->p.r;
+    ag.Fp = ag.Fm = ag.Fq = pl->rp;
+    ag.nf = pl->rp / 32;
+    ag.xr = 0;
+    ag.ldh = 260;
+    ag.kc = 1;
+    ag.n_ch1 = 0;
+    ag.slabs = pl->gram_slabs;
+    auto kern = k_wstats<8, 4, 4, 2, 3, BM_EUC, false, 32>;
+    SN_TRY(ensure_dyn_lds(pl->ctx->device, (const void*)kern, pl->kq_lds));
+    const int nfg = (ag.nf + 3) / 4;
+    hipLaunchKernelGGL(kern, dim3(pl->kq_chunks, nfg, pl->kq_kg), dim3(512), pl->kq_lds, pl->ctx->stream, ag, pl->kq_chunks, 0, 1);
+    HIP_TRY(hipGetLastError());
+    const size_t n = (size_t)pl->rp * pl->rp;
+    hipLaunchKernelGGL(k_gram_sum, dim3((int)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, pl->ctx->stream,
+                       (const float*)pl->gram_slabs, pl->kq_chunks, n, pl->gram32, (const int*)&pl->st->stop);
+    HIP_TRY(hipGetLastError());
+    // P(f, k) = sum_j W(f, j) Gram(j, k) -> slab of chunk 0, matrix 1, element (f, k) at k * Fp + f
+    return g_gemm(pl, pl->Wcf, 1, pl->Fp, pl->gram32, 1, pl->rp, pl->slabs + (size_t)pl->Fp * pl->rp, 1, pl->Fp, pl->p.F, pl->p.r,
+                  pl->p.r, 0, 0);
+}
 template <int NK, int NWB, int NL, int WPS, int TT = 32>
 static int launch_wstats_geo(snmf_plan* pl, const StepArgs& a, bool obj) {
     if (pl->bm == BM_KL) {
@@ -1057,8 +1096,10 @@ static int launch_wstats_geo(snmf_plan* pl, const StepArgs& a, bool obj) {
                    : launch_wstats_one<NK, NWB, NL, WPS, 0, BM_KL, false, TT>(pl, a, 0);
     }
     if (pl->bm == BM_EUC) {
-        SN_TRY(obj ? (launch_wstats_one<NK, NWB, NL, WPS, 1, BM_EUC, true, TT>(pl, a, 1))
-                   : (launch_wstats_one<NK, NWB, NL, WPS, 1, BM_EUC, false, TT>(pl, a, 1)));
+        if (pl->gram_p && !pl->M && !obj) SN_TRY(launch_gram_p(pl, a));
+        else
+            SN_TRY(obj ? (launch_wstats_one<NK, NWB, NL, WPS, 1, BM_EUC, true, TT>(pl, a, 1))
+                       : (launch_wstats_one<NK, NWB, NL, WPS, 1, BM_EUC, false, TT>(pl, a, 1)));
         if (pl->kq_kg) {  // V * H^T by 256-column kappa-groups on the loader-wave geometry (see snmf_plan_create)
             StepArgs aq = a;
             aq.ldh = 260;

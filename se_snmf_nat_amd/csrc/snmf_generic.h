@@ -177,4 +177,16 @@ __global__ __launch_bounds__(256) void k_g_rowsum(const float* __restrict__ H, i
     }
 }
 
+// out[i] = sum over the chunks of slabs[c][i] (fp64 accumulation, chunk order), i < n: the Gram matrix H*H' of the
+// Euclidean W step (see launch_gram_p in snmf_api.hip)
+__global__ __launch_bounds__(256) void k_gram_sum(const float* __restrict__ slabs, int n_chunks, size_t n, float* __restrict__ out,
+                                                  const int* stop) {
+    if (stop && *stop) return;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        double s = 0.0;
+        for (int c = 0; c < n_chunks; ++c) s += (double)slabs[(size_t)c * n + i];
+        out[i] = (float)s;
+    }
+}
+
 }  // namespace snmf

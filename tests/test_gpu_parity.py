@@ -541,6 +541,26 @@ def test_dnmf_adapt_caller(gpu_ctx):
     assert B_a.shape == (129, 6) and rel(B_a, ref) < REL_WH
 
 
+def test_euclidean_w_step_through_the_gram_matrix(gpu_ctx):
+    """beta = 2, r > 256, full update: P = max(W*H, flr) * H' (src/sparse_nmf.m:224-231) is formed as W * (H*H'), which
+    differs from the reference's expression only where W*H sits at the 1e-9 floor.  Silent rows of V (exact zeros, floored
+    to 1e-9 by :169) drive whole rows of W*H to that floor: the result must still meet the solver tolerance."""
+    from se_snmf_nat_amd import Plan, sparse_nmf
+    F, T, r = 300, 1500, 300
+    rs = np.random.default_rng(5)
+    V = rs.gamma(0.5, 1.0, (F, 12)) @ rs.gamma(0.3, 1.0, (12, T)) + 1e-3
+    V[:20, :] = 0.0
+    V[:, 700:760] = 0.0
+    p = dict(cf="ed", sparsity=5, max_iter=8, conv_eps=0, cost_check=1, init_w=rs.random((F, r)), init_h=rs.random((r, T)))
+    pl = Plan(gpu_ctx, F, T, r, beta=2.0, max_iter=2, cost_check=True)
+    assert "Gram matrix" in pl.describe()
+    pl.close()
+    w, h, o = sparse_nmf(V, p, ctx=gpu_ctx)
+    wr, hr, orf = oracle_nmf(V, p)
+    assert rel(w, wr) < REL_WH and rel(h, hr) < REL_WH
+    assert np.max(np.abs(o["cost"] - orf["cost"]) / np.abs(orf["cost"])) < 1e-5
+
+
 def test_shapes_beyond_the_fused_kernels_take_the_out_of_envelope_path(gpu_ctx):
     """What the fused kernels cannot hold in LDS / registers -- F + r beyond the 16-frame tile images (~2540), W updates
     with r > 1024 under KL or with F = 32n+1 rows -- is no longer refused (src/sparse_nmf.m has no such limit): the plan
