@@ -2102,7 +2102,7 @@ static int online_make_solvers(snmf_online* o) {
         int coop = 0;
         hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, ctx->device);
         o->wa_nwg = (F + kWaRB - 1) / kWaRB;
-        o->wa_lds = (size_t)(kWaRB * kWaRP + 4 * kWaRP + 8 + 256) * 8 +
+        o->wa_lds = (size_t)(kWaRB * kWaRP + 4 * kWaRP + 32 + 256) * 8 +
                     (size_t)(2 * kWaRB * kWaRP + kWaRP + 2 * kWaRB * p->m_a + p->R_a * p->m_a + p->m_a * (kWaRP + 1)) * 4;
         o->wadapt = coop != 0 && o->wa_nwg <= ctx->n_cu && o->wa_nwg <= 2 * kWaQ && o->wa_lds <= 160 * 1024;
         if (o->wadapt) {
@@ -2382,7 +2382,7 @@ static int online_adapt(snmf_online* o, int32_t* iters) {
         wa.bar = o->wa_bar;
         HIP_TRY(hipMemsetAsync(o->wa_bar, 0, 4, st));
         void* kargs[] = {&wa};
-        if (hipLaunchCooperativeKernel((const void*)k_wadapt, dim3(o->wa_nwg), dim3(256), kargs, (unsigned)o->wa_lds, st) == hipSuccess) {
+        if (hipLaunchCooperativeKernel((const void*)k_wadapt, dim3(o->wa_nwg), dim3(kWaNT), kargs, (unsigned)o->wa_lds, st) == hipSuccess) {
             HIP_TRY(hipMemcpyAsync(iters, o->wa_nit, 4, hipMemcpyDeviceToHost, st));
             // the solve's verdict is read BEFORE its W is merged into the dictionary: a timed-out grid barrier leaves
             // wa_W invalid, and B_d, its fp32 mirror and the frame-solve plan must not see it

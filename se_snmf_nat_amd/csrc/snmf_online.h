@@ -606,17 +606,19 @@ constexpr int kWaQ = 40;  // workgroups per thread group: covers nwg <= 80
 __device__ __forceinline__ void cross_sum(const double* __restrict__ part, int stride, int ncol, int nwg, double* scratch /*[2][128]*/,
                                           double* out /*[128]*/) {
     const int g = threadIdx.x >> 7, c = threadIdx.x & 127;
-    const int per = (nwg + 1) / 2, q0 = g * per;
-    double v[kWaQ];
+    if (threadIdx.x < 256) {  // (a workgroup may have more threads than the exchange needs)
+        const int per = (nwg + 1) / 2, q0 = g * per;
+        double v[kWaQ];
 #pragma unroll
-    for (int i = 0; i < kWaQ; ++i) {
-        const int q = q0 + i;
-        v[i] = (i < per && q < nwg && c < ncol) ? xload(part + (size_t)q * stride + c) : 0.0;
+        for (int i = 0; i < kWaQ; ++i) {
+            const int q = q0 + i;
+            v[i] = (i < per && q < nwg && c < ncol) ? xload(part + (size_t)q * stride + c) : 0.0;
+        }
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < kWaQ; ++i) s += v[i];
+        scratch[g * 128 + c] = s;
     }
-    double s = 0.0;
-#pragma unroll
-    for (int i = 0; i < kWaQ; ++i) s += v[i];
-    scratch[g * 128 + c] = s;
     __syncthreads();
     if (threadIdx.x < 128 && threadIdx.x < ncol) out[threadIdx.x] = scratch[c] + scratch[128 + c];
     __syncthreads();
@@ -638,7 +640,8 @@ struct WAdaptArgs {
     double conv_eps;
 };
 
-constexpr int kWaRB = 8, kWaRP = 64;
+constexpr int kWaRB = 8, kWaRP = 64;    // rows of W per workgroup (32 threads each), padded rank (32 rows x 1024 threads: 2261 instead of 2743 frames/s)
+constexpr int kWaNT = kWaRB * 32;         // threads per workgroup
 
 // Grid barrier on a monotonic device counter (zeroed before the launch).  cooperative_groups' grid.sync()
 // measured ~20 us per call here, and an agent-scope release/acquire pair costs a write-back plus an
@@ -669,8 +672,8 @@ __device__ __forceinline__ bool grid_bar(unsigned* ctr, unsigned nwg, unsigned& 
     return ok_s != 0;
 }
 
-__global__ __launch_bounds__(256) void k_wadapt(WAdaptArgs a) {
-    constexpr int RB = kWaRB, RP = kWaRP;
+__global__ __launch_bounds__(kWaNT) void k_wadapt(WAdaptArgs a) {
+    constexpr int RB = kWaRB, RP = kWaRP, NT = kWaNT, NWV = kWaNT / 64;
     unsigned gen = 0;
     bool bar_ok = true;
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -679,8 +682,8 @@ __global__ __launch_bounds__(256) void k_wadapt(WAdaptArgs a) {
     double* Wd = reinterpret_cast<double*>(sm);          // [RB][RP]
     double* cq = Wd + RB * RP;                            // [RP] reduced column quantities
     double* cs = cq + RP;                                 // [RP] colsum(W)
-    double* red = cs + RP;                                // [8]
-    double* scr = red + 8;                                // [2][128] cross_sum scratch
+    double* red = cs + RP;                                // [NWV + 1] (padded to 32)
+    double* scr = red + 32;                               // [2][128] cross_sum scratch
     double* tmp = scr + 256;                              // [2*RP] reduced quantities of one exchange
     float* Wf = reinterpret_cast<float*>(tmp + 2 * RP);   // [RB][RP]
     float* Gs = Wf + RB * RP;                             // [RB][RP]
@@ -693,15 +696,15 @@ __global__ __launch_bounds__(256) void k_wadapt(WAdaptArgs a) {
     const bool row_ok = f0 + f < F;
 
     // ---- load + src/sparse_nmf.m:157-169 ------------------------------------------------------
-    for (int i = tid; i < RB * RP; i += 256) {
+    for (int i = tid; i < RB * RP; i += NT) {
         const int ff = i / RP, k = i - ff * RP;
         Wd[i] = (k < Ra && f0 + ff < F) ? a.W0[(size_t)k * F + f0 + ff] : 0.0;
     }
-    for (int i = tid; i < RB * ma; i += 256) {
+    for (int i = tid; i < RB * ma; i += NT) {
         const int ff = i / ma, t = i - ff * ma;
         Vs[i] = (f0 + ff < F) ? fmaxf(a.V[(size_t)t * F + f0 + ff], a.flr) : 0.f;   // :169
     }
-    for (int i = tid; i < Ra * ma; i += 256) {
+    for (int i = tid; i < Ra * ma; i += NT) {
         const int t = i / Ra, k = i - t * Ra;
         Hs[k * ma + t] = a.H[i];
     }
@@ -716,18 +719,18 @@ __global__ __launch_bounds__(256) void k_wadapt(WAdaptArgs a) {
     cross_sum(a.part2, 2 * RP, RP, nwg, scr, tmp);
     if (tid < RP) cq[tid] = tid < Ra ? sqrt(tmp[tid]) : 1.0;  // wn
     __syncthreads();
-    for (int i = tid; i < RB * RP; i += 256) {
+    for (int i = tid; i < RB * RP; i += NT) {
         const int k = i % RP;
         const double w = k < Ra ? Wd[i] / cq[k] : 0.0;   // w = w ./ wn
         Wd[i] = w;
         Wf[i] = (float)w;
     }
-    for (int i = tid; i < Ra * ma; i += 256) {
+    for (int i = tid; i < Ra * ma; i += NT) {
         const int k = i / ma;
         Hs[i] = (float)((double)Hs[i] * cq[k]);          // h = h .* wn'  (:160)
     }
     __syncthreads();
-    for (int i = tid; i < ma * (RP + 1); i += 256) {
+    for (int i = tid; i < ma * (RP + 1); i += NT) {
         const int t = i / (RP + 1), k = i - t * (RP + 1);
         HT[i] = k < Ra ? Hs[k * ma + t] : 0.f;
     }
@@ -780,14 +783,19 @@ __global__ __launch_bounds__(256) void k_wadapt(WAdaptArgs a) {
             for (int ff = 0; ff < RB; ++ff) s += (double)Gs[ff * RP + tid] * Wd[ff * RP + tid];
             xstore(a.part1 + (size_t)wg * (RP + 1) + tid, s);  // colsum(G .* W) partial (:217)
         }
-        if (tid == RP) xstore(a.part1 + (size_t)wg * (RP + 1) + RP, red[0] + red[1] + red[2] + red[3]);
+        if (tid == RP) {
+            double dsum = 0.0;
+#pragma unroll
+            for (int q = 0; q < NWV; ++q) dsum += red[q];
+            xstore(a.part1 + (size_t)wg * (RP + 1) + RP, dsum);
+        }
         bar_ok &= grid_bar(a.bar, (unsigned)nwg, gen);
         cross_sum(a.part1, RP + 1, RP + 1, nwg, scr, tmp);     // colsum(G .* W) | div
         if (tid < RP) cq[tid] = tmp[tid];
-        if (tid == RP) red[4] = tmp[RP];
+        if (tid == RP) red[NWV] = tmp[RP];
         __syncthreads();
         if (a.cost_check && j > 1) {                      // cost of iterate j-1 (:260-284)
-            const double cost = red[4] + sh_const;
+            const double cost = red[NWV] + sh_const;
             const int it = j - 1;
             bool stopnow = false;
             if (it > 1 && a.conv_eps > 0.0) stopnow = fabs(cost - last_cost) / last_cost < a.conv_eps;
@@ -801,7 +809,7 @@ __global__ __launch_bounds__(256) void k_wadapt(WAdaptArgs a) {
         }
         if (j > a.max_iter) break;
         // ---- W update (:215-222) on this block's rows, then the norms ------------------------------
-        for (int i = tid; i < RB * RP; i += 256) {
+        for (int i = tid; i < RB * RP; i += NT) {
             const int k = i % RP;
             double wv = Wd[i];
             if (k < Ra && a.w_ind[k]) {
@@ -831,7 +839,7 @@ __global__ __launch_bounds__(256) void k_wadapt(WAdaptArgs a) {
             cs[tid] = tmp[RP + tid] / nrm;               // colsum of the normalised W
         }
         __syncthreads();
-        for (int i = tid; i < RB * RP; i += 256) {
+        for (int i = tid; i < RB * RP; i += NT) {
             const int k = i % RP;
             const double w = k < Ra ? Wd[i] / cq[k] : 0.0;   // :242, ALL columns
             Wd[i] = w;
@@ -840,7 +848,7 @@ __global__ __launch_bounds__(256) void k_wadapt(WAdaptArgs a) {
         __syncthreads();
     }
     __syncthreads();
-    for (int i = tid; i < RB * RP; i += 256) {
+    for (int i = tid; i < RB * RP; i += NT) {
         const int ff = i / RP, k = i - ff * RP;
         if (k < Ra && f0 + ff < F) a.Wout[(size_t)k * F + f0 + ff] = Wd[i];
     }
