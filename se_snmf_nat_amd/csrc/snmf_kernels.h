@@ -15,6 +15,10 @@
 //             chunk and written once as a split-T partial slab
 //   k_reduce: partial slabs + partial objective sums -> fp64 statistics (fixed order)
 //   k_wapply: F x r epilogue (dpw, dmw, update, column normalise) + convergence test
+//   k_wfin  : k_reduce + k_wapply in one launch (the loop of one device: nothing is exchanged between them)
+// KL update launches of the headline geometries are role pipelines of the same arithmetic: k_hstep_rp (two tile buffers in
+// LDS), k_hstep_rh (F = 513: one ratio image, pipelined by half tiles); k_wstats has LDS-DMA loader waves.  Shapes that do
+// not fit a tile's images into the LDS at all take snmf_generic.h (intermediates in HBM).
 //
 // MFMA 32x32x2 f32 operand map (lane l, fl = l&31, h = l>>5):
 //   A[i=fl][k=h], B[k=h][j=fl], D[row=(reg&3)+8*(reg>>2)+4*h][col=fl]  (reg in [0,16)).
