@@ -58,6 +58,14 @@ for ci in range(n_cases):
         break
     F, T, r, beta, mode, sp = draw()
     V = (rs.gamma(0.5, 1.0, (F, 12)) @ rs.gamma(0.3, 1.0, (12, T)) + 1e-3)
+    dv = int(rs.integers(0, 8))  # data variants: spectrogram-like dynamic range, global scale, silent rows / frames
+    if dv == 0:
+        V = V ** 3 * 1e3
+    elif dv == 1:
+        V = V * float(rs.choice([1e-5, 1e5]))
+    elif dv == 2:
+        V[rs.random(F) < 0.1, :] = 0.0
+        V[:, rs.random(T) < 0.05] = 0.0
     W0 = rs.random((F, r))
     H0 = rs.random((r, T))
     iters = int(rs.integers(2, 6))
@@ -71,7 +79,7 @@ for ci in range(n_cases):
         p["h_update_ind"] = np.zeros(r, bool)
     elif mode == "semi":
         p["w_update_ind"] = np.arange(r) >= r // 2
-    tag = f"F={F} T={T} r={r} beta={beta} {mode} sp={sp} it={iters} cc={p['cost_check']}"
+    tag = f"F={F} T={T} r={r} beta={beta} {mode} sp={sp} it={iters} cc={p['cost_check']} dv={dv}"
     try:
         w, h, o = sparse_nmf(V, p)
     except SnmfError as e:
