@@ -12,7 +12,7 @@
 //             then the ordinary k_reduce (fixed-order fp64 sum of the slabs) and k_wapply.
 // So the statistics buffer, the W update, the objective bookkeeping, the early stop and the multi-rank exchange are the
 // ones of the fast path; only the two big products and the element-wise passes differ.  Correctness first: the GEMM is
-// a plain LDS-tiled fp32 FMA kernel (no MFMA), contractions over the frames are cut into chunks of kGChunkT frames whose
+// a plain LDS-tiled kernel (64 x 64 x 16 tiles, one f32-MFMA quadrant per wave, no operand pipelining), contractions over the frames are cut into chunks of kGChunkT frames whose
 // fp32 partial sums are added in fp64 by k_reduce, like the fast path's chunk slabs.
 // ============================================================================================
 #pragma once
@@ -40,14 +40,16 @@ __global__ __launch_bounds__(256) void k_g_gemm(GemmArgs g) {
     constexpr int BM = 64, BN = 64, BK = 16;
     __shared__ float As[BK][BM + 4];
     __shared__ float Bs[BK][BN + 4];
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int tid = threadIdx.x;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;  // (x runs over N: the frames, the one dimension that can pass 65535 tiles)
     const int k_lo = blockIdx.z * g.kchunk, k_hi = min(g.K, k_lo + g.kchunk);
-    float acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    // four waves, one 32 x 32 quadrant of the block tile each, on the f32 MFMA (operand map: snmf_kernels.h).  The product
+    // is formed as C^T = B^T * A^T when C's unit stride runs along m, so that the lanes of a D register (its columns)
+    // always run along C's unit stride and the stores coalesce.
+    const int w = tid >> 6, lane = tid & 63, fl = lane & 31, h = lane >> 5;
+    const int wm = (w >> 1) * 32, wn = (w & 1) * 32;
+    const bool c_m_fast = g.rsC == 1;
+    f32x16 acc = zero16();
     // the faster-running index of each operand picks how a tile is read (coalesced along the unit stride)
     const bool a_m_fast = g.rsA == 1, b_n_fast = g.csB == 1;
     for (int k0 = k_lo; k0 < k_hi; k0 += BK) {
@@ -66,29 +68,21 @@ __global__ __launch_bounds__(256) void k_g_gemm(GemmArgs g) {
             }
         }
         __syncthreads();
+        if (c_m_fast) {
 #pragma unroll
-        for (int kk = 0; kk < BK; ++kk) {
-            float av[4], bv[4];
+            for (int kk = 0; kk < BK; kk += 2) acc = mfma32(Bs[kk + h][wn + fl], As[kk + h][wm + fl], acc);
+        } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) av[i] = As[kk][ty * 4 + i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = Bs[kk][tx * 4 + j];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+            for (int kk = 0; kk < BK; kk += 2) acc = mfma32(As[kk + h][wm + fl], Bs[kk + h][wn + fl], acc);
         }
         __syncthreads();
     }
     float* C = g.C + (long long)blockIdx.z * g.zC;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + ty * 4 + i;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + tx * 4 + j;
-            if (m < g.M && n < g.N) C[(long long)m * g.rsC + (long long)n * g.csC] = acc[i][j];
-        }
+    for (int i = 0; i < 16; ++i) {
+        // D[row = drow(i, h)][col = fl]: rows come from the first MFMA operand, columns from the second
+        const int m = m0 + wm + (c_m_fast ? fl : drow(i, h)), n = n0 + wn + (c_m_fast ? drow(i, h) : fl);
+        if (m < g.M && n < g.N) C[(long long)m * g.rsC + (long long)n * g.csC] = acc[i];
     }
 }
 
