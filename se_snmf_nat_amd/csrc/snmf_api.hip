@@ -241,6 +241,7 @@ struct snmf_plan {
     // Euclidean W step, r > 256, full updates: P = max(W*H, flr) * H' is formed as W * (H*H') -- the r x r Gram matrix
     // costs 2 r^2 T flop instead of the P launch's 4 F T r (C5: 4.75 -> ~2.5 ms); see launch_gram_p
     bool gram_p = false;
+    int gram_chunks = 0;
     float *gram_slabs = nullptr, *gram32 = nullptr;
     bool generic = false;
     float *gLam = nullptr, *gR = nullptr, *gD = nullptr, *gNum = nullptr, *gDen = nullptr;
@@ -508,7 +509,14 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         pl->kq_kg = (pl->nk + 7) / 8;
         pl->kq_chunks = std::max(1, std::min(std::min(n_tiles_w, pl->n_chunks), ctx->n_cu / std::max(1, pl->n_fg * pl->kq_kg)));
         pl->kq_lds = (size_t)2 * 32 * (260 + 32 * 4) * 4 + (size_t)pl->rp * 4 + 320 + (size_t)4 * 256 * 4;
-        pl->gram_p = pl->upd_h && r < 2 * F;  // (W-only solves take their objective from the P launch's Lam')
+    }
+    // Euclidean full updates: P through the Gram matrix (launch_gram_p) wherever it is the cheaper form (2 r^2 T against
+    // 4 F T r; W-only solves take their objective from the P launch's Lam' and keep it)
+    if (pl->bm == BM_EUC && pl->upd_w && pl->upd_h && pl->TTW == 32 && r < 2 * F) {
+        pl->gram_p = true;
+        const int nfg_g = (pl->rp / 32 + pl->NWB - 1) / pl->NWB;
+        pl->gram_chunks = pl->kq_kg ? pl->kq_chunks
+                                    : std::max(1, std::min(n_tiles_w, ctx->n_cu * (pl->NLW ? 1 : pl->WPS) / std::max(1, nfg_g)));
     }
     // k_wstats keeps the row sums of H (KL) and the extra row of the slab (F = 32n+1) in per-thread registers: 1024 columns
     if (pl->rp > 4 * pl->NWB * 64 && pl->upd_w && (pl->bm == BM_KL || pl->xr)) pl->generic = true;
@@ -578,7 +586,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         A(dalloc(&pl->spart, (size_t)pl->n_chunks * pl->rp));
     }
     if (pl->gram_p) {
-        A(dalloc(&pl->gram_slabs, (size_t)pl->kq_chunks * pl->rp * pl->rp));
+        A(dalloc(&pl->gram_slabs, (size_t)pl->gram_chunks * pl->rp * pl->rp));
         A(dalloc(&pl->gram32, (size_t)pl->rp * pl->rp));
     }
     if (pl->generic) {
@@ -1054,6 +1062,7 @@ static int launch_wstats_one(snmf_plan* pl, const StepArgs& a, int mat_index) {
 // engine's fp32 rounding of P).  H*H' is the V*H' launch with the H image as "V" (r rows, no extra row), by kappa-groups
 // like the Q launch; its chunk slabs are added in fp64, and W * Gram is one small GEMM into the P slab of chunk 0 (the P
 // slabs of the other chunks stay zero from plan creation), so k_reduce / k_wfin / k_wapply see an ordinary P.
+template <int NK, int NWB, int NL, int WPS>
 static int launch_gram_p(snmf_plan* pl, const StepArgs& a) {
     StepArgs ag = a;
     ag.V = a.Hin;
@@ -1061,22 +1070,35 @@ static int launch_gram_p(snmf_plan* pl, const StepArgs& a) {
     ag.Fp = ag.Fm = ag.Fq = pl->rp;
     ag.nf = pl->rp / 32;
     ag.xr = 0;
-    ag.ldh = 260;
-    ag.kc = 1;
     ag.n_ch1 = 0;
     ag.slabs = pl->gram_slabs;
-    auto kern = k_wstats<8, 4, 4, 2, 3, BM_EUC, false, 32>;
-    SN_TRY(ensure_dyn_lds(pl->ctx->device, (const void*)kern, pl->kq_lds));
-    const int nfg = (ag.nf + 3) / 4;
-    hipLaunchKernelGGL(kern, dim3(pl->kq_chunks, nfg, pl->kq_kg), dim3(512), pl->kq_lds, pl->ctx->stream, ag, pl->kq_chunks, 0, 1);
+    if (pl->kq_kg) {  // r > 256: by kappa-groups on the loader-wave geometry, like the Q launch
+        ag.ldh = 260;
+        ag.kc = 1;
+        auto kern = k_wstats<8, 4, 4, 2, 3, BM_EUC, false, 32>;
+        SN_TRY(ensure_dyn_lds(pl->ctx->device, (const void*)kern, pl->kq_lds));
+        hipLaunchKernelGGL(kern, dim3(pl->gram_chunks, (ag.nf + 3) / 4, pl->kq_kg), dim3(512), pl->kq_lds, pl->ctx->stream, ag,
+                           pl->gram_chunks, 0, 1);
+    } else {          // r <= 256: the plan's own V * H' kernel
+        auto kern = k_wstats<NK, NWB, NL, WPS, 3, BM_EUC, false, 32>;
+        SN_TRY(ensure_dyn_lds(pl->ctx->device, (const void*)kern, pl->lds_w));
+        hipLaunchKernelGGL(kern, dim3(pl->gram_chunks, (ag.nf + NWB - 1) / NWB, 1), dim3((NWB + NL) * 64), pl->lds_w, pl->ctx->stream, ag,
+                           pl->gram_chunks, 0, 1);
+    }
     HIP_TRY(hipGetLastError());
     const size_t n = (size_t)pl->rp * pl->rp;
-    hipLaunchKernelGGL(k_gram_sum, dim3((int)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, pl->ctx->stream,
-                       (const float*)pl->gram_slabs, pl->kq_chunks, n, pl->gram32, (const int*)&pl->st->stop);
+    hipLaunchKernelGGL(k_gram_sum, dim3((int)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, pl->ctx->stream,
+                       (const float*)pl->gram_slabs, pl->gram_chunks, n, pl->gram32, (const int*)&pl->st->stop);
     HIP_TRY(hipGetLastError());
-    // P(f, k) = sum_j W(f, j) Gram(j, k) -> slab of chunk 0, matrix 1, element (f, k) at k * Fp + f
-    return g_gemm(pl, pl->Wcf, 1, pl->Fp, pl->gram32, 1, pl->rp, pl->slabs + (size_t)pl->Fp * pl->rp, 1, pl->Fp, pl->p.F, pl->p.r,
-                  pl->p.r, 0, 0);
+    // P(f, k) = sum_j W(f, j) Gram(j, k), element (f, k) at k * Fp + f of a P slab.  The product is tiny and, as one
+    // launch over K = r, a chain of r / 16 dependent tile steps on a few workgroups (33 us at r = 256): the contraction is
+    // cut into up to eight ranges whose partial products go to the P slabs of chunks 0 .. 7 -- k_reduce adds the chunks in
+    // fixed order anyway; the P slabs of the remaining chunks stay zero from plan creation.
+    const int nsplit = std::max(1, std::min(std::min(8, pl->n_chunks), (pl->p.r + 31) / 32));
+    const int kchunk = (((pl->p.r + nsplit - 1) / nsplit) + 15) / 16 * 16;
+    const long long nW = (long long)pl->Fp * pl->rp;
+    return g_gemm(pl, pl->Wcf, 1, pl->Fp, pl->gram32, 1, pl->rp, pl->slabs + nW, 1, pl->Fp, pl->p.F, pl->p.r, pl->p.r, kchunk,
+                  nW * pl->n_mat);
 }
 template <int NK, int NWB, int NL, int WPS, int TT = 32>
 static int launch_wstats_geo(snmf_plan* pl, const StepArgs& a, bool obj) {
@@ -1096,7 +1118,7 @@ static int launch_wstats_geo(snmf_plan* pl, const StepArgs& a, bool obj) {
                    : launch_wstats_one<NK, NWB, NL, WPS, 0, BM_KL, false, TT>(pl, a, 0);
     }
     if (pl->bm == BM_EUC) {
-        if (pl->gram_p && !pl->M && !obj) SN_TRY(launch_gram_p(pl, a));
+        if (pl->gram_p && !pl->M && !obj && TT == 32) SN_TRY((launch_gram_p<NK, NWB, NL, WPS>(pl, a)));
         else
             SN_TRY(obj ? (launch_wstats_one<NK, NWB, NL, WPS, 1, BM_EUC, true, TT>(pl, a, 1))
                        : (launch_wstats_one<NK, NWB, NL, WPS, 1, BM_EUC, false, TT>(pl, a, 1)));

@@ -178,7 +178,15 @@ __global__ __launch_bounds__(256) void k_gram_sum(const float* __restrict__ slab
     if (stop && *stop) return;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         double s = 0.0;
-        for (int c = 0; c < n_chunks; ++c) s += (double)slabs[(size_t)c * n + i];
+        int c = 0;
+        for (; c + 8 <= n_chunks; c += 8) {  // eight loads in flight, added in chunk order
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = slabs[(size_t)(c + j) * n + i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (double)x[j];
+        }
+        for (; c < n_chunks; ++c) s += (double)slabs[(size_t)c * n + i];
         out[i] = (float)s;
     }
 }
