@@ -76,3 +76,27 @@ def test_fused_w_finish_equals_reduce_then_apply(gpu_ctx, name):
         assert 1 < n_a < c["iters"]  # the case does stop early
     assert np.array_equal(Wa, Wb) and np.array_equal(Ha, Hb)
     assert np.array_equal(cost_a, cost_b) and np.array_equal(div_a, div_b)
+
+
+@pytest.mark.parametrize("shape", [(257, 9000, 256, 1.0), (513, 9000, 100, 1.0), (300, 1500, 300, 2.0)], ids=lambda s: "F%d_T%d_r%d_b%g" % s)
+def test_run_in_pieces_and_plan_reuse(gpu_ctx, shape):
+    """snmf_plan_run(n) twice is snmf_plan_run(2n) once, and a second solve on the same plan (set_w / set_h / init again)
+    repeats the first bit for bit: nothing a launch leaves behind -- the split tiles' arrival counters, the slabs of the
+    Gram form, the extra-row sums in LDS -- may leak into the next one."""
+    from se_snmf_nat_amd import Plan
+    F, T, r, beta = shape
+    rs = np.random.default_rng(F + r)
+    V = (rs.gamma(0.5, 1.0, (F, 8)) @ rs.gamma(0.3, 1.0, (8, T)) + 1e-3).astype(np.float32)
+    W0 = rs.random((F, r))
+    H0 = rs.random((r, T)).astype(np.float32)
+    pl = Plan(gpu_ctx, F, T, r, beta=beta, max_iter=10, conv_eps=0.0, cost_check=True, sparsity=2.0)
+    pl.set_v(V)
+    res = []
+    for pieces in ((10,), (3, 4, 3), (10,)):
+        pl.set_w(W0); pl.set_h(H0); pl.init()
+        for n in pieces:
+            pl.run(n)
+        res.append((pl.get_w(), pl.get_h(), pl.get_objective()[1].copy()))
+    pl.close()
+    for w, h, c in res[1:]:
+        assert np.array_equal(w, res[0][0]) and np.array_equal(h, res[0][1]) and np.array_equal(c, res[0][2])
