@@ -3165,6 +3165,18 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
             if (i4 < n4) {
                 const float* p = a.slabs + 4 * pos_of(i4);
                 int c = cb;
+                for (; c + 16 <= ce; c += 16) {  // (sixteen loads in flight: a 128-chunk launch is one round trip per group)
+                    f32x4 x[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) x[j] = *reinterpret_cast<const f32x4*>(p + (size_t)(c + j) * cstride);
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        s0 += (double)x[j][0];
+                        s1 += (double)x[j][1];
+                        s2 += (double)x[j][2];
+                        s3 += (double)x[j][3];
+                    }
+                }
                 for (; c + 8 <= ce; c += 8) {
                     f32x4 x[8];
 #pragma unroll
