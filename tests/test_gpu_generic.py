@@ -75,3 +75,17 @@ def test_mdi_still_refuses_out_of_envelope_shapes(gpu_ctx):
     p = dict(cf="kl", sparsity_mdi=0.5, conv_eps_mdi=0, max_iter=3, cost_check=1, init_w=rs.random((2700, 8)), init_h=rs.random((8, 64)))
     with pytest.raises(SnmfError, match="too large"):
         snmf_mdi(V, M, p, ctx=gpu_ctx)
+
+
+def test_out_of_envelope_shape_over_a_device_list(gpu_ctx):
+    """The multi-rank entry shards the frames of an out-of-envelope problem like any other: the statistics buffer and the
+    exchange are the fast path's (csrc/snmf_multi.h), only the per-rank products differ."""
+    from se_snmf_nat_amd import sparse_nmf
+    rs = np.random.default_rng(9)
+    F, T, r = 2600, 360, 24
+    V = rs.gamma(0.5, 1.0, (F, 10)) @ rs.gamma(0.3, 1.0, (10, T)) + 1e-3
+    p = dict(cf="kl", sparsity=2, max_iter=6, conv_eps=0, cost_check=1, init_w=rs.random((F, r)), init_h=rs.random((r, T)))
+    w1, h1, o1 = sparse_nmf(V, p, ctx=gpu_ctx)
+    w2, h2, o2 = sparse_nmf(V, p, devices=[0, 0])
+    assert rel(w2, w1) < 1e-5 and rel(h2, h1) < 1e-5
+    assert np.max(np.abs(o2["cost"] - o1["cost"]) / np.abs(o1["cost"])) < 1e-6
