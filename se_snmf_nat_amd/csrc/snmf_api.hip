@@ -234,6 +234,7 @@ struct snmf_plan {
     // kappa-group, each staging only its own columns of H (kq_chunks frame chunks, kq_kg kappa-groups; 0 = off)
     int kq_chunks = 0, kq_kg = 0;
     // snmf_plan_run: k_reduce + k_wapply as one launch (k_wfin) when a column's chunk-group sums fit the LDS
+    bool rh_lxh = false;
     bool wfin = false;
     size_t lds_wfin = 0;
     // shapes beyond the fused kernels' LDS / register envelope: the same iteration with its intermediates in HBM
@@ -397,8 +398,15 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     if ((T + 31) / 32 <= ctx->n_cu) pl->hstep_rp = false;
     // F = 513 (9..16 row tiles): two whole tile buffers do not fit, but two H blocks + ONE ratio image do -- k_hstep_rh
     // pipelines on half tiles.  One pair of column tiles per wave of its P2 team: rp <= 256.
-    pl->lds_rh = std::max<size_t>(((size_t)2 * 32 * pl->ldh + (size_t)32 * pl->ldr + pl->rp) * 4 + 128, 2 * kMaxNW * 64 * sizeof(double));
+    pl->lds_rh = std::max<size_t>(((size_t)2 * 32 * pl->ldh + (size_t)32 * pl->ldr + pl->rp) * 4 + 160, 2 * kMaxNW * 64 * sizeof(double));
     pl->rh = pl->hstep_rp && pl->NLH != 4 && pl->bm == BM_KL && pl->nf >= 9 && pl->nf <= 16 && pl->rp <= 256 && pl->lds_rh <= lds_cap;
+    // r = 97..100 on 16 row tiles (the reference's R = 100 at F = 513): P2 cut over the contraction, the 1..4 real columns of
+    // the fourth column tile as VALU work (k_hstep_rh<OBJ, LXH>); needs 60 KB more LDS for the waves' partial tiles
+    {
+        const size_t lx = pl->lds_rh + (size_t)(pl->Fm + 8) * 16 + 4 * 3 * 1024 * 4 + 4 * 64 * 16;
+        pl->rh_lxh = pl->rh && pl->nf == 16 && pl->nk == 4 && r > 96 && r <= 100 && lx <= lds_cap;
+        if (pl->rh_lxh) pl->lds_rh = lx;
+    }
     pl->lds_h = std::max<size_t>(pl->NLH ? 2 * lds1 - lds_extra : (pl->NT == 1 ? (size_t)pl->TTH * per_col + lds_extra : lds2),
                                  2 * kMaxNW * 64 * sizeof(double));
     pl->lds_mdi = std::max<size_t>(lds1, 2 * kMaxNW * 64 * sizeof(double));  // MDI pass: (NW=8, NT=1, NL=0)
@@ -552,7 +560,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     if (pl->generic) {
         // none of the fused geometries applies; contractions over the frames are split into chunks of kGChunkT frames,
         // whose slabs k_reduce adds like the fast path's
-        pl->hstep_rp = pl->rh = false;
+        pl->hstep_rp = pl->rh = pl->rh_lxh = false;
         pl->rp_S = 0;
         pl->kq_kg = 0;
         pl->gram_p = false;
@@ -661,11 +669,11 @@ extern "C" int64_t snmf_plan_stats_len(const snmf_plan* pl) {
 extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
     if (!pl || !buf) return fail(SNMF_ERR_INVALID, "NULL argument");
     const bool kl_pipe = pl->NWH == 8 && pl->NLH == 4 && pl->bm == BM_KL && pl->upd_h && !pl->M && pl->hstep_rp;
-    char hs[160];
+    char hs[256];
     const bool rh_pipe = pl->rh && pl->upd_h && !pl->M;
     if (rh_pipe)
-        snprintf(hs, sizeof hs, "k_hstep_rh (4 P1 + 4 P2 + 4 loader waves on half tiles; %d of %d tiles pipelined, last round split %d ways, grid %d)",
-                 pl->rp_full, pl->rp_tiles, pl->rp_S, pl->rp_grid);
+        snprintf(hs, sizeof hs, "k_hstep_rh (4 P1 + 4 P2 + 4 loader waves on half tiles%s; %d of %d tiles pipelined, last round split %d ways, grid %d)",
+                 pl->rh_lxh ? ", P2 cut over the contraction + leftover columns on the VALU" : "", pl->rp_full, pl->rp_tiles, pl->rp_S, pl->rp_grid);
     else if (kl_pipe)
         snprintf(hs, sizeof hs, "k_hstep_rp (4 P1 + 4 P2 + 4 loader waves; %d of %d tiles pipelined, last round split %d ways, grid %d)",
                  pl->rp_full, pl->rp_tiles, pl->rp_S, pl->rp_grid);
@@ -1022,6 +1030,11 @@ static int launch_hstep(snmf_plan* pl, bool obj, bool upd) {
         a.part_S = pl->rp_S;
         a.part_buf = pl->part_buf;
         a.part_cnt = pl->part_cnt;
+        if (pl->rh_lxh) {
+            a.lxh = 1;
+            return obj ? launch_big(k_hstep_rh<true, true>, g, b, pl->lds_rh, pl->ctx->stream, a)
+                       : launch_big(k_hstep_rh<false, true>, g, b, pl->lds_rh, pl->ctx->stream, a);
+        }
         return obj ? launch_big(k_hstep_rh<true>, g, b, pl->lds_rh, pl->ctx->stream, a)
                    : launch_big(k_hstep_rh<false>, g, b, pl->lds_rh, pl->ctx->stream, a);
     }

@@ -146,6 +146,7 @@ struct StepArgs {
     float* Vw;            // MDI: V, writable (re-imputed in place by the Lam pass)
     int impute;           // MDI: this pass carries the re-imputation of the previous iteration (:251-254)
     int n_ch1;            // k_wstats: > 0 = row group 1 has its own, smaller, number of frame chunks (1-D grid)
+    int lxh;              // k_hstep_rh: P2 cut over the contraction, leftover columns on the VALU (nk = 4, r = 97..100)
     int kc;               // k_wstats, WM = 3 (V * H^T needs no Lam'): each kappa-group stages only ITS 32*NK columns of H
     int F, T, Fp, rp, Tp, nf, nk;
     int nqk;              // 8-deep k-blocks of the contractions over the components = ceil(r / 8): W's columns / H's rows
@@ -1817,7 +1818,7 @@ __device__ __forceinline__ void rh_p2_tile(const StepArgs& a, float* Hs, const f
     if (NACC == 2) rp_p2_epilogue<OBJ>(a, acc[NACC - 1], Hs, kap + NB, t0, lane, dp1, shsum);
 }
 
-template <bool OBJ>
+template <bool OBJ, bool LXH = false>
 __global__ __launch_bounds__(768, 3) void k_hstep_rh(StepArgs a) {
     constexpr int NA = 4, NB = 4, NL = 4, NTHR = (NA + NB + NL) * 64, Tt = 32, PR = Tt / NL;
     if (a.stop && *a.stop) return;
@@ -1835,7 +1836,25 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rh(StepArgs a) {
         // the unused cells of the extra 8-deep k-block stay zero for the whole kernel (the V commits write Fm .. Fm+3)
         for (int i = threadIdx.x; i < Tt * 8; i += NTHR) Rs[(i >> 3) * ldr + a.Fm + (i & 7)] = 0.f;
     }
-    if (threadIdx.x < 25) cnt[threadIdx.x] = 0u;
+    if (threadIdx.x < 40) cnt[threadIdx.x] = 0u;
+    // lxh (nk = 4 with 1..4 real columns in the fourth column tile: r = 97..100, the reference's R = 100): P2 is cut over
+    // the CONTRACTION instead of over the column tiles -- B wave wb takes k-blocks [16 wb, 16 wb + 16) (+ the extra row's
+    // for the last wave) of the three full column tiles (three accumulators share each LDS fragment: 192 MFMAs a wave
+    // instead of 260 on a tile that is 87 % padding), the leftover columns of its rows as VALU work from a small LDS copy
+    // of those columns of W (wl), and the waves' partial tiles are added through LDS (Ps, Pl) before the epilogue: every
+    // SIMD then carries the same work (a re-deal of whole tiles cannot balance them).
+    unsigned *wdone = cnt + 28, *rdone = cnt + 32;            // B waves: partials of place j written / read
+    float* wl = reinterpret_cast<float*>(cnt + 40);          // [Fm + 8][4]  W[f][96 .. 99] (row Fm: the extra row)
+    float* Ps = wl + (a.Fm + 8) * 4;                          // [4 waves][3 tiles][4 g][64 lanes][4] partial accumulators
+    float* Pl = Ps + 4 * 3 * 1024;                            // [4 waves][64 lanes][4] partial leftover columns
+    if (LXH) {
+        for (int f = threadIdx.x; f < a.Fm + 8; f += NTHR) {
+            f32x4 wv = {0.f, 0.f, 0.f, 0.f};
+            if (f < a.Fm) wv = *reinterpret_cast<const f32x4*>(a.Wt4 + ((((size_t)(f >> 5) * (rp / 8) + 12) * 2) * 128 + (f & 31) * 4));
+            else if (f == a.Fm && a.xr) wv = *reinterpret_cast<const f32x4*>(a.wx + 96);
+            *reinterpret_cast<f32x4*>(wl + f * 4) = wv;
+        }
+    }
     __syncthreads();
     // The split last round as in k_hstep_rp ("the split last round" above), with 16 row tiles: part p of S owns the
     // CONTIGUOUS row tiles [p nfp, (p+1) nfp), nfp = 16 / S -- half a half (S = 4: one row tile per A wave) or a whole
@@ -2055,6 +2074,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rh(StepArgs a) {
             rp_p2_consts(a, wb, lane, dp0);
             if (wb + NB < a.nk) rp_p2_consts(a, wb + NB, lane, dp1);
         }
+        unsigned lx_seq = 0;  // lxh: tiles this wave has put through the partial buffers
         auto b_item = [&](const int j) {  // P2 of the whole tile in place j of the list
             const int t0 = tile_of(j) * Tt;
             float* Hs = lds + (j & 1) * hsz;
@@ -2062,17 +2082,105 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rh(StepArgs a) {
             auto g0 = [&]() { rp_await(p1, (unsigned)(2 * j + 1), a.stop); };
             auto g1 = [&]() { rp_await(p1, (unsigned)(2 * j + 2), a.stop); };
             auto gx = [&]() { rp_await(xdone, (unsigned)(j + 1), a.stop); };
-            if (wb + NB < a.nk) rh_p2_tile<2, OBJ>(a, Hs, Rs, wb, t0, lane, wb, j, bdone, dp0, dp1, shsum, g0, g1, gx);
-            else if (wb < a.nk) rh_p2_tile<1, OBJ>(a, Hs, Rs, wb, t0, lane, wb, j, bdone, dp0, dp1, shsum, g0, g1, gx);
-            else {  // a wave without a column tile keeps step (the slots are progress numbers)
+            if constexpr (LXH) {
+                const int fl = lane & 31, h = lane >> 5;
+                const float* sp = Rs + fl * ldr + 4 * h;
+                // k-blocks [8 wb, 8 wb + 8) of EACH ratio half (a wave with all its blocks in one half would leave its SIMD idle
+                // through the other half's phase and crowd it in its own: 0.150 -> 0.167 ms), + the extra row's for the last wave
+                const int qb = 8 * wb;
+                const __amdgpu_buffer_rsrc_t rsk = wimage_rsrc(a.Wk4, (size_t)a.nk * a.Fq * 32);
+                f32x16 acc[3] = {zero16(), zero16(), zero16()};
+                int so[3] = {qb * 1024, a.Fq * 128 + qb * 1024, 2 * a.Fq * 128 + qb * 1024};
+                // leftover columns over the same rows: lane (t = fl, h) takes rows [f0 + 32 h, + 32) of the wave's 64 rows of a
+                // half.  The first half's rows go AHEAD of its contraction (nothing else is live there; between the contractions
+                // this code cost 70..100 spilled VGPRs) so that its bdone can be posted as early as before; the second half's
+                // follow the last contraction.
+                f32x4 gl = {0.f, 0.f, 0.f, 0.f};
+                auto lx_rows = [&](const int f0) {
+                    const float* rrow = Rs + fl * ldr + f0 + 32 * h;
+                    const float* wrow = wl + (f0 + 32 * h) * 4;
+#pragma unroll 4
+                    for (int f4 = 0; f4 < 8; ++f4) {
+                        const f32x4 r4 = *reinterpret_cast<const f32x4*>(rrow + 4 * f4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wrow + (4 * f4 + e) * 4);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) gl[c] = fmaf(r4[e], w4[c], gl[c]);
+                        }
+                    }
+                };
                 g0();
+                lx_rows(64 * wb);
+                SNMF_PIN();
+                contract_shared_buf<3>(acc, rsk, lane * 16, so, sp + 8 * qb, 8, NoGate());
                 rp_post(bdone, wb, (unsigned)(2 * j + 1), lane);
-                g1();
-                if (a.xr) gx();
+#pragma unroll
+                for (int i = 0; i < 3; ++i) so[i] += 32 * 1024;
+                contract_shared_buf<3>(acc, rsk, lane * 16, so, sp + 8 * (32 + qb), 8, g1);
+                if (wb == 3 && a.xr) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) so[i] = i * a.Fq * 128 + 64 * 1024;
+                    contract_shared_buf<3>(acc, rsk, lane * 16, so, sp + 8 * 64, 1, gx);
+                }
+                lx_rows(256 + 64 * wb);
+                if (wb == 3 && a.xr && h == 1) {
+                    const float rx = Rs[fl * ldr + a.Fm];
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wl + a.Fm * 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) gl[c] = fmaf(rx, w4[c], gl[c]);
+                }
                 rp_post(bdone, wb, (unsigned)(2 * j + 2), lane);
+                // partial tiles -> LDS, once every wave has read the previous tile's
+                rp_await(rdone, lx_seq, a.stop);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 o = {acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
+                        *reinterpret_cast<f32x4*>(Ps + ((wb * 3 + i) * 4 + g) * 256 + lane * 4) = o;
+                    }
+                *reinterpret_cast<f32x4*>(Pl + (wb * 64 + lane) * 4) = gl;
+                ++lx_seq;
+                rp_post(wdone, wb, lx_seq, lane);
+                rp_await(wdone, lx_seq, a.stop);
+                f32x16 tot = zero16();
+                if (wb < 3) {
+#pragma unroll
+                    for (int ww = 0; ww < 4; ++ww)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 x = *reinterpret_cast<const f32x4*>(Ps + ((ww * 3 + wb) * 4 + g) * 256 + lane * 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) tot[4 * g + e] += x[e];
+                        }
+                } else if (h == 0) {  // columns 96 .. 99 = this column tile's registers 0 .. 3 of the lanes h = 0
+#pragma unroll
+                    for (int ww = 0; ww < 4; ++ww) {
+                        const f32x4 x0 = *reinterpret_cast<const f32x4*>(Pl + (ww * 64 + fl) * 4);
+                        const f32x4 x1 = *reinterpret_cast<const f32x4*>(Pl + (ww * 64 + 32 + fl) * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) tot[e] += x0[e] + x1[e];
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                rp_post(rdone, wb, lx_seq, lane);
+                rp_p2_epilogue<OBJ>(a, tot, Hs, wb, t0, lane, dp0, shsum);
+                if (OBJ) acc_sh += (double)shsum;
+                rp_post(p2done, wb, (unsigned)(j + 1), lane);
+            } else {
+                if (wb + NB < a.nk) rh_p2_tile<2, OBJ>(a, Hs, Rs, wb, t0, lane, wb, j, bdone, dp0, dp1, shsum, g0, g1, gx);
+                else if (wb < a.nk) rh_p2_tile<1, OBJ>(a, Hs, Rs, wb, t0, lane, wb, j, bdone, dp0, dp1, shsum, g0, g1, gx);
+                else {  // a wave without a column tile keeps step (the slots are progress numbers)
+                    g0();
+                    rp_post(bdone, wb, (unsigned)(2 * j + 1), lane);
+                    g1();
+                    if (a.xr) gx();
+                    rp_post(bdone, wb, (unsigned)(2 * j + 2), lane);
+                }
+                if (OBJ) acc_sh += (double)shsum;
+                rp_post(p2done, wb, (unsigned)(j + 1), lane);
             }
-            if (OBJ) acc_sh += (double)shsum;
-            rp_post(p2done, wb, (unsigned)(j + 1), lane);
         };
         for (int j = 0; j < (has_part ? nmy - 1 : nmy); ++j) b_item(j);
         if (has_part) {

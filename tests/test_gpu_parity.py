@@ -541,6 +541,26 @@ def test_dnmf_adapt_caller(gpu_ctx):
     assert B_a.shape == (129, 6) and rel(B_a, ref) < REL_WH
 
 
+@pytest.mark.parametrize("F,r,T,mode", [(513, 100, 8300, "full"), (513, 97, 8200, "h"), (512, 98, 8500, "full"), (513, 99, 16500, "h"),
+                                        (512, 100, 8193, "semi")])
+def test_h_step_cut_over_the_contraction(gpu_ctx, F, r, T, mode):
+    """r = 97..100 on 16 row tiles (the reference's R = 100 at F = 513, settings/initial_setting_SNMF_NAT.m:48-49): k_hstep_rh
+    cuts P2 over the contraction and takes the leftover columns on the VALU (src/sparse_nmf.m:189-195 is what it computes)."""
+    from se_snmf_nat_amd import Plan, sparse_nmf
+    rs = np.random.default_rng(F + r + T)
+    V = rs.gamma(0.5, 1.0, (F, 12)) @ rs.gamma(0.3, 1.0, (12, T)) + 1e-3
+    p = dict(cf="kl", sparsity=rs.random(r) * 4, max_iter=4, conv_eps=0, cost_check=1, init_w=rs.random((F, r)), init_h=rs.random((r, T)))
+    kw = {}
+    if mode == "h":
+        p["w_update_ind"] = kw["w_update_ind"] = np.zeros(r, bool)
+    if mode == "semi":
+        p["w_update_ind"] = kw["w_update_ind"] = np.arange(r) >= 50
+    pl = Plan(gpu_ctx, F, T, r, beta=1.0, max_iter=2, cost_check=True, **kw)
+    assert "P2 cut over the contraction" in pl.describe()
+    pl.close()
+    check(sparse_nmf(V, p, ctx=gpu_ctx), oracle_nmf(V, p))
+
+
 def test_euclidean_w_step_through_the_gram_matrix(gpu_ctx):
     """beta = 2, r > 256, full update: P = max(W*H, flr) * H' (src/sparse_nmf.m:224-231) is formed as W * (H*H'), which
     differs from the reference's expression only where W*H sits at the 1e-9 floor.  Silent rows of V (exact zeros, floored

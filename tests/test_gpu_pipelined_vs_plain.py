@@ -29,7 +29,7 @@ SHAPES = [(65, 70, 12000), (129, 70, 12000), (65, 32, 12000), (64, 70, 12000), (
           # 9..16 row tiles: k_hstep_rh (one ratio image, pipelined by half tiles) and k_wstats with loader waves on a
           # compact V image -- the reference's shipped F = 513 at R = 100 / 200 (settings/initial_setting_SNMF_NAT.m:21-29,48-49)
           (513, 100, 12000), (513, 200, 9000), (513, 256, 5000), (385, 100, 12000), (449, 250, 9000), (512, 128, 8000),
-          (289, 40, 20000), (513, 200, 100), (513, 100, 9000), (512, 256, 10000)]
+          (289, 40, 20000), (513, 200, 100), (513, 100, 9000), (512, 256, 10000), (513, 97, 12000), (512, 99, 9000)]
 
 
 def _run(ctx, V, W0, H0, r, *, h_only, iters):
@@ -72,12 +72,22 @@ def test_pipelined_kernels_equal_plain_kernels(gpu_ctx, shape, monkeypatch):
     h_old, _, geo_old, obj_old = _run(gpu_ctx, V, W0, H0, r, h_only=True, iters=2)
     _, w_old, _, _ = _run(gpu_ctx, V, W0, H0, r, h_only=False, iters=3)
     assert "k_hstep_rp" not in geo_old and "k_hstep_rh" not in geo_old
-    # every tile in the pipeline: the plain kernels bit for bit
-    assert np.array_equal(h_ns, h_old)
+    # every tile in the pipeline: the plain kernels bit for bit -- except where k_hstep_rh cuts P2 over the contraction
+    # (r = 97..100 on 16 row tiles: four partial sums per numerator instead of one chain), which is a summation order of its own
+    lxh = "P2 cut over the contraction" in geo
+    if lxh:
+        d = np.abs(h_ns - h_old)
+        assert (d <= 2e-5 * np.abs(h_old) + 1e-30).all(), d.max()
+    else:
+        assert np.array_equal(h_ns, h_old)
     assert np.abs(w_ns - w_old).max() <= 1e-6 * np.abs(w_old).max()
     # default path: pipelined tiles bit for bit, split tiles to the summation-order tolerance
     t_split = 32 * n_full if S else T
-    assert np.array_equal(h_new[:, :t_split], h_old[:, :t_split])
+    if lxh:
+        d = np.abs(h_new[:, :t_split] - h_old[:, :t_split])
+        assert (d <= 2e-5 * np.abs(h_old[:, :t_split]) + 1e-30).all(), d.max()
+    else:
+        assert np.array_equal(h_new[:, :t_split], h_old[:, :t_split])
     if S:
         assert n_full < n_tiles
         d = np.abs(h_new[:, t_split:] - h_old[:, t_split:])
