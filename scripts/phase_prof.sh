@@ -5,11 +5,7 @@
 set -e
 cd "$(dirname "$0")/.."
 PROF=scripts/prof_build/libsnmf_hip_prof.so
-if [ ! -f "$PROF" ] || [ se_snmf_nat_amd/csrc/snmf_kernels.h -nt "$PROF" ] || [ se_snmf_nat_amd/csrc/snmf_api.hip -nt "$PROF" ]; then
-    mkdir -p scripts/prof_build
-    /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -Wno-unused-value -DSNMF_PROF \
-        -Iinclude -Ise_snmf_nat_amd/csrc -o "$PROF" se_snmf_nat_amd/csrc/snmf_api.hip
-fi
+python scripts/build_variant.py hip_prof -DSNMF_PROF > /dev/null   # (rebuilds only the translation units whose sources changed)
 export SNMF_LIB_PATH="$PWD/$PROF"
 run() { echo "== $*"; env "$@" python bench.py --steps 200 --warmup 2 --no-cpu-baseline 2>&1 | grep -E "SNMF_PROF|kernel_ms" | python -c "
 import sys,json

@@ -14,9 +14,21 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libsnmf_hip.so")
-SRC = [os.path.join(_HERE, "csrc", "snmf_api.hip")]
 import glob as _glob
-# every header the translation unit includes (an edit to any of them must rebuild the library)
+# The library is several translation units compiled in parallel and linked once (csrc/snmf_internal.h says which is which).
+SRC = sorted(_glob.glob(os.path.join(_HERE, "csrc", "*.hip")))
+OBJ_DIR = os.path.join(_ROOT, "build", "obj")
+# headers each translation unit includes beyond the ones every unit does (an edit to a header rebuilds only its users)
+_COMMON_HDRS = ["snmf_internal.h", "snmf_kernels.h", os.path.join(_ROOT, "include", "snmf.h")]
+_TU_HDRS = {
+    "snmf_api.hip": ["snmf_frontend.h", "snmf_generic.h", "snmf_prof.h"],
+    "snmf_tu_wstats.hip": ["snmf_generic.h", "snmf_wstats_dispatch.h"],
+    "snmf_tu_wstats4.hip": ["snmf_generic.h", "snmf_wstats_dispatch.h"],
+    "snmf_tu_wstats8.hip": ["snmf_generic.h", "snmf_wstats_dispatch.h"],
+    "snmf_tu_online.hip": ["snmf_online.h"],
+    "snmf_tu_multi.hip": ["snmf_multi.h"],
+    "snmf_tu_dnmf.hip": ["snmf_frontend.h"],
+}
 HDRS = sorted(_glob.glob(os.path.join(_HERE, "csrc", "*.h"))) + [os.path.join(_ROOT, "include", "snmf.h")]
 
 # every symbol include/snmf.h declares
@@ -104,20 +116,47 @@ class SnmfError(RuntimeError):
         self.message = message
 
 
-def build(force=False, verbose=False):
-    """Compile libsnmf_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    if not force and os.path.exists(LIB_PATH):
-        newest = max(os.path.getmtime(p) for p in SRC + HDRS)
-        if os.path.getmtime(LIB_PATH) >= newest:
-            return LIB_PATH
+def _tu_deps(src):
+    hs = _COMMON_HDRS + _TU_HDRS.get(os.path.basename(src), [])
+    return [src] + [h if os.path.isabs(h) else os.path.join(_HERE, "csrc", h) for h in hs]
+
+
+def build(force=False, verbose=False, jobs=None, extra_flags=(), lib_path=None, obj_dir=None):
+    """Compile libsnmf_hip.so for gfx950 with hipcc (cross-compiles without a GPU): every csrc/*.hip to an object file
+    (in parallel, only the ones whose sources changed), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+    lib_path = lib_path or LIB_PATH
+    obj_dir = obj_dir or OBJ_DIR
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_HERE, "csrc"),
-           "-o", LIB_PATH] + SRC
+    flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value",
+             "-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_HERE, "csrc")] + list(extra_flags)
+    todo, objs = [], []
+    for src in SRC:
+        obj = os.path.join(obj_dir, os.path.splitext(os.path.basename(src))[0] + ".o")
+        objs.append(obj)
+        deps = [d for d in _tu_deps(src) if os.path.exists(d)]
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(d) for d in deps):
+            todo.append((src, obj))
+    if not todo and os.path.exists(lib_path) and os.path.getmtime(lib_path) >= max(os.path.getmtime(o) for o in objs):
+        return lib_path
+
+    def compile_one(job):
+        src, obj = job
+        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+
+    jobs = jobs or max(1, min(len(todo), os.cpu_count() or 1, 8))
+    if todo:
+        with ThreadPoolExecutor(max_workers=jobs) as ex:
+            list(ex.map(compile_one, todo))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-z,defs", "-o", lib_path] + objs + ["-lpthread"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
-    return LIB_PATH
+    return lib_path
 
 
 _lib = None

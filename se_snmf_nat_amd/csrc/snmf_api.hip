@@ -3,30 +3,15 @@
 // Orchestrates the kernels of snmf_kernels.h into the loop of the reference solver
 // (lordet01/SE_SNMF_NAT src/sparse_nmf.m:157-292).  No CPU compute fallback exists here: every
 // numeric step is a HIP kernel launch; without a device the entry points fail.
-#include "snmf_kernels.h"
+#include "snmf_internal.h"
 #include "snmf_frontend.h"
 #include "snmf_generic.h"
-
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <deque>
-#include <map>
-#include <mutex>
-#include <string>
-#include <vector>
-
-#include "snmf.h"
-
-using namespace snmf;
 
 // ------------------------------------------------------------------------------------------
 // errors
 // ------------------------------------------------------------------------------------------
-static thread_local std::string g_err;
-static int fail(int code, const char* fmt, ...) {
+thread_local std::string g_err;
+int fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -35,65 +20,11 @@ static int fail(int code, const char* fmt, ...) {
     g_err = buf;
     return code;
 }
-#define HIP_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess)                                                                      \
-            return fail(e_ == hipErrorOutOfMemory ? SNMF_ERR_NOMEM : SNMF_ERR_NO_DEVICE, "%s: %s", \
-                        #expr, hipGetErrorString(e_));                                             \
-    } while (0)
-// lazy chain: the call is only MADE while no earlier one has failed, so the first failure's status AND message survive
-#define SN_STEP(s, expr)                      \
-    do {                                      \
-        if ((s) == SNMF_OK) (s) = (expr);     \
-    } while (0)
-#define SN_TRY(expr)              \
-    do {                          \
-        int s_ = (expr);          \
-        if (s_ != SNMF_OK) return s_; \
-    } while (0)
 
 // ------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------
-struct TimerPair {
-    hipEvent_t a, b;
-    int fam;
-};
-enum { FAM_HSTEP = 0, FAM_WSTATS, FAM_WAPPLY, FAM_REDUCE, FAM_WFIN, FAM_N };
 static const char* kFamNames[FAM_N] = {"hstep", "wstats", "wapply", "reduce", "wfin"};
-
-struct snmf_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    int n_cu = 256;
-    size_t lds_max = 160 * 1024;
-    bool timing = false;
-    std::vector<TimerPair> pending;
-    double fam_ms[FAM_N] = {0, 0, 0, 0, 0};
-    int64_t fam_n[FAM_N] = {0, 0, 0, 0, 0};
-};
-
-struct ScopedTimer {
-    snmf_ctx* c;
-    TimerPair tp;
-    bool on;
-    ScopedTimer(snmf_ctx* c_, int fam) : c(c_), on(c_->timing) {
-        if (on) {
-            tp.fam = fam;
-            hipEventCreate(&tp.a);
-            hipEventCreate(&tp.b);
-            hipEventRecord(tp.a, c->stream);
-        }
-    }
-    ~ScopedTimer() {
-        if (on) {
-            hipEventRecord(tp.b, c->stream);
-            c->pending.push_back(tp);
-        }
-    }
-};
 
 static void drain_timers(snmf_ctx* c) {
     if (c->pending.empty()) return;
@@ -210,94 +141,8 @@ extern "C" int snmf_ctx_timing_get(snmf_ctx* c, const char* family, double* avg_
 
 // ------------------------------------------------------------------------------------------
 // plan
-// ------------------------------------------------------------------------------------------
-struct snmf_plan {
-    snmf_ctx* ctx = nullptr;
-    snmf_params p{};
-    // geometry
-    int Fp = 0, rp = 0, Tp = 0, nf = 0, nk = 0;
-    int Fm = 0, Fq = 0, xr = 0;
-    int NT = 1, NWH = 8, NLH = 0;  // k_hstep: frame tile = 32*NT, NWH consumer + NLH loader waves
-    int TTH = 32, TTW = 32;        // frames per tile of k_hstep (NT == 1) / k_wstats; 16 = narrow tiles (images too big for 32 frames)
-    bool hstep_rp = true;          // KL update launches of the (8, 1, 4) geometry use the role pipeline k_hstep_rp (SNMF_HSTEP_RP=0: k_hstep)
-    // k_hstep_rp launch geometry: tiles [0, rp_full) through the pipeline on rp_grid workgroups, the tiles of the last
-    // partial round [rp_full, rp_tiles) cut into rp_S row parts, one workgroup each (rp_S = 0: no split)
-    int rp_tiles = 0, rp_full = 0, rp_S = 0, rp_grid = 1;
-    bool rh = false;               // KL update launches run k_hstep_rh (9..16 row tiles, e.g. F = 513: one ratio image, pipelined by half tiles)
-    size_t lds_rh = 0;
-    float* part_buf = nullptr;     // partial numerators of the split tiles [rp_grid][32][rp]
-    unsigned* part_cnt = nullptr;  // arrivals per split tile (monotonic)
-    int NKT = 8, NWB = 4, WPS = 2, NLW = 0;  // k_wstats template geometry (NLW loader waves)
-    int n_fg = 1, n_kg = 1, n_chunks = 1;
-    int n_ch1 = 0;  // k_wstats: chunks of row group 1 when the two row groups are split unevenly (else 0)
-    // beta = 2, r > 256: the V*H^T launch (needs no Lam') runs the loader-wave geometry <8,4,4,2> once per 256-column
-    // kappa-group, each staging only its own columns of H (kq_chunks frame chunks, kq_kg kappa-groups; 0 = off)
-    int kq_chunks = 0, kq_kg = 0;
-    // snmf_plan_run: k_reduce + k_wapply as one launch (k_wfin) when a column's chunk-group sums fit the LDS
-    bool rh_lxh = false;
-    bool wfin = false;
-    size_t lds_wfin = 0;
-    // shapes beyond the fused kernels' LDS / register envelope: the same iteration with its intermediates in HBM
-    // (csrc/snmf_generic.h); Lam / ratio / denominator images [Tp][Fp], numerator / denominator of the H update [Tp][rp]
-    // Euclidean W step, r > 256, full updates: P = max(W*H, flr) * H' is formed as W * (H*H') -- the r x r Gram matrix
-    // costs 2 r^2 T flop instead of the P launch's 4 F T r (C5: 4.75 -> ~2.5 ms); see launch_gram_p
-    bool gram_p = false;
-    int gram_chunks = 0;
-    float *gram_slabs = nullptr, *gram32 = nullptr;
-    bool generic = false;
-    float *gLam = nullptr, *gR = nullptr, *gD = nullptr, *gNum = nullptr, *gDen = nullptr;
-    size_t kq_lds = 0;
-    int grid_h = 1;
-    int ldh = 0, ldr = 0, ldhw = 0;
-    int stagger_h = 0, stagger_w = 0;
-    size_t lds_h = 0, lds_w = 0;
-    int bm = BM_KL;
-    int n_mat = 1;
-    bool upd_h = true, upd_w = true;
-    // device buffers
-    float *V = nullptr, *H[2] = {nullptr, nullptr}, *Wt4 = nullptr, *Wk4 = nullptr;
-    double* Wc = nullptr;  // fp64 master copy of W (see k_wapply)
-    float* Wcf = nullptr;  // fp32 rounding of Wc, column-major [rp][Fp] (k_hsolve_frame)
-    int frame_fb = 0, frame_kb = 0;  // register-block geometry of k_hsolve_frame (0: shape not admitted)
-    float* M = nullptr;    // MDI: observed/missing mask in V's layout (src/snmf_mdi.m); non-null = MDI solve
-    bool mdi_v_fresh = false, mdi_final = false;
-    size_t lds_mdi = 0;
-    int grid_mdi = 1;
-    size_t lds_frame = 0;
-    float *dphv = nullptr, *colsum = nullptr, *lamk = nullptr, *S = nullptr, *wx = nullptr;
-    float *slabs = nullptr, *spart = nullptr;
-    double *part = nullptr, *stats = nullptr, *divh = nullptr, *costh = nullptr, *wn = nullptr;
-    DevState* st = nullptr;
-    unsigned long long* prof = nullptr;
-    uint8_t* w_ind = nullptr;
-    void* staging = nullptr;
-    size_t staging_bytes = 0;
-    int n_part = 0;
-    // state
-    bool have_v = false, have_w = false, have_h = false, have_s = false, inited = false;
-    bool w_dirty = true;      // W changed since its last normalisation (online: W stays, only V/H change)
-    bool small = false;       // T <= 32 H-only solve: one persistent single-workgroup launch
-    bool small_ok = false;
-    size_t lds_small = 0;
-    bool small_done = false;
-    int cur = 0;          // H[cur] holds the current iterate
-    int it_done = 0;      // update iterations launched
-    bool final_done = false;
-    double sh_const = 0.0;
-    std::vector<uint8_t> h_w_ind;
-};
 
-static size_t roundup(size_t x, size_t m) { return (x + m - 1) / m * m; }
-
-template <typename T>
-static int dalloc(T** p, size_t n) {
-    *p = nullptr;
-    hipError_t e = hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T));
-    if (e != hipSuccess) return fail(SNMF_ERR_NOMEM, "hipMalloc(%zu bytes): %s", n * sizeof(T), hipGetErrorString(e));
-    return SNMF_OK;
-}
-
-static int validate_params(const snmf_params* p) {
+int validate_params(const snmf_params* p) {
     if (!p) return fail(SNMF_ERR_INVALID, "params is NULL");
     if (p->F <= 0 || p->T <= 0) return fail(SNMF_ERR_INVALID, "F and T must be positive (F=%d, T=%d)", p->F, p->T);
     if (p->r <= 0) return fail(SNMF_ERR_NO_INIT, "Number of components or initialization must be given");
@@ -709,7 +554,6 @@ static int ensure_staging(snmf_plan* pl, size_t bytes) {
     return SNMF_OK;
 }
 
-static int grid_for(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 4096); }
 
 template <typename TIn, typename TDst = float>
 static int pack_in(snmf_plan* pl, const TIn* src, int64_t ld, int rows, int cols, TDst* dst, int rowsP, int colsP,
@@ -760,15 +604,9 @@ static int unpack_out(snmf_plan* pl, const TSrc* src, int rowsP, int rows, int c
     return SNMF_OK;
 }
 
-// Every plan entry point starts from a clean HIP error state: hipGetLastError() is sticky per thread, so an error some
-// EARLIER, unrelated call left behind (a refused device ordinal, the caller's own HIP code, torch) would otherwise be
-// reported by the first kernel-launch check of this library as if the launch had failed.
-#define PLAN_CHECK(pl)                                           \
-    if (!(pl)) return fail(SNMF_ERR_INVALID, "plan is NULL");    \
-    (void)hipGetLastError()
 
 template <typename T>
-static int set_v(snmf_plan* pl, const T* V, int64_t ld, int dev) {
+int set_v(snmf_plan* pl, const T* V, int64_t ld, int dev) {
     PLAN_CHECK(pl);
     SN_TRY(pack_in<T>(pl, V, ld, pl->p.F, pl->p.T, pl->V, pl->Fp, pl->Tp, pl->p.floor_v != 0, dev));
     pl->have_v = true;
@@ -793,7 +631,7 @@ static int set_mask(snmf_plan* pl, const T* M, int64_t ld, int dev) {
 extern "C" int snmf_plan_set_mask_f64(snmf_plan* pl, const double* M, int64_t ld, int dev) { return set_mask<double>(pl, M, ld, dev); }
 extern "C" int snmf_plan_set_mask_f32(snmf_plan* pl, const float* M, int64_t ld, int dev) { return set_mask<float>(pl, M, ld, dev); }
 template <typename T>
-static int set_w(snmf_plan* pl, const T* W, int64_t ld, int dev) {
+int set_w(snmf_plan* pl, const T* W, int64_t ld, int dev) {
     PLAN_CHECK(pl);
     SN_TRY((pack_in<T, double>(pl, W, ld, pl->p.F, pl->p.r, pl->Wc, pl->Fp, pl->rp, false, dev)));
     pl->have_w = true;
@@ -802,7 +640,7 @@ static int set_w(snmf_plan* pl, const T* W, int64_t ld, int dev) {
     return SNMF_OK;
 }
 template <typename T>
-static int set_h(snmf_plan* pl, const T* H, int64_t ld, int dev) {
+int set_h(snmf_plan* pl, const T* H, int64_t ld, int dev) {
     PLAN_CHECK(pl);
     SN_TRY(pack_in<T>(pl, H, ld, pl->p.r, pl->p.T, pl->H[0], pl->rp, pl->Tp, false, dev));
     pl->have_h = true;
@@ -811,7 +649,7 @@ static int set_h(snmf_plan* pl, const T* H, int64_t ld, int dev) {
     return SNMF_OK;
 }
 template <typename T>
-static int set_s(snmf_plan* pl, const T* S, int dev) {
+int set_s(snmf_plan* pl, const T* S, int dev) {
     PLAN_CHECK(pl);
     if (pl->p.sparsity_kind == SNMF_SPARSITY_SCALAR) return fail(SNMF_ERR_STATE, "plan has scalar sparsity");
     if (pl->p.sparsity_kind == SNMF_SPARSITY_RVEC)
@@ -831,6 +669,15 @@ extern "C" int snmf_plan_set_h_f64(snmf_plan* pl, const double* H, int64_t ld, i
 extern "C" int snmf_plan_set_h_f32(snmf_plan* pl, const float* H, int64_t ld, int d) { return set_h(pl, H, ld, d); }
 extern "C" int snmf_plan_set_sparsity_f64(snmf_plan* pl, const double* S, int d) { return set_s(pl, S, d); }
 extern "C" int snmf_plan_set_sparsity_f32(snmf_plan* pl, const float* S, int d) { return set_s(pl, S, d); }
+// (used by the other translation units: snmf_tu_online.hip, snmf_tu_multi.hip, snmf_tu_dnmf.hip)
+template int set_v<float>(snmf_plan*, const float*, int64_t, int);
+template int set_v<double>(snmf_plan*, const double*, int64_t, int);
+template int set_w<float>(snmf_plan*, const float*, int64_t, int);
+template int set_w<double>(snmf_plan*, const double*, int64_t, int);
+template int set_h<float>(snmf_plan*, const float*, int64_t, int);
+template int set_h<double>(snmf_plan*, const double*, int64_t, int);
+template int set_s<float>(snmf_plan*, const float*, int);
+template int set_s<double>(snmf_plan*, const double*, int);
 
 extern "C" int snmf_plan_get_w_f64(snmf_plan* pl, double* W, int64_t ld, int d) {
     PLAN_CHECK(pl);
@@ -842,7 +689,7 @@ extern "C" int snmf_plan_get_w_f32(snmf_plan* pl, float* W, int64_t ld, int d) {
 }
 
 // ---- launch helpers --------------------------------------------------------------------------
-static StepArgs make_args(snmf_plan* pl) {
+StepArgs make_args(snmf_plan* pl) {
     StepArgs a{};
     a.V = pl->V;
     a.Hin = pl->H[pl->cur];
@@ -884,7 +731,7 @@ static StepArgs make_args(snmf_plan* pl) {
 // hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: the cache of "already raised to"
 // is keyed by (device, kernel) and guarded, so that a second context on another device, or two host threads, cannot
 // skip a call they need (launches with more than 64 KiB of LDS would fail) or race on the map.
-static int ensure_dyn_lds(int device, const void* kern, size_t lds) {
+int ensure_dyn_lds(int device, const void* kern, size_t lds) {
     if (lds <= 64 * 1024) return SNMF_OK;
     static std::mutex mu;
     static std::map<std::pair<int, const void*>, size_t> raised;
@@ -897,43 +744,8 @@ static int ensure_dyn_lds(int device, const void* kern, size_t lds) {
     return SNMF_OK;
 }
 
-template <typename K>
-static int launch_big(K kern, dim3 grid, dim3 block, size_t lds, hipStream_t st, StepArgs a) {
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));  // every caller has set the plan's device
-    SN_TRY(ensure_dyn_lds(dev, (const void*)kern, lds));
-    hipLaunchKernelGGL(kern, grid, block, lds, st, a);
-    HIP_TRY(hipGetLastError());
-    return SNMF_OK;
-}
-
-// k_hstep dispatch over (NW, NT, NL, BM, OBJ, UPD)
-template <int NW, int NT, int NL, int BM, int TT>
-static int launch_hstep_nb(snmf_plan* pl, const StepArgs& a, bool obj, bool upd) {
-    dim3 g(pl->grid_h), b((NW + NL) * 64);
-    hipStream_t st = pl->ctx->stream;
-    if (obj && upd) return launch_big(k_hstep<NW, NT, NL, BM, true, true, false, TT>, g, b, pl->lds_h, st, a);
-    if (!obj && upd) return launch_big(k_hstep<NW, NT, NL, BM, false, true, false, TT>, g, b, pl->lds_h, st, a);
-    if (obj && !upd) return launch_big(k_hstep<NW, NT, NL, BM, true, false, false, TT>, g, b, pl->lds_h, st, a);
-    return SNMF_OK;
-}
-template <int NW, int NT, int NL, int TT = 32>
-static int launch_hstep_g(snmf_plan* pl, const StepArgs& a, bool obj, bool upd) {
-    if (pl->bm == BM_KL) return launch_hstep_nb<NW, NT, NL, BM_KL, TT>(pl, a, obj, upd);
-    if (pl->bm == BM_EUC) return launch_hstep_nb<NW, NT, NL, BM_EUC, TT>(pl, a, obj, upd);
-    return launch_hstep_nb<NW, NT, NL, BM_GEN, TT>(pl, a, obj, upd);
-}
-// MDI pass (src/snmf_mdi.m:251-257 fused into the Lam pass): synchronous-staging geometry, V rewritten in place
-template <int BM>
-static int launch_hstep_mdi_b(snmf_plan* pl, const StepArgs& a, bool obj, bool upd) {
-    dim3 g(pl->grid_mdi), b(8 * 64);
-    hipStream_t st = pl->ctx->stream;
-    if (upd) return obj ? launch_big(k_hstep<8, 1, 0, BM, true, true, true>, g, b, pl->lds_mdi, st, a)
-                        : launch_big(k_hstep<8, 1, 0, BM, false, true, true>, g, b, pl->lds_mdi, st, a);
-    return launch_big(k_hstep<8, 1, 0, BM, true, false, true>, g, b, pl->lds_mdi, st, a);  // imputation (+ objective)
-}
 // ---- the out-of-envelope path (csrc/snmf_generic.h) ---------------------------------------------
-static int g_gemm(snmf_plan* pl, const float* A, long long rsA, long long csA, const float* B, long long rsB, long long csB, float* C,
+int g_gemm(snmf_plan* pl, const float* A, long long rsA, long long csA, const float* B, long long rsB, long long csB, float* C,
                   long long rsC, long long csC, int M, int N, int K, int kchunk, long long zC) {
     GemmArgs g{};
     g.A = A; g.B = B; g.C = C;
@@ -967,7 +779,7 @@ static int g_lam_ratio(snmf_plan* pl, const float* H, bool obj) {
     if (pl->bm == BM_EUC) return g_lam_ratio<BM_EUC>(pl, H, obj);
     return g_lam_ratio<BM_GEN>(pl, H, obj);
 }
-static int generic_hstep(snmf_plan* pl, bool obj, bool upd) {
+int generic_hstep(snmf_plan* pl, bool obj, bool upd) {
     const int F = pl->p.F, T = pl->p.T, r = pl->p.r;
     const float* Hin = pl->H[pl->cur];
     SN_TRY(g_lam_ratio(pl, Hin, obj));
@@ -987,7 +799,7 @@ static int generic_hstep(snmf_plan* pl, bool obj, bool upd) {
     return SNMF_OK;
 }
 // W statistics of the current H as split-T slabs (+ the divergence of the previous iterate in W-only solves)
-static int generic_wstats(snmf_plan* pl, bool obj) {
+int generic_wstats(snmf_plan* pl, bool obj) {
     const int F = pl->p.F, T = pl->p.T, r = pl->p.r;
     const float* H = pl->H[pl->cur];
     SN_TRY(g_lam_ratio(pl, H, obj));
@@ -1002,173 +814,6 @@ static int generic_wstats(snmf_plan* pl, bool obj) {
         HIP_TRY(hipGetLastError());
     }
     return SNMF_OK;
-}
-
-static int launch_hstep(snmf_plan* pl, bool obj, bool upd) {
-    if (pl->generic) {
-        ScopedTimer tm(pl->ctx, FAM_HSTEP);
-        return generic_hstep(pl, obj, upd);
-    }
-    StepArgs a = make_args(pl);
-    a.n_tiles = pl->Tp / (pl->TTH * pl->NT);
-    a.stagger = pl->stagger_h;
-    ScopedTimer tm(pl->ctx, FAM_HSTEP);
-    if (pl->M) {
-        a.n_tiles = pl->Tp / 32;
-        a.stagger = 0;
-        a.M = pl->M;
-        a.Vw = pl->V;
-        a.impute = pl->it_done >= 1 ? 1 : 0;  // the first Lam pass precedes any imputation (:175 only)
-        if (pl->bm == BM_KL) return launch_hstep_mdi_b<BM_KL>(pl, a, obj, upd);
-        if (pl->bm == BM_EUC) return launch_hstep_mdi_b<BM_EUC>(pl, a, obj, upd);
-        return launch_hstep_mdi_b<BM_GEN>(pl, a, obj, upd);
-    }
-    if (pl->rh && upd) {  // KL update launches of the 9..16-row-tile geometry: the half-tile role pipeline (k_hstep_rh)
-        dim3 g(pl->rp_grid), b(768);
-        a.n_tiles = pl->rp_tiles;
-        a.n_full = pl->rp_full;
-        a.part_S = pl->rp_S;
-        a.part_buf = pl->part_buf;
-        a.part_cnt = pl->part_cnt;
-        if (pl->rh_lxh) {
-            a.lxh = 1;
-            return obj ? launch_big(k_hstep_rh<true, true>, g, b, pl->lds_rh, pl->ctx->stream, a)
-                       : launch_big(k_hstep_rh<false, true>, g, b, pl->lds_rh, pl->ctx->stream, a);
-        }
-        return obj ? launch_big(k_hstep_rh<true>, g, b, pl->lds_rh, pl->ctx->stream, a)
-                   : launch_big(k_hstep_rh<false>, g, b, pl->lds_rh, pl->ctx->stream, a);
-    }
-    if (pl->NWH == 8 && pl->NLH == 4) {
-        if (pl->hstep_rp && pl->bm == BM_KL && upd) {  // KL update launches: the role pipeline (k_hstep_rp)
-            dim3 g(pl->rp_grid), b(768);
-            a.n_tiles = pl->rp_tiles;
-            a.n_full = pl->rp_full;
-            a.part_S = pl->rp_S;
-            a.part_buf = pl->part_buf;
-            a.part_cnt = pl->part_cnt;
-            SN_TRY(obj ? launch_big(k_hstep_rp<true>, g, b, pl->lds_h, pl->ctx->stream, a)
-                       : launch_big(k_hstep_rp<false>, g, b, pl->lds_h, pl->ctx->stream, a));
-            return SNMF_OK;
-        }
-        return launch_hstep_g<8, 1, 4>(pl, a, obj, upd);
-    }
-    if (pl->NWH == 4) return pl->NT == 2 ? launch_hstep_g<4, 2, 0>(pl, a, obj, upd) : launch_hstep_g<4, 1, 0>(pl, a, obj, upd);
-    if (pl->TTH == 16) return launch_hstep_g<8, 1, 0, 16>(pl, a, obj, upd);
-    return pl->NT == 2 ? launch_hstep_g<8, 2, 0>(pl, a, obj, upd) : launch_hstep_g<8, 1, 0>(pl, a, obj, upd);
-}
-
-// k_wstats dispatch
-template <int NK, int NWB, int NL, int WPS, int WM, int BM, bool OBJ, int TT = 32, int LX = 0>
-static int launch_wstats_one(snmf_plan* pl, const StepArgs& a, int mat_index) {
-    const bool split = pl->n_ch1 > 0;  // uneven row-group split: 1-D grid, group 0's chunks first
-    dim3 g(split ? pl->n_chunks + (pl->n_fg - 1) * pl->n_ch1 : pl->n_chunks, split ? 1 : pl->n_fg, pl->n_kg), b((NWB + NL) * 64);
-    StepArgs as = a;
-    as.n_ch1 = split ? pl->n_ch1 : 0;
-    auto kern = k_wstats<NK, NWB, NL, WPS, WM, BM, OBJ, TT, LX>;
-    SN_TRY(ensure_dyn_lds(pl->ctx->device, (const void*)kern, pl->lds_w));
-    hipLaunchKernelGGL(kern, g, b, pl->lds_w, pl->ctx->stream, as, pl->n_chunks, mat_index, pl->n_mat);
-    HIP_TRY(hipGetLastError());
-    return SNMF_OK;
-}
-// The "P" statistics of a Euclidean W step without the Lam' pass: P = max(W*H, flr) * H' = W * (H*H') wherever W*H is above
-// the 1e-9 floor (everywhere that matters: an entry at the floor contributes < 1e-9 * sum(h) either way, far below the
-// engine's fp32 rounding of P).  H*H' is the V*H' launch with the H image as "V" (r rows, no extra row), by kappa-groups
-// like the Q launch; its chunk slabs are added in fp64, and W * Gram is one small GEMM into the P slab of chunk 0 (the P
-// slabs of the other chunks stay zero from plan creation), so k_reduce / k_wfin / k_wapply see an ordinary P.
-template <int NK, int NWB, int NL, int WPS>
-static int launch_gram_p(snmf_plan* pl, const StepArgs& a) {
-    StepArgs ag = a;
-    ag.V = a.Hin;
-    ag.F = pl->p.r;
-    ag.Fp = ag.Fm = ag.Fq = pl->rp;
-    ag.nf = pl->rp / 32;
-    ag.xr = 0;
-    ag.n_ch1 = 0;
-    ag.slabs = pl->gram_slabs;
-    if (pl->kq_kg) {  // r > 256: by kappa-groups on the loader-wave geometry, like the Q launch
-        ag.ldh = 260;
-        ag.kc = 1;
-        auto kern = k_wstats<8, 4, 4, 2, 3, BM_EUC, false, 32>;
-        SN_TRY(ensure_dyn_lds(pl->ctx->device, (const void*)kern, pl->kq_lds));
-        hipLaunchKernelGGL(kern, dim3(pl->gram_chunks, (ag.nf + 3) / 4, pl->kq_kg), dim3(512), pl->kq_lds, pl->ctx->stream, ag,
-                           pl->gram_chunks, 0, 1);
-    } else {          // r <= 256: the plan's own V * H' kernel
-        auto kern = k_wstats<NK, NWB, NL, WPS, 3, BM_EUC, false, 32>;
-        SN_TRY(ensure_dyn_lds(pl->ctx->device, (const void*)kern, pl->lds_w));
-        hipLaunchKernelGGL(kern, dim3(pl->gram_chunks, (ag.nf + NWB - 1) / NWB, 1), dim3((NWB + NL) * 64), pl->lds_w, pl->ctx->stream, ag,
-                           pl->gram_chunks, 0, 1);
-    }
-    HIP_TRY(hipGetLastError());
-    const size_t n = (size_t)pl->rp * pl->rp;
-    hipLaunchKernelGGL(k_gram_sum, dim3((int)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, pl->ctx->stream,
-                       (const float*)pl->gram_slabs, pl->gram_chunks, n, pl->gram32, (const int*)&pl->st->stop);
-    HIP_TRY(hipGetLastError());
-    // P(f, k) = sum_j W(f, j) Gram(j, k), element (f, k) at k * Fp + f of a P slab.  The product is tiny and, as one
-    // launch over K = r, a chain of r / 16 dependent tile steps on a few workgroups (33 us at r = 256): the contraction is
-    // cut into up to eight ranges whose partial products go to the P slabs of chunks 0 .. 7 -- k_reduce adds the chunks in
-    // fixed order anyway; the P slabs of the remaining chunks stay zero from plan creation.
-    const int nsplit = std::max(1, std::min(std::min(8, pl->n_chunks), (pl->p.r + 31) / 32));
-    const int kchunk = (((pl->p.r + nsplit - 1) / nsplit) + 15) / 16 * 16;
-    const long long nW = (long long)pl->Fp * pl->rp;
-    return g_gemm(pl, pl->Wcf, 1, pl->Fp, pl->gram32, 1, pl->rp, pl->slabs + nW, 1, pl->Fp, pl->p.F, pl->p.r, pl->p.r, kchunk,
-                  nW * pl->n_mat);
-}
-template <int NK, int NWB, int NL, int WPS, int TT = 32>
-static int launch_wstats_geo(snmf_plan* pl, const StepArgs& a, bool obj) {
-    if (pl->bm == BM_KL) {
-        // statistics columns past the last full 32-column tile: up to 8 go through the VALU (k_wstats<..., LX>; loader
-        // geometries only: r = 100 at the reference's settings)
-        const int left = pl->p.r - 32 * (pl->nk - 1);
-        const int lx = (pl->nk >= 2 && pl->n_kg == 1 && left <= 8) ? (left + 3) / 4 : 0;
-        // (NK = 4 geometries only: at NK = 8 -- 128 accumulator registers -- the extra code spills: 69 VGPRs at LX = 2)
-        if constexpr (NL > 0 && TT == 32 && NK == 4) {
-            if (lx == 1) return obj ? launch_wstats_one<NK, NWB, NL, WPS, 0, BM_KL, true, TT, 1>(pl, a, 0)
-                                    : launch_wstats_one<NK, NWB, NL, WPS, 0, BM_KL, false, TT, 1>(pl, a, 0);
-            if (lx == 2) return obj ? launch_wstats_one<NK, NWB, NL, WPS, 0, BM_KL, true, TT, 2>(pl, a, 0)
-                                    : launch_wstats_one<NK, NWB, NL, WPS, 0, BM_KL, false, TT, 2>(pl, a, 0);
-        }
-        return obj ? launch_wstats_one<NK, NWB, NL, WPS, 0, BM_KL, true, TT>(pl, a, 0)
-                   : launch_wstats_one<NK, NWB, NL, WPS, 0, BM_KL, false, TT>(pl, a, 0);
-    }
-    if (pl->bm == BM_EUC) {
-        if (pl->gram_p && !pl->M && !obj && TT == 32) SN_TRY((launch_gram_p<NK, NWB, NL, WPS>(pl, a)));
-        else
-            SN_TRY(obj ? (launch_wstats_one<NK, NWB, NL, WPS, 1, BM_EUC, true, TT>(pl, a, 1))
-                       : (launch_wstats_one<NK, NWB, NL, WPS, 1, BM_EUC, false, TT>(pl, a, 1)));
-        if (pl->kq_kg) {  // V * H^T by 256-column kappa-groups on the loader-wave geometry (see snmf_plan_create)
-            StepArgs aq = a;
-            aq.ldh = 260;
-            aq.kc = 1;
-            aq.n_ch1 = 0;
-            auto kern = k_wstats<8, 4, 4, 2, 3, BM_EUC, false, 32>;
-            SN_TRY(ensure_dyn_lds(pl->ctx->device, (const void*)kern, pl->kq_lds));
-            hipLaunchKernelGGL(kern, dim3(pl->kq_chunks, pl->n_fg, pl->kq_kg), dim3(512), pl->kq_lds, pl->ctx->stream, aq, pl->kq_chunks, 0,
-                               pl->n_mat);
-            HIP_TRY(hipGetLastError());
-            return SNMF_OK;
-        }
-        return launch_wstats_one<NK, NWB, NL, WPS, 3, BM_EUC, false, TT>(pl, a, 0);
-    }
-    SN_TRY(obj ? (launch_wstats_one<NK, NWB, NL, WPS, 1, BM_GEN, true, TT>(pl, a, 1))
-               : (launch_wstats_one<NK, NWB, NL, WPS, 1, BM_GEN, false, TT>(pl, a, 1)));
-    return launch_wstats_one<NK, NWB, NL, WPS, 2, BM_GEN, false, TT>(pl, a, 0);
-}
-static int launch_wstats(snmf_plan* pl, bool obj) {
-    if (pl->generic) {
-        ScopedTimer tm(pl->ctx, FAM_WSTATS);
-        return generic_wstats(pl, obj);
-    }
-    StepArgs a = make_args(pl);
-    a.n_tiles = (pl->p.T + pl->TTW - 1) / pl->TTW;
-    a.ldh = pl->ldhw;
-    a.stagger = pl->stagger_w;
-
-    ScopedTimer tm(pl->ctx, FAM_WSTATS);
-    if (pl->NKT == 4 && pl->NWB == 8) return launch_wstats_geo<4, 8, 4, 3>(pl, a, obj);
-    if (pl->NKT == 4) return pl->NLW ? launch_wstats_geo<4, 4, 4, 2>(pl, a, obj) : launch_wstats_geo<4, 4, 0, 2>(pl, a, obj);
-    if (pl->NKT == 8) return pl->NLW ? launch_wstats_geo<8, 4, 4, 2>(pl, a, obj) : launch_wstats_geo<8, 4, 0, 2>(pl, a, obj);
-    if (pl->TTW == 16) return launch_wstats_geo<16, 4, 0, 1, 16>(pl, a, obj);
-    return launch_wstats_geo<16, 4, 0, 1>(pl, a, obj);
 }
 
 static ReduceArgs make_reduce_args(snmf_plan* pl, double* stats, bool do_mats, bool do_obj, int n_part, bool sh_const) {
@@ -1235,7 +880,7 @@ static ApplyArgs make_apply_args(snmf_plan* pl, const double* stats, int check_i
     aa.wn = pl->wn;
     return aa;
 }
-static int launch_wapply(snmf_plan* pl, const double* stats, int check_it, bool do_update, bool init_mode) {
+int launch_wapply(snmf_plan* pl, const double* stats, int check_it, bool do_update, bool init_mode) {
     const ApplyArgs aa = make_apply_args(pl, stats, check_it, do_update, init_mode);
     ScopedTimer tm(pl->ctx, FAM_WAPPLY);
     hipLaunchKernelGGL(k_wapply, dim3(pl->p.r), dim3(256), 0, pl->ctx->stream, aa);
@@ -1420,7 +1065,7 @@ extern "C" int snmf_plan_objapply(snmf_plan* pl, const double* stats) {
     return SNMF_OK;
 }
 
-static int read_state(snmf_plan* pl, DevState* hs) {
+int read_state(snmf_plan* pl, DevState* hs) {
     HIP_TRY(hipMemcpyAsync(hs, pl->st, sizeof(DevState), hipMemcpyDeviceToHost, pl->ctx->stream));
     HIP_TRY(hipStreamSynchronize(pl->ctx->stream));
     if (hs->fault) return fail(SNMF_ERR_INTERNAL, "a device-side producer/consumer wait timed out: results are invalid");
@@ -1440,64 +1085,6 @@ static int finalize_objective(snmf_plan* pl) {
     if (pl->final_done || !pl->p.cost_check || pl->it_done < 1) return SNMF_OK;
     SN_TRY(snmf_plan_objstats(pl, pl->stats));
     return snmf_plan_objapply(pl, pl->stats);
-}
-
-// persistent single-launch H-only solves: n_solves independent workgroups of tps <= 32 frames each
-static int launch_small(snmf_plan* pl, int n_solves, int tps, double* divh, double* costh, DevState* st,
-                        float* recon = nullptr, int recon_rx = 0) {
-    StepArgs a = make_args(pl);
-    a.Hout = pl->H[pl->cur];  // in place
-    a.n_tiles = 1;
-    SmallArgs sa{};
-    sa.max_iter = pl->p.max_iter;
-    sa.cost_check = pl->p.cost_check;
-    sa.conv_eps = pl->p.conv_eps;
-    sa.divh = divh;
-    sa.costh = costh;
-    sa.st = st;
-    sa.tps = tps;
-    sa.recon = (tps == 1 && pl->frame_fb) ? recon : nullptr;  // only k_hsolve_frame produces the reconstructions
-    sa.wn = pl->wn;
-    sa.Rx = recon_rx;
-    auto launch = [&](auto kern) -> int {
-        SN_TRY(ensure_dyn_lds(pl->ctx->device, (const void*)kern, pl->lds_small));
-        hipLaunchKernelGGL(kern, dim3(n_solves), dim3(512), pl->lds_small, pl->ctx->stream, a, sa);
-        HIP_TRY(hipGetLastError());
-        return SNMF_OK;
-    };
-    ScopedTimer tm(pl->ctx, FAM_HSTEP);
-    const bool obj = pl->p.cost_check != 0;
-    if (tps == 1 && pl->frame_fb) {
-        auto launch_f = [&](auto kern) -> int {
-            SN_TRY(ensure_dyn_lds(pl->ctx->device, (const void*)kern, pl->lds_frame));
-            hipLaunchKernelGGL(kern, dim3(n_solves), dim3(512), pl->lds_frame, pl->ctx->stream, a, sa, (const float*)pl->Wcf);
-            HIP_TRY(hipGetLastError());
-            return SNMF_OK;
-        };
-        auto by_bm = [&](auto fbc, auto kbc) -> int {
-            constexpr int FB = decltype(fbc)::value, KB = decltype(kbc)::value;
-            auto by_obj = [&](auto bmc, auto rc) -> int {
-                constexpr int BM = decltype(bmc)::value;
-                constexpr bool RC = decltype(rc)::value;
-                return obj ? launch_f(k_hsolve_frame<FB, KB, BM, true, RC>) : launch_f(k_hsolve_frame<FB, KB, BM, false, RC>);
-            };
-            auto by_rc = [&](auto bmc) -> int {
-                return sa.recon ? by_obj(bmc, std::true_type{}) : by_obj(bmc, std::false_type{});
-            };
-            if (pl->bm == BM_KL) return by_rc(std::integral_constant<int, BM_KL>{});
-            if (pl->bm == BM_EUC) return by_rc(std::integral_constant<int, BM_EUC>{});
-            return by_rc(std::integral_constant<int, BM_GEN>{});
-        };
-        using I4 = std::integral_constant<int, 4>;
-        using I8 = std::integral_constant<int, 8>;
-        using I16 = std::integral_constant<int, 16>;
-        using I25 = std::integral_constant<int, 25>;
-        if (pl->frame_fb == 4) return pl->frame_kb == 16 ? by_bm(I4{}, I16{}) : by_bm(I4{}, I25{});
-        return pl->frame_kb == 16 ? by_bm(I8{}, I16{}) : by_bm(I8{}, I25{});
-    }
-    if (pl->bm == BM_KL) return obj ? launch(k_hsolve_small<BM_KL, true>) : launch(k_hsolve_small<BM_KL, false>);
-    if (pl->bm == BM_EUC) return obj ? launch(k_hsolve_small<BM_EUC, true>) : launch(k_hsolve_small<BM_EUC, false>);
-    return obj ? launch(k_hsolve_small<BM_GEN, true>) : launch(k_hsolve_small<BM_GEN, false>);
 }
 
 extern "C" int snmf_plan_run(snmf_plan* pl, int32_t n_iters, int32_t* iters_done) {
@@ -1568,7 +1155,7 @@ extern "C" int snmf_plan_run(snmf_plan* pl, int32_t n_iters, int32_t* iters_done
 // n (detected while iteration n+1 was in flight): hstep(n+1) already wrote H_{n+1} into the
 // other buffer before the flag was raised, later launches were no-ops although the host kept
 // flipping `cur`; H_n is the buffer with index parity n (H_0 lives in buffer 0 after set_h).
-static int result_h_index(snmf_plan* pl, int* idx) {
+int result_h_index(snmf_plan* pl, int* idx) {
     DevState hs{};
     SN_TRY(read_state(pl, &hs));
     if (hs.stop && pl->upd_h && !pl->small_done) *idx = hs.n_iter & 1;
@@ -1975,686 +1562,3 @@ extern "C" int snmf_tf_dd_f32(snmf_ctx* ctx, double alpha_eta, int32_t F, int32_
     return rc;
 }
 
-// ---- online separation loop (include/snmf.h: snmf_online_*) -------------------------------------
-// Host side of src/bnmf_sep_event_RT_IS16.m + the frame loop of src/NTF_sep_event_RT.m:54-135.  The
-// host only sequences launches: per frame it reads one 32-byte status (did the adaptation condition
-// fire?) and, when it did, runs the W-only adaptation solve through the engine's ordinary plan.
-#include "snmf_online.h"
-
-constexpr size_t kTraceCap = 1u << 16;  // diagnostics ring: the newest 65536 frames (~11 min at 100 frames/s)
-struct snmf_online {
-    snmf_ctx* ctx = nullptr;
-    snmf_online_params p{};
-    int F = 0, r = 0, N = 0, nov = 0;
-    int Fs = 0;               // rows of the solves: F, or F_order in Mel mode
-    int mel = 0, mel_conv = 0, n1 = 0;  // B_sep_mode = 'Mel' (snmf_online_set_mel)
-    float *melmat = nullptr, *Bmf = nullptr, *Ymel = nullptr;
-    double *Bm = nullptr, *Bmtmp = nullptr;  // [n1 x r] Mel dictionaries [B_Mel_x | B_Mel_d], fp64 like B
-    snmf_plan* hp = nullptr;  // frame solve: Fs x 1, rank r, H-only
-    snmf_plan* ap = nullptr;  // adaptation solve: F x m_a, rank R_a, W-only
-    snmf_plan* hsemi = nullptr;  // semi-supervised frame solve (basis_update_N / _E): generic path, W reset every frame
-    snmf_plan* hb = nullptr;  // fixed dictionary (no adaptation): the frame solves of a whole batch in one launch
-    DevState* bst = nullptr;
-    double *bdiv = nullptr, *bcost = nullptr;
-    OnlineStatus* bstatus = nullptr;
-    float *recon1 = nullptr, *breco = nullptr;
-    // cooperative single-launch adaptation solve (k_wadapt)
-    bool wadapt = false;
-    int wa_nwg = 0;
-    size_t wa_lds = 0;
-    double *wa_W = nullptr, *wa_p1 = nullptr, *wa_p2 = nullptr, *wa_cost = nullptr;
-    int* wa_nit = nullptr;
-    unsigned* wa_bar = nullptr;  // B_x*A_x | B_d*A_d from the frame solve: one frame / a batch
-    double *B = nullptr, *Bfix = nullptr, *Btmp = nullptr;  // fp64 like the engine's W master copy (k_wapply)
-    float *Bf = nullptr;                                    // fp32 mirror of B for the reconstructions
-    float *H0 = nullptr, *lambda_dav = nullptr, *Xm_tilde = nullptr,
-          *r_blk = nullptr, *ldblk = nullptr, *adblk = nullptr, *Vad = nullptr, *Had = nullptr, *win_s = nullptr,
-          *win_i = nullptr, *syn_tail = nullptr, *syn_tail_x = nullptr, *syn_tail_d = nullptr;
-    float2* tw = nullptr;
-    uint8_t* rup = nullptr;
-    OnlineDev* dev = nullptr;
-    OnlineStatus* status = nullptr;
-    DevState* hst = nullptr;
-    double *hdiv = nullptr, *hcost = nullptr;
-    OnlineStatus* h_status = nullptr;  // pinned
-    // per-call buffers (grown on demand)
-    int cap_frames = 0;
-    float *sig = nullptr, *Ym = nullptr, *Xt = nullptr, *Xh = nullptr, *Dh = nullptr, *syn = nullptr, *outf = nullptr;
-    float2* Yph = nullptr;
-    int16_t* out16 = nullptr;
-    // host state of the driver loop
-    std::vector<float> pending, hist;
-    int64_t l = 0;  // frames processed
-    bool finished = false;
-    bool failed = false;  // a device batch failed midway: frame counter, history and rings are no longer consistent
-    std::deque<snmf_online_frame> trace;  // bounded: the newest kTraceCap frames (a real-time stream runs for days)
-};
-
-static void online_free_call_buffers(snmf_online* o) {
-    void* ptrs[] = {o->sig, o->Ym, o->Xt, o->Xh, o->Dh, o->syn, o->outf, o->Yph, o->out16, o->bst, o->bdiv, o->bcost, o->bstatus, o->breco, o->Ymel};
-    o->Ymel = nullptr;
-    o->breco = nullptr;
-    if (o->hb) {
-        snmf_plan_destroy(o->hb);
-        o->hb = nullptr;
-    }
-    o->bst = nullptr;
-    o->bdiv = o->bcost = nullptr;
-    o->bstatus = nullptr;
-    for (void* q : ptrs)
-        if (q) hipFree(q);
-    o->sig = o->Ym = o->Xt = o->Xh = o->Dh = o->syn = o->outf = nullptr;
-    o->Yph = nullptr;
-    o->out16 = nullptr;
-    o->cap_frames = 0;
-}
-
-extern "C" void snmf_online_destroy(snmf_online* o) {
-    if (!o) return;
-    hipSetDevice(o->ctx->device);
-    hipStreamSynchronize(o->ctx->stream);
-    if (o->hp) snmf_plan_destroy(o->hp);
-    if (o->ap) snmf_plan_destroy(o->ap);
-    if (o->hsemi) snmf_plan_destroy(o->hsemi);
-    online_free_call_buffers(o);
-    void* ptrs[] = {o->B,   o->Bfix, o->Btmp,  o->H0,    o->lambda_dav, o->Xm_tilde, o->r_blk, o->ldblk, o->adblk,  o->Vad,
-                    o->Had, o->win_s, o->win_i, o->syn_tail, o->tw,       o->rup,      o->dev,   o->status, o->hst,   o->hdiv,
-                    o->hcost, o->syn_tail_x, o->syn_tail_d, o->Bf, o->recon1, o->wa_W, o->wa_p1, o->wa_p2, o->wa_cost, o->wa_nit, o->wa_bar, o->melmat, o->Bmf, o->Bm, o->Bmtmp};
-    for (void* q : ptrs)
-        if (q) hipFree(q);
-    if (o->h_status) hipHostFree(o->h_status);
-    delete o;
-}
-
-static int online_validate(const snmf_online_params* p) {
-    if (!p) return fail(SNMF_ERR_INVALID, "online params is NULL");
-    const int N = p->fftlength;
-    if (N < 64 || N > 4096 || (N & (N - 1))) return fail(SNMF_ERR_UNSUPPORTED, "fftlength must be a power of two in [64,4096]");
-    if (p->framelength < 1 || p->framelength > N || p->frameshift < 1 || p->frameshift > p->framelength)
-        return fail(SNMF_ERR_INVALID, "need 1 <= frameshift <= framelength <= fftlength");
-    const int F = N / 2 + 1;
-    if (p->dcbin < 0 || p->dcbin > F || p->dcbin_back < 0 || p->dcbin_back > F || p->delay < 0)
-        return fail(SNMF_ERR_INVALID, "bad DCbin / DCbin_back / delay");
-    if (p->R_x < 1 || p->R_d < 1) return fail(SNMF_ERR_INVALID, "R_x and R_d must be positive");
-    if (p->max_iter < 1) return fail(SNMF_ERR_INVALID, "max_iter must be positive");
-    if (p->enhance_method != 0 && p->enhance_method != 1) return fail(SNMF_ERR_INVALID, "enhance_method: 0 Wiener, 1 MMSE");
-    if (p->blk_sparse) {
-        if (p->blk_gap < 1 || p->blk_gap % 2 == 0) return fail(SNMF_ERR_INVALID, "blk_gap must be odd (src/blk_sparse.m:4)");
-        if (p->P_len_k < 2 || p->P_len_k % 2 || p->P_len_l < 1) return fail(SNMF_ERR_INVALID, "P_len_k must be even and >= 2, P_len_l >= 1");
-        if (p->P_len_k + p->dcbin > F) return fail(SNMF_ERR_INVALID, "P_len_k + DCbin exceeds the number of bins");
-    }
-    if (p->adapt_train_N) {
-        if (p->R_a < 1 || p->R_a > p->R_d || p->m_a < 1) return fail(SNMF_ERR_INVALID, "need 1 <= R_a <= R_d and m_a >= 1");
-    }
-    return SNMF_OK;
-}
-
-// (re)create the resident solves for o->Fs rows: the frame solve, the optional semi-supervised variant, the
-// adaptation plan and the cooperative adaptation kernel's buffers
-static int online_make_solvers(snmf_online* o) {
-    const snmf_online_params* p = &o->p;
-    snmf_ctx* ctx = o->ctx;
-    const int F = o->Fs, r = o->r;
-    const int Ra = p->adapt_train_N ? p->R_a : 1, ma = p->adapt_train_N ? p->m_a : 1;
-    hipStreamSynchronize(ctx->stream);
-    for (snmf_plan** q : {&o->hp, &o->hsemi, &o->ap}) {
-        if (*q) snmf_plan_destroy(*q);
-        *q = nullptr;
-    }
-    for (void** q : {(void**)&o->wa_W, (void**)&o->wa_p1, (void**)&o->wa_p2, (void**)&o->wa_cost, (void**)&o->wa_nit, (void**)&o->wa_bar}) {
-        if (*q) hipFree(*q);
-        *q = nullptr;
-    }
-    o->wadapt = false;
-    int s = SNMF_OK;
-    auto A = [&](int v) { if (s == SNMF_OK) s = v; };
-    // the two resident solves
-    snmf_params hp{};
-    hp.F = F; hp.T = 1; hp.r = r; hp.beta = p->beta_div; hp.max_iter = p->max_iter; hp.conv_eps = p->conv_eps;
-    hp.cost_check = p->cost_check; hp.floor_v = 1; hp.sparsity_kind = SNMF_SPARSITY_SCALAR; hp.sparsity_scalar = p->sparsity;
-    std::vector<uint8_t> zeros(std::max(r, Ra), 0), ones(std::max(r, Ra), 1);
-    hp.w_update_ind = zeros.data();  // supervised (:139)
-    hp.h_update_ind = ones.data();   // :148
-    A(snmf_plan_create(ctx, &hp, &o->hp));
-    // !small_ok (F + r too large for the persistent single-launch kernels, e.g. the exemplar setting R_x = R_d = 500 of
-    // settings/bak_IS16_results/initial_setting_Exemplar.m:47-48): the frame solve runs through the ordinary plan loop
-    if (p->basis_update_N || p->basis_update_E) {
-        snmf_params sp = hp;
-        std::vector<uint8_t> wm(r, 0);
-        for (int k = 0; k < r; ++k) wm[k] = p->basis_update_N ? (k >= p->R_x) : (k < p->R_x);  // :125-131
-        sp.w_update_ind = wm.data();
-        A(snmf_plan_create(ctx, &sp, &o->hsemi));
-    }
-    if (p->adapt_train_N) {
-        snmf_params ap = hp;
-        ap.T = ma; ap.r = Ra;
-        ap.w_update_ind = ones.data();   // :330 (the per-solve subset r_up is written on the device)
-        ap.h_update_ind = zeros.data();  // :331
-        A(snmf_plan_create(ctx, &ap, &o->ap));
-    }
-    auto D = [&](auto** ptr, size_t n) { if (s == SNMF_OK) s = dalloc(ptr, n); };
-    if (p->adapt_train_N && p->beta_div == 1.0 && p->R_a <= kWaRP && !getenv("SNMF_NO_WADAPT")) {
-        int coop = 0;
-        hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, ctx->device);
-        o->wa_nwg = (F + kWaRB - 1) / kWaRB;
-        o->wa_lds = (size_t)(kWaRB * kWaRP + 4 * kWaRP + 32 + 256) * 8 +
-                    (size_t)(2 * kWaRB * kWaRP + kWaRP + 2 * kWaRB * p->m_a + p->R_a * p->m_a + p->m_a * (kWaRP + 1)) * 4;
-        o->wadapt = coop != 0 && o->wa_nwg <= ctx->n_cu && o->wa_nwg <= 2 * kWaQ && o->wa_lds <= 160 * 1024;
-        if (o->wadapt) {
-            D(&o->wa_W, (size_t)p->R_a * F);
-            D(&o->wa_p1, (size_t)o->wa_nwg * (kWaRP + 1));
-            D(&o->wa_p2, (size_t)o->wa_nwg * 2 * kWaRP);
-            D(&o->wa_cost, (size_t)p->max_iter);
-            D(&o->wa_nit, (size_t)1);
-            D(&o->wa_bar, (size_t)1);
-        }
-    }
-    return s;
-}
-
-extern "C" int snmf_online_create(snmf_ctx* ctx, const snmf_online_params* p, const float* Bx, const float* Bd, const float* H0,
-                                  const float* Ad0, const float* win_stft, const float* win_istft, snmf_online** out) {
-    if (!ctx || !out || !Bx || !Bd || !H0 || !win_stft || !win_istft) return fail(SNMF_ERR_INVALID, "NULL argument");
-    *out = nullptr;
-    SN_TRY(online_validate(p));
-    if (p->adapt_train_N && !Ad0) return fail(SNMF_ERR_INVALID, "Ad_blk0 is required when adapt_train_N is set");
-    HIP_TRY(hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
-    snmf_online* o = new snmf_online();
-    o->ctx = ctx;
-    o->p = *p;
-    const int N = p->fftlength, F = N / 2 + 1, r = p->R_x + p->R_d, sz = p->framelength, hop = p->frameshift;
-    const int Ra = p->adapt_train_N ? p->R_a : 1, ma = p->adapt_train_N ? p->m_a : 1, Pl = p->blk_sparse ? p->P_len_l : 1;
-    o->F = F;
-    o->r = r;
-    o->N = N;
-    o->nov = (sz + hop - 1) / hop;
-    int s = SNMF_OK;
-    auto A = [&](int v) { if (s == SNMF_OK) s = v; };
-    o->Fs = F;
-    A(online_make_solvers(o));
-    auto D = [&](auto** ptr, size_t n) { if (s == SNMF_OK) s = dalloc(ptr, n); };
-    D(&o->B, (size_t)F * r); D(&o->Bfix, (size_t)F * p->R_d); D(&o->Btmp, (size_t)F * p->R_d); D(&o->H0, (size_t)r);
-    D(&o->Bf, (size_t)F * r);
-    D(&o->recon1, (size_t)2 * F);
-    D(&o->lambda_dav, (size_t)F); D(&o->Xm_tilde, (size_t)F); D(&o->r_blk, (size_t)F * Pl); D(&o->ldblk, (size_t)F * ma);
-    D(&o->adblk, (size_t)Ra * ma); D(&o->Vad, (size_t)F * ma); D(&o->Had, (size_t)Ra * ma); D(&o->win_s, (size_t)sz);
-    D(&o->win_i, (size_t)sz); D(&o->syn_tail, (size_t)std::max(1, o->nov - 1) * sz); D(&o->tw, (size_t)N / 2);
-    if (p->class_outputs) {
-        D(&o->syn_tail_x, (size_t)std::max(1, o->nov - 1) * sz);
-        D(&o->syn_tail_d, (size_t)std::max(1, o->nov - 1) * sz);
-    }
-    D(&o->rup, (size_t)Ra); D(&o->dev, (size_t)1); D(&o->status, (size_t)1); D(&o->hst, (size_t)1);
-    D(&o->hdiv, (size_t)p->max_iter); D(&o->hcost, (size_t)p->max_iter);
-    if (s == SNMF_OK && hipHostMalloc((void**)&o->h_status, sizeof(OnlineStatus)) != hipSuccess) A(fail(SNMF_ERR_NOMEM, "hipHostMalloc"));
-    if (s != SNMF_OK) {
-        snmf_online_destroy(o);
-        return s;
-    }
-    std::vector<float2> htw(N / 2);
-    for (int q = 0; q < N / 2; ++q) {
-        const double ang = -2.0 * M_PI * (double)q / (double)N;
-        htw[q] = make_float2((float)cos(ang), (float)sin(ang));
-    }
-    OnlineDev d0{0, 1, 0, 0};  // update_switch = 1 (src/init_buff.m:42)
-    std::vector<double> hB((size_t)F * r);
-    for (size_t i = 0; i < (size_t)F * p->R_x; ++i) hB[i] = (double)Bx[i];
-    for (size_t i = 0; i < (size_t)F * p->R_d; ++i) hB[(size_t)F * p->R_x + i] = (double)Bd[i];
-    hipMemcpyAsync(o->B, hB.data(), hB.size() * 8, hipMemcpyHostToDevice, st);
-    hipMemcpyAsync(o->Bfix, hB.data() + (size_t)F * p->R_x, (size_t)F * p->R_d * 8, hipMemcpyHostToDevice, st);  // B_Mel_d in DFT mode (:328)
-    hipMemcpyAsync(o->Bf, Bx, (size_t)F * p->R_x * 4, hipMemcpyHostToDevice, st);
-    hipMemcpyAsync(o->Bf + (size_t)F * p->R_x, Bd, (size_t)F * p->R_d * 4, hipMemcpyHostToDevice, st);
-    hipMemcpyAsync(o->H0, H0, (size_t)r * 4, hipMemcpyHostToDevice, st);
-    hipMemcpyAsync(o->win_s, win_stft, (size_t)sz * 4, hipMemcpyHostToDevice, st);
-    hipMemcpyAsync(o->win_i, win_istft, (size_t)sz * 4, hipMemcpyHostToDevice, st);
-    hipMemcpyAsync(o->tw, htw.data(), htw.size() * 8, hipMemcpyHostToDevice, st);
-    hipMemcpyAsync(o->dev, &d0, sizeof d0, hipMemcpyHostToDevice, st);
-    hipMemsetAsync(o->lambda_dav, 0, (size_t)F * 4, st);
-    hipMemsetAsync(o->Xm_tilde, 0, (size_t)F * 4, st);
-    hipMemsetAsync(o->r_blk, 0, (size_t)F * Pl * 4, st);
-    hipMemsetAsync(o->ldblk, 0, (size_t)F * ma * 4, st);
-    hipMemsetAsync(o->adblk, 0, (size_t)Ra * ma * 4, st);
-    hipMemsetAsync(o->syn_tail, 0, (size_t)std::max(1, o->nov - 1) * sz * 4, st);
-    if (p->class_outputs) {
-        hipMemsetAsync(o->syn_tail_x, 0, (size_t)std::max(1, o->nov - 1) * sz * 4, st);
-        hipMemsetAsync(o->syn_tail_d, 0, (size_t)std::max(1, o->nov - 1) * sz * 4, st);
-    }
-    hipMemsetAsync(o->rup, 0, (size_t)Ra, st);
-    if (p->adapt_train_N) hipMemcpyAsync(o->adblk, Ad0, (size_t)Ra * ma * 4, hipMemcpyHostToDevice, st);  // column-major R_a x m_a
-    hipError_t e = hipStreamSynchronize(st);
-    if (e != hipSuccess) {
-        snmf_online_destroy(o);
-        return fail(SNMF_ERR_NO_DEVICE, "online create: %s", hipGetErrorString(e));
-    }
-    A(set_w<double>(o->hp, o->B, F, 1));
-    if (s != SNMF_OK) {
-        snmf_online_destroy(o);
-        return s;
-    }
-    o->hist.assign((size_t)(sz - hop), 0.f);
-    *out = o;
-    return SNMF_OK;
-}
-
-// B_sep_mode = 'Mel' (src/bnmf_sep_event_RT_IS16.m:106-120, src/init_buff.m:45-47): the solves run on Mel features
-extern "C" int snmf_online_set_mel(snmf_online* o, int32_t F_order, int32_t mel_conv, const float* melmat, const float* BMx,
-                                   const float* BMd) {
-    if (!o || !melmat || !BMx || !BMd) return fail(SNMF_ERR_INVALID, "NULL argument");
-    if (o->l != 0 || !o->pending.empty()) return fail(SNMF_ERR_STATE, "snmf_online_set_mel must precede the first process call");
-    if (F_order < 2 || F_order > o->F) return fail(SNMF_ERR_INVALID, "F_order must be in [2, fftlength/2+1]");
-    HIP_TRY(hipSetDevice(o->ctx->device));
-    hipStream_t st = o->ctx->stream;
-    const int n1 = F_order, r = o->r, F = o->F, Rx = o->p.R_x, Rd = o->p.R_d;
-    o->mel = 1;
-    o->mel_conv = mel_conv != 0;
-    o->n1 = n1;
-    o->Fs = n1;
-    SN_TRY(online_make_solvers(o));
-    for (void** q : {(void**)&o->melmat, (void**)&o->Bmf, (void**)&o->Bm, (void**)&o->Bmtmp}) {
-        if (*q) hipFree(*q);
-        *q = nullptr;
-    }
-    SN_TRY(dalloc(&o->melmat, (size_t)n1 * F));
-    SN_TRY(dalloc(&o->Bmf, (size_t)n1 * r));
-    SN_TRY(dalloc(&o->Bm, (size_t)n1 * r));
-    SN_TRY(dalloc(&o->Bmtmp, (size_t)n1 * Rd));
-    std::vector<double> hB((size_t)n1 * r);
-    for (size_t i = 0; i < (size_t)n1 * Rx; ++i) hB[i] = (double)BMx[i];
-    for (size_t i = 0; i < (size_t)n1 * Rd; ++i) hB[(size_t)n1 * Rx + i] = (double)BMd[i];
-    HIP_TRY(hipMemcpyAsync(o->Bm, hB.data(), hB.size() * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(o->Bmf, BMx, (size_t)n1 * Rx * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(o->Bmf + (size_t)n1 * Rx, BMd, (size_t)n1 * Rd * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(o->melmat, melmat, (size_t)n1 * F * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    SN_TRY(set_w<double>(o->hp, o->Bm, n1, 1));
-    online_free_call_buffers(o);  // batch buffers depend on the solve geometry
-    return SNMF_OK;
-}
-
-/* Current B_Mel_d (n1 x R_d): what the Mel-mode adaptation updates (src/bnmf_sep_event_RT_IS16.m:318). */
-extern "C" int snmf_online_get_mel_basis_f32(snmf_online* o, float* BMd, int64_t ld) {
-    if (!o || !BMd) return fail(SNMF_ERR_INVALID, "NULL argument");
-    if (!o->mel) return fail(SNMF_ERR_STATE, "not in Mel mode");
-    if (ld < o->n1) return fail(SNMF_ERR_INVALID, "ld < F_order");
-    HIP_TRY(hipSetDevice(o->ctx->device));
-    HIP_TRY(hipStreamSynchronize(o->ctx->stream));
-    HIP_TRY(hipMemcpy2D(BMd, (size_t)ld * 4, o->Bmf + (size_t)o->n1 * o->p.R_x, (size_t)o->n1 * 4, (size_t)o->n1 * 4, (size_t)o->p.R_d,
-                        hipMemcpyDeviceToHost));
-    return SNMF_OK;
-}
-
-static int online_reserve(snmf_online* o, int n) {
-    if (n <= o->cap_frames) return SNMF_OK;
-    hipStreamSynchronize(o->ctx->stream);
-    online_free_call_buffers(o);
-    const int cap = std::max(n, 64);
-    const size_t F = o->F, sz = o->p.framelength, hop = o->p.frameshift;
-    SN_TRY(dalloc(&o->sig, (sz - hop) + (size_t)cap * hop));
-    SN_TRY(dalloc(&o->Ym, F * cap));
-    SN_TRY(dalloc(&o->Yph, F * cap));
-    if (o->mel) SN_TRY(dalloc(&o->Ymel, (size_t)o->n1 * cap));
-    SN_TRY(dalloc(&o->Xt, F * cap));
-    if (o->p.class_outputs) {
-        SN_TRY(dalloc(&o->Xh, F * cap));
-        SN_TRY(dalloc(&o->Dh, F * cap));
-    }
-    SN_TRY(dalloc(&o->syn, (size_t)(cap + o->nov - 1) * sz));
-    SN_TRY(dalloc(&o->outf, (size_t)cap * hop));
-    SN_TRY(dalloc(&o->out16, (size_t)cap * hop));
-    if (!o->p.adapt_train_N && !o->hsemi && o->hp->small_ok) {
-        snmf_params bp = o->hp->p;
-        bp.T = cap;
-        std::vector<uint8_t> zeros(o->r, 0), ones(o->r, 1);
-        bp.w_update_ind = zeros.data();
-        bp.h_update_ind = ones.data();
-        SN_TRY(snmf_plan_create(o->ctx, &bp, &o->hb));
-        SN_TRY(set_w<double>(o->hb, o->mel ? o->Bm : o->B, o->Fs, 1));
-        SN_TRY(dalloc(&o->bst, (size_t)cap));
-        SN_TRY(dalloc(&o->bdiv, (size_t)cap * o->p.max_iter));
-        SN_TRY(dalloc(&o->bcost, (size_t)cap * o->p.max_iter));
-        SN_TRY(dalloc(&o->bstatus, (size_t)cap));
-        SN_TRY(dalloc(&o->breco, (size_t)cap * 2 * o->Fs));
-    }
-    o->cap_frames = cap;
-    return SNMF_OK;
-}
-
-template <typename K>
-static void launch_by_logn(K&& f, int N) {
-    switch (N) {
-        case 64: f(std::integral_constant<int, 6>{}); break;
-        case 128: f(std::integral_constant<int, 7>{}); break;
-        case 256: f(std::integral_constant<int, 8>{}); break;
-        case 512: f(std::integral_constant<int, 9>{}); break;
-        case 1024: f(std::integral_constant<int, 10>{}); break;
-        case 2048: f(std::integral_constant<int, 11>{}); break;
-        default: f(std::integral_constant<int, 12>{}); break;
-    }
-}
-
-// the frame solve (:148-154): V = Ym (device), W resident, H0 the fixed start; leaves A in hp->H[0]
-static int online_solve_frame(snmf_online* o, const float* dV, const float** A_out, const DevState** st_out, const float** recon_out) {
-    hipStream_t st = o->ctx->stream;
-    if (o->hsemi) {
-        // semi-supervised: an ordinary solve with part of W free; init_w = [B_DFT_x, B_DFT_d] again every frame (:140-146)
-        snmf_plan* ps = o->hsemi;
-        SN_TRY(set_v<float>(ps, dV, o->Fs, 1));
-        SN_TRY(set_w<double>(ps, o->mel ? o->Bm : o->B, o->Fs, 1));
-        SN_TRY(set_h<float>(ps, o->H0, o->r, 1));
-        SN_TRY(snmf_plan_init(ps));
-        SN_TRY(snmf_plan_run(ps, o->p.max_iter, nullptr));
-        int idx = 0;
-        SN_TRY(result_h_index(ps, &idx));
-        *A_out = ps->H[idx];
-        *st_out = ps->st;
-        *recon_out = nullptr;
-        return SNMF_OK;
-    }
-    snmf_plan* pl = o->hp;
-    if (!pl->small_ok) {
-        // large rank: the ordinary plan loop (16-frame tiles), one solve per frame; reconstructions are formed in k_opost
-        SN_TRY(set_v<float>(pl, dV, o->Fs, 1));
-        SN_TRY(set_h<float>(pl, o->H0, o->r, 1));
-        SN_TRY(snmf_plan_init(pl));  // W and its norms are reused unless the adaptation has replaced the dictionary
-        SN_TRY(snmf_plan_run(pl, o->p.max_iter, nullptr));
-        int idx = 0;
-        SN_TRY(result_h_index(pl, &idx));
-        *A_out = pl->H[idx];
-        *st_out = pl->st;
-        *recon_out = nullptr;
-        return SNMF_OK;
-    }
-    *A_out = pl->H[0];
-    *st_out = o->hst;
-    *recon_out = (pl->frame_fb && (!o->mel || o->mel_conv)) ? o->recon1 : nullptr;  // Mel without MelConv: B_DFT*A, formed in k_opost
-    const size_t nVp = (size_t)pl->Fp * pl->Tp;
-    hipLaunchKernelGGL(k_pack<float>, dim3(grid_for(nVp)), dim3(256), 0, st, dV, (int64_t)o->Fs, o->Fs, 1, pl->V, pl->Fp, pl->Tp, kFlr,
-                       pl->p.floor_v ? 1 : 0);
-    HIP_TRY(hipGetLastError());
-    pl->have_v = true;
-    if (pl->w_dirty) SN_TRY(launch_wapply(pl, pl->stats, 0, false, true));  // wn, w./wn (:157-159)
-    pl->w_dirty = false;
-    pl->cur = 0;
-    hipLaunchKernelGGL(k_tile_h0<float>, dim3(grid_for((size_t)pl->rp)), dim3(256), 0, st, (const float*)o->H0, pl->wn, o->r, pl->rp, 1,
-                       1, pl->H[0]);  // h .* wn' (:160)
-    HIP_TRY(hipGetLastError());
-    pl->have_h = true;
-    pl->inited = false;
-    HIP_TRY(hipMemsetAsync(o->hst, 0, sizeof(DevState), st));
-    return launch_small(pl, 1, 1, o->hdiv, o->hcost, o->hst, (o->mel && !o->mel_conv) ? nullptr : o->recon1, o->p.R_x);
-}
-
-// :296-336 once the status says the solve is due
-static int online_adapt(snmf_online* o, int32_t* iters) {
-    const snmf_online_params& p = o->p;
-    hipStream_t st = o->ctx->stream;
-    snmf_plan* ap = o->ap;
-    // DFT mode adapts B_DFT_d on lambda_d_blk (:320-338); Mel mode adapts B_Mel_d on melmat*lambda_d_blk (:298-318)
-    const int Fs = o->Fs;
-    double* Ball = o->mel ? o->Bm : o->B;
-    double* Bd = Ball + (size_t)Fs * p.R_x;
-    double* Btmp = o->mel ? o->Bmtmp : o->Btmp;
-    float* mirror = (o->mel ? o->Bmf : o->Bf) + (size_t)Fs * p.R_x;
-    const double* Bfix = o->mel ? Bd : o->Bfix;  // columns beyond R_a never change; :328 takes them from B_Mel_d
-    if (o->mel) {
-        hipLaunchKernelGGL(k_oprep_mel, dim3(p.m_a), dim3(256), 0, st, (const float*)o->ldblk, (const float*)o->adblk, (const uint8_t*)o->rup,
-                           (const OnlineDev*)o->dev, (const float*)o->melmat, o->F, o->n1, p.R_a, p.m_a, o->Vad, o->Had, ap->w_ind);
-    } else {
-        const size_t n = (size_t)o->F * p.m_a + (size_t)p.R_a * p.m_a + p.R_a;
-        hipLaunchKernelGGL(k_oprep, dim3(grid_for(n)), dim3(256), 0, st, (const float*)o->ldblk, (const float*)o->adblk,
-                           (const uint8_t*)o->rup, (const OnlineDev*)o->dev, o->F, p.R_a, p.m_a, o->Vad, o->Had, ap->w_ind);
-    }
-    HIP_TRY(hipGetLastError());
-    const double* Wres = nullptr;
-    int ldw = 0;
-    if (o->wadapt) {
-        // the whole solve in one cooperative launch (k_wadapt)
-        WAdaptArgs wa{};
-        wa.V = o->Vad; wa.H = o->Had; wa.W0 = Bd; wa.w_ind = ap->w_ind; wa.Wout = o->wa_W; wa.part1 = o->wa_p1; wa.part2 = o->wa_p2;
-        wa.costh = o->wa_cost; wa.n_iter_out = o->wa_nit; wa.F = Fs; wa.Ra = p.R_a; wa.ma = p.m_a; wa.max_iter = p.max_iter;
-        wa.cost_check = p.cost_check; wa.sparsity = (float)p.sparsity; wa.flr = kFlr; wa.conv_eps = p.conv_eps;
-        SN_TRY(ensure_dyn_lds(o->ctx->device, (const void*)k_wadapt, o->wa_lds));
-        wa.bar = o->wa_bar;
-        HIP_TRY(hipMemsetAsync(o->wa_bar, 0, 4, st));
-        void* kargs[] = {&wa};
-        if (hipLaunchCooperativeKernel((const void*)k_wadapt, dim3(o->wa_nwg), dim3(kWaNT), kargs, (unsigned)o->wa_lds, st) == hipSuccess) {
-            HIP_TRY(hipMemcpyAsync(iters, o->wa_nit, 4, hipMemcpyDeviceToHost, st));
-            // the solve's verdict is read BEFORE its W is merged into the dictionary: a timed-out grid barrier leaves
-            // wa_W invalid, and B_d, its fp32 mirror and the frame-solve plan must not see it
-            HIP_TRY(hipStreamSynchronize(st));
-            if (*iters < 0) return fail(SNMF_ERR_INTERNAL, "adaptation kernel: grid barrier timed out (dictionary left untouched)");
-            Wres = o->wa_W;
-            ldw = Fs;
-        } else {
-            (void)hipGetLastError();  // cooperative launch refused (e.g. CUs not all available): generic path from now on
-            o->wadapt = false;
-        }
-    }
-    if (!Wres) {
-        SN_TRY(set_v<float>(ap, o->Vad, Fs, 1));       // lambda_d_blk[_Mel] (floored at 1e-9 inside, sparse_nmf.m:169)
-        SN_TRY(set_w<double>(ap, Bd, Fs, 1));          // init_w: first R_a noise columns (:332)
-        SN_TRY(set_h<float>(ap, o->Had, p.R_a, 1));    // init_h (:333)
-        SN_TRY(snmf_plan_init(ap));
-        SN_TRY(snmf_plan_run(ap, p.max_iter, iters));
-        Wres = ap->Wc;
-        ldw = ap->Fp;
-    }
-    hipLaunchKernelGGL(k_oassemble, dim3(p.R_d), dim3(256), 0, st, (const double*)Bd, Wres, ldw, Bfix, (const uint8_t*)o->rup, Fs, p.R_a,
-                       p.R_d, Btmp, mirror);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(Bd, Btmp, (size_t)Fs * p.R_d * 8, hipMemcpyDeviceToDevice, st));
-    SN_TRY(set_w<double>(o->hp, Ball, Fs, 1));         // next frame's init_w (:140-146)
-    return SNMF_OK;  // `iters` is already on the host (both paths synchronised when they read it)
-}
-
-// n frames whose samples are sig = [history | n hops] (host); appends the hops the driver would write
-static int online_run_frames(snmf_online* o, const std::vector<float>& sig, int n, std::vector<float>* outf,
-                             std::vector<int16_t>* out16, std::vector<float>* xh, std::vector<float>* dh) {
-    const snmf_online_params& p = o->p;
-    const int F = o->F, sz = p.framelength, hop = p.frameshift, nov = o->nov;
-    hipStream_t st = o->ctx->stream;
-    SN_TRY(online_reserve(o, n));
-    HIP_TRY(hipMemcpyAsync(o->sig, sig.data(), sig.size() * 4, hipMemcpyHostToDevice, st));
-    OStftArgs sa{};
-    sa.sig = o->sig; sa.sz = sz; sa.hop = hop; sa.dcbin = p.dcbin; sa.preemph = (float)p.preemph; sa.win = o->win_s; sa.tw = o->tw;
-    sa.powv = (float)p.pow; sa.floorv = (float)p.nonzerofloor; sa.Ym = o->Ym; sa.Yph = o->Yph; sa.ld = F; sa.n_frames = n;
-    launch_by_logn([&](auto L) { hipLaunchKernelGGL(k_ostft<decltype(L)::value>, dim3(n), dim3(256), 0, st, sa); }, o->N);
-    HIP_TRY(hipGetLastError());
-    if (o->mel) {
-        hipLaunchKernelGGL(k_omel_frame, dim3(n), dim3(256), (size_t)(o->n1 + 2) * 4, st, (const float*)o->Ym, (const float*)o->melmat, F, o->n1, n,
-                           o->Ymel);
-        HIP_TRY(hipGetLastError());
-    }
-    const size_t lds_post = (size_t)(o->r + 7 * F + 3 * o->n1) * 4;
-    auto post_args = [&](int i, int64_t l) {
-        OPostArgs a{};
-        a.B = o->Bf; a.Ym = o->Ym + (size_t)i * F; a.lambda_dav = o->lambda_dav; a.Xm_tilde = o->Xm_tilde;
-        a.r_blk = o->r_blk; a.ldblk = o->ldblk; a.adblk = o->adblk; a.rup = o->rup; a.dev = o->dev;
-        a.Xt_out = o->Xt + (size_t)i * F;
-        a.Xh_out = o->Xh ? o->Xh + (size_t)i * F : nullptr;
-        a.Dh_out = o->Dh ? o->Dh + (size_t)i * F : nullptr;
-        a.F = F; a.Rx = p.R_x; a.Rd = p.R_d; a.Ra = p.adapt_train_N ? p.R_a : 1; a.ma = p.adapt_train_N ? p.m_a : 1;
-        a.Pl = p.blk_sparse ? p.P_len_l : 1; a.Pk = p.P_len_k; a.dcbin = p.dcbin; a.gap = p.blk_gap;
-        a.l = (int)std::min<int64_t>(l, 1 << 30);
-        a.blk_sparse = p.blk_sparse; a.adapt = p.adapt_train_N; a.wiener = p.enhance_method == 0; a.init_N_len = p.init_N_len;
-        a.switch_at = (int)std::floor(p.overlap_m_a * p.m_a);
-        a.alpha_p = (float)p.alpha_p; a.alpha_eta = (float)p.alpha_eta; a.alpha_d = (float)p.alpha_d; a.beta0 = (float)p.beta;
-        a.beta_max = (float)p.beta_max; a.Ar_up = (float)p.Ar_up; a.flr = (float)p.nonzerofloor;
-        a.n = 1;
-        a.a_stride = 0;
-        a.mel = o->mel; a.mel_conv = o->mel_conv; a.n1 = o->n1; a.melmat = o->melmat; a.Bmf = o->Bmf;
-        a.Ymel = o->mel ? o->Ymel + (size_t)i * o->n1 : nullptr;
-        a.recon_len = o->Fs;
-        return a;
-    };
-    if (!p.adapt_train_N && !o->hsemi && o->hb) {
-        // Fixed dictionary: nothing the host decides sits between frames.  All frame solves of the batch run
-        // in ONE launch (one workgroup per frame, W normalised once), then ONE k_opost launch walks the
-        // sequential post-filter recurrences.
-        snmf_plan* pl = o->hb;
-        const size_t nVp = (size_t)pl->Fp * pl->Tp;
-        hipLaunchKernelGGL(k_pack<float>, dim3(grid_for(nVp)), dim3(256), 0, st, (const float*)(o->mel ? o->Ymel : o->Ym), (int64_t)o->Fs, o->Fs, n,
-                           pl->V, pl->Fp, pl->Tp, kFlr, pl->p.floor_v ? 1 : 0);
-        HIP_TRY(hipGetLastError());
-        pl->have_v = true;
-        if (pl->w_dirty) SN_TRY(launch_wapply(pl, pl->stats, 0, false, true));
-        pl->w_dirty = false;
-        pl->cur = 0;
-        hipLaunchKernelGGL(k_tile_h0<float>, dim3(grid_for((size_t)n * pl->rp)), dim3(256), 0, st, (const float*)o->H0, pl->wn, o->r, pl->rp,
-                           1, n, pl->H[0]);
-        HIP_TRY(hipGetLastError());
-        pl->have_h = true;
-        pl->inited = false;
-        HIP_TRY(hipMemsetAsync(o->bst, 0, (size_t)n * sizeof(DevState), st));
-        SN_TRY(launch_small(pl, n, 1, o->bdiv, o->bcost, o->bst, (o->mel && !o->mel_conv) ? nullptr : o->breco, p.R_x));
-        OPostArgs a = post_args(0, o->l + 1);
-        a.A = pl->H[0]; a.hst = o->bst; a.status = o->bstatus; a.n = n; a.a_stride = pl->rp;
-        a.recon = (pl->frame_fb && (!o->mel || o->mel_conv)) ? o->breco : nullptr;
-        hipLaunchKernelGGL(k_opost, dim3(1), dim3(1024), lds_post, st, a);
-        HIP_TRY(hipGetLastError());
-        std::vector<OnlineStatus> hst((size_t)n);
-        HIP_TRY(hipMemcpyAsync(hst.data(), o->bstatus, (size_t)n * sizeof(OnlineStatus), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        for (const OnlineStatus& hs : hst) {
-            snmf_online_frame tr{};
-            tr.n_iter = hs.n_iter; tr.trig = hs.trig; tr.n_up = hs.n_up; tr.beta = hs.beta; tr.A_x_mag = hs.A_x_mag; tr.A_d_mag = hs.A_d_mag;
-            tr.Q_control = hs.Q_control;
-            o->trace.push_back(tr);
-            if (o->trace.size() > kTraceCap) o->trace.pop_front();
-        }
-    } else {
-        for (int i = 0; i < n; ++i) {
-            OPostArgs a = post_args(i, o->l + 1 + i);
-            SN_TRY(online_solve_frame(o, o->mel ? o->Ymel + (size_t)i * o->n1 : o->Ym + (size_t)i * F, &a.A, &a.hst, &a.recon));
-            a.status = o->status;
-            hipLaunchKernelGGL(k_opost, dim3(1), dim3(1024), lds_post, st, a);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(o->h_status, o->status, sizeof(OnlineStatus), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            const OnlineStatus hs = *o->h_status;
-            snmf_online_frame tr{};
-            tr.n_iter = hs.n_iter; tr.trig = hs.trig; tr.n_up = hs.n_up; tr.beta = hs.beta; tr.A_x_mag = hs.A_x_mag; tr.A_d_mag = hs.A_d_mag;
-            tr.Q_control = hs.Q_control;
-            if (hs.do_solve && hs.n_up > 0) {
-                int32_t it = 0;
-                SN_TRY(online_adapt(o, &it));
-                tr.solved = 1;
-                tr.adapt_iters = it;
-            }
-            o->trace.push_back(tr);
-            if (o->trace.size() > kTraceCap) o->trace.pop_front();
-        }
-    }
-    // inverse STFT of the n frames behind the nov-1 frames kept from the previous call, overlap-add
-    const int l0 = (int)std::min<int64_t>(o->l + 1, 1 << 30);
-    const int i_first = (int)std::max<int64_t>(0, (int64_t)p.delay + 1 - l0);
-    const int n_out = std::max(0, n - i_first);
-    auto synth = [&](const float* mag, std::vector<float>* of, std::vector<int16_t>* o16, bool keep_tail, float* tail) -> int {
-        if (nov > 1) HIP_TRY(hipMemcpyAsync(o->syn, tail, (size_t)(nov - 1) * sz * 4, hipMemcpyDeviceToDevice, st));
-        OIstftArgs ia{};
-        ia.mag = mag; ia.ph = o->Yph; ia.ld = F; ia.n_frames = n; ia.sz = sz; ia.dcb = p.dcbin_back; ia.powv = (float)p.pow;
-        ia.scale = (float)(p.overlapscale / (double)o->N); ia.preemph = (float)p.preemph; ia.win = o->win_i; ia.tw = o->tw;
-        ia.syn = o->syn + (size_t)(nov - 1) * sz;
-        launch_by_logn([&](auto L) { hipLaunchKernelGGL(k_oistft<decltype(L)::value>, dim3(n), dim3(256), 0, st, ia); }, o->N);
-        HIP_TRY(hipGetLastError());
-        if (n_out > 0) {
-            hipLaunchKernelGGL(k_oola, dim3(grid_for((size_t)n_out * hop)), dim3(256), 0, st, (const float*)o->syn, n, l0, p.delay, sz, hop, nov,
-                               i_first, n_out, o->outf, o16 ? o->out16 : nullptr);
-            HIP_TRY(hipGetLastError());
-            if (of) {
-                const size_t at = of->size();
-                of->resize(at + (size_t)n_out * hop);
-                HIP_TRY(hipMemcpyAsync(of->data() + at, o->outf, (size_t)n_out * hop * 4, hipMemcpyDeviceToHost, st));
-            }
-            if (o16) {
-                const size_t at = o16->size();
-                o16->resize(at + (size_t)n_out * hop);
-                HIP_TRY(hipMemcpyAsync(o16->data() + at, o->out16, (size_t)n_out * hop * 2, hipMemcpyDeviceToHost, st));
-            }
-        }
-        if (keep_tail && nov > 1)
-            HIP_TRY(hipMemcpyAsync(tail, o->syn + (size_t)n * sz, (size_t)(nov - 1) * sz * 4, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        return SNMF_OK;
-    };
-    SN_TRY(synth(o->Xt, outf, out16, true, o->syn_tail));
-    if (o->p.class_outputs) {  // x_hat / d_hat of :350-361 (summed over the classes), same synthesis
-        SN_TRY(synth(o->Xh, xh, nullptr, true, o->syn_tail_x));
-        SN_TRY(synth(o->Dh, dh, nullptr, true, o->syn_tail_d));
-    }
-    o->l += n;
-    return SNMF_OK;
-}
-
-extern "C" int snmf_online_process_f32(snmf_online* o, const float* pcm, int64_t n, int flush, float* xt_f32, int16_t* xt_i16,
-                                       float* xh_f32, float* dh_f32, int64_t cap, int64_t* n_out) {
-    if (!o) return fail(SNMF_ERR_INVALID, "online handle is NULL");
-    if (n_out) *n_out = 0;
-    if (n < 0 || (n > 0 && !pcm)) return fail(SNMF_ERR_INVALID, "pcm is NULL");
-    if (o->finished) return fail(SNMF_ERR_STATE, "the stream was flushed; create a new separator");
-    if (o->failed) return fail(SNMF_ERR_STATE, "an earlier call failed midway through a batch; the separator state is not reusable, create a new one");
-    if ((xh_f32 || dh_f32) && !o->p.class_outputs) return fail(SNMF_ERR_STATE, "class outputs were not requested at creation");
-    (void)hipGetLastError();  // clean sticky error state, see PLAN_CHECK
-    HIP_TRY(hipSetDevice(o->ctx->device));
-    const int sz = o->p.framelength, hop = o->p.frameshift;
-    o->pending.insert(o->pending.end(), pcm, pcm + n);
-    const int64_t nfr = (int64_t)(o->pending.size() / (size_t)hop);
-    const int64_t tail_frames = flush ? o->p.delay + 1 : 0;
-    const int64_t max_out = (nfr + tail_frames) * hop;
-    if ((xt_f32 || xt_i16 || xh_f32 || dh_f32) && cap < max_out) {
-        o->pending.resize(o->pending.size() - (size_t)n);
-        return fail(SNMF_ERR_INVALID, "output capacity %lld < %lld samples", (long long)cap, (long long)max_out);
-    }
-    std::vector<float> of, ox, od;
-    std::vector<int16_t> o16;
-    const int64_t chunk = 4096;  // frames per device batch
-    int64_t done = 0;
-    while (done < nfr) {
-        const int nb = (int)std::min(chunk, nfr - done);
-        std::vector<float> sig(o->hist);
-        sig.insert(sig.end(), o->pending.begin() + done * hop, o->pending.begin() + (done + nb) * hop);
-        if (int rc = online_run_frames(o, sig, nb, xt_f32 ? &of : nullptr, xt_i16 ? &o16 : nullptr, xh_f32 ? &ox : nullptr, dh_f32 ? &od : nullptr)) {
-            o->failed = true;  // frames of this call were consumed and the device state advanced: never retry on it
-            return rc;
-        }
-        o->hist.assign(sig.end() - (sz - hop), sig.end());
-        done += nb;
-    }
-    o->pending.erase(o->pending.begin(), o->pending.begin() + nfr * hop);
-    if (flush) {
-        // a partial hop is dropped and delay+1 all-zero frames follow (src/NTF_sep_event_RT.m:69-76)
-        std::vector<float> sig((size_t)(sz - hop) + (size_t)tail_frames * hop, 0.f);
-        if (int rc = online_run_frames(o, sig, (int)tail_frames, xt_f32 ? &of : nullptr, xt_i16 ? &o16 : nullptr, xh_f32 ? &ox : nullptr, dh_f32 ? &od : nullptr)) {
-            o->failed = true;
-            return rc;
-        }
-        o->pending.clear();
-        o->finished = true;
-    }
-    if (xt_f32) std::memcpy(xt_f32, of.data(), of.size() * 4);
-    if (xt_i16) std::memcpy(xt_i16, o16.data(), o16.size() * 2);
-    if (xh_f32) std::memcpy(xh_f32, ox.data(), ox.size() * 4);
-    if (dh_f32) std::memcpy(dh_f32, od.data(), od.size() * 4);
-    if (n_out) *n_out = (int64_t)std::max(std::max(of.size(), o16.size()), std::max(ox.size(), od.size()));
-    return SNMF_OK;
-}
-
-extern "C" int snmf_online_get_basis_f32(snmf_online* o, float* Bd, int64_t ld) {
-    if (!o || !Bd) return fail(SNMF_ERR_INVALID, "NULL argument");
-    if (ld < o->F) return fail(SNMF_ERR_INVALID, "ld < F");
-    HIP_TRY(hipSetDevice(o->ctx->device));
-    HIP_TRY(hipStreamSynchronize(o->ctx->stream));
-    HIP_TRY(hipMemcpy2D(Bd, (size_t)ld * 4, o->Bf + (size_t)o->F * o->p.R_x, (size_t)o->F * 4, (size_t)o->F * 4, (size_t)o->p.R_d,
-                        hipMemcpyDeviceToHost));
-    return SNMF_OK;
-}
-
-extern "C" int snmf_online_trace(snmf_online* o, snmf_online_frame* out, int64_t cap, int64_t* n) {
-    if (!o) return fail(SNMF_ERR_INVALID, "online handle is NULL");
-    if (n) *n = (int64_t)o->trace.size();
-    if (out && cap > 0) std::copy_n(o->trace.begin(), (size_t)std::min<int64_t>(cap, (int64_t)o->trace.size()), out);
-    return SNMF_OK;
-}
-
-// ---- multi-GPU entry behind the C ABI (one process, several devices) --------------------------------------------
-#include "snmf_multi.h"

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_stft(StftArgs a) {
 
 // src/frame_splice.m:8-23 on the powered magnitudes, then + nonzerofloor (run_basis_train.m:62-63):
 // out[(S+s)*K + f, t] = src[f, t+s],  out[(S-s)*K + f, t] = src[f, t-s]  (zero outside 1..T)
-__global__ void k_splice(const float* __restrict__ src, int64_t ld_src, int K, int T, int S, float floorv,
+static __global__ void k_splice(const float* __restrict__ src, int64_t ld_src, int K, int T, int S, float floorv,
                          float* __restrict__ out, int64_t ld_out) {
     const int64_t n = (int64_t)(2 * S + 1) * K * T;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -97,7 +97,7 @@ __global__ void k_splice(const float* __restrict__ src, int64_t ld_src, int K, i
 }
 
 // run_basis_train.m:70-78: out[k*M + m, t] = sum_f mel[m, f] * V[k*n + f, t]; one thread per output
-__global__ void k_mel(const float* __restrict__ mel /*[M][n] row-major*/, int M, int n, int K,
+static __global__ void k_mel(const float* __restrict__ mel /*[M][n] row-major*/, int M, int n, int K,
                       const float* __restrict__ V, int64_t ldv, int T, float* __restrict__ out, int64_t ldo) {
     const int64_t tot = (int64_t)K * M * T;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) {
@@ -113,7 +113,7 @@ __global__ void k_mel(const float* __restrict__ mel /*[M][n] row-major*/, int M,
 }
 
 // v = max(v, flr) on the real F x T entries of a padded [T][Fp] matrix (src/sparse_nmf.m:169)
-__global__ void k_floor_real(float* V, int Fp, int F, int T, float flr) {
+static __global__ void k_floor_real(float* V, int Fp, int F, int T, float flr) {
     const int64_t n = (int64_t)Fp * T;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         if ((int)(i % Fp) < F) V[i] = fmaxf(V[i], flr);
@@ -129,7 +129,7 @@ __global__ void k_floor_real(float* V, int Fp, int F, int T, float flr) {
 //   k_tfdd_apply : every (chunk, row) re-runs its chunk from the true start state and writes the result
 // State and coefficients in fp64 (the features are fp32; the recursion then adds no error of its own).
 constexpr int kDdChunk = 256;
-__global__ __launch_bounds__(256) void k_tfdd_carry(const float* __restrict__ X, int64_t ld, int F, int T, double a, double* __restrict__ carry) {
+static __global__ __launch_bounds__(256) void k_tfdd_carry(const float* __restrict__ X, int64_t ld, int F, int T, double a, double* __restrict__ carry) {
     const int f = blockIdx.y * 256 + threadIdx.x, j = blockIdx.x;
     if (f >= F) return;
     const int t0 = j * kDdChunk, t1 = min(T, t0 + kDdChunk);
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void k_tfdd_carry(const float* __restrict__ X,
     for (int t = t0; t < t1; ++t) s = a * s + (1.0 - a) * (double)X[(int64_t)t * ld + f];
     carry[(int64_t)j * F + f] = s;
 }
-__global__ __launch_bounds__(256) void k_tfdd_state(const float* __restrict__ X, int F, int T, double a, double* __restrict__ carry /* in: carries, out: start states */) {
+static __global__ __launch_bounds__(256) void k_tfdd_state(const float* __restrict__ X, int F, int T, double a, double* __restrict__ carry /* in: carries, out: start states */) {
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= F) return;
     const int nch = (T + kDdChunk - 1) / kDdChunk;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void k_tfdd_state(const float* __restrict__ X,
         s = pow(a, (double)len) * s + c;
     }
 }
-__global__ __launch_bounds__(256) void k_tfdd_apply(const float* __restrict__ X, int64_t ld, int F, int T, double a, const double* __restrict__ state,
+static __global__ __launch_bounds__(256) void k_tfdd_apply(const float* __restrict__ X, int64_t ld, int F, int T, double a, const double* __restrict__ state,
                                                     float* __restrict__ out, int64_t ldo) {
     const int f = blockIdx.y * 256 + threadIdx.x, j = blockIdx.x;
     if (f >= F) return;

@@ -35,7 +35,7 @@ struct GemmArgs {
     const int* stop;
 };
 
-__global__ __launch_bounds__(256) void k_g_gemm(GemmArgs g) {
+static __global__ __launch_bounds__(256) void k_g_gemm(GemmArgs g) {
     if (g.stop && *g.stop) return;
     constexpr int BM = 64, BN = 64, BK = 16;
     __shared__ float As[BK][BM + 4];
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_g_hupd(const float* __restrict__ Hin, f
 }
 
 // spart[z][k] = sum over the frames of split z of H[k, t]  (KL W step: the "P" of every row)
-__global__ __launch_bounds__(256) void k_g_rowsum(const float* __restrict__ H, int rp, int r, int T, int kchunk, float* __restrict__ spart,
+static __global__ __launch_bounds__(256) void k_g_rowsum(const float* __restrict__ H, int rp, int r, int T, int kchunk, float* __restrict__ spart,
                                                   const int* stop) {
     if (stop && *stop) return;
     const int z = blockIdx.y, t_lo = z * kchunk, t_hi = min(T, t_lo + kchunk);
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void k_g_rowsum(const float* __restrict__ H, i
 
 // out[i] = sum over the chunks of slabs[c][i] (fp64 accumulation, chunk order), i < n: the Gram matrix H*H' of the
 // Euclidean W step (see launch_gram_p in snmf_api.hip)
-__global__ __launch_bounds__(256) void k_gram_sum(const float* __restrict__ slabs, int n_chunks, size_t n, float* __restrict__ out,
+static __global__ __launch_bounds__(256) void k_gram_sum(const float* __restrict__ slabs, int n_chunks, size_t n, float* __restrict__ out,
                                                   const int* stop) {
     if (stop && *stop) return;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {

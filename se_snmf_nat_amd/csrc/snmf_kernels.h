@@ -3248,7 +3248,7 @@ struct ReduceArgs {
     DevState* st;
 };
 
-__global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
+static __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
     if (a.stop && *a.stop) return;
     const size_t nel = (size_t)a.rp * a.Fp;   // multiple of 4
     const size_t nmat = nel * a.n_mat;
@@ -3502,7 +3502,7 @@ __device__ __forceinline__ void wapply_column(const ApplyArgs& a, int k, int tid
     }
 }
 
-__global__ __launch_bounds__(256) void k_wapply(ApplyArgs a) {
+static __global__ __launch_bounds__(256) void k_wapply(ApplyArgs a) {
     __shared__ double red[3][256];
     if (!a.init_mode && a.st->stop) return;  // normalising a fresh W never depends on an earlier solve's flag
     const int k = blockIdx.x;
@@ -3650,7 +3650,7 @@ __global__ __launch_bounds__(768) void k_wfin(ReduceArgs ra, ApplyArgs a) {
 
 
 // Convergence check alone (H-only mode and the final objective pass): one thread.
-__global__ void k_check(const double* stats, size_t sc_off, double* divh, double* costh, DevState* st, int it,
+static __global__ void k_check(const double* stats, size_t sc_off, double* divh, double* costh, DevState* st, int it,
                         double conv_eps) {
     if (st->stop) return;
     if (threadIdx.x == 0 && blockIdx.x == 0) conv_test(stats + sc_off, divh, costh, st, it, conv_eps, true);
@@ -3658,7 +3658,7 @@ __global__ void k_check(const double* stats, size_t sc_off, double* divh, double
 
 // ---- small utility kernels -------------------------------------------------------------------
 // h = h .* wn'  (src/sparse_nmf.m:160), H in [Tp][rp] layout
-__global__ void k_scale_h(float* H, const double* wn, int rp, int r, size_t n) {
+static __global__ void k_scale_h(float* H, const double* wn, int rp, int r, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         int k = (int)(i % rp);
         if (k < r) H[i] = (float)((double)H[i] * wn[k]);
@@ -3666,7 +3666,7 @@ __global__ void k_scale_h(float* H, const double* wn, int rp, int r, size_t n) {
 }
 
 // partial sums of S.*H over the real entries (W-only mode: constant over the iterations)
-__global__ __launch_bounds__(256) void k_sum_sh(const float* H, const float* S, const float* lamk, int rp, int r, int T,
+static __global__ __launch_bounds__(256) void k_sum_sh(const float* H, const float* S, const float* lamk, int rp, int r, int T,
                                                 double* out /*[grid]*/) {
     __shared__ double red[256];
     double s = 0.0;
@@ -3685,7 +3685,7 @@ __global__ __launch_bounds__(256) void k_sum_sh(const float* H, const float* S, 
 }
 
 // k_sum_sh partials -> stats.sh (tiny kernel: 256 doubles)
-__global__ void k_fold_sh(const double* part, int n, double* sc, const int* stop) {
+static __global__ void k_fold_sh(const double* part, int n, double* sc, const int* stop) {
     if (*stop) return;
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         double s = 0.0;
@@ -3695,7 +3695,7 @@ __global__ void k_fold_sh(const double* part, int n, double* sc, const int* stop
 }
 
 // per-solve bookkeeping of the online stream: iteration count and last recorded cost
-__global__ void k_collect(const DevState* st, const double* costh, int n_solves, int max_iter, int cost_check,
+static __global__ void k_collect(const DevState* st, const double* costh, int n_solves, int max_iter, int cost_check,
                           int* n_iter_out, double* cost_out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < n_solves) {
@@ -3748,7 +3748,7 @@ __global__ void k_unpack(const TSrc* __restrict__ src, int rowsP, int rows, int 
 
 // ---- MDI helpers (src/snmf_mdi.m) ---------------------------------------------------------------
 // v = max(v .* M, flr) on the real entries (:175); pads stay zero
-__global__ void k_mdi_start(float* V, const float* __restrict__ M, int Fp, int F, int T, float flr) {
+static __global__ void k_mdi_start(float* V, const float* __restrict__ M, int Fp, int F, int T, float flr) {
     const size_t n = (size_t)Fp * T;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         if ((int)(i % Fp) < F) V[i] = fmaxf(V[i] * M[i], flr);
