@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SNMF_ABI_VERSION 2  /* 2: snmf_multi_* family, snmf_multi_set_exchange, snmf_online_trace is a ring of the newest frames */
+#define SNMF_ABI_VERSION 3  /* 3: snmf_run_basis_dnmf_*, snmf_run_basis_train_audio_f64, snmf_plan_set_h_random, snmf_ctx_xfer_stats; 2: snmf_multi_* */
 
 typedef enum snmf_status {
     SNMF_OK = 0,
@@ -220,6 +220,52 @@ int snmf_mel_features_f32(snmf_ctx* ctx, const float* mel, int32_t M, int32_t n,
 int snmf_tf_dd_f32(snmf_ctx* ctx, double alpha_eta, int32_t F, int32_t T, const float* X, int64_t ldx, float* out,
                    int64_t ldo, int on_device);
 
+/* ---- the training callers, device-resident ------------------------------------------------------- */
+/* h = rand(r, n) of src/sparse_nmf.m:133-134 for a caller that supplies no init_h: Philox-4x32-10 keyed by `seed`, counter =
+ * column-major element index / 4, value = ((x >> 8) + 0.5) * 2^-24 in (0, 1), written straight into the plan's resident H
+ * (MATLAB's legacy rand('seed', s) stream is not reproducible; a wrapper that wants ITS draws passes them to snmf_plan_set_h).
+ * Every entry below that takes `H0` uses this generator when H0 is NULL. */
+int snmf_plan_set_h_random(snmf_plan* plan, uint64_t seed);
+
+/* B_hat = run_basis_DNMF(x, d, B, p), the 3-solve loop run_basis_DNMF.m:36-55 on formed features:
+ *     [~, A_hat]   = sparse_nmf(Y, p)   H-only,  init_w = B                                         (:37-40)
+ *     [B_hat_x, ~] = sparse_nmf(X, p)   W-only,  init_w = B(:,1:R_x),        init_h = A_hat(1:R_x,:)      (:43-47)
+ *     [B_hat_d, ~] = sparse_nmf(D, p)   W-only,  init_w = B(:,R_x+1:R_x+R_d), init_h = A_hat(R_x+1:end,:)  (:49-53)
+ *     B_hat = [B_hat_x, B_hat_d]                                                                   (:55)
+ * Result-identical to three snmf_sparse_nmf_* calls, but Y, X, D cross PCIe once each (X and D on a second stream under solve
+ * 1), A_hat never leaves HBM, and only B_hat (and A_hat if asked for) comes back.
+ *   p      : F, T, r = R_x + R_d, beta, max_iter, conv_eps, cost_check, floor_v, scalar sparsity; the update masks are set by
+ *            the loop (p->w_update_ind / h_update_ind are ignored)
+ *   Y, X, D: F x T host matrices (mixture / clean / noise features, :13-34), never modified
+ *   B      : F x (R_x + R_d) exemplar basis;  H0: (R_x + R_d) x T initial activations of solve 1 (leading dimension r) or NULL
+ *   B_hat  : F x (R_x + R_d) out;  A_hat: (R_x + R_d) x T out or NULL;  n_iter_out: 3 iteration counts or NULL */
+int snmf_run_basis_dnmf_f64(snmf_ctx* ctx, const snmf_params* p, int32_t R_x, int32_t R_d, const double* Y, int64_t ldY,
+                            const double* X, int64_t ldX, const double* D, int64_t ldD, const double* B, int64_t ldB,
+                            const double* H0, uint64_t seed, double* B_hat, int64_t ldBh, double* A_hat, int64_t ldA,
+                            int32_t* n_iter_out);
+int snmf_run_basis_dnmf_f32(snmf_ctx* ctx, const snmf_params* p, int32_t R_x, int32_t R_d, const float* Y, int64_t ldY,
+                            const float* X, int64_t ldX, const float* D, int64_t ldD, const float* B, int64_t ldB,
+                            const float* H0, uint64_t seed, float* B_hat, int64_t ldBh, float* A_hat, int64_t ldA,
+                            int32_t* n_iter_out);
+/* The same from the two WAVEFORMS, as the reference's function takes them (run_basis_DNMF.m:1): truncation to equal length
+ * (:5-9), y = x + d (:10), the three feature sets (:13-34) and the loop on the device -- only audio in, B_hat out.
+ * mel != NULL: run_basis_DNMF_Mel.m (mel: mel_M x (fftlength/2+1) ROW-major = mel_matrix(...)', features projected as :21-69,
+ * B the Mel exemplar basis).  p->F / p->T must equal the feature rows and snmf_stft_num_frames(sp, min(n_x, n_d)). */
+int snmf_run_basis_dnmf_audio_f64(snmf_ctx* ctx, const snmf_params* p, const snmf_stft_params* sp, int32_t R_x, int32_t R_d,
+                                  const float* x, int64_t n_x, const float* d, int64_t n_d, const float* mel, int32_t mel_M,
+                                  const double* B, int64_t ldB, const double* H0, uint64_t seed, double* B_hat, int64_t ldBh,
+                                  double* A_hat, int64_t ldA, int32_t* n_iter_out);
+/* run_basis_train.m:58-91 for one event class from its assembled training signal: TF_mag (:60-63; alpha_eta_dd >= 0: TF_DD,
+ * :64-67), TF_Mel (:70-78; mel / B_Mel NULL: DFT only), exemplar columns sample_idx (r ZERO-based frame indices -- the wrapper
+ * draws them, rng(1); randsample(...), :80-81), and the two full-update solves (:84-91; train_exemplar != 0: none, the exemplars
+ * are returned).  V is formed in HBM and never crosses PCIe.  p: F = DFT feature rows, T = frames, r = number of exemplars,
+ * solver fields.  B_DFT: F x r, A_DFT: r x T or NULL, B_Mel: (2*splice+1)*mel_M x r, A_Mel: r x T or NULL (all fp64, tight);
+ * the post-normalisation (+1e-9, :113-116) and the k-means rank reduction (:118-134) stay with the caller. */
+int snmf_run_basis_train_audio_f64(snmf_ctx* ctx, const snmf_params* p, const snmf_stft_params* sp, double alpha_eta_dd,
+                                   const float* mel, int32_t mel_M, const float* s_full, int64_t n_samples,
+                                   const int64_t* sample_idx, int32_t train_exemplar, const double* H0, uint64_t seed,
+                                   double* B_DFT, double* A_DFT, double* B_Mel, double* A_Mel, int32_t* n_iter_out);
+
 /* ---- missing-data imputation variants --------------------------------
  * [v_MDI, h, objective] = snmf_mdi(v, Dm, p)     src/snmf_mdi.m:1      (binary observed mask)
  * [v_MDI, h, objective] = snmf_mdi_Sm(v, Sm, p)  src/snmf_mdi_Sm.m:1   (soft mask in [0,1])
@@ -369,6 +415,10 @@ int snmf_sparse_nmf_multi_f32(const int32_t* devices, int32_t n_dev, const snmf_
  * recorded since snmf_ctx_timing(ctx, 1) was switched on.  Families: "hstep", "wstats",
  * "wapply", "reduce".  Timing inserts hipEvents around each launch (off by default). */
 int snmf_ctx_timing(snmf_ctx* ctx, int enable);
+/* Host <-> device transfer counters of a context since the last reset (host arrays move as a pipeline of column chunks through
+ * pinned bounce buffers, csrc/snmf_tu_xfer.hip).  out8 = { host->device: bytes of the callers' arrays, wall seconds inside the
+ * calls, seconds of host-side copying, calls;  device->host: the same four }. */
+int snmf_ctx_xfer_stats(snmf_ctx* ctx, double* out8, int reset);
 int snmf_ctx_timing_get(snmf_ctx* ctx, const char* family, double* avg_ms, int64_t* launches);
 /* Kernel geometry chosen for a plan, for DESIGN.md / profiles bookkeeping. */
 int snmf_plan_describe(const snmf_plan* plan, char* buf, size_t buflen);

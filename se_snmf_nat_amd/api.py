@@ -19,7 +19,7 @@ import numpy as np
 from . import _lib
 from ._lib import SnmfError, SnmfParams
 
-__all__ = ["Context", "Plan", "sparse_nmf", "sparse_nmf_GPU", "run_basis_dnmf", "dnmf_adapt", "snmf_mdi", "snmf_mdi_Sm", "SnmfError",
+__all__ = ["Context", "Plan", "sparse_nmf", "sparse_nmf_GPU", "run_basis_dnmf", "philox_uniform", "dnmf_adapt", "snmf_mdi", "snmf_mdi_Sm", "SnmfError",
            "default_context"]
 
 
@@ -51,6 +51,13 @@ class Context:
         ms, n = C.c_double(), C.c_int64()
         _lib.check(self._lib.snmf_ctx_timing_get(self._h, family.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def xfer_stats(self, reset=False):
+        """Host <-> device transfer counters (include/snmf.h: snmf_ctx_xfer_stats)."""
+        out = np.zeros(8)
+        _lib.check(self._lib.snmf_ctx_xfer_stats(self._h, _ptr(out), 1 if reset else 0))
+        keys = ("h2d_bytes", "h2d_wall_s", "h2d_host_copy_s", "h2d_calls", "d2h_bytes", "d2h_wall_s", "d2h_host_copy_s", "d2h_calls")
+        return dict(zip(keys, out.tolist()))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -264,18 +271,72 @@ def sparse_nmf_GPU(v, p=None, *, ctx=None, dtype=np.float64, rng=None):
     return _solve(v, p, gpu_variant=True, ctx=ctx, dtype=dtype, rng=rng)
 
 
-def run_basis_dnmf(Y, X, D, B, R_x, R_d, p, *, ctx=None, dtype=np.float64, devices=None):
+def philox4x32_10(ctr, key0, key1):
+    """Philox-4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11) on arrays of counters:
+    ctr = four uint64 arrays holding 32-bit words, key = two 32-bit words.  tests/ check the published known-answer vectors."""
+    M32 = np.uint64(0xFFFFFFFF)
+    c = [np.asarray(x, dtype=np.uint64) & M32 for x in ctr]
+    k0, k1 = np.uint64(key0), np.uint64(key1)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[0]
+        p1 = np.uint64(0xCD9E8D57) * c[2]
+        c = [((p1 >> np.uint64(32)) ^ c[1] ^ k0) & M32, p1 & M32, ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & M32, p0 & M32]
+        k0 = (k0 + np.uint64(0x9E3779B9)) & M32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & M32
+    return c
+
+
+def philox_uniform(seed, r, n):
+    """The r x n uniforms the engine draws on the device for an initial H the caller does not supply (include/snmf.h:
+    snmf_plan_set_h_random; csrc/snmf_tu_dnmf.hip): Philox-4x32-10 keyed by `seed`, counter = column-major element index // 4,
+    value = ((x >> 8) + 0.5) * 2^-24.  NumPy restatement, so that a host can reproduce the device's draws bit for bit."""
+    tot = int(r) * int(n)
+    n4 = (tot + 3) // 4
+    q = np.arange(n4, dtype=np.uint64)
+    c = philox4x32_10([q & np.uint64(0xFFFFFFFF), q >> np.uint64(32), np.zeros(n4, np.uint64), np.zeros(n4, np.uint64)],
+                      int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF)
+    x = np.stack(c, axis=1).reshape(-1)[:tot]
+    u = ((x >> np.uint64(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    return u.reshape((int(n), int(r))).T  # element (k, t) = draw k + r*t
+
+
+def _solver_scalars(p):
+    """(beta, max_iter, conv_eps, cost_check, scalar sparsity) of a settings dict for the callers' entries (run_basis_DNMF.m,
+    run_basis_train.m pass the settings struct through: src/sparse_nmf.m:79-110, :260)."""
+    if "cost_check" not in p:  # src/sparse_nmf.m:260
+        raise SnmfError(4, "Reference to non-existent field 'cost_check'.")
+    sp = np.asarray(p.get("sparsity", 0), dtype=np.float64)
+    if sp.size != 1:
+        raise SnmfError(3, "this caller needs a scalar p.sparsity")
+    return _cf_to_beta(p), int(p.get("max_iter", 100)), float(p.get("conv_eps", 0)), 1 if p["cost_check"] else 0, float(sp.reshape(-1)[0])
+
+
+def run_basis_dnmf(Y, X, D, B, R_x, R_d, p, *, ctx=None, dtype=np.float64, devices=None, resident=None, h0="host"):
     """The 3-solve discriminative re-training loop of run_basis_DNMF.m:36-55 on formed features.
 
     Y, X, D are the F x T features of mixture / clean / noise (run_basis_DNMF.m:13-34); B is the
     F x (R_x+R_d) exemplar basis.  Returns (B_hat, A_hat).  `devices`: shard the frames of all three solves over
-    these GPUs inside this process (BASELINE config 4 behind the reference's own call)."""
+    these GPUs inside this process (BASELINE config 4 behind the reference's own call).
+    resident (default: on one device): ONE call of snmf_run_basis_dnmf_* -- Y, X, D uploaded once each, A_hat stays in HBM
+    between the solves; False = three separate sparse_nmf calls (the same bits, three host round trips).
+    h0: "host" = rand(r, n) of src/sparse_nmf.m:133-134 drawn here (the RandomState stand-in, as sparse_nmf does);
+    "device" = drawn on the device (philox_uniform(random_seed, r, n): nothing but the features crosses PCIe); or the
+    r x n array itself (what integration/run_basis_DNMF.m passes: MATLAB's own draws)."""
     p = dict(p)
     B = np.asarray(B, dtype=np.float64)
+    if resident is None:
+        resident = devices is None
+    if resident and devices is None:
+        return _run_basis_dnmf_resident(Y, X, D, B, int(R_x), int(R_d), p, ctx=ctx, dtype=dtype, h0=h0)
     p["w_update_ind"] = np.zeros(R_x + R_d, bool)  # :37
     p["h_update_ind"] = np.ones(R_x + R_d, bool)  # :38
     p["init_w"] = B  # :39
     p.pop("init_h", None)
+    if isinstance(h0, np.ndarray):
+        p["init_h"] = h0
+    elif h0 == "device":
+        seed = int(p.get("random_seed", 1))
+        p["init_h"] = philox_uniform(seed, R_x + R_d, np.asarray(Y).shape[1]).astype(np.float64)
     _, A_hat, _ = sparse_nmf(Y, p, ctx=ctx, dtype=dtype, devices=devices)  # :40
     p["w_update_ind"] = np.ones(R_x, bool)  # :43
     p["h_update_ind"] = np.zeros(R_x, bool)  # :44
@@ -288,6 +349,50 @@ def run_basis_dnmf(Y, X, D, B, R_x, R_d, p, *, ctx=None, dtype=np.float64, devic
     p["init_h"] = A_hat[R_x:R_x + R_d, :]  # :52
     B_hat_d, _, _ = sparse_nmf(D, p, ctx=ctx, dtype=dtype, devices=devices)  # :53
     return np.concatenate([B_hat_x, B_hat_d], axis=1), A_hat  # :55
+
+
+def _colmajor(M, dt):
+    """M as a column-major array of dtype dt WITHOUT a copy when it already is one (possibly with a leading dimension larger
+    than its row count, e.g. the top rows of a taller Fortran array); a copy otherwise."""
+    M = np.asarray(M)
+    if M.ndim == 2 and M.dtype == dt and M.strides[0] == dt.itemsize and (M.shape[1] <= 1 or M.strides[1] >= M.shape[0] * dt.itemsize):
+        return M
+    return np.asfortranarray(M, dtype=dt)
+
+
+def _run_basis_dnmf_resident(Y, X, D, B, R_x, R_d, p, *, ctx, dtype, h0, want_a=True):
+    dt = np.dtype(dtype)
+    if dt not in (np.dtype(np.float64), np.dtype(np.float32)):
+        raise SnmfError(1, "dtype must be float64 or float32")
+    Y, X, D = (_colmajor(M, dt) for M in (Y, X, D))
+    F, T = Y.shape
+    r = R_x + R_d
+    if X.shape != (F, T) or D.shape != (F, T):
+        raise SnmfError(3, "Y, X and D must have one size")
+    if B.shape != (F, r):
+        raise SnmfError(3, f"B is {B.shape}, expected ({F}, {r})")
+    beta, max_iter, conv_eps, cost_check, lam = _solver_scalars(p)
+    sp = _make_params(F, T, r, beta, max_iter, conv_eps, cost_check, True, 0, lam, None, None)
+    seed = int(p.get("random_seed", 1))
+    H0 = None
+    if isinstance(h0, np.ndarray):
+        if h0.shape != (r, T):
+            raise SnmfError(3, f"init_h is {h0.shape}, expected ({r}, {T})")
+        H0 = np.asfortranarray(h0, dtype=dt)
+    elif h0 == "host":  # what sparse_nmf draws for solve 1 (:112-114, :133-134; init_w is given, so h is the first draw)
+        rs = np.random.RandomState(seed if seed > 0 else None)
+        H0 = np.asfortranarray(rs.random_sample((r, T)), dtype=dt)
+    Bc = np.asfortranarray(B, dtype=dt)
+    B_hat = np.empty((F, r), dtype=dt, order="F")
+    A_hat = np.empty((r, T), dtype=dt, order="F") if want_a else None
+    nit = np.zeros(3, np.int32)
+    lib = _lib.load()
+    ctx = ctx or default_context()
+    fn = lib.snmf_run_basis_dnmf_f64 if dt == np.float64 else lib.snmf_run_basis_dnmf_f32
+    ldc = lambda M: M.strides[1] // dt.itemsize if M.shape[1] > 1 else M.shape[0]
+    _lib.check(fn(ctx._h, C.byref(sp), R_x, R_d, _ptr(Y), ldc(Y), _ptr(X), ldc(X), _ptr(D), ldc(D), _ptr(Bc), F,
+                  _ptr(H0) if H0 is not None else None, seed, _ptr(B_hat), F, _ptr(A_hat) if want_a else None, r, _ptr(nit)))
+    return B_hat, A_hat
 
 
 def dnmf_adapt(Y, D, B, p, *, ctx=None, dtype=np.float64):
@@ -371,6 +476,10 @@ class Plan:
 
     def set_h(self, h):
         self._set("h", h, self.r)
+
+    def set_h_random(self, seed=1):
+        """h = rand(r, n) drawn on the device (philox_uniform(seed, r, T)): nothing crosses PCIe."""
+        _lib.check(self._lib.snmf_plan_set_h_random(self._h, int(seed)))
 
     def set_mask(self, m):
         """Observed (1) / missing (0) mask, binary or soft: turns the plan into an MDI solve (src/snmf_mdi.m)."""

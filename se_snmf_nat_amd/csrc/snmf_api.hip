@@ -106,10 +106,10 @@ extern "C" void snmf_ctx_destroy(snmf_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     drain_timers(c);
-    if (c->own_stream && c->stream) {
-        hipStreamSynchronize(c->stream);
-        hipStreamDestroy(c->stream);
-    }
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->aux) snmf_ctx_destroy(c->aux);
+    xfer_destroy(c);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -555,25 +555,19 @@ static int ensure_staging(snmf_plan* pl, size_t bytes) {
 }
 
 
+// Host arrays go through the chunked, pinned, overlapped pipeline of snmf_tu_xfer.hip (pack_in returns as soon as the caller's
+// array has been read; the tail of the pipeline is ordered on the engine's stream); device arrays are converted in place.
 template <typename TIn, typename TDst = float>
 static int pack_in(snmf_plan* pl, const TIn* src, int64_t ld, int rows, int cols, TDst* dst, int rowsP, int colsP,
                    bool do_floor, int is_device) {
     if (!src) return fail(SNMF_ERR_INVALID, "source pointer is NULL");
     if (ld < rows) return fail(SNMF_ERR_INVALID, "leading dimension %lld < rows %d", (long long)ld, rows);
     HIP_TRY(hipSetDevice(pl->ctx->device));
-    hipStream_t st = pl->ctx->stream;
-    const TIn* dsrc = src;
-    if (!is_device) {
-        const size_t bytes = ((size_t)(cols - 1) * ld + rows) * sizeof(TIn);
-        SN_TRY(ensure_staging(pl, bytes));
-        HIP_TRY(hipMemcpyAsync(pl->staging, src, bytes, hipMemcpyHostToDevice, st));
-        dsrc = (const TIn*)pl->staging;
-    }
+    if (!is_device) return xfer_pack_in<TIn, TDst>(pl->ctx, src, ld, rows, cols, dst, rowsP, colsP, do_floor);
     const size_t n = (size_t)rowsP * colsP;
-    hipLaunchKernelGGL((k_pack<TIn, TDst>), dim3(grid_for(n)), dim3(256), 0, st, dsrc, ld, rows, cols, dst, rowsP, colsP, kFlr,
+    hipLaunchKernelGGL((k_pack<TIn, TDst>), dim3(grid_for(n)), dim3(256), 0, pl->ctx->stream, src, ld, rows, cols, dst, rowsP, colsP, kFlr,
                        do_floor ? 1 : 0);
     HIP_TRY(hipGetLastError());
-    if (!is_device) HIP_TRY(hipStreamSynchronize(st));  // staging / host buffer reusable on return
     return SNMF_OK;
 }
 
@@ -583,27 +577,12 @@ static int unpack_out(snmf_plan* pl, const TSrc* src, int rowsP, int rows, int c
     if (!dst) return fail(SNMF_ERR_INVALID, "destination pointer is NULL");
     if (ld < rows) return fail(SNMF_ERR_INVALID, "leading dimension %lld < rows %d", (long long)ld, rows);
     HIP_TRY(hipSetDevice(pl->ctx->device));
-    hipStream_t st = pl->ctx->stream;
+    if (!is_device) return xfer_unpack_out<TOut, TSrc>(pl->ctx, src, rowsP, rows, cols, dst, ld);
     const size_t n = (size_t)rows * cols;
-    if (is_device) {
-        hipLaunchKernelGGL((k_unpack<TOut, TSrc>), dim3(grid_for(n)), dim3(256), 0, st, src, rowsP, rows, cols, dst, ld);
-        HIP_TRY(hipGetLastError());
-        return SNMF_OK;
-    }
-    SN_TRY(ensure_staging(pl, n * sizeof(TOut)));
-    hipLaunchKernelGGL((k_unpack<TOut, TSrc>), dim3(grid_for(n)), dim3(256), 0, st, src, rowsP, rows, cols,
-                       (TOut*)pl->staging, (int64_t)rows);
+    hipLaunchKernelGGL((k_unpack<TOut, TSrc>), dim3(grid_for(n)), dim3(256), 0, pl->ctx->stream, src, rowsP, rows, cols, dst, ld);
     HIP_TRY(hipGetLastError());
-    if (ld == rows) {
-        HIP_TRY(hipMemcpyAsync(dst, pl->staging, n * sizeof(TOut), hipMemcpyDeviceToHost, st));
-    } else {
-        HIP_TRY(hipMemcpy2DAsync(dst, ld * sizeof(TOut), pl->staging, rows * sizeof(TOut), rows * sizeof(TOut), cols,
-                                 hipMemcpyDeviceToHost, st));
-    }
-    HIP_TRY(hipStreamSynchronize(st));
     return SNMF_OK;
 }
-
 
 template <typename T>
 int set_v(snmf_plan* pl, const T* V, int64_t ld, int dev) {
@@ -918,6 +897,9 @@ extern "C" int snmf_plan_init(snmf_plan* pl) {
     HIP_TRY(hipSetDevice(pl->ctx->device));
     hipStream_t st = pl->ctx->stream;
     HIP_TRY(hipMemsetAsync(pl->st, 0, sizeof(DevState), st));
+    // arrival counters of the split tiles: "last to arrive" is old % S == S - 1, so a launch that ended in the fault path
+    // (or was otherwise left partial) must not leave them misaligned for the next solve
+    if (pl->part_cnt) HIP_TRY(hipMemsetAsync(pl->part_cnt, 0, (size_t)(pl->rp_tiles - pl->rp_full) * 4, st));
     HIP_TRY(hipMemsetAsync(pl->divh, 0, sizeof(double) * std::max(1, pl->p.max_iter), st));
     HIP_TRY(hipMemsetAsync(pl->costh, 0, sizeof(double) * std::max(1, pl->p.max_iter), st));
     // wn = sqrt(sum(w.^2)); w = w./wn  (+ operand images, colsum, dphv).  When only V / H changed since
@@ -1345,7 +1327,7 @@ extern "C" int64_t snmf_stft_num_frames(const snmf_stft_params* sp, int64_t L) {
     return (lim + sp->frameshift - 1) / sp->frameshift;
 }
 
-static int validate_stft(const snmf_stft_params* sp) {
+int validate_stft(const snmf_stft_params* sp) {
     if (!sp || !sp->window) return fail(SNMF_ERR_INVALID, "stft params / window is NULL");
     const int N = sp->fftlength;
     if (N < 64 || N > 4096 || (N & (N - 1))) return fail(SNMF_ERR_UNSUPPORTED, "fftlength must be a power of two in [64,4096]");
@@ -1359,7 +1341,7 @@ static int validate_stft(const snmf_stft_params* sp) {
 }
 
 // features into a device buffer `dst` (column t at dst + t*ld); scratch allocations are freed on return
-static int stft_to_device(snmf_ctx* ctx, const snmf_stft_params* sp, const float* samples, int64_t n_samples,
+int stft_to_device(snmf_ctx* ctx, const snmf_stft_params* sp, const float* samples, int64_t n_samples,
                           int samples_on_device, float* dst, int64_t ld, int64_t n_frames) {
     hipStream_t st = ctx->stream;
     const int N = sp->fftlength, K = N / 2 + 1, S = sp->splice;
@@ -1507,12 +1489,15 @@ extern "C" int snmf_mel_features_f32(snmf_ctx* ctx, const float* mel, int32_t M,
     } else {
         if (hipMalloc((void**)&d_v, (size_t)ldv * T * 4) != hipSuccess || hipMalloc((void**)&d_o, (size_t)ldo * T * 4) != hipSuccess)
             rc = fail(SNMF_ERR_NOMEM, "hipMalloc failed");
-        else hipMemcpyAsync(d_v, V, (size_t)ldv * T * 4, hipMemcpyHostToDevice, st);
+        else if (hipMemcpy2DAsync(d_v, (size_t)ldv * 4, V, (size_t)ldv * 4, (size_t)K * n * 4, (size_t)T, hipMemcpyHostToDevice, st) != hipSuccess)
+            rc = fail(SNMF_ERR_NO_DEVICE, "hipMemcpy2DAsync (Mel input) failed");
     }
     if (rc == SNMF_OK) {
         hipLaunchKernelGGL(k_mel, dim3(grid_for((size_t)K * M * T)), dim3(256), 0, st, d_mel, M, n, K, d_v, ldv, T, d_o, ldo);
         if (hipGetLastError() != hipSuccess) rc = fail(SNMF_ERR_NO_DEVICE, "k_mel launch failed");
-        if (!on_device && rc == SNMF_OK) hipMemcpyAsync(out, d_o, (size_t)ldo * T * 4, hipMemcpyDeviceToHost, st);
+        if (!on_device && rc == SNMF_OK &&
+            hipMemcpy2DAsync(out, (size_t)ldo * 4, d_o, (size_t)ldo * 4, (size_t)K * M * 4, (size_t)T, hipMemcpyDeviceToHost, st) != hipSuccess)
+            rc = fail(SNMF_ERR_NO_DEVICE, "hipMemcpy2DAsync (Mel output) failed");
     }
     hipStreamSynchronize(st);
     hipFree(d_mel);
@@ -1543,7 +1528,9 @@ extern "C" int snmf_tf_dd_f32(snmf_ctx* ctx, double alpha_eta, int32_t F, int32_
     } else if (hipMalloc((void**)&d_x, (size_t)ldx * T * 4) != hipSuccess || hipMalloc((void**)&d_o, (size_t)ldo * T * 4) != hipSuccess) {
         rc = fail(SNMF_ERR_NOMEM, "hipMalloc failed");
     } else {
-        hipMemcpyAsync(d_x, X, (size_t)ldx * T * 4, hipMemcpyHostToDevice, st);
+        // only the F x T entries belong to the caller (ldx may exceed F, and the last column then holds just F elements)
+        if (hipMemcpy2DAsync(d_x, (size_t)ldx * 4, X, (size_t)ldx * 4, (size_t)F * 4, (size_t)T, hipMemcpyHostToDevice, st) != hipSuccess)
+            rc = fail(SNMF_ERR_NO_DEVICE, "hipMemcpy2DAsync (TF_DD input) failed");
     }
     if (rc == SNMF_OK) {
         const dim3 g(nch, (F + 255) / 256);
@@ -1551,7 +1538,10 @@ extern "C" int snmf_tf_dd_f32(snmf_ctx* ctx, double alpha_eta, int32_t F, int32_
         hipLaunchKernelGGL(k_tfdd_state, dim3((F + 255) / 256), dim3(256), 0, st, (const float*)d_x, (int)F, (int)T, alpha_eta, d_c);
         hipLaunchKernelGGL(k_tfdd_apply, g, dim3(256), 0, st, (const float*)d_x, ldx, (int)F, (int)T, alpha_eta, (const double*)d_c, d_o, ldo);
         if (hipGetLastError() != hipSuccess) rc = fail(SNMF_ERR_NO_DEVICE, "TF_DD launch failed");
-        if (!on_device && rc == SNMF_OK) hipMemcpyAsync(out, d_o, (size_t)ldo * T * 4, hipMemcpyDeviceToHost, st);
+        // (rows F .. ldo-1 of the caller's out are padding the header does not promise: left untouched)
+        if (!on_device && rc == SNMF_OK &&
+            hipMemcpy2DAsync(out, (size_t)ldo * 4, d_o, (size_t)ldo * 4, (size_t)F * 4, (size_t)T, hipMemcpyDeviceToHost, st) != hipSuccess)
+            rc = fail(SNMF_ERR_NO_DEVICE, "hipMemcpy2DAsync (TF_DD output) failed");
     }
     hipStreamSynchronize(st);
     hipFree(d_c);

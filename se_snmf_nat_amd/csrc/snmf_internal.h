@@ -50,6 +50,11 @@ struct TimerPair {
 };
 enum { FAM_HSTEP = 0, FAM_WSTATS, FAM_WAPPLY, FAM_REDUCE, FAM_WFIN, FAM_N };
 
+struct HostXfer;  // pinned bounce buffers + copy stream of the chunked host <-> device pipeline (snmf_tu_xfer.hip)
+struct XferStats {
+    double h2d_bytes = 0, h2d_wall = 0, h2d_host = 0, h2d_calls = 0, d2h_bytes = 0, d2h_wall = 0, d2h_host = 0, d2h_calls = 0;
+};
+
 struct snmf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -60,6 +65,9 @@ struct snmf_ctx {
     std::vector<TimerPair> pending;
     double fam_ms[FAM_N] = {0, 0, 0, 0, 0};
     int64_t fam_n[FAM_N] = {0, 0, 0, 0, 0};
+    HostXfer* xf = nullptr;  // created by the first host-array transfer
+    snmf_ctx* aux = nullptr; // a second stream + transfer pipeline on the same device (uploads under a running solve: snmf_tu_dnmf.hip)
+    XferStats xs;
 };
 
 struct ScopedTimer {
@@ -189,11 +197,21 @@ int generic_hstep(snmf_plan* pl, bool obj, bool upd);
 int generic_wstats(snmf_plan* pl, bool obj);
 int launch_wapply(snmf_plan* pl, const double* stats, int check_it, bool do_update, bool init_mode);
 int read_state(snmf_plan* pl, DevState* hs);
+int validate_stft(const snmf_stft_params* sp);
+int stft_to_device(snmf_ctx* ctx, const snmf_stft_params* sp, const float* samples, int64_t n_samples, int samples_on_device,
+                   float* dst, int64_t ld, int64_t n_frames);
 int result_h_index(snmf_plan* pl, int* idx);
 template <typename T> int set_v(snmf_plan* pl, const T* V, int64_t ld, int dev);
 template <typename T> int set_w(snmf_plan* pl, const T* W, int64_t ld, int dev);
 template <typename T> int set_h(snmf_plan* pl, const T* H, int64_t ld, int dev);
 template <typename T> int set_s(snmf_plan* pl, const T* S, int dev);
+// snmf_tu_xfer.hip: a host matrix (column-major, leading dimension ld) <-> the padded device layout, as a chunked pipeline
+template <typename TIn, typename TDst>
+int xfer_pack_in(snmf_ctx* ctx, const TIn* src, int64_t ld, int rows, int cols, TDst* dst, int rowsP, int colsP, bool do_floor);
+template <typename TOut, typename TSrc>
+int xfer_unpack_out(snmf_ctx* ctx, const TSrc* src, int rowsP, int rows, int cols, TOut* dst, int64_t ld);
+void xfer_destroy(snmf_ctx* c);
+int xfer_sync(snmf_ctx* c);
 // snmf_tu_hstep.hip / snmf_tu_wstats.hip / snmf_tu_small.hip
 int launch_hstep(snmf_plan* pl, bool obj, bool upd);
 int launch_hstep_rp(snmf_plan* pl, StepArgs a, bool obj);  // snmf_tu_hstep_rp.hip
