@@ -321,6 +321,34 @@ def main():
             "final_cost": float(last_cost[-1]) if last_cost else None,
         }
         out["cost_vs_oracle"] = cost_vs_oracle(F, T, r, len(last_cost), out["final_cost"])
+        # What a caller of the drop-in boundary waits for (outside the timed region; never `value`): the same K iterations
+        # through [w, h, objective] = sparse_nmf(v, p) on HOST fp64 arrays -- MATLAB's doubles in, W / H / objective out
+        # (snmf_sparse_nmf_f64: chunked pinned upload, solve, download).  scripts/bench_dropin.py has the full breakdown.
+        for pl in plans:
+            pl.close()
+        try:
+            from se_snmf_nat_amd import sparse_nmf
+            Vh, Wh, Hh = (np.asfortranarray(M, dtype=np.float64) for M in (V, W0, H0))
+            pd = dict(cf="kl", sparsity=SPARSITY, max_iter=K, conv_eps=0, cost_check=1, init_w=Wh, init_h=Hh)
+            sparse_nmf(Vh[:, :4096], dict(pd, init_h=Hh[:, :4096], max_iter=2), ctx=ctx)  # pinned buffers exist, code objects loaded
+            best = None
+            for _ in range(2):
+                ctx.xfer_stats(reset=True)
+                t = time.perf_counter()
+                sparse_nmf(Vh, pd, ctx=ctx)
+                dtd = time.perf_counter() - t
+                st = ctx.xfer_stats()
+                if best is None or dtd < best[0]:
+                    best = (dtd, st)
+            dtd, st = best
+            out["dropin_ms"] = dtd * 1e3
+            out["dropin"] = {"call": "sparse_nmf(v, p): host fp64 arrays in, w / h / objective out (snmf_sparse_nmf_f64)", "iterations": K,
+                             "call_ms": dtd * 1e3, "resident_ms": ms * K, "h2d_ms": st["h2d_wall_s"] * 1e3, "h2d_MB": st["h2d_bytes"] / 1e6,
+                             "d2h_ms": st["d2h_wall_s"] * 1e3, "d2h_MB": st["d2h_bytes"] / 1e6,
+                             "note": "includes plan creation / destruction and the mirror's copies of the in/out arrays"}
+        except Exception as e:  # noqa: BLE001 -- the extra leg must never fail the bench
+            out["dropin_ms"] = None
+            out["dropin"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(F, T, r)
         print(json.dumps(out))

@@ -266,6 +266,9 @@ int xfer_unpack_out(snmf_ctx* ctx, const TSrc* src, int rowsP, int rows, int col
     HostXfer* x = nullptr;
     SN_TRY(xfer_get(ctx, &x));
     hipStream_t st = ctx->stream;
+    // the data must exist before it can move: waiting for the producer here (instead of inside the first chunk's wait) costs
+    // nothing and keeps the transfer counters free of solve time
+    HIP_TRY(hipStreamSynchronize(st));
     const double t0 = now_s();
     double t_host = 0.0;
     if ((size_t)rows * sizeof(TS) > kChunkBytes) return fail(SNMF_ERR_UNSUPPORTED, "a column of %d rows does not fit a transfer chunk", rows);
