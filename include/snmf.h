@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SNMF_ABI_VERSION 3  /* 3: snmf_run_basis_dnmf_*, snmf_run_basis_train_audio_f64, snmf_plan_set_h_random, snmf_ctx_xfer_stats; 2: snmf_multi_* */
+#define SNMF_ABI_VERSION 3  /* 3: snmf_run_basis_dnmf_*, snmf_run_basis_train_audio_f64, snmf_sparse_nmf_oop_*, snmf_plan_set_h_random, snmf_ctx_xfer_stats; 2: snmf_multi_* */
 
 typedef enum snmf_status {
     SNMF_OK = 0,
@@ -98,6 +98,14 @@ int snmf_sparse_nmf_f64(snmf_ctx* ctx, const snmf_params* p, const double* V, in
 int snmf_sparse_nmf_f32(snmf_ctx* ctx, const snmf_params* p, const float* V, int64_t ldV,
                         float* W, float* H, const float* sparsity, double* div_out,
                         double* cost_out, int32_t* n_iter_out);
+/* Out-of-place form: W0 (F x r) and H0 (r x T) are read-only, the results go to W and H (tight: leading dimensions F and r).
+ * This is MATLAB's value semantics without a copy of init_h on the host first -- what the MEX shim calls. */
+int snmf_sparse_nmf_oop_f64(snmf_ctx* ctx, const snmf_params* p, const double* V, int64_t ldV, const double* W0,
+                            const double* H0, const double* sparsity, double* W, double* H, double* div_out,
+                            double* cost_out, int32_t* n_iter_out);
+int snmf_sparse_nmf_oop_f32(snmf_ctx* ctx, const snmf_params* p, const float* V, int64_t ldV, const float* W0,
+                            const float* H0, const float* sparsity, float* W, float* H, double* div_out,
+                            double* cost_out, int32_t* n_iter_out);
 
 /* ---- resident-plan API (benchmarks, on-device pipelines, multi-GPU sharding) -------------- */
 /* A plan owns fp32 device copies of V (F x T), W (F x r), H (r x T) in the engine's padded

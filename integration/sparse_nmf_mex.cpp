@@ -117,12 +117,8 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         mexErrMsgIdAndTxt("snmf:dim", "sparsity must be a scalar, r x 1 or r x n");
     }
 
-    // MATLAB value semantics: inputs are never modified; W and H are in/out in the C ABI, so copy.
-    plhs[0] = mxDuplicateArray(w0);
-    mxArray* hout = mxDuplicateArray(h0);
-    mxArray* divv = mxCreateDoubleMatrix(1, p.max_iter > 0 ? p.max_iter : 1, mxREAL);
-    mxArray* costv = mxCreateDoubleMatrix(1, p.max_iter > 0 ? p.max_iter : 1, mxREAL);
-    int32_t n_iter = 0;
+    // MATLAB value semantics: inputs are never modified, outputs are fresh arrays.  The out-of-place entry reads init_w / init_h
+    // where they lie, so nothing is duplicated on the host first (the multi-device entry is in/out: it gets copies).
     // opts.devices = [0 1 ... 7]: the same call over several GPUs (run_basis_DNMF.m:40,47,53 / run_basis_train.m:88 at scale)
     std::vector<int32_t> devices;
     if (const mxArray* dv = mxGetField(opts, 0, "devices")) {
@@ -132,9 +128,14 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
             for (size_t i = 0; i < mxGetNumberOfElements(dv); ++i) devices.push_back((int32_t)d[i]);
         }
     }
+    mxArray* hout = devices.empty() ? mxCreateDoubleMatrix((mwSize)r, (mwSize)T, mxREAL) : mxDuplicateArray(h0);
+    plhs[0] = devices.empty() ? mxCreateDoubleMatrix((mwSize)F, (mwSize)r, mxREAL) : mxDuplicateArray(w0);
+    mxArray* divv = mxCreateDoubleMatrix(1, p.max_iter > 0 ? p.max_iter : 1, mxREAL);
+    mxArray* costv = mxCreateDoubleMatrix(1, p.max_iter > 0 ? p.max_iter : 1, mxREAL);
+    int32_t n_iter = 0;
     const int st = devices.empty()
-        ? snmf_sparse_nmf_f64(g_ctx, &p, mxGetDoubles(v), (int64_t)F, mxGetDoubles(plhs[0]), mxGetDoubles(hout), sparsity,
-                              mxGetDoubles(divv), mxGetDoubles(costv), &n_iter)
+        ? snmf_sparse_nmf_oop_f64(g_ctx, &p, mxGetDoubles(v), (int64_t)F, mxGetDoubles(w0), mxGetDoubles(h0), sparsity,
+                                  mxGetDoubles(plhs[0]), mxGetDoubles(hout), mxGetDoubles(divv), mxGetDoubles(costv), &n_iter)
         : snmf_sparse_nmf_multi_f64(devices.data(), (int32_t)devices.size(), &p, mxGetDoubles(v), (int64_t)F,
                                     mxGetDoubles(plhs[0]), mxGetDoubles(hout), sparsity, mxGetDoubles(divv),
                                     mxGetDoubles(costv), &n_iter);

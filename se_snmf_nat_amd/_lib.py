@@ -55,7 +55,7 @@ SYMBOLS = [
     "snmf_multi_get_w_rank_f64", "snmf_multi_get_h_f64", "snmf_multi_get_h_f32", "snmf_multi_get_objective",
     "snmf_sparse_nmf_multi_f64", "snmf_sparse_nmf_multi_f32", "snmf_multi_set_exchange",
     "snmf_plan_set_h_random", "snmf_run_basis_dnmf_f64", "snmf_run_basis_dnmf_f32", "snmf_run_basis_dnmf_audio_f64",
-    "snmf_run_basis_train_audio_f64", "snmf_ctx_xfer_stats",
+    "snmf_run_basis_train_audio_f64", "snmf_ctx_xfer_stats", "snmf_sparse_nmf_oop_f64", "snmf_sparse_nmf_oop_f32",
 ]
 ABI_VERSION = 3  # include/snmf.h: SNMF_ABI_VERSION this binding was written against
 EXCHANGE_AUTO, EXCHANGE_FLAGS, EXCHANGE_EVENTS = 0, 1, 2
@@ -273,6 +273,8 @@ def load():
     sig["snmf_run_basis_dnmf_audio_f64"] = (C.c_int, [vp, PP, SP, i32, i32, vp, i64, vp, i64, vp, i32, vp, i64, vp, u64, vp, i64, vp, i64, vp])
     sig["snmf_run_basis_train_audio_f64"] = (C.c_int, [vp, PP, SP, dbl, vp, i32, vp, i64, vp, i32, vp, u64, vp, vp, vp, vp, vp])
     sig["snmf_ctx_xfer_stats"] = (C.c_int, [vp, vp, C.c_int])
+    for ty in ("f64", "f32"):
+        sig[f"snmf_sparse_nmf_oop_{ty}"] = (C.c_int, [vp, PP, vp, i64, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i32)])
     lib.snmf_abi_version.restype = C.c_int
     if lib.snmf_abi_version() != ABI_VERSION:  # a stale library must not be driven through newer prototypes
         raise ImportError(f"{path} has ABI version {lib.snmf_abi_version()}, this binding needs {ABI_VERSION}: rebuild the library")

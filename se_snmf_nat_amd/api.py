@@ -133,6 +133,15 @@ def _sparsity_form(sparsity, r, n, dtype):
     return 2, 0.0, np.asfortranarray(sp)
 
 
+def _colmajor(M, dt):
+    """M as a column-major array of dtype dt WITHOUT a copy when it already is one (possibly with a leading dimension larger
+    than its row count, e.g. the top rows of a taller Fortran array); a copy otherwise."""
+    M = np.asarray(M)
+    if M.ndim == 2 and M.dtype == dt and M.strides[0] == dt.itemsize and (M.shape[1] <= 1 or M.strides[1] >= M.shape[0] * dt.itemsize):
+        return M
+    return np.asfortranarray(M, dtype=dt)
+
+
 def _solve(v, p, *, gpu_variant, ctx, dtype, rng, devices=None):
     p = dict(p or {})
     dt = np.dtype(dtype)
@@ -191,9 +200,9 @@ def _solve(v, p, *, gpu_variant, ctx, dtype, rng, devices=None):
         cost_check = 1 if p["cost_check"] else 0
 
     sp = _make_params(m, n, r, beta, max_iter, conv_eps, cost_check, not gpu_variant, kind, scalar, w_ind, h_ind)
-    vv = np.asfortranarray(v, dtype=dt)
-    W = np.asfortranarray(w0, dtype=dt).copy(order="F")
-    H = np.asfortranarray(h0, dtype=dt).copy(order="F")
+    vv = _colmajor(v, dt)
+    W = np.asfortranarray(w0, dtype=dt)
+    H = np.asfortranarray(h0, dtype=dt)
     div = np.zeros(max(max_iter, 1))
     cost = np.zeros(max(max_iter, 1))
     n_iter = C.c_int32(0)
@@ -203,14 +212,20 @@ def _solve(v, p, *, gpu_variant, ctx, dtype, rng, devices=None):
         # the same call over several GPUs: frames sharded over len(devices) ranks, one-shot exchange of the W statistics
         # per iteration (include/snmf.h: snmf_sparse_nmf_multi_*; the MEX shim's opts.devices)
         devs = np.ascontiguousarray(np.asarray(devices, dtype=np.int32).reshape(-1))
+        # (the multi-device entry is in/out in W and H: it gets copies, inputs are never modified)
+        W, H = W.copy(order="F"), H.copy(order="F")
         fn = lib.snmf_sparse_nmf_multi_f64 if dt == np.float64 else lib.snmf_sparse_nmf_multi_f32
         _lib.check(fn(_ptr(devs), int(devs.size), C.byref(sp), _ptr(vv), ldv, _ptr(W), _ptr(H),
                       _ptr(sarr) if sarr is not None else None, _ptr(div), _ptr(cost), C.byref(n_iter)))
     else:
+        # out-of-place entry: init_w / init_h are read where they lie, the results land in fresh arrays (no host copy of init_h)
         ctx = ctx or default_context()
-        fn = lib.snmf_sparse_nmf_f64 if dt == np.float64 else lib.snmf_sparse_nmf_f32
-        _lib.check(fn(ctx._h, C.byref(sp), _ptr(vv), ldv, _ptr(W), _ptr(H),
-                      _ptr(sarr) if sarr is not None else None, _ptr(div), _ptr(cost), C.byref(n_iter)))
+        W0c, H0c = W, H
+        W = np.empty((m, r), dtype=dt, order="F")
+        H = np.empty((r, n), dtype=dt, order="F")
+        fn = lib.snmf_sparse_nmf_oop_f64 if dt == np.float64 else lib.snmf_sparse_nmf_oop_f32
+        _lib.check(fn(ctx._h, C.byref(sp), _ptr(vv), ldv, _ptr(W0c), _ptr(H0c), _ptr(sarr) if sarr is not None else None,
+                      _ptr(W), _ptr(H), _ptr(div), _ptr(cost), C.byref(n_iter)))
     ni = n_iter.value
     if p.get("display", 0) != 0:  # :162-164 default 0
         _display(beta, div, cost, ni, max_iter, cost_check, conv_eps, gpu_variant)
@@ -349,15 +364,6 @@ def run_basis_dnmf(Y, X, D, B, R_x, R_d, p, *, ctx=None, dtype=np.float64, devic
     p["init_h"] = A_hat[R_x:R_x + R_d, :]  # :52
     B_hat_d, _, _ = sparse_nmf(D, p, ctx=ctx, dtype=dtype, devices=devices)  # :53
     return np.concatenate([B_hat_x, B_hat_d], axis=1), A_hat  # :55
-
-
-def _colmajor(M, dt):
-    """M as a column-major array of dtype dt WITHOUT a copy when it already is one (possibly with a leading dimension larger
-    than its row count, e.g. the top rows of a taller Fortran array); a copy otherwise."""
-    M = np.asarray(M)
-    if M.ndim == 2 and M.dtype == dt and M.strides[0] == dt.itemsize and (M.shape[1] <= 1 or M.strides[1] >= M.shape[0] * dt.itemsize):
-        return M
-    return np.asfortranarray(M, dtype=dt)
 
 
 def _run_basis_dnmf_resident(Y, X, D, B, R_x, R_d, p, *, ctx, dtype, h0, want_a=True):
