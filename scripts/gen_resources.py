@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""profiles/<tag>_resources.csv: registers, spills, scratch and LDS of EVERY kernel instantiation in libsnmf_hip.so, generated from
+the compiler's own remarks (hipcc --cuda-device-only -Rpass-analysis=kernel-resource-usage over each translation unit) -- not
+narrated.  The instantiation each BASELINE config / shipped shape launches is marked in the `launched_by` column (the kernel
+names below are what se_snmf_nat_amd's plan.describe() and the rocprofv3 kernel traces under profiles/ show for those shapes).
+
+    python scripts/gen_resources.py [tag]        (no GPU needed: cross-compiles for gfx950)
+"""
+import csv
+import glob
+import os
+import re
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+CSRC = os.path.join(ROOT, "se_snmf_nat_amd", "csrc")
+OUT = os.path.join(ROOT, "profiles", f"{TAG}_resources.csv")
+
+# kernel (demangled prefix) -> the configs / shapes that launch it (from plan.describe() of those shapes and the committed traces)
+LAUNCHED = [
+    ("snmf::k_hstep_rp<true>", "C2 257x100000 r=256 KL (headline): H step, iterations with the objective"),
+    ("snmf::k_hstep_rp<false>", "C2: H step of iteration 1 / cost_check = 0"),
+    ("snmf::k_wstats<8, 4, 4, 2, 0, 1, false, 32, 0>", "C2: W statistics (full update: the objective rides on the H step)"),
+    ("snmf::k_wfin<1>", "C2 / a11 / C4 W-only: chunk reduction + W update (snmf_plan_run)"),
+    ("snmf::k_hstep_rh<true, true>", "a11 513x72000 r=100 KL full (run_basis_train.m:88): H step"),
+    ("snmf::k_wstats<4, 8, 4, 3, 0, 1, false, 32, 1>", "a11: W statistics"),
+    ("snmf::k_hstep_rh<true, false>", "C4 solve 1, 513x100000 r=200 H-only (run_basis_DNMF.m:40)"),
+    ("snmf::k_wstats<4, 8, 4, 3, 0, 1, true, 32, 1>", "C4 solves 2/3, 513x100000 r=100 W-only (run_basis_DNMF.m:47,53): statistics + objective"),
+    ("snmf::k_hstep<8, 1, 0, 2, true, true, false, 32>", "C5 513x500000 r=512 beta=2: H step"),
+    ("snmf::k_wstats<8, 4, 4, 2, 3, 2, false, 32, 0>", "C5: V*H' and H*H' (Gram) launches by kappa-groups"),
+    ("snmf::k_wfin<2>", "C5: chunk reduction + W update"),
+    ("snmf::k_hsolve_frame<8, 25, 1, true, true>", "C3 online: per-frame H-only solve 513x1 r=200 with reconstructions"),
+    ("snmf::k_hsolve_frame<8, 25, 1, true, false>", "C3: snmf_plan_solve_frames (no reconstructions)"),
+    ("snmf::k_wadapt", "C3 online: W-only adaptation solve 513x100 r<=50"),
+    ("snmf::k_opost", "C3 online: post-filter"),
+    ("snmf::k_hstep<4, 1, 0, 1, true, true, false, 32>", "C1 257x2000 r=40 KL: H step"),
+    ("snmf::k_wstats<4, 4, 0, 2, 0, 1, false, 32, 0>", "C1: W statistics"),
+]
+
+
+def one(src):
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value", "-I" + os.path.join(ROOT, "include"),
+           "-I" + CSRC, "--cuda-device-only", "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
+    pr = subprocess.run(cmd, stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+    if pr.returncode != 0:
+        sys.stderr.write(pr.stderr[-2000:])
+        raise SystemExit(f"{src}: compile failed")
+    rows, cur = [], None
+    for ln in pr.stderr.splitlines():
+        m = re.search(r"remark:\s+(Function Name|[A-Za-z ]+(?:\[[^\]]*\])?):\s*(\S+)", ln)
+        if not m:
+            continue
+        k, v = m.group(1).strip(), m.group(2)
+        if k == "Function Name":
+            cur = {"tu": os.path.basename(src), "mangled": v}
+            rows.append(cur)
+        elif cur is not None:
+            cur[k] = v
+    return rows
+
+
+srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+    allrows = [r for rows in ex.map(one, srcs) for r in rows]
+names = subprocess.run(["c++filt"], input="\n".join(r["mangled"] for r in allrows), stdout=subprocess.PIPE, text=True).stdout.splitlines()
+seen = set()
+out = []
+for r, nm in zip(allrows, names):
+    nm = re.sub(r"\(.*$", "", nm).replace("(anonymous namespace)::", "")
+    nm = re.sub(r"^void ", "", nm)
+    if nm in seen:
+        continue
+    seen.add(nm)
+    mark = "; ".join(d for k, d in LAUNCHED if nm == k or (not k.endswith(">") and nm.startswith(k)))
+    out.append([nm, r.get("VGPRs", ""), r.get("AGPRs", ""), r.get("TotalSGPRs", ""), r.get("SGPRs Spill", ""), r.get("VGPRs Spill", ""),
+                r.get("ScratchSize [bytes/lane]", ""), r.get("LDS Size [bytes/block]", ""), r.get("Occupancy [waves/SIMD]", ""), r["tu"], mark])
+out.sort(key=lambda x: (x[-1] == "", x[0]))
+with open(OUT, "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["kernel", "VGPRs", "AGPRs", "SGPRs", "SGPR_spill", "VGPR_spill", "scratch_bytes_per_lane", "static_LDS_bytes", "occupancy_waves_per_SIMD",
+                "translation_unit", "launched_by"])
+    w.writerows(out)
+unmatched = [k for k, _ in LAUNCHED if not any(o[0] == k or (not k.endswith(">") and o[0].startswith(k)) for o in out)]
+print(f"{OUT}: {len(out)} kernels, {sum(1 for o in out if o[5] not in ('', '0'))} with spilled VGPRs, {sum(1 for o in out if o[-1])} marked as launched by a BASELINE config")
+if unmatched:
+    print("WARNING: no kernel matched", unmatched)
+for o in out:
+    if o[-1]:
+        print("  %-58s VGPR %3s AGPR %3s SGPRspill %3s VGPRspill %3s scratch %3s  <- %s" % (o[0][:58], o[1], o[2], o[4], o[5], o[6], o[-1][:60]))

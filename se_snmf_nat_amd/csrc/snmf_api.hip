@@ -3,6 +3,7 @@
 // Orchestrates the kernels of snmf_kernels.h into the loop of the reference solver
 // (lordet01/SE_SNMF_NAT src/sparse_nmf.m:157-292).  No CPU compute fallback exists here: every
 // numeric step is a HIP kernel launch; without a device the entry points fail.
+#define SNMF_AUX_KERNELS 1  // this translation unit launches k_reduce, k_wapply, k_check, ... (snmf_kernels.h)
 #include "snmf_internal.h"
 #include "snmf_frontend.h"
 #include "snmf_generic.h"
@@ -304,7 +305,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         // loaders + double buffering when the accumulators allow 2 waves per SIMD and LDS has room; the loader waves
         // stage only the row group's 32 * NWB columns of V (the kernel's ldv), so F = 513 fits as well
         const size_t buf_ld = ((size_t)pl->TTW * pl->ldhw + (size_t)pl->TTW * 32 * pl->NWB) * 4;
-        pl->NLW = (pl->WPS == 2 && 2 * buf_ld + (size_t)pl->rp * 4 + 320 <= lds_cap) ? 4 : 0;
+        pl->NLW = (pl->WPS == 2 && 2 * buf_ld + (size_t)pl->rp * 4 + 512 + (size_t)pl->NWB * std::min(pl->rp, 256) * 4 <= lds_cap) ? 4 : 0;
         // (loader waves pay from the second tile of a workgroup on; with one tile each -- C1: 63 tiles -- the synchronous
         //  4-wave geometry is faster: 12.7 us against 16.4)
         if (n_tiles_w <= ctx->n_cu / std::max(1, ((pl->nf + 3) / 4) * pl->n_kg)) pl->NLW = 0;
@@ -318,7 +319,13 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         // (the fixed-order sums at the end of the kernel use [4][rp] floats / one double per thread of the same memory)
         // (+ ready/done slots + the extra row's V values [2][32] + the consumers' partial extra rows of the slab, NK <= 8)
         const size_t gxs = pl->NKT <= 8 ? (size_t)pl->NWB * std::min(pl->rp, 256) * 4 : 0;
-        pl->lds_w = std::max<size_t>(std::max<size_t>((pl->NLW ? 2 * buf_ld : buf) + (size_t)pl->rp * 4 + 320 + gxs,
+        // a THIRD tile buffer where it fits (r <= 128 at F = 513, C2's geometry): the loader waves then stage two tiles ahead
+        // and the consumers stop waiting for `ready` (k_wstats; SNMF_WSTATS_NBUF=2 keeps two)
+        const size_t tail = (size_t)pl->rp * 4 + 512 + gxs;  // extra row of W, progress slots + the extra row's V values, gxs
+        pl->nbw = pl->NLW ? 2 : 1;
+        if (pl->NLW && 3 * buf_ld + tail <= lds_cap) pl->nbw = 3;
+        if (const char* e = getenv("SNMF_WSTATS_NBUF")) if (pl->NLW && atoi(e) == 2) pl->nbw = 2;
+        pl->lds_w = std::max<size_t>(std::max<size_t>((pl->NLW ? pl->nbw * buf_ld : buf) + tail,
                                                       (size_t)std::max(4, pl->NWB) * pl->rp * 4),
                                      (size_t)(pl->NWB + pl->NLW) * 64 * sizeof(double));
     }
@@ -352,6 +359,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         pl->stagger_h = (pl->grid_h > ctx->n_cu) ? mf_h * 64 : 0;
         const int mf_w = pl->rp / 2 + 16 * pl->NKT;
         pl->stagger_w = 0;
+        if (const char* e = getenv("SNMF_WSTAG")) pl->stagger_w = atoi(e);  // (experiment: intra-workgroup stagger of k_wstats' second consumer wave per SIMD, cycles)
         (void)mf_w;
     }
     if (pl->lds_w > lds_cap && pl->upd_w) pl->generic = true;  // r too large for k_wstats' H image
@@ -361,7 +369,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         // spilled VGPRs) is replaced for this launch by <8,4,4,2> with double-buffered LDS-DMA staging
         pl->kq_kg = (pl->nk + 7) / 8;
         pl->kq_chunks = std::max(1, std::min(std::min(n_tiles_w, pl->n_chunks), ctx->n_cu / std::max(1, pl->n_fg * pl->kq_kg)));
-        pl->kq_lds = (size_t)2 * 32 * (260 + 32 * 4) * 4 + (size_t)pl->rp * 4 + 320 + (size_t)4 * 256 * 4;
+        pl->kq_lds = (size_t)2 * 32 * (260 + 32 * 4) * 4 + (size_t)pl->rp * 4 + 512 + (size_t)4 * 256 * 4;
     }
     // Euclidean full updates: P through the Gram matrix (launch_gram_p) wherever it is the cheaper form (2 r^2 T against
     // 4 F T r; W-only solves take their objective from the P launch's Lam' and keep it)
@@ -684,6 +692,7 @@ StepArgs make_args(snmf_plan* pl) {
     a.part = pl->part;
     a.stop = &pl->st->stop;
     a.stagger_shift = -1;
+    a.nbuf = 2;
     a.prof = pl->prof;
     a.wx = pl->wx;
     a.Fm = pl->Fm;

@@ -108,6 +108,7 @@ struct snmf_plan {
     float* part_buf = nullptr;     // partial numerators of the split tiles [rp_grid][32][rp]
     unsigned* part_cnt = nullptr;  // arrivals per split tile (monotonic)
     int NKT = 8, NWB = 4, WPS = 2, NLW = 0;  // k_wstats template geometry (NLW loader waves)
+    int nbw = 2;                             // k_wstats tile buffers in LDS with loader waves (3 where they fit)
     int n_fg = 1, n_kg = 1, n_chunks = 1;
     int n_ch1 = 0;  // k_wstats: chunks of row group 1 when the two row groups are split unevenly (else 0)
     // beta = 2, r > 256: the V*H^T launch (needs no Lam') runs the loader-wave geometry <8,4,4,2> once per 256-column

@@ -148,6 +148,7 @@ struct StepArgs {
     int n_ch1;            // k_wstats: > 0 = row group 1 has its own, smaller, number of frame chunks (1-D grid)
     int lxh;              // k_hstep_rh: P2 cut over the contraction, leftover columns on the VALU (nk = 4, r = 97..100)
     int kc;               // k_wstats, WM = 3 (V * H^T needs no Lam'): each kappa-group stages only ITS 32*NK columns of H
+    int nbuf;             // k_wstats with loader waves: tile buffers in LDS (2, or 3 where they fit: the loaders then run two tiles ahead)
     int F, T, Fp, rp, Tp, nf, nk;
     int nqk;              // 8-deep k-blocks of the contractions over the components = ceil(r / 8): W's columns / H's rows
                           // r .. rp-1 are zero padding, so the blocks past it (r = 100: 3 of 16) only add zeros and are skipped
@@ -2693,7 +2694,11 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
                                                                  int n_mat) {
     static_assert(TT == 32 || (TT == 16 && NL == 0), "narrow tiles: 16 frames, synchronous staging");
     constexpr int NTHR = (NWB + NL) * 64;
-    constexpr int NBUF = NL > 0 ? 2 : 1;
+    // Tile buffers: 1 without loader waves; with them 2, or 3 where the LDS has room (host: a.nbuf).  With two buffers the DMA
+    // of tile i+1 can only be issued once the SLOWEST consumer has finished tile i-1 and must have landed before the fastest
+    // finishes tile i: the consumers of a11 (513 x 72000, r = 100) spent 11.6 % of their time waiting for `ready` (phase stamps
+    // of the diagnostic build).  With three the loaders run up to two tiles ahead and the wait disappears.
+    const int NBUF = NL > 0 ? (a.nbuf == 3 ? 3 : 2) : 1;
     if (a.stop && *a.stop) return;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // V image: only the columns of this workgroup's row group are staged, so it is [TT][32 * NWB] (F = 513, four row
@@ -2738,7 +2743,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     if (do_x && WM != 3)
         for (int k = threadIdx.x; k < rp; k += NTHR) wxs[k] = a.wx[k];
     if (GXL && do_x)  // (the consumers' partial extra rows start at zero; a barrier separates this from their first use)
-        for (int k = threadIdx.x; k < NWB * gxw; k += NTHR) (lds + NBUF * TT * (a.ldh + 32 * NWB) + a.rp + 80)[k] = 0.f;
+        for (int k = threadIdx.x; k < NWB * gxw; k += NTHR) (lds + NBUF * TT * (a.ldh + 32 * NWB) + a.rp + 128)[k] = 0.f;
     const int phi = by * NWB + w;
     const int fc = w * 32 + fl;  // this lane's column of the staged V image
     const bool active = !is_loader && phi < a.nf;
@@ -2780,8 +2785,8 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     static_assert(NL == 0 || (NL == 4 && (NWB == 4 || NWB == 8)), "progress slots: four per loader role, NWB consumers");
     unsigned* ready = reinterpret_cast<unsigned*>(wxs + rp);  // [4] loader waves: tiles staged
     unsigned* done = ready + 4;                               // [NWB] consumer waves: tiles finished
-    float* vx = reinterpret_cast<float*>(done + NWB);         // [2][32] V of the extra row, one value per frame (DMA loaders)
-    float* gxs = wxs + rp + 80;                               // [NWB][gxw] partial extra row of the slab per consumer wave (GXL)
+    float* vx = reinterpret_cast<float*>(done + NWB);         // [NBUF][32] V of the extra row, one value per frame (DMA loaders)
+    float* gxs = wxs + rp + 128;                              // [NWB][gxw] partial extra row of the slab per consumer wave (GXL)
     // (the read-modify-write is inline assembly: as C++ stores into the LDS array inside the tile loop they alias every
     //  tile read as far as the compiler knows, and the 168-VGPR geometries went from 16 to 211 spilled registers)
     const unsigned gxa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(gxs + w * gxw + 4 * lane);
@@ -2870,7 +2875,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         // the V block crosses L2 once per iteration instead of twice (447 -> 344 MB per launch on C2)
         const int c0 = by * NWB * 32;                                  // first column (float) of the group
         const int cw = (a.Fm - c0 < NWB * 32 ? a.Fm - c0 : NWB * 32);  // its width in floats (multiple of 32)
-        auto dma_tile = [&](int tile, float* dst) {
+        auto dma_tile = [&](int tile, float* dst, int bi) {
             const __amdgpu_buffer_rsrc_t rh =
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Hin + (size_t)tile * TT * rp), 0, TT * rp * 4, 0x00020000);
             const int pc0 = kc ? (int)blockIdx.z : 0, pcn = kc ? 1 : npc;  // kc: only this kappa-group's 1 KiB piece of every row
@@ -2887,7 +2892,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(dst + TT * ldh + t * ldv + pc * 256), 16, lane * 16,
                                                                  (t * Fp + c0 + pc * 256) * 4, 0, 0);
             if (do_x && lw == 0 && lane < TT)  // one dword per frame: V[Fm, t] -> vx[buffer][t]
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(vx + (dst == lds ? 0 : 32)), 4, lane * Fp * 4, a.Fm * 4, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(vx + bi * 32), 4, lane * Fp * 4, a.Fm * 4, 0, 0);
         };
         auto sums_of = [&](const float* H) {
             if (!do_s) return;
@@ -2901,27 +2906,43 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
                     }
         };
         if (tb < te) {
-            dma_tile(tb, lds);
+            dma_tile(tb, lds, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing else orders a ds_read behind an LDS-DMA
             sums_of(lds);
             rp_post(ready, lw, 1u, lane);
         }
+        int nb = 0;  // buffer of the tile being staged: tile `it + 1` of the chunk lives in buffer (it + 1) % NBUF
         for (int tile = tb, it = 0; tile + 1 < te; ++tile, ++it) {
-            float* nH = lds + ((it & 1) ^ 1) * bufsz;
-            rp_await(done, (unsigned)it, a.stop);  // every consumer has finished tile-1, which lives in nH
-            if (NWB == 8) rp_await(done + 4, (unsigned)it, a.stop);
-            dma_tile(tile + 1, nH);
+            nb = nb + 1 == NBUF ? 0 : nb + 1;
+            float* nH = lds + nb * bufsz;
+            // the buffer's last tenant was tile it + 1 - NBUF: every consumer must have finished it + 2 - NBUF tiles
+            if (it + 2 - NBUF > 0) {
+                rp_await(done, (unsigned)(it + 2 - NBUF), a.stop);
+                if (NWB == 8) rp_await(done + 4, (unsigned)(it + 2 - NBUF), a.stop);
+            }
+            dma_tile(tile + 1, nH, nb);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             sums_of(nH);
             rp_post(ready, lw, (unsigned)(it + 2), lane);
         }
     }
 
+    // Two consumer waves per SIMD (NWB = 8) start together and do identical work, so left alone they run in LOCKSTEP: both wait
+    // for the first W fragments of P3 at the same time, both sit in their epilogues at the same time -- every latency is
+    // exposed on both at once and the SIMD idles (a11: 20 % of its cycles with neither an MFMA nor a VALU instruction in
+    // flight, rocprofv3 PMC).  Nothing synchronises the consumers with each other, so a one-off delay of the second wave of
+    // each SIMD at kernel start persists for the whole chunk: one wave's stalls then fall into the other's MFMA loops.
+    if (NL > 0 && NWB == 8 && !is_loader && w >= 4 && a.stagger > 0 && tb < te) {
+        const unsigned long long ts = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - ts < (unsigned long long)a.stagger) __builtin_amdgcn_s_sleep(16);
+    }
     SNMF_STAMP_DECL
+    int cb = NL > 0 ? NBUF - 1 : 0;  // buffer of the consumers' current tile (advanced at the loop top)
     for (int tile = tb, it = 0; tile < te && !is_loader; ++tile, ++it) {
         const int t0 = tile * TT;
         SNMF_STAMP(0);
-        float* Hs = lds + (NL > 0 ? (it & 1) * bufsz : 0);  // [32][ldh]
+        if (NL > 0) cb = cb + 1 == NBUF ? 0 : cb + 1;
+        float* Hs = lds + cb * bufsz;  // [32][ldh]
         float* Vs = Hs + TT * ldh;                            // [TT][ldv]  (no HBM access in the MFMA loops)
         if (NL == 0) {
             __syncthreads();
@@ -2962,7 +2983,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
                 }
             }
         }
-        if (do_x) xrow_tile(Hs, t0, w, vx + (NL > 0 ? (it & 1) * 32 : 0));
+        if (do_x) xrow_tile(Hs, t0, w, vx + cb * 32);
         SNMF_STAMP(2);
         if (!active) {
             if (NL > 0) rp_post(done, w, (unsigned)(it + 1), lane);
@@ -3248,6 +3269,7 @@ struct ReduceArgs {
     DevState* st;
 };
 
+#ifdef SNMF_AUX_KERNELS  // k_reduce .. k_mdi_start: launched by snmf_api.hip only (the other translation units skip their code generation)
 static __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
     if (a.stop && *a.stop) return;
     const size_t nel = (size_t)a.rp * a.Fp;   // multiple of 4
@@ -3371,6 +3393,7 @@ static __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
         }
     }
 }
+#endif  // SNMF_AUX_KERNELS (k_reduce)
 
 struct ApplyArgs {
     const double* stats;
@@ -3502,6 +3525,7 @@ __device__ __forceinline__ void wapply_column(const ApplyArgs& a, int k, int tid
     }
 }
 
+#ifdef SNMF_AUX_KERNELS
 static __global__ __launch_bounds__(256) void k_wapply(ApplyArgs a) {
     __shared__ double red[3][256];
     if (!a.init_mode && a.st->stop) return;  // normalising a fresh W never depends on an earlier solve's flag
@@ -3520,6 +3544,7 @@ static __global__ __launch_bounds__(256) void k_wapply(ApplyArgs a) {
     const double sk = (a.n_mat == 2 || a.init_mode) ? 0.0 : a.stats[nel * a.n_mat + k];
     wapply_column(a, k, tid, Q, P, sk, red);
 }
+#endif  // SNMF_AUX_KERNELS (k_wapply)
 
 // ============================================================================================
 // k_wfin: k_reduce and k_wapply in ONE launch, for the loop of a single device (snmf_plan_run): nothing is exchanged
@@ -3649,6 +3674,7 @@ __global__ __launch_bounds__(768) void k_wfin(ReduceArgs ra, ApplyArgs a) {
 }
 
 
+#ifdef SNMF_AUX_KERNELS
 // Convergence check alone (H-only mode and the final objective pass): one thread.
 static __global__ void k_check(const double* stats, size_t sc_off, double* divh, double* costh, DevState* st, int it,
                         double conv_eps) {
@@ -3703,6 +3729,7 @@ static __global__ void k_collect(const DevState* st, const double* costh, int n_
         cost_out[b] = (cost_check && st[b].n_iter > 0) ? costh[(size_t)b * max_iter + st[b].n_iter - 1] : 0.0;
     }
 }
+#endif  // SNMF_AUX_KERNELS (k_check, k_scale_h, k_sum_sh, k_fold_sh, k_collect)
 // H[0][(s*tps + t)*rp + k] = H0[t*r + k] * wn[k]: the same initial activations for every solve,
 // already rescaled by the column norms of init_w (src/sparse_nmf.m:160)
 template <typename TIn>
@@ -3747,12 +3774,14 @@ __global__ void k_unpack(const TSrc* __restrict__ src, int rowsP, int rows, int 
 }
 
 // ---- MDI helpers (src/snmf_mdi.m) ---------------------------------------------------------------
+#ifdef SNMF_AUX_KERNELS
 // v = max(v .* M, flr) on the real entries (:175); pads stay zero
 static __global__ void k_mdi_start(float* V, const float* __restrict__ M, int Fp, int F, int T, float flr) {
     const size_t n = (size_t)Fp * T;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         if ((int)(i % Fp) < F) V[i] = fmaxf(V[i] * M[i], flr);
 }
+#endif  // SNMF_AUX_KERNELS (k_mdi_start)
 
 // v_MDI = max(v.*M + Nt .* max(w*h,flr) .* (1-M), flr),  Nt = sum(v.*M) ./ max(sum(max(w*h,flr).*M), flr)  (:298-306)
 // One 256-thread workgroup per group of NC columns; W from its fp32 column-major copy, h columns in LDS.

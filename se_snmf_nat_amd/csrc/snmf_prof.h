@@ -68,6 +68,30 @@ static void snmf_prof_report(snmf_plan* pl) {
                 fprintf(stderr, " ; by blockIdx/32:");
                 for (int x = 0; x < 8; ++x) fprintf(stderr, " %.1f", ng[x] ? sg[x] / ng[x] : 0.0);
             }
+            if (wlast && !st.empty()) {
+                // k_wstats: wave end times by (row group, tiles in the workgroup's chunk) and by blockIdx % 8 (XCD)
+                const int nt = (pl->p.T + pl->TTW - 1) / pl->TTW;
+                std::map<std::pair<int, int>, std::pair<double, double>> agg;  // -> (sum, max)
+                std::map<std::pair<int, int>, int> cnt;
+                double sx[8] = {0}, nx[8] = {0}, mx[8] = {0};
+                for (int i = 0; i < nw; ++i) {
+                    if (!hs0[i]) continue;
+                    const int wg = i / pl->NWB;
+                    int grp = 0, chunk = wg, nch = pl->n_chunks;
+                    if (pl->n_ch1 > 0) {
+                        if (wg >= pl->n_chunks) { grp = 1 + (wg - pl->n_chunks) / pl->n_ch1; chunk = (wg - pl->n_chunks) % pl->n_ch1; nch = pl->n_ch1; }
+                    } else { grp = wg / pl->n_chunks; chunk = wg % pl->n_chunks; }
+                    const int tiles = (int)(((long long)nt * (chunk + 1)) / nch) - (int)(((long long)nt * chunk) / nch);
+                    const double e = (double)(hs0[i] - t0 + hc[2 * i + 1]) * 0.01;
+                    auto& a2 = agg[{grp, tiles}];
+                    a2.first += e; a2.second = std::max(a2.second, e); cnt[{grp, tiles}] += 1;
+                    sx[wg % 8] += e; nx[wg % 8] += 1; mx[wg % 8] = std::max(mx[wg % 8], e);
+                }
+                fprintf(stderr, " | end us by (group, tiles): ");
+                for (auto& kv : agg) fprintf(stderr, "(g%d, %d tiles, %d waves): mean %.1f max %.1f; ", kv.first.first, kv.first.second, cnt[kv.first], kv.second.first / cnt[kv.first], kv.second.second);
+                fprintf(stderr, "| by blockIdx%%8 mean/max:");
+                for (int x = 0; x < 8; ++x) fprintf(stderr, " %.1f/%.1f", nx[x] ? sx[x] / nx[x] : 0.0, mx[x]);
+            }
             if (!st.empty()) {
                 std::sort(st.begin(), st.end());
                 std::sort(en.begin(), en.end());

@@ -11,6 +11,7 @@ int launch_wstats(snmf_plan* pl, bool obj) {
     a.n_tiles = (pl->p.T + pl->TTW - 1) / pl->TTW;
     a.ldh = pl->ldhw;
     a.stagger = pl->stagger_w;
+    a.nbuf = pl->nbw;
 
     ScopedTimer tm(pl->ctx, FAM_WSTATS);
     if (pl->NKT == 4) return launch_wstats_nk4(pl, a, obj);

@@ -36,6 +36,7 @@ static int launch_gram_p(snmf_plan* pl, const StepArgs& a) {
     if (pl->kq_kg) {  // r > 256: by kappa-groups on the loader-wave geometry, like the Q launch
         ag.ldh = 260;
         ag.kc = 1;
+        ag.nbuf = 2;  // (kq_lds holds two tile buffers)
         auto kern = k_wstats<8, 4, 4, 2, 3, BM_EUC, false, 32>;
         SN_TRY(ensure_dyn_lds(pl->ctx->device, (const void*)kern, pl->kq_lds));
         hipLaunchKernelGGL(kern, dim3(pl->gram_chunks, (ag.nf + 3) / 4, pl->kq_kg), dim3(512), pl->kq_lds, pl->ctx->stream, ag,
@@ -87,6 +88,7 @@ static int launch_wstats_geo(snmf_plan* pl, const StepArgs& a, bool obj) {
             StepArgs aq = a;
             aq.ldh = 260;
             aq.kc = 1;
+            aq.nbuf = 2;
             aq.n_ch1 = 0;
             auto kern = k_wstats<8, 4, 4, 2, 3, BM_EUC, false, 32>;
             SN_TRY(ensure_dyn_lds(pl->ctx->device, (const void*)kern, pl->kq_lds));
