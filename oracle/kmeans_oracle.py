@@ -24,8 +24,19 @@ def _batch(X, C, max_iter):
         counts = [new.count(j) for j in range(k)]
         for j in range(k):
             if counts[j] == 0:
-                far = max(range(n), key=lambda i: (own[i] if counts[new[i]] > 1 else -1.0, -i))  # donor keeps a member
-                counts[new[far]] -= 1
+                # 'emptyaction','singleton' as MATLAB's kmeans documents and implements it (batch phase): the observation
+                # furthest from its current centroid founds the new cluster -- [dlarge, lonely] = max(d) over ALL observations --
+                # and "in the very unusual event that the cluster had only one member, pick any other non-singleton point":
+                # from = find(m > 1, 1, 'first'); lonely = find(idx == from, 1, 'first').
+                far = 0
+                for i in range(1, n):
+                    if own[i] > own[far]:
+                        far = i
+                frm = new[far]
+                if counts[frm] < 2:
+                    frm = next(c for c in range(k) if counts[c] > 1)
+                    far = next(i for i in range(n) if new[i] == frm)
+                counts[frm] -= 1
                 new[far] = j
                 counts[j] = 1
                 own[far] = 0.0

@@ -110,6 +110,10 @@ struct snmf_multi {
     std::vector<hipEvent_t> ev[2];    // ev[parity][rank]: "rank has pushed"  (EVENTS mode)
     int mode = 0;                     // SNMF_EXCHANGE_FLAGS / _EVENTS (resolved from AUTO at creation)
     bool shared_dev = false;          // two ranks on one device: submissions of push and sum are ordered by the host in every mode
+    // every gather buffer and arrival word is fine-grained (coherent) device memory.  If the runtime refused one of them the
+    // buffers are coarse-grained: a kernel that POLLS them while peers write (FLAGS) could see the flag and still read stale
+    // slot lines from its L2, so only EVENTS ordering -- a kernel boundary between push and sum -- is allowed then.
+    bool fine_grained = true;
     unsigned xseq = 0;                // exchanges issued so far (the next one is number xseq + 1)
     std::vector<uint8_t> w_ind, h_ind;
     size_t len = 0, xoff = 0, xlen = 0;  // statistics length; the exchanged part [xoff, xoff + xlen)
@@ -240,10 +244,12 @@ extern "C" int snmf_multi_create(const int32_t* devices, int32_t n_dev, const sn
             const size_t sb = (size_t)2 * n_dev * m->xlen * sizeof(double), fb = ((size_t)2 * n_dev + 1) * sizeof(unsigned);
             if (hipExtMallocWithFlags((void**)&m->slots[g], sb, hipDeviceMallocFinegrained) != hipSuccess) {
                 (void)hipGetLastError();
+                m->fine_grained = false;  // (coarse-grained memory: only EVENTS ordering is safe, see snmf_multi_set_exchange)
                 s = dalloc(&m->slots[g], (size_t)2 * n_dev * m->xlen);
             }
             if (s == SNMF_OK && hipExtMallocWithFlags((void**)&m->flags[g], fb, hipDeviceMallocFinegrained) != hipSuccess) {
                 (void)hipGetLastError();
+                m->fine_grained = false;
                 s = dalloc(&m->flags[g], (size_t)2 * n_dev + 1);
             }
             if (s == SNMF_OK) hipMemset(m->flags[g], 0, fb);
@@ -275,6 +281,7 @@ extern "C" int snmf_multi_create(const int32_t* devices, int32_t n_dev, const sn
         g_err = keep;
         return s;
     }
+    if (!m->fine_grained) m->mode = SNMF_EXCHANGE_EVENTS;  // (AUTO resolved above before the allocations were known)
     *out = m;
     return SNMF_OK;
 }
@@ -288,8 +295,10 @@ extern "C" int snmf_multi_set_exchange(snmf_multi* m, int32_t mode) {
         bool distinct = true;
         for (int g = 0; g < m->n; ++g)
             for (int q = 0; q < g; ++q) distinct = distinct && m->dev[g] != m->dev[q];
-        mode = distinct ? SNMF_EXCHANGE_FLAGS : SNMF_EXCHANGE_EVENTS;
+        mode = (distinct && m->fine_grained) ? SNMF_EXCHANGE_FLAGS : SNMF_EXCHANGE_EVENTS;
     }
+    if (mode == SNMF_EXCHANGE_FLAGS && !m->fine_grained)
+        return fail(SNMF_ERR_UNSUPPORTED, "FLAGS ordering needs fine-grained gather buffers, which this runtime refused to allocate (EVENTS is in use)");
     m->mode = mode;
     return SNMF_OK;
 }

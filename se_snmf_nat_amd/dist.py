@@ -145,7 +145,20 @@ class ShardedTrainer:
         return self.plan.get_w(), self.plan.get_h(), self.plan.get_objective()
 
 
-def run_basis_dnmf_sharded(Y_local, X_local, D_local, B, R_x, R_d, p, *, device=0, group=None):
+def h0_columns(seed, r, t0, n_cols, T_total):
+    """Columns [t0, t0 + n_cols) of the r x T_total matrix the UNSHARDED mirror draws for rand(r, n) of solve 1
+    (api.sparse_nmf: RandomState(seed).random_sample((r, T_total)), src/sparse_nmf.m:112-114,:133-134), so that a sharded run
+    starts from the same numbers whatever the number of ranks.  NumPy fills row by row: row k of the block is a slice of the
+    k-th run of T_total draws (the stream has no jump-ahead, so every rank walks the whole stream once: host work, 80 ms at
+    BASELINE config 4; api.run_basis_dnmf(..., h0="device") avoids host draws altogether)."""
+    rs = np.random.RandomState(seed if seed > 0 else None)
+    H0 = np.empty((int(r), int(n_cols)), order="F")
+    for k in range(int(r)):
+        H0[k] = rs.random_sample(int(T_total))[t0:t0 + n_cols]
+    return H0
+
+
+def run_basis_dnmf_sharded(Y_local, X_local, D_local, B, R_x, R_d, p, *, device=0, group=None, columns=None):
     """The 3-solve loop of run_basis_DNMF.m:36-55 with the frame axis sharded over the ranks of
     `group` (BASELINE config 4): every rank passes ITS columns of the mixture / clean / noise
     features and the replicated exemplar basis B (F x (R_x+R_d)).
@@ -154,6 +167,7 @@ def run_basis_dnmf_sharded(Y_local, X_local, D_local, B, R_x, R_d, p, *, device=
       2. W-only on X with H = A_hat(1:R_x,:) (:43-47)   -- one all-reduce of the statistics / iteration
       3. W-only on D with H = A_hat(R_x+1:end,:) (:49-53)
 
+    columns = (t0, T_total): where this rank's columns sit in the whole problem (for the initial activations of solve 1).
     Returns (B_hat [replicated, bit-identical on every rank], A_hat_local)."""
     def beta_of(p):
         cf = p.get("cf", "kl")
@@ -163,8 +177,12 @@ def run_basis_dnmf_sharded(Y_local, X_local, D_local, B, R_x, R_d, p, *, device=
                   conv_eps=float(p.get("conv_eps", 0)), cost_check=bool(p["cost_check"]), device=device, group=group)
     B = np.asarray(B, dtype=np.float64)
     r = R_x + R_d
-    rs = np.random.RandomState(int(p.get("random_seed", 1)) or None)
-    H0 = rs.random_sample((r, np.asarray(Y_local).shape[1]))  # stand-in for rand(r,n) (src/sparse_nmf.m:133-134)
+    # rand(r, n) of solve 1 (src/sparse_nmf.m:133-134): every rank takes ITS columns [t0, t0 + T_loc) of the draw the unsharded
+    # call makes for the whole T, so that B_hat does not depend on the number of GPUs (with early stops a different start
+    # ends elsewhere).  `columns` = (t0, T_total) of this rank; default: an unsharded call.
+    T_loc = np.asarray(Y_local).shape[1]
+    t0, T_total = columns if columns is not None else (0, T_loc)
+    H0 = h0_columns(int(p.get("random_seed", 1)), r, int(t0), T_loc, int(T_total))
     t1 = ShardedTrainer(Y_local, B, H0, w_update_ind=np.zeros(r, bool), h_update_ind=np.ones(r, bool), **common)
     t1.run()
     _, A_hat, _ = t1.result()

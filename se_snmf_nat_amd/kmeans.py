@@ -11,7 +11,8 @@ restates the documented behaviour of MATLAB's kmeans for exactly these options:
   * 'start','cluster': a preliminary clustering on a random 10 % subsample (itself started from k random observations)
     when that subsample has more than k observations, else k observations of X at random;
   * 'onlinephase','off': batch updates only (assign all, then move all), at most 100 iterations (MaxIter default);
-  * 'emptyaction','singleton': an empty cluster is re-created from the one observation furthest from its centroid.
+  * 'emptyaction','singleton': an empty cluster is re-created from the one observation furthest from its centroid
+    (over all observations; should that one be its cluster's only member: the first member of the first cluster with two).
 MATLAB's random stream cannot be reproduced, so the draws come from a seeded NumPy generator: the
 result is the reference's ALGORITHM on its data, not MATLAB's bits.  tests/test_kmeans.py checks it against an
 independent loop restatement (oracle/kmeans_oracle.py) and by its invariants.
@@ -42,14 +43,19 @@ def _batch_phase(X, C, max_iter):
         D = _cityblock(X, C)
         new = D.argmin(1)
         own = D[np.arange(n), new]
-        # 'singleton': every empty cluster takes the observation that is furthest from its own centroid
+        # 'singleton' as MATLAB's kmeans implements it in the batch phase: every empty cluster is re-created from the observation
+        # furthest from its current centroid, [dlarge, lonely] = max(d) over ALL observations (first maximum); "in the very
+        # unusual event that the cluster had only one member, pick any other non-singleton point": from = find(m > 1, 1,
+        # 'first'), lonely = find(idx == from, 1, 'first') -- so the repair never empties its donor (n >= k: while a cluster
+        # is empty another holds two).
         counts = np.bincount(new, minlength=k)
-        # -- taken from a cluster that keeps at least one member (n >= k: while a cluster is empty another holds two), so
-        # the repair can never empty its donor (duplicate observations make every own-distance 0 and argmax would then
-        # pick a singleton's only member: a NaN centroid)
         for j in np.flatnonzero(counts == 0):
-            far = int(np.where(counts[new] > 1, own, -1.0).argmax())
-            counts[new[far]] -= 1
+            far = int(own.argmax())
+            frm = int(new[far])
+            if counts[frm] < 2:
+                frm = int(np.flatnonzero(counts > 1)[0])
+                far = int(np.flatnonzero(new == frm)[0])
+            counts[frm] -= 1
             new[far] = j
             counts[j] = 1
             own[far] = 0.0

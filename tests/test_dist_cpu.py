@@ -119,3 +119,17 @@ def test_shard_bounds_cover():
             b = [shard_bounds(T, ws, r) for r in range(ws)]
             assert b[0][0] == 0 and b[-1][1] == T
             assert all(b[i][1] == b[i + 1][0] for i in range(ws - 1))
+
+
+def test_sharded_initial_activations_are_the_unsharded_draw():
+    """dist.h0_columns: the column blocks the ranks draw for rand(r, n) of solve 1 (src/sparse_nmf.m:133-134) are the columns of
+    the ONE matrix the unsharded mirror draws, for any world size -- so the sharded DNMF loop does not depend on the number of GPUs."""
+    from se_snmf_nat_amd.dist import h0_columns, shard_bounds
+    r, T, seed = 7, 101, 3
+    full = np.random.RandomState(seed).random_sample((r, T))
+    for world in (1, 2, 3, 8):
+        parts = []
+        for rank in range(world):
+            t0, t1 = shard_bounds(T, world, rank)
+            parts.append(h0_columns(seed, r, t0, t1 - t0, T))
+        assert np.array_equal(np.concatenate(parts, axis=1), full)

@@ -197,3 +197,54 @@ def test_bench_single_gpu_line_keeps_the_contract():
     assert "separate" in rf["kernel_ms_note"].lower() and "traffic_source" in rf
     cb = d["cpu_baseline"]
     assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("port", "reference") and cb["sample"]
+
+
+def _dnmf_worker(rank, world, port, prob, q):
+    import torch
+    import torch.distributed as dist
+    from se_snmf_nat_amd.dist import run_basis_dnmf_sharded, shard_bounds
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    Y, X, D, B, R_x, R_d, p = prob
+    T = Y.shape[1]
+    t0, t1 = shard_bounds(T, world, rank)
+    B_hat, A_loc = run_basis_dnmf_sharded(Y[:, t0:t1], X[:, t0:t1], D[:, t0:t1], B, R_x, R_d, p, device=0, columns=(t0, T))
+    q.put((rank, B_hat, A_loc))
+    dist.barrier()
+    dist.destroy_process_group()
+    torch.cuda.synchronize()
+
+
+def test_sharded_dnmf_loop_world2_equals_the_unsharded_call(gpu_ctx):
+    """run_basis_DNMF.m:36-55 with the frames sharded over two ranks (gloo, one GPU) against the unsharded host mirror: every
+    rank starts solve 1 from ITS columns of the unsharded call's rand(r, n) (dist.h0_columns), so A_hat -- frames are
+    independent given W, nothing but the two cost scalars is exchanged -- comes out BIT FOR BIT the same for any number of
+    ranks, early stop included; B_hat's statistics are summed in another order (per rank, then across ranks: fp64), which
+    moves W by a few fp32 ulp."""
+    import torch.multiprocessing as mp
+    from se_snmf_nat_amd import run_basis_dnmf
+    rs = np.random.default_rng(8)
+    F, T, R_x, R_d = 513, 900, 12, 9
+    X = rs.gamma(0.5, 1.0, (F, 6)) @ rs.gamma(0.3, 1.0, (6, T)) + 1e-9
+    D = rs.gamma(0.5, 1.0, (F, 5)) @ rs.gamma(0.3, 1.0, (5, T)) + 1e-9
+    Y = X + D
+    B = rs.random((F, R_x + R_d)) + 0.05
+    p = dict(cf="kl", sparsity=5, max_iter=40, conv_eps=1e-3, cost_check=1, random_seed=1)
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dnmf_worker, args=(rk, world, port, (Y, X, D, B, R_x, R_d, p), q)) for rk in range(world)]
+    for pr in procs:
+        pr.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda x: x[0])
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    B1, A1 = run_basis_dnmf(Y, X, D, B, R_x, R_d, p, ctx=gpu_ctx)
+    A = np.concatenate([r_[2] for r_ in res], axis=1)
+    assert np.array_equal(res[0][1], res[1][1]), "replicas of B_hat must be bit-identical across ranks"
+    assert np.array_equal(A, A1)
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    assert rel(res[0][1], B1) < 5e-6
