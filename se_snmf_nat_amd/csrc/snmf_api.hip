@@ -297,7 +297,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     pl->n_kg = (pl->nk + pl->NKT - 1) / pl->NKT;
     pl->n_fg = (pl->nf + pl->NWB - 1) / pl->NWB;
     // H image of k_wstats: rows padded to whole NKT-tile groups (branch-free P4, see the kernel)
-    pl->ldhw = std::max(pl->rp, 32 * pl->NKT * pl->n_kg) + 4;
+    pl->ldhw = std::max(pl->rp, 32 * pl->NKT * pl->n_kg) + 4;  // (NKT = 4: always 132 -- k_wstats<4, ...> has it as a compile-time constant)
     if (((size_t)32 * pl->ldhw + (size_t)32 * 32 * pl->NWB) * 4 + (size_t)pl->rp * 4 + 320 > lds_cap && pl->NKT == 16)
         pl->TTW = 16;  // large r: 16-frame tiles (the 32-frame H + V images do not fit the LDS)
     const int n_tiles_w = (T + pl->TTW - 1) / pl->TTW;  // tiles that hold a frame (an all-padding tile adds exact zeros: skipped)
@@ -338,7 +338,11 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     pl->n_ch1 = 0;
     if (pl->xr && pl->n_fg >= 2 && pl->n_kg == 1 && pl->NLW && pl->upd_w && n_tiles_w >= 4 * pl->n_chunks) {
         const int tot = pl->n_fg * pl->n_chunks, ng1 = pl->n_fg - 1;  // group 0: n0 workgroups, every other group n1
-        const double x = (600.0 + 6.0 * pl->rp) / (82.0 * (pl->rp / 2 + 16 * pl->nk)) * 4.0 / pl->NWB;  // (the row is shared by the group's NWB waves)
+        // (the row is shared by the group's NWB waves.  Round 4 re-measured it with phase stamps at 513 x 72000, r = 100 -- a group-0
+        //  tile takes 12 % longer per wave -- and swept x over 0.065 .. 0.22: the split this model picks (x = 0.065 there) is within
+        //  0.5 % of the best one, larger x loses 4 % to the tile-count quantisation; SNMF_WSTATS_X overrides it for such sweeps)
+        double x = (600.0 + 6.0 * pl->rp) / (82.0 * (pl->rp / 2 + 16 * pl->nk)) * 4.0 / pl->NWB;
+        if (const char* e = getenv("SNMF_WSTATS_X")) x = atof(e);  // (experiment: relative cost of the extra row per tile)
         auto n1_of = [&](int n0) { return (tot - n0) / ng1; };
         auto cost = [&](int n0) {
             return std::max(std::ceil((double)n_tiles_w / n0) * (1.0 + x), std::ceil((double)n_tiles_w / n1_of(n0)));

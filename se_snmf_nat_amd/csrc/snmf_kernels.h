@@ -2705,12 +2705,17 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     // groups: 16 KiB instead of 64 -- what lets two tile buffers fit -- and the V block crosses L2 once per iteration, not
     // once per row group); the extra row's V values go to a small array of their own (vx)
     const int ldv = 32 * NWB;
-    const int bufsz = TT * (a.ldh + ldv);   // floats per buffer: Hs [TT][ldh] then Vs [TT][ldv]
+    // NK = 4 (r <= 128) with full tiles: the H image's leading dimension is always 128 + 4 (host: ldhw), a COMPILE-TIME constant
+    // here -- P4's sixteen row bases become one base + immediate offsets (15 VGPRs less: the LX variants of the 8+4-wave
+    // geometry spilled 1..4 registers into scratch, which costs a kernel ~4 us per launch, and carried the adds per tile)
+    constexpr bool LDHC = NK == 4 && TT == 32;
+    const int ldh = LDHC ? 132 : a.ldh;
+    const int bufsz = TT * (ldh + ldv);     // floats per buffer: Hs [TT][ldh] then Vs [TT][ldv]
     float* wxs = lds + NBUF * bufsz;        // [rp] extra row of W
     const int lane = threadIdx.x & 63, w = wave_index();
     const bool is_loader = NL > 0 && w >= NWB;
     const int fl = lane & 31, h = lane >> 5;
-    const int rp = a.rp, Fp = a.Fp, ldh = a.ldh;
+    const int rp = a.rp, Fp = a.Fp;
     // Row group and frame chunk of this workgroup.  Row groups of which only group 0 carries the extra row are not
     // equally expensive per tile (the VALU row costs ~14 % of a tile on the MFMA-issuing waves), so the host may give
     // them DIFFERENT numbers of frame chunks: a 1-D grid of n_chunks workgroups of group 0 followed by a.n_ch1 for each
@@ -2743,7 +2748,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     if (do_x && WM != 3)
         for (int k = threadIdx.x; k < rp; k += NTHR) wxs[k] = a.wx[k];
     if (GXL && do_x)  // (the consumers' partial extra rows start at zero; a barrier separates this from their first use)
-        for (int k = threadIdx.x; k < NWB * gxw; k += NTHR) (lds + NBUF * TT * (a.ldh + 32 * NWB) + a.rp + 128)[k] = 0.f;
+        for (int k = threadIdx.x; k < NWB * gxw; k += NTHR) (lds + NBUF * TT * (ldh + 32 * NWB) + a.rp + 128)[k] = 0.f;
     const int phi = by * NWB + w;
     const int fc = w * 32 + fl;  // this lane's column of the staged V image
     const bool active = !is_loader && phi < a.nf;

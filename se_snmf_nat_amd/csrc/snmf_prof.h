@@ -91,6 +91,21 @@ static void snmf_prof_report(snmf_plan* pl) {
                 for (auto& kv : agg) fprintf(stderr, "(g%d, %d tiles, %d waves): mean %.1f max %.1f; ", kv.first.first, kv.first.second, cnt[kv.first], kv.second.first / cnt[kv.first], kv.second.second);
                 fprintf(stderr, "| by blockIdx%%8 mean/max:");
                 for (int x = 0; x < 8; ++x) fprintf(stderr, " %.1f/%.1f", nx[x] ? sx[x] / nx[x] : 0.0, mx[x]);
+                // phase cycles per wave of the workgroups that end last / first (what are the stragglers doing?)
+                std::vector<std::pair<double, int>> byend;
+                for (int i = 0; i < nw; ++i)
+                    if (hs0[i]) byend.push_back({(double)(hs0[i] - t0 + hc[2 * i + 1]) * 0.01, i});
+                std::sort(byend.begin(), byend.end());
+                const size_t nq = byend.size() / 10;
+                for (int side = 0; side < 2 && nq > 0; ++side) {
+                    double ph[6] = {0};
+                    for (size_t q2 = 0; q2 < nq; ++q2) {
+                        const int i = byend[side ? byend.size() - 1 - q2 : q2].second;
+                        for (int j = 0; j < 6; ++j) ph[j] += (double)hp[(size_t)i * 12 + j];
+                    }
+                    fprintf(stderr, " | %s 10 %% of the waves, k cycles/wave:", side ? "LAST" : "first");
+                    for (int j = 0; j < 6; ++j) fprintf(stderr, " %s=%.1f", nmw[j], ph[j] / nq / 1e3);
+                }
             }
             if (!st.empty()) {
                 std::sort(st.begin(), st.end());
