@@ -247,9 +247,9 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     pl->lds_rh = std::max<size_t>(((size_t)2 * 32 * pl->ldh + (size_t)32 * pl->ldr + pl->rp) * 4 + 160, 2 * kMaxNW * 64 * sizeof(double));
     pl->rh = pl->hstep_rp && pl->NLH != 4 && pl->bm == BM_KL && pl->nf >= 9 && pl->nf <= 16 && pl->rp <= 256 && pl->lds_rh <= lds_cap;
     // r = 97..100 on 16 row tiles (the reference's R = 100 at F = 513): P2 cut over the contraction, the 1..4 real columns of
-    // the fourth column tile as VALU work (k_hstep_rh<OBJ, LXH>); needs 60 KB more LDS for the waves' partial tiles
+    // the fourth column tile as 4x4x1 MFMAs on the same ratio fragments (k_hstep_rh<OBJ, LXH>); needs 52 KB more LDS for the waves' partial tiles
     {
-        const size_t lx = pl->lds_rh + (size_t)(pl->Fm + 8) * 16 + 4 * 3 * 1024 * 4 + 4 * 64 * 16;
+        const size_t lx = pl->lds_rh + 4 * 3 * 1024 * 4 + 4 * 64 * 16;  // the B waves' partial tiles + partial leftover columns
         pl->rh_lxh = pl->rh && pl->nf == 16 && pl->nk == 4 && r > 96 && r <= 100 && lx <= lds_cap;
         if (pl->rh_lxh) pl->lds_rh = lx;
     }
@@ -530,7 +530,7 @@ extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
     const bool rh_pipe = pl->rh && pl->upd_h && !pl->M;
     if (rh_pipe)
         snprintf(hs, sizeof hs, "k_hstep_rh (4 P1 + 4 P2 + 4 loader waves on half tiles%s; %d of %d tiles pipelined, last round split %d ways, grid %d)",
-                 pl->rh_lxh ? ", P2 cut over the contraction + leftover columns on the VALU" : "", pl->rp_full, pl->rp_tiles, pl->rp_S, pl->rp_grid);
+                 pl->rh_lxh ? ", P2 cut over the contraction + leftover columns as 4x4x1 MFMAs" : "", pl->rp_full, pl->rp_tiles, pl->rp_S, pl->rp_grid);
     else if (kl_pipe)
         snprintf(hs, sizeof hs, "k_hstep_rp (4 P1 + 4 P2 + 4 loader waves; %d of %d tiles pipelined, last round split %d ways, grid %d)",
                  pl->rp_full, pl->rp_tiles, pl->rp_S, pl->rp_grid);

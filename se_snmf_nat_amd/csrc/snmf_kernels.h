@@ -1057,6 +1057,64 @@ __device__ __forceinline__ void contract_shared_buf(f32x16 (&acc)[NA], __amdgpu_
     if (q + 1 < nq) mm(wB, sB);
 }
 
+// v_mfma_f32_4x4x1_16b_f32: sixteen independent 4x4 outer products per instruction.  Block b = lane / 4: A[i] is the a operand
+// of lane 4b + i, B[j] the b operand of lane 4b + j, D[i][j] lands in register i of lane 4b + j (scripts/mfma_4x4x1_probe.hip
+// checks this on the device; 15 cycles an instruction there, i.e. half the 32x32x2 shape's MAC rate -- but none of it padding).
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+
+// contract_shared_buf + the LEFTOVER COLUMNS of the numerator: r = 100 is three full 32-column tiles + 4 columns, r = 200 six + 8
+// (the reference's own ranks, settings/initial_setting_SNMF_NAT.m:48-49); a fourth / seventh 32-column MFMA tile would be 87 % /
+// 75 % padding.  One group of four leftover columns rides along with the full tiles' contraction instead: the SAME ratio fragment
+// sf[e] (lane (t = fl, h): ratio[8q + 4h + e][t]) is the B operand of a 4x4x1 MFMA whose A operand is W[8q + 4h + e][c0 + (lane & 3)]
+// -- a 16-byte piece of the ordinary Wk4 image (column tile c0 / 32, column c0 % 32 + (lane & 3)), so no table of its own --
+// and gl[i] accumulates column c0 + i for frame fl over this lane half's rows: per k-block one more 16-byte load and four
+// short MFMAs.  (Round 3 did these columns on the VALU from a small LDS copy of W: 1.6 k cycles per tile and SIMD at r = 100.)
+//   voff_l / soff_l: this lane's byte offset into the leftover columns' image block ((h * 128 + (c0 % 32 + (lane & 3)) * 4) * 4)
+//   and the block's scalar byte offset ((c0 / 32) * Fq * 128 + first k-block * 1024).
+template <int NA, typename Gate>
+__device__ __forceinline__ void contract_shared_buf_lx(f32x16 (&acc)[NA], f32x4& gl, __amdgpu_buffer_rsrc_t rs, int voff, const int (&soff)[NA],
+                                                       int voff_l, int soff_l, const float* sp, int nq, Gate gate) {
+    f32x4 wA[NA], wB[NA], wC[NA], lA, lB, lC, sA, sB, sC;
+    auto ldw = [&](f32x4 (&w)[NA], f32x4& l, int q) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) w[i] = ldw_buf(rs, voff, soff[i] + q * 1024);
+        l = ldw_buf(rs, voff_l, soff_l + q * 1024);
+    };
+    auto mm = [&](const f32x4 (&w)[NA], const f32x4& l, const f32x4& sf) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) acc[i] = mfma32(w[i][e], sf[e], acc[i]);
+            gl = mfma4(l[e], sf[e], gl);
+        }
+    };
+    ldw(wA, lA, 0);
+    ldw(wB, lB, 1);
+    SNMF_PIN();
+    gate();
+    const float* bp = sp;  // moving base: block q + j at bp + 8 * j
+    sA = *reinterpret_cast<const f32x4*>(bp);
+    sB = *reinterpret_cast<const f32x4*>(bp + 8);
+    int q = 0;
+    for (; q + 2 < nq; q += 3) {
+        ldw(wC, lC, q + 2);
+        sC = *reinterpret_cast<const f32x4*>(bp + 16);
+        SNMF_PIN();
+        mm(wA, lA, sA);
+        ldw(wA, lA, q + 3);
+        sA = *reinterpret_cast<const f32x4*>(bp + 24);
+        SNMF_PIN();
+        mm(wB, lB, sB);
+        ldw(wB, lB, q + 4);
+        sB = *reinterpret_cast<const f32x4*>(bp + 32);
+        bp += 24;
+        SNMF_PIN();
+        mm(wC, lC, sC);
+    }
+    if (q < nq) mm(wA, lA, sA);
+    if (q + 1 < nq) mm(wB, lB, sB);
+}
+
 // P1 epilogue of one 32-row tile: Lam -> ratio in place over the staged V (+ the divergence terms of the previous iterate).
 // The per-element bounds masks of the objective are only evaluated for the tiles that need them: a wave-uniform test
 // picks the unmasked loop for interior tiles (a quarter of the epilogue's VALU instructions; no measurable effect on
@@ -1845,17 +1903,8 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rh(StepArgs a) {
     // of those columns of W (wl), and the waves' partial tiles are added through LDS (Ps, Pl) before the epilogue: every
     // SIMD then carries the same work (a re-deal of whole tiles cannot balance them).
     unsigned *wdone = cnt + 28, *rdone = cnt + 32;            // B waves: partials of place j written / read
-    float* wl = reinterpret_cast<float*>(cnt + 40);          // [Fm + 8][4]  W[f][96 .. 99] (row Fm: the extra row)
-    float* Ps = wl + (a.Fm + 8) * 4;                          // [4 waves][3 tiles][4 g][64 lanes][4] partial accumulators
+    float* Ps = reinterpret_cast<float*>(cnt + 40);          // [4 waves][3 tiles][4 g][64 lanes][4] partial accumulators
     float* Pl = Ps + 4 * 3 * 1024;                            // [4 waves][64 lanes][4] partial leftover columns
-    if (LXH) {
-        for (int f = threadIdx.x; f < a.Fm + 8; f += NTHR) {
-            f32x4 wv = {0.f, 0.f, 0.f, 0.f};
-            if (f < a.Fm) wv = *reinterpret_cast<const f32x4*>(a.Wt4 + ((((size_t)(f >> 5) * (rp / 8) + 12) * 2) * 128 + (f & 31) * 4));
-            else if (f == a.Fm && a.xr) wv = *reinterpret_cast<const f32x4*>(a.wx + 96);
-            *reinterpret_cast<f32x4*>(wl + f * 4) = wv;
-        }
-    }
     __syncthreads();
     // The split last round as in k_hstep_rp ("the split last round" above), with 16 row tiles: part p of S owns the
     // CONTIGUOUS row tiles [p nfp, (p+1) nfp), nfp = 16 / S -- half a half (S = 4: one row tile per A wave) or a whole
@@ -2092,44 +2141,21 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rh(StepArgs a) {
                 const __amdgpu_buffer_rsrc_t rsk = wimage_rsrc(a.Wk4, (size_t)a.nk * a.Fq * 32);
                 f32x16 acc[3] = {zero16(), zero16(), zero16()};
                 int so[3] = {qb * 1024, a.Fq * 128 + qb * 1024, 2 * a.Fq * 128 + qb * 1024};
-                // leftover columns over the same rows: lane (t = fl, h) takes rows [f0 + 32 h, + 32) of the wave's 64 rows of a
-                // half.  The first half's rows go AHEAD of its contraction (nothing else is live there; between the contractions
-                // this code cost 70..100 spilled VGPRs) so that its bdone can be posted as early as before; the second half's
-                // follow the last contraction.
+                // the leftover columns 96 .. 99 ride along as 4x4x1 MFMAs on the same ratio fragments (contract_shared_buf_lx):
+                // gl[c] = column 96 + c for frame fl, partial over this wave's k-blocks and this lane half's rows
                 f32x4 gl = {0.f, 0.f, 0.f, 0.f};
-                auto lx_rows = [&](const int f0) {
-                    const float* rrow = Rs + fl * ldr + f0 + 32 * h;
-                    const float* wrow = wl + (f0 + 32 * h) * 4;
-#pragma unroll 4
-                    for (int f4 = 0; f4 < 8; ++f4) {
-                        const f32x4 r4 = *reinterpret_cast<const f32x4*>(rrow + 4 * f4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wrow + (4 * f4 + e) * 4);
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) gl[c] = fmaf(r4[e], w4[c], gl[c]);
-                        }
-                    }
-                };
-                g0();
-                lx_rows(64 * wb);
-                SNMF_PIN();
-                contract_shared_buf<3>(acc, rsk, lane * 16, so, sp + 8 * qb, 8, NoGate());
+                const int voff_l = (h * 128 + (lane & 3) * 4) * 4;
+                int so_l = 3 * a.Fq * 128 + qb * 1024;
+                contract_shared_buf_lx<3>(acc, gl, rsk, lane * 16, so, voff_l, so_l, sp + 8 * qb, 8, g0);
                 rp_post(bdone, wb, (unsigned)(2 * j + 1), lane);
 #pragma unroll
                 for (int i = 0; i < 3; ++i) so[i] += 32 * 1024;
-                contract_shared_buf<3>(acc, rsk, lane * 16, so, sp + 8 * (32 + qb), 8, g1);
-                if (wb == 3 && a.xr) {
+                so_l += 32 * 1024;
+                contract_shared_buf_lx<3>(acc, gl, rsk, lane * 16, so, voff_l, so_l, sp + 8 * (32 + qb), 8, g1);
+                if (wb == 3 && a.xr) {  // the extra row's k-block (rows Fm+1 .. Fm+7 of the ratio image and of W are zero)
 #pragma unroll
                     for (int i = 0; i < 3; ++i) so[i] = i * a.Fq * 128 + 64 * 1024;
-                    contract_shared_buf<3>(acc, rsk, lane * 16, so, sp + 8 * 64, 1, gx);
-                }
-                lx_rows(256 + 64 * wb);
-                if (wb == 3 && a.xr && h == 1) {
-                    const float rx = Rs[fl * ldr + a.Fm];
-                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wl + a.Fm * 4);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) gl[c] = fmaf(rx, w4[c], gl[c]);
+                    contract_shared_buf_lx<3>(acc, gl, rsk, lane * 16, so, voff_l, 3 * a.Fq * 128 + 64 * 1024, sp + 8 * 64, 1, gx);
                 }
                 rp_post(bdone, wb, (unsigned)(2 * j + 2), lane);
                 // partial tiles -> LDS, once every wave has read the previous tile's
