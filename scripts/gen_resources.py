@@ -25,9 +25,9 @@ LAUNCHED = [
     ("snmf::k_hstep_rp<false>", "C2: H step of iteration 1 / cost_check = 0"),
     ("snmf::k_wstats<8, 4, 4, 2, 0, 1, false, 32, 0>", "C2: W statistics (full update: the objective rides on the H step)"),
     ("snmf::k_wfin<1>", "C2 / a11 / C4 W-only: chunk reduction + W update (snmf_plan_run)"),
-    ("snmf::k_hstep_rh<true, true>", "a11 513x72000 r=100 KL full (run_basis_train.m:88): H step"),
+    ("snmf::k_hstep_rh<true, 1>", "a11 513x72000 r=100 KL full (run_basis_train.m:88): H step"),
     ("snmf::k_wstats<4, 8, 4, 3, 0, 1, false, 32, 1>", "a11: W statistics"),
-    ("snmf::k_hstep_rh<true, false>", "C4 solve 1, 513x100000 r=200 H-only (run_basis_DNMF.m:40)"),
+    ("snmf::k_hstep_rh<true, 2>", "C4 solve 1, 513x100000 r=200 H-only (run_basis_DNMF.m:40)"),
     ("snmf::k_wstats<4, 8, 4, 3, 0, 1, true, 32, 1>", "C4 solves 2/3, 513x100000 r=100 W-only (run_basis_DNMF.m:47,53): statistics + objective"),
     ("snmf::k_hstep<8, 1, 0, 2, true, true, false, 32>", "C5 513x500000 r=512 beta=2: H step"),
     ("snmf::k_wstats<8, 4, 4, 2, 3, 2, false, 32, 0>", "C5: V*H' and H*H' (Gram) launches by kappa-groups"),

@@ -250,8 +250,16 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     // the fourth column tile as 4x4x1 MFMAs on the same ratio fragments (k_hstep_rh<OBJ, LXH>); needs 52 KB more LDS for the waves' partial tiles
     {
         const size_t lx = pl->lds_rh + 4 * 3 * 1024 * 4 + 4 * 64 * 16;  // the B waves' partial tiles + partial leftover columns
-        pl->rh_lxh = pl->rh && pl->nf == 16 && pl->nk == 4 && r > 96 && r <= 100 && lx <= lds_cap;
+        pl->rh_lxh = (pl->rh && pl->nf == 16 && pl->nk == 4 && r > 96 && r <= 100 && lx <= lds_cap) ? 1 : 0;
         if (pl->rh_lxh) pl->lds_rh = lx;
+        // r = 193..200 on 16 row tiles (R_x + R_d = 200 at F = 513, run_basis_DNMF.m:40): seven column tiles -> the B waves work
+        // in pairs over three full tiles each, cut in two over the contraction (k_hstep_rh<OBJ, 2>); 29 KB more LDS
+        const size_t lx2 = pl->lds_rh + (size_t)(4 * 6 * 256 + 4 * 64 * 4 + pl->rp) * 4;
+        const char* ec = getenv("SNMF_RH_CUT2");
+        if (pl->rh && !pl->rh_lxh && pl->nf == 16 && pl->nk == 7 && r > 192 && r <= 200 && lx2 <= lds_cap && !(ec && atoi(ec) == 0)) {
+            pl->rh_lxh = 2;
+            pl->lds_rh = lx2;
+        }
     }
     pl->lds_h = std::max<size_t>(pl->NLH ? 2 * lds1 - lds_extra : (pl->NT == 1 ? (size_t)pl->TTH * per_col + lds_extra : lds2),
                                  2 * kMaxNW * 64 * sizeof(double));
@@ -417,7 +425,8 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     if (pl->generic) {
         // none of the fused geometries applies; contractions over the frames are split into chunks of kGChunkT frames,
         // whose slabs k_reduce adds like the fast path's
-        pl->hstep_rp = pl->rh = pl->rh_lxh = false;
+        pl->hstep_rp = pl->rh = false;
+        pl->rh_lxh = 0;
         pl->rp_S = 0;
         pl->kq_kg = 0;
         pl->gram_p = false;
@@ -530,7 +539,7 @@ extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
     const bool rh_pipe = pl->rh && pl->upd_h && !pl->M;
     if (rh_pipe)
         snprintf(hs, sizeof hs, "k_hstep_rh (4 P1 + 4 P2 + 4 loader waves on half tiles%s; %d of %d tiles pipelined, last round split %d ways, grid %d)",
-                 pl->rh_lxh ? ", P2 cut over the contraction + leftover columns as 4x4x1 MFMAs" : "", pl->rp_full, pl->rp_tiles, pl->rp_S, pl->rp_grid);
+                 pl->rh_lxh == 1 ? ", P2 cut four ways over the contraction + leftover columns as 4x4x1 MFMAs" : (pl->rh_lxh == 2 ? ", P2 in wave pairs cut over the contraction + leftover columns as 4x4x1 MFMAs" : ""), pl->rp_full, pl->rp_tiles, pl->rp_S, pl->rp_grid);
     else if (kl_pipe)
         snprintf(hs, sizeof hs, "k_hstep_rp (4 P1 + 4 P2 + 4 loader waves; %d of %d tiles pipelined, last round split %d ways, grid %d)",
                  pl->rp_full, pl->rp_tiles, pl->rp_S, pl->rp_grid);

@@ -115,7 +115,7 @@ struct snmf_plan {
     // kappa-group, each staging only its own columns of H (kq_chunks frame chunks, kq_kg kappa-groups; 0 = off)
     int kq_chunks = 0, kq_kg = 0;
     // snmf_plan_run: k_reduce + k_wapply as one launch (k_wfin) when a column's chunk-group sums fit the LDS
-    bool rh_lxh = false;
+    int rh_lxh = 0;  // k_hstep_rh: P2 cut over the contraction (1: r = 97..100 four ways; 2: r = 193..200 in pairs), leftover columns as 4x4x1 MFMAs
     bool wfin = false;
     size_t lds_wfin = 0;
     // shapes beyond the fused kernels' LDS / register envelope: the same iteration with its intermediates in HBM

@@ -1207,6 +1207,44 @@ __device__ __forceinline__ void rp_p2_epilogue(const StepArgs& a, const f32x16& 
         }
     }
 }
+// The same for register groups [GB, GE) of a tile only (columns kap*32 + 8g + 4h + j, g in [GB, GE)): the CUT2 mode of k_hstep_rh
+// hands a wave one whole tile and HALF of another.  rdph: 1 ./ max(colsum(W) + lambda, flr) for all rp columns in LDS (scalar /
+// r-vector sparsity; the waves of that mode finish parts of three different tiles, too many constants to keep in registers).
+template <bool OBJ, int GB, int GE>
+__device__ __forceinline__ void rh_cut_epilogue(const StepArgs& a, const f32x16& acc, float* Hs, int kap, int t0, int lane,
+                                                const float* rdph, float& shsum) {
+    const int fl = lane & 31, h = lane >> 5;
+    const int t = t0 + fl;
+    float* hsp = Hs + fl * a.ldh + kap * 32 + 4 * h;
+    float hs = 0.f;
+#pragma unroll
+    for (int g = GB; g < GE; ++g) {
+        const int k0 = kap * 32 + 8 * g + 4 * h;
+        const f32x4 hov = *reinterpret_cast<f32x4*>(hsp + 8 * g);
+        f32x4 dp, spv = {0.f, 0.f, 0.f, 0.f};
+        if (a.S) {
+            const f32x4 cs = *reinterpret_cast<const f32x4*>(a.colsum + k0);
+            spv = *reinterpret_cast<const f32x4*>(a.S + (size_t)t * a.rp + k0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dp[j] = fast_rcp(fmaxf(cs[j] + spv[j], kFlr));
+        } else {
+            dp = *reinterpret_cast<const f32x4*>(rdph + k0);
+            if (OBJ && !a.lam_is_u) spv = *reinterpret_cast<const f32x4*>(a.lamk + k0);
+        }
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = hov[j] * acc[4 * g + j] * dp[j];
+        *reinterpret_cast<f32x4*>(hsp + 8 * g) = o;
+        if (OBJ) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (a.lam_is_u && !a.S) hs += hov[j];
+                else shsum += spv[j] * hov[j];
+            }
+        }
+    }
+    if (OBJ && a.lam_is_u && !a.S) shsum += a.lam_u * hs;
+}
 __device__ __forceinline__ void rp_p2_consts(const StepArgs& a, int kap, int lane, f32x4 (&dpf)[4]) {
     const int h = lane >> 5;
     if (!a.S) {
@@ -1877,7 +1915,7 @@ __device__ __forceinline__ void rh_p2_tile(const StepArgs& a, float* Hs, const f
     if (NACC == 2) rp_p2_epilogue<OBJ>(a, acc[NACC - 1], Hs, kap + NB, t0, lane, dp1, shsum);
 }
 
-template <bool OBJ, bool LXH = false>
+template <bool OBJ, int LXH = 0>
 __global__ __launch_bounds__(768, 3) void k_hstep_rh(StepArgs a) {
     constexpr int NA = 4, NB = 4, NL = 4, NTHR = (NA + NB + NL) * 64, Tt = 32, PR = Tt / NL;
     if (a.stop && *a.stop) return;
@@ -1902,9 +1940,18 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rh(StepArgs a) {
     // instead of 260 on a tile that is 87 % padding), the leftover columns of its rows as VALU work from a small LDS copy
     // of those columns of W (wl), and the waves' partial tiles are added through LDS (Ps, Pl) before the epilogue: every
     // SIMD then carries the same work (a re-deal of whole tiles cannot balance them).
+    // LXH == 2 (CUT2; nk = 7 with 1..8 real columns in the seventh tile: r = 193..200, run_basis_DNMF.m:40 at the shipped
+    // R_x + R_d): seven column tiles on four B waves are 2, 2, 2, 1 -- three SIMDs carry 920 MFMAs a tile, the fourth 660.  Here
+    // the B waves work in PAIRS: pair p owns the full tiles 3p .. 3p+2 and the leftover column group p (columns 192 + 4p .. + 3,
+    // 4x4x1 MFMAs on the same fragments); inside a pair wave s takes k-blocks [16 s, 16 s + 16) of EACH ratio half (+ the extra
+    // row's, s = 1): 396 + 132 short MFMAs a wave, every SIMD the same.  The partners swap what the other finishes through LDS
+    // (one whole tile + half of the third, 6 KB a wave) and each runs 1.5 tile epilogues; wave 0 also the leftover columns'.
     unsigned *wdone = cnt + 28, *rdone = cnt + 32;            // B waves: partials of place j written / read
-    float* Ps = reinterpret_cast<float*>(cnt + 40);          // [4 waves][3 tiles][4 g][64 lanes][4] partial accumulators
-    float* Pl = Ps + 4 * 3 * 1024;                            // [4 waves][64 lanes][4] partial leftover columns
+    float* Ps = reinterpret_cast<float*>(cnt + 40);          // LXH 1: [4 waves][3 tiles][4 g][64 lanes][4]; LXH 2: [4 waves][6][64 lanes][4]
+    float* Pl = Ps + (LXH == 2 ? 4 * 6 * 256 : 4 * 3 * 1024);  // [4 waves][64 lanes][4] partial leftover columns
+    float* rdph = Pl + 4 * 64 * 4;                            // LXH 2: [rp] 1 ./ dph (rh_cut_epilogue)
+    if (LXH == 2 && !a.S)
+        for (int k = threadIdx.x; k < rp; k += NTHR) rdph[k] = fast_rcp(a.dphv[k]);
     __syncthreads();
     // The split last round as in k_hstep_rp ("the split last round" above), with 16 row tiles: part p of S owns the
     // CONTIGUOUS row tiles [p nfp, (p+1) nfp), nfp = 16 / S -- half a half (S = 4: one row tile per A wave) or a whole
@@ -2124,7 +2171,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rh(StepArgs a) {
             rp_p2_consts(a, wb, lane, dp0);
             if (wb + NB < a.nk) rp_p2_consts(a, wb + NB, lane, dp1);
         }
-        unsigned lx_seq = 0;  // lxh: tiles this wave has put through the partial buffers
+        unsigned lx_seq = 0;  // LXH: tiles this wave has put through the partial buffers
         auto b_item = [&](const int j) {  // P2 of the whole tile in place j of the list
             const int t0 = tile_of(j) * Tt;
             float* Hs = lds + (j & 1) * hsz;
@@ -2132,7 +2179,91 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rh(StepArgs a) {
             auto g0 = [&]() { rp_await(p1, (unsigned)(2 * j + 1), a.stop); };
             auto g1 = [&]() { rp_await(p1, (unsigned)(2 * j + 2), a.stop); };
             auto gx = [&]() { rp_await(xdone, (unsigned)(j + 1), a.stop); };
-            if constexpr (LXH) {
+            if constexpr (LXH == 2) {
+                const int fl = lane & 31, h = lane >> 5;
+                const float* sp = Rs + fl * ldr + 4 * h;
+                const int pr = wb >> 1, sh = wb & 1, qb = 16 * sh;
+                const __amdgpu_buffer_rsrc_t rsk = wimage_rsrc(a.Wk4, (size_t)a.nk * a.Fq * 32);
+                f32x16 acc[3] = {zero16(), zero16(), zero16()};
+                int so[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) so[i] = (3 * pr + i) * a.Fq * 128 + qb * 1024;
+                f32x4 gl = {0.f, 0.f, 0.f, 0.f};  // leftover column 192 + 4 pr + c for frame fl, partial over this wave's k-blocks / lane half
+                const int voff_l = (h * 128 + (4 * pr + (lane & 3)) * 4) * 4;
+                int so_l = 6 * a.Fq * 128 + qb * 1024;
+                contract_shared_buf_lx<3>(acc, gl, rsk, lane * 16, so, voff_l, so_l, sp + 8 * qb, 16, g0);
+                rp_post(bdone, wb, (unsigned)(2 * j + 1), lane);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) so[i] += 32 * 1024;
+                so_l += 32 * 1024;
+                contract_shared_buf_lx<3>(acc, gl, rsk, lane * 16, so, voff_l, so_l, sp + 8 * (32 + qb), 16, g1);
+                if (sh == 1 && a.xr) {  // the extra row's k-block: the pair's second wave
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) so[i] = (3 * pr + i) * a.Fq * 128 + 64 * 1024;
+                    contract_shared_buf_lx<3>(acc, gl, rsk, lane * 16, so, voff_l, 6 * a.Fq * 128 + 64 * 1024, sp + 8 * 64, 1, gx);
+                }
+                rp_post(bdone, wb, (unsigned)(2 * j + 2), lane);
+                // what the partner finishes -> LDS (once every wave has read the previous tile's): its whole tile (slots 0..3) and its
+                // half of the pair's third tile (slots 4, 5: register groups 2 sh' .. 2 sh' + 1 of the PARTNER, sh' = 1 - sh)
+                rp_await(rdone, lx_seq, a.stop);
+                float* pw = Ps + wb * 6 * 256 + lane * 4;
+                auto put = [&](int slot, const f32x16& x, int g) {
+                    const f32x4 o = {x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(pw + slot * 256) = o;
+                };
+                if (sh == 0) {
+                    put(0, acc[1], 0); put(1, acc[1], 1); put(2, acc[1], 2); put(3, acc[1], 3);
+                    put(4, acc[2], 2); put(5, acc[2], 3);
+                } else {
+                    put(0, acc[0], 0); put(1, acc[0], 1); put(2, acc[0], 2); put(3, acc[0], 3);
+                    put(4, acc[2], 0); put(5, acc[2], 1);
+                }
+                *reinterpret_cast<f32x4*>(Pl + (wb * 64 + lane) * 4) = gl;
+                ++lx_seq;
+                rp_post(wdone, wb, lx_seq, lane);
+                rp_await(wdone, lx_seq, a.stop);
+                const float* pq = Ps + (wb ^ 1) * 6 * 256 + lane * 4;  // the partner's slots
+                f32x4 in[6];
+#pragma unroll
+                for (int q6 = 0; q6 < 6; ++q6) in[q6] = *reinterpret_cast<const f32x4*>(pq + q6 * 256);
+                f32x16 t6 = zero16();
+                if (wb == 0) {  // leftover columns: group h of this lane half = the sum over that pair's two waves and both row halves
+                    const float* pl0 = Pl + (2 * h) * 256 + fl * 4;
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(pl0), x1 = *reinterpret_cast<const f32x4*>(pl0 + 128);
+                    const f32x4 x2 = *reinterpret_cast<const f32x4*>(pl0 + 256), x3 = *reinterpret_cast<const f32x4*>(pl0 + 384);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t6[e] = (x0[e] + x1[e]) + (x2[e] + x3[e]);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                rp_post(rdone, wb, lx_seq, lane);
+                // own partial + the partner's, in wave order (s = 0 first), so that both orders of arrival give the same bits
+                if (sh == 0) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[0][4 * g + e] += in[g][e];
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[2][4 * g + e] += in[4 + g][e];
+                    rh_cut_epilogue<OBJ, 0, 4>(a, acc[0], Hs, 3 * pr, t0, lane, rdph, shsum);
+                    rh_cut_epilogue<OBJ, 0, 2>(a, acc[2], Hs, 3 * pr + 2, t0, lane, rdph, shsum);
+                    if (wb == 0) rh_cut_epilogue<OBJ, 0, 1>(a, t6, Hs, 6, t0, lane, rdph, shsum);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[1][4 * g + e] = in[g][e] + acc[1][4 * g + e];
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[2][8 + 4 * g + e] = in[4 + g][e] + acc[2][8 + 4 * g + e];
+                    rh_cut_epilogue<OBJ, 0, 4>(a, acc[1], Hs, 3 * pr + 1, t0, lane, rdph, shsum);
+                    rh_cut_epilogue<OBJ, 2, 4>(a, acc[2], Hs, 3 * pr + 2, t0, lane, rdph, shsum);
+                }
+                if (OBJ) acc_sh += (double)shsum;
+                rp_post(p2done, wb, (unsigned)(j + 1), lane);
+            } else if constexpr (LXH == 1) {
                 const int fl = lane & 31, h = lane >> 5;
                 const float* sp = Rs + fl * ldr + 4 * h;
                 // k-blocks [8 wb, 8 wb + 8) of EACH ratio half (a wave with all its blocks in one half would leave its SIMD idle

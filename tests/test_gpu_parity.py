@@ -542,10 +542,15 @@ def test_dnmf_adapt_caller(gpu_ctx):
 
 
 @pytest.mark.parametrize("F,r,T,mode", [(513, 100, 8300, "full"), (513, 97, 8200, "h"), (512, 98, 8500, "full"), (513, 99, 16500, "h"),
-                                        (512, 100, 8193, "semi")])
+                                        (512, 100, 8193, "semi"),
+                                        # r = 193..200: the B waves in pairs (R_x + R_d = 200 at F = 513, run_basis_DNMF.m:40); 196 / 193:
+                                        # the second leftover group is all / mostly padding; 16500 frames: with a split last round
+                                        (513, 200, 8300, "h"), (513, 200, 8200, "full"), (512, 196, 8500, "h"), (513, 193, 16500, "h"),
+                                        (513, 197, 8193, "semi")])
 def test_h_step_cut_over_the_contraction(gpu_ctx, F, r, T, mode):
-    """r = 97..100 on 16 row tiles (the reference's R = 100 at F = 513, settings/initial_setting_SNMF_NAT.m:48-49): k_hstep_rh
-    cuts P2 over the contraction and takes the leftover columns on the VALU (src/sparse_nmf.m:189-195 is what it computes)."""
+    """r = 97..100 and r = 193..200 on 16 row tiles (the reference's R = 100 and R_x + R_d = 200 at F = 513,
+    settings/initial_setting_SNMF_NAT.m:48-49): k_hstep_rh cuts P2 over the contraction (four ways / in wave pairs) and takes
+    the leftover columns as 4x4x1 MFMAs on the same ratio fragments (src/sparse_nmf.m:189-195 is what it computes)."""
     from se_snmf_nat_amd import Plan, sparse_nmf
     rs = np.random.default_rng(F + r + T)
     V = rs.gamma(0.5, 1.0, (F, 12)) @ rs.gamma(0.3, 1.0, (12, T)) + 1e-3
@@ -556,7 +561,7 @@ def test_h_step_cut_over_the_contraction(gpu_ctx, F, r, T, mode):
     if mode == "semi":
         p["w_update_ind"] = kw["w_update_ind"] = np.arange(r) >= 50
     pl = Plan(gpu_ctx, F, T, r, beta=1.0, max_iter=2, cost_check=True, **kw)
-    assert "P2 cut over the contraction" in pl.describe()
+    assert "over the contraction" in pl.describe()
     pl.close()
     check(sparse_nmf(V, p, ctx=gpu_ctx), oracle_nmf(V, p))
 
