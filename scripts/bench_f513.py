@@ -20,7 +20,7 @@ from se_snmf_nat_amd import Context, Plan  # noqa: E402
 
 PEAK = 157.3
 K = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 0
-which = [a for a in sys.argv[1:] if a in ("a11", "c4h", "c4w", "c5")] or ["a11", "c4h", "c4w", "c5"]
+which = [a for a in sys.argv[1:] if a in ("a11", "c4h", "c4w", "c5", "mel", "smallr")] or ["a11", "c4h", "c4w", "c5"]
 ctx = Context(0)
 
 SHAPES = {
@@ -28,7 +28,11 @@ SHAPES = {
     "c4h": dict(F=513, T=100000, r=200, beta=1.0, sparsity=5.0, mode="h", iters=100, settle=150),
     "c4w": dict(F=513, T=100000, r=100, beta=1.0, sparsity=5.0, mode="w", iters=100, settle=150),
     "c5": dict(F=513, T=500000, r=512, beta=2.0, sparsity=50.0, mode="full", iters=10, settle=4),
+    # the HBM-side regime: the Mel solve of run_basis_train.m:90-91 (64 x 72000, r = 100) and a small-rank shape
+    "mel": dict(F=64, T=72000, r=100, beta=1.0, sparsity=5.0, mode="full", iters=200, settle=300),
+    "smallr": dict(F=257, T=100000, r=32, beta=1.0, sparsity=5.0, mode="full", iters=200, settle=300),
 }
+HBM_PEAK, HBM_ACHIEVABLE = 8.0e12, 6.3e12  # /opt/skills/guides/MI355X_MICROARCH.md: peak, and what a streaming kernel reaches
 
 
 def synth(F, T, r, seed=0):
@@ -78,6 +82,13 @@ for name in which:
     out = {"shape": name, "F": F, "T": T, "r": r, "beta": c["beta"], "mode": c["mode"], "iterations_per_s": iters / dt,
            "ms_per_iteration": ms, "whole_iteration_TFLOPs": per_it / (ms * 1e-3) / 1e12,
            "whole_iteration_frac": per_it / (ms * 1e-3) / 1e12 / PEAK, "kernel_ms": {}, "kernel_frac": {}, "geometry": plan.describe()}
+    # algorithmic HBM bytes: full 4 (2 F T + 3 r T); H-only 4 (F T + 2 r T); W-only 4 (F T + r T)
+    nbytes = {"full": 4.0 * (2 * F * T + 3 * r * T), "h": 4.0 * (F * T + 2 * r * T), "w": 4.0 * (F * T + r * T)}[c["mode"]]
+    out["algorithmic_bytes_per_iteration"] = nbytes
+    out["algorithmic_GBps"] = nbytes / (ms * 1e-3) / 1e9
+    out["hbm_frac_of_8TBps"] = nbytes / (ms * 1e-3) / HBM_PEAK
+    out["hbm_frac_of_6.3TBps"] = nbytes / (ms * 1e-3) / HBM_ACHIEVABLE
+    out["flop_per_byte"] = per_it / nbytes
     for f, (avg, n) in fam.items():
         if n:
             per_launch_groups = n / iters  # event pairs per iteration (a beta != 1 W step is two launches under one pair)

@@ -7,7 +7,7 @@ for s in $SETS; do
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        d = json.loads(l); print(d['shape'], round(d['iterations_per_s'], 1), 'it/s', {k: round(v, 4) for k, v in d['kernel_ms'].items()}, {k: round(v, 3) for k, v in d['kernel_frac'].items()})
+        d = json.loads(l); print(d['shape'], round(d['iterations_per_s'], 1), 'it/s', {k: round(v, 4) for k, v in d['kernel_ms'].items()}, {k: round(v, 3) for k, v in d['kernel_frac'].items()}, 'whole', round(d['whole_iteration_frac'], 3), 'hbm6.3', round(d.get('hbm_frac_of_6.3TBps', 0), 3), 'fl/B', round(d.get('flop_per_byte', 0), 1)); print('   ', d['geometry'])
     else: print(l.rstrip())
 "
 done

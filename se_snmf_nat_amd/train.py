@@ -82,14 +82,25 @@ def run_basis_train_signal(s_full, R, p, *, DC_bin=None, sample_idx=None, ctx=No
     return {"B_DFT_sub": B_DFT, "B_Mel_sub": B_Mel, "A_DFT_sub": A_DFT, "A_Mel_sub": A_Mel}  # :130-134
 
 
-def save_basis_mat(path, out):
-    """run_basis_train.m:136 (`save ... -v7.3`); written as MAT-5 like the three .mat files the
-    reference ships (basis/*/R_100.mat, B_D_u.mat), which MATLAB's `load` reads the same way."""
-    import scipy.io as sio
-    sio.savemat(path, {k: np.asarray(v, dtype=np.float64) for k, v in out.items()}, do_compression=True)
+def save_basis_mat(path, out, v73=True):
+    """run_basis_train.m:136: `save(..., 'B_DFT_sub', 'B_Mel_sub', 'A_DFT_sub', 'A_Mel_sub', '-v7.3')` -- an HDF5-based MAT-file
+    (se_snmf_nat_amd/mat73.py); v73=False writes MAT-5 like the three .mat files the reference ships (basis/*/R_100.mat, B_D_u.mat).
+    MATLAB's `load` reads either."""
+    vars_ = {k: np.asarray(v, dtype=np.float64) for k, v in out.items()}
+    if v73:
+        from .mat73 import save_mat73
+        save_mat73(path, vars_)
+    else:
+        import scipy.io as sio
+        sio.savemat(path, vars_, do_compression=True)
 
 
 def load_basis_mat(path):
+    """run_basis_train.m:138 / src/NTF_sep_event_RT.m:28-38: `load` of a dictionary file, MAT-5 or -v7.3 (what the reference's own
+    run_basis_train.m:136 writes)."""
+    from .mat73 import is_mat73, load_mat73
+    if is_mat73(path):
+        return load_mat73(path)
     import scipy.io as sio
     m = sio.loadmat(path)
     return {k: v for k, v in m.items() if not k.startswith("__")}
