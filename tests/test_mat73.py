@@ -89,4 +89,4 @@ def test_the_hdf5_library_reads_what_the_writer_wrote(tmp_path):
     # every value, through the library's own reader
     one = subprocess.run([H5DUMP, "-d", "/B_DFT_sub", "-y", "-w", "0", f], stdout=subprocess.PIPE, text=True).stdout
     vals = [float(x) for x in one[one.index("DATA {") + 6:one.index("}", one.index("DATA {"))].replace(",", " ").split()]
-    np.testing.assert_allclose(np.array(vals).reshape(3, 6).T, d["B_DFT_sub"], rtol=1e-6)
+    np.testing.assert_allclose(np.array(vals).reshape(3, 6).T, d["B_DFT_sub"], rtol=1e-5)  # (h5dump prints six significant digits)
