@@ -128,7 +128,7 @@ def self_launch(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
            "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--dim-F", str(args.F), "--dim-T", str(args.T), "--dim-r", str(args.r)]
+           "--dim-F", str(args.F), "--dim-T", str(args.T), "--dim-r", str(args.r), "--c5-T", str(args.c5_T)]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
     pr = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
@@ -228,6 +228,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--oneshot-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--c5-T", dest="c5_T", type=int, default=500_000, help=argparse.SUPPRESS)  # frames of the extra C5 leg (tests shrink it)
     # --dim-*: the spellings self_launch() passes on (torch.distributed.run's own parser prefix-matches a bare --r)
     ap.add_argument("--F", "--dim-F", dest="F", type=int, default=F_)
     ap.add_argument("--T", "--dim-T", dest="T", type=int, default=T_)
@@ -426,17 +427,75 @@ def main():
         }
         out["cost_vs_oracle"] = cost_vs_oracle(F, T, r, len(last_cost), out["final_cost"])
         # the contract times the CPU baseline on rank 0 at N = 1 only
+    del tr
+    torch.cuda.empty_cache()
     if world > 1:
+        # SURVEY.md section 8d asks strong scaling on "C2 and C5": the SAME loop on BASELINE configs[4] (513 x 500000, r = 512,
+        # beta = 2, lambda = 50: 11 ms per iteration on one GPU, the config where the fixed costs of an iteration are small
+        # beside its compute).  Reported beside `value`, never instead of it; a failure of this extra leg never fails the bench.
+        c5 = c5_strong_leg(world, rank, local_rank, torch, dist, T=args.c5_T)
+        if rank == 0:
+            out["c5_strong"] = c5
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         if world > 1:
             # the same problem through the one-shot peer-store exchange behind the C ABI, AFTER the timed RCCL leg (the
             # other ranks are gone or idle by now); reported beside `value`, never instead of it
-            del tr
-            torch.cuda.empty_cache()
             out["exchange_oneshot"] = finish_oneshot_child(oneshot)
         print(json.dumps(out), flush=True)
+
+
+def c5_strong_leg(world, rank, local_rank, torch, dist, F=513, T=500_000, r=512, steps=10, warm=4):
+    """BASELINE configs[4] frame-sharded over the ranks (strong scaling), timed like the headline leg: barrier + synchronize on
+    both sides, MAX over ranks.  Every rank reports whether its set-up worked BEFORE anybody enters the loop's collectives."""
+    from se_snmf_nat_amd.dist import ShardedTrainer, shard_bounds
+    tr, err = None, None
+    try:
+        t0, t1 = shard_bounds(T, world, rank)
+        g = np.random.default_rng([5, rank])
+        Wt = np.random.default_rng(5).gamma(0.5, 1.0, size=(F, 32)).astype(np.float32)
+        V = np.empty((F, t1 - t0), np.float32, order="F")
+        H0 = np.empty((r, t1 - t0), np.float32, order="F")
+        for a in range(0, t1 - t0, 50000):  # in blocks: 513 x 500000 floats are 1 GB
+            b = min(t1 - t0, a + 50000)
+            V[:, a:b] = Wt @ g.gamma(0.3, 1.0, size=(32, b - a)).astype(np.float32) + 1e-9
+            H0[:, a:b] = g.random((r, b - a), dtype=np.float32)
+        W0 = np.random.default_rng(6).random((F, r))
+        tr = ShardedTrainer(V, W0, H0, beta=2.0, sparsity=50.0, max_iter=warm + steps + 1, conv_eps=0.0, cost_check=True, device=local_rank)
+        del V, H0
+    except Exception as e:  # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    ok = torch.tensor([0.0 if err else 1.0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if float(ok.item()) < 1.0:
+        return {"error": err or "another rank could not set the C5 shard up"}
+    try:
+        tr.run(warm)
+        tr.sync()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        tr.run(steps)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device="cuda")
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        dt = float(dt.item())
+        _d, cost, _n = tr.plan.get_objective()
+        last = [c for c in cost if c != 0.0]
+        desc = tr.plan.describe()
+        del tr
+        torch.cuda.empty_cache()
+        # executed flop per iteration on this path: H step 6 F T r, W step V*H' 2 F T r + Gram 2 r^2 T (+ W*Gram, small)
+        fl = 8.0 * F * T * r + 2.0 * r * r * T
+        return {"workload": f"{world}xMI355X frame-sharded BASELINE configs[4]: {F}x{T} r={r} beta=2 lambda=50", "ms_per_step": dt / steps * 1e3,
+                "value": steps / dt, "unit": "iterations/s", "steps": steps, "warmup": warm, "scaling": "strong",
+                "executed_TFLOPs": fl * steps / dt / 1e12, "frac_of_peak": fl * steps / dt / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
+                "final_cost": float(last[-1]) if last else None, "geometry": desc}
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 if __name__ == "__main__":

@@ -843,6 +843,16 @@ static int launch_reduce(snmf_plan* pl, double* stats, bool do_mats, bool do_obj
     ra.divh = pl->divh;
     ra.costh = pl->costh;
     ra.st = pl->st;
+    if (const snmf_plan::Exchange* x = pl->xpush) {  // the multi-device entry: reduce and push in one launch
+        pl->xpush = nullptr;
+        ra.npush = x->n;
+        for (int q = 0; q < x->n; ++q) {
+            ra.push_dst[q] = x->push_dst[q];
+            ra.push_flag[q] = x->push_flag[q];
+        }
+        ra.push_done = x->push_done;
+        ra.push_seq = x->seq;
+    }
     const size_t tot = do_mats ? ((size_t)pl->n_mat * pl->p.r * pl->Fp) / 4 : 1;
     ScopedTimer tm(pl->ctx, FAM_REDUCE);
     hipLaunchKernelGGL(k_reduce, dim3((int)std::max<size_t>(1, std::min<size_t>((tot + 31) / 32, 4096))), dim3(256),
@@ -882,9 +892,20 @@ static ApplyArgs make_apply_args(snmf_plan* pl, const double* stats, int check_i
     return aa;
 }
 int launch_wapply(snmf_plan* pl, const double* stats, int check_it, bool do_update, bool init_mode) {
-    const ApplyArgs aa = make_apply_args(pl, stats, check_it, do_update, init_mode);
+    ApplyArgs aa = make_apply_args(pl, stats, check_it, do_update, init_mode);
+    size_t lds = 0;
+    if (const snmf_plan::Exchange* x = pl->xgather) {  // the multi-device entry: sum the ranks' slots and apply in one launch
+        pl->xgather = nullptr;
+        aa.gather = x->gather;
+        aa.ngather = x->n;
+        aa.gather_len = x->len;
+        aa.gflags = x->gflags;
+        aa.gseq = x->seq;
+        aa.fault = &pl->st->fault;
+        lds = (size_t)2 * pl->Fp * sizeof(double);
+    }
     ScopedTimer tm(pl->ctx, FAM_WAPPLY);
-    hipLaunchKernelGGL(k_wapply, dim3(pl->p.r), dim3(256), 0, pl->ctx->stream, aa);
+    hipLaunchKernelGGL(k_wapply, dim3(pl->p.r), dim3(256), lds, pl->ctx->stream, aa);
     HIP_TRY(hipGetLastError());
     return SNMF_OK;
 }

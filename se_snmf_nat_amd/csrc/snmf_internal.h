@@ -154,6 +154,20 @@ struct snmf_plan {
     void* staging = nullptr;
     size_t staging_bytes = 0;
     int n_part = 0;
+    // the multi-device entry's fused exchange (csrc/snmf_multi.h): set around snmf_plan_wstats / snmf_plan_wapply of one
+    // iteration, consumed (and cleared) by launch_reduce / launch_wapply
+    struct Exchange {
+        int n = 0;                       // ranks
+        double* push_dst[16] = {};       // this rank's slot on every rank
+        unsigned* push_flag[16] = {};    // FLAGS: this rank's arrival word on every rank (else nullptr)
+        unsigned* push_done = nullptr;   // FLAGS: this rank's workgroup counter
+        const double* gather = nullptr;  // this rank's gather buffer of the exchange's parity
+        size_t len = 0;                  // doubles per slot
+        const unsigned* gflags = nullptr;
+        unsigned seq = 0;
+    };
+    const Exchange* xpush = nullptr;     // next launch_reduce pushes while it reduces
+    const Exchange* xgather = nullptr;   // next launch_wapply sums the slots while it applies
     // state
     bool have_v = false, have_w = false, have_h = false, have_s = false, inited = false;
     bool w_dirty = true;      // W changed since its last normalisation (online: W stays, only V/H change)

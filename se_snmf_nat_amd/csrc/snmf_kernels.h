@@ -3429,6 +3429,15 @@ struct ReduceArgs {
     double* divh;
     double* costh;
     DevState* st;
+    // Fused push of the multi-device entry (csrc/snmf_multi.h): npush > 0 = every reduced value ALSO goes straight into this
+    // rank's slot of the gather buffer of npush ranks (peer stores) instead of a second launch copying the statistics there;
+    // push_done / push_flag / push_seq: the FLAGS ordering's completion protocol (the last workgroup posts the sequence
+    // number on every peer), nullptr in EVENTS mode.
+    int npush;
+    double* push_dst[16];
+    unsigned* push_flag[16];
+    unsigned* push_done;
+    unsigned push_seq;
 };
 
 #ifdef SNMF_AUX_KERNELS  // k_reduce .. k_mdi_start: launched by snmf_api.hip only (the other translation units skip their code generation)
@@ -3501,7 +3510,9 @@ static __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
                     double t = 0.0;
 #pragma unroll
                     for (int gg = 0; gg < 8; ++gg) t += part[gg][ee][j];
-                    a.stats[4 * pos_of(b4 + ee) + j] = t;
+                    const size_t idx = 4 * pos_of(b4 + ee) + j;
+                    a.stats[idx] = t;
+                    for (int q = 0; q < a.npush; ++q) a.push_dst[q][idx] = t;
                 }
             }
         }
@@ -3525,6 +3536,7 @@ static __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
 #pragma unroll
                 for (int gg = 0; gg < 8; ++gg) t += part[gg][threadIdx.x][0];
                 a.stats[nmat + k0 + threadIdx.x] = t;
+                for (int q = 0; q < a.npush; ++q) a.push_dst[q][nmat + k0 + threadIdx.x] = t;
             }
         }
     }
@@ -3551,7 +3563,23 @@ static __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
         if (threadIdx.x == 0) {
             sc[0] = a.do_obj ? red2[0][0] : 0.0;
             sc[1] = a.do_obj ? (a.use_sh_const ? a.sh_const : red2[1][0]) : 0.0;
+            for (int q = 0; q < a.npush; ++q) {
+                a.push_dst[q][nmat + a.rp] = sc[0];
+                a.push_dst[q][nmat + a.rp + 1] = sc[1];
+            }
             if (a.check_it > 0) conv_test(sc, a.divh, a.costh, a.st, a.check_it, a.conv_eps, true);
+        }
+    }
+    if (a.npush > 0 && a.push_done) {  // FLAGS ordering (as k_push_stats): the last workgroup announces the push on every peer
+        __threadfence_system();        // this thread's peer stores are performed before it reports
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned old = __hip_atomic_fetch_add(a.push_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == gridDim.x - 1) {
+                __hip_atomic_store(a.push_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __threadfence_system();
+                for (int q = 0; q < a.npush; ++q) __hip_atomic_store(a.push_flag[q], a.push_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }
@@ -3578,6 +3606,16 @@ struct ApplyArgs {
     int init_mode;    // 1: normalise the given W only (src/sparse_nmf.m:157-159), write wn
     double conv_eps;
     double* wn;       // init_mode: column norms out [rp]
+    // Fused sum of the multi-device entry (csrc/snmf_multi.h): gather != nullptr = the statistics are the sum, in RANK ORDER,
+    // of ngather slots of gather_len doubles each (the one-shot exchange's gather buffer of this rank) -- every column's
+    // workgroup adds its own column, instead of a launch of its own summing the whole buffer first.  gflags / gseq / fault: the
+    // FLAGS ordering's arrival words (nullptr: EVENTS -- the stream already waited for every push).
+    const double* gather;
+    int ngather;
+    size_t gather_len;
+    const unsigned* gflags;
+    unsigned gseq;
+    int* fault;
 };
 
 // One workgroup (256 threads) per column k of W.  src/sparse_nmf.m:215-244.
@@ -3689,18 +3727,67 @@ __device__ __forceinline__ void wapply_column(const ApplyArgs& a, int k, int tid
 
 #ifdef SNMF_AUX_KERNELS
 static __global__ __launch_bounds__(256) void k_wapply(ApplyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double wap_cols[];  // gather mode: [n_mat][Fp] this column's summed statistics
     __shared__ double red[3][256];
+    __shared__ double scs[2];
     if (!a.init_mode && a.st->stop) return;  // normalising a fresh W never depends on an earlier solve's flag
     const int k = blockIdx.x;
     const int tid = threadIdx.x;
     const size_t nel = (size_t)a.rp * a.Fp;
+    if (a.gather) {
+        if (a.gflags) {  // FLAGS ordering: every rank's push of this exchange must have arrived (k_sum_ranks' bounded wait)
+            if (tid < a.ngather && !__hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                while ((int)(__hip_atomic_load(a.gflags + tid, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - a.gseq) < 0) {
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) {  // 5 s
+                        atomicExch(a.fault, 1);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(32);
+                }
+            }
+            __syncthreads();
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        }
+        if (tid < 2) {  // the two cost scalars, summed like everything else: slot 0 + slot 1 + ...
+            const size_t i = nel * a.n_mat + a.rp + tid;
+            double v = a.gather[i];
+            for (int q = 1; q < a.ngather; ++q) v += a.gather[(size_t)q * a.gather_len + i];
+            scs[tid] = v;
+        }
+        __syncthreads();
+    }
     if (a.check_it > 0) {
-        const double* sc = a.stats + nel * a.n_mat + a.rp;
+        const double* sc = a.gather ? scs : a.stats + nel * a.n_mat + a.rp;
         bool stopnow = conv_test(sc, a.divh, a.costh, a.st, a.check_it, a.conv_eps, k == 0 && tid == 0);
         if (stopnow) return;
     }
     if (!a.do_update && !a.init_mode) return;
     if (k >= a.r) return;
+    if (a.gather) {
+        double* Qs = wap_cols;
+        double* Ps = wap_cols + a.Fp;
+        for (int f = tid; f < a.Fp; f += 256) {
+            const size_t i = (size_t)k * a.Fp + f;
+            double v = a.gather[i];
+            for (int q = 1; q < a.ngather; ++q) v += a.gather[(size_t)q * a.gather_len + i];
+            Qs[f] = v;
+            if (a.n_mat == 2) {
+                double u = a.gather[nel + i];
+                for (int q = 1; q < a.ngather; ++q) u += a.gather[(size_t)q * a.gather_len + nel + i];
+                Ps[f] = u;
+            }
+        }
+        double sk = 0.0;
+        if (a.n_mat != 2) {
+            const size_t i = nel * a.n_mat + k;
+            sk = a.gather[i];
+            for (int q = 1; q < a.ngather; ++q) sk += a.gather[(size_t)q * a.gather_len + i];
+        }
+        __syncthreads();
+        wapply_column(a, k, tid, Qs, a.n_mat == 2 ? Ps : nullptr, sk, red);
+        return;
+    }
     const double* Q = a.stats + (size_t)k * a.Fp;
     const double* P = (a.n_mat == 2) ? a.stats + nel + (size_t)k * a.Fp : nullptr;
     const double sk = (a.n_mat == 2 || a.init_mode) ? 0.0 : a.stats[nel * a.n_mat + k];

@@ -253,6 +253,7 @@ extern "C" int snmf_multi_create(const int32_t* devices, int32_t n_dev, const sn
                 s = dalloc(&m->flags[g], (size_t)2 * n_dev + 1);
             }
             if (s == SNMF_OK) hipMemset(m->flags[g], 0, fb);
+            if (s == SNMF_OK) hipMemset(m->slots[g], 0, sb);  // (the fused push writes the r real rows only: the pad rows stay zero)
         }
         if (s == SNMF_OK) {
             hipMemset(m->stats[g], 0, m->len * sizeof(double));
@@ -363,7 +364,10 @@ extern "C" int snmf_multi_init(snmf_multi* m) {
 // nobody re-records an event a peer has not yet waited on; a failed rank still takes part in the barrier.
 // Returns false when the ranks agreed to stop (some rank failed; EVENTS mode only -- in FLAGS mode a failed rank is
 // found at the barrier behind the loop, and its peers' polls time out on the device).
-static bool multi_exchange(snmf_multi* m, int g, int par, unsigned xs, int& seq, int& rc, std::string& err) {
+// fused = the push already happened inside this rank's k_reduce launch (snmf_plan::xpush) and the sum will happen inside its
+// k_wapply launch (snmf_plan::xgather): only the ORDERING between the two is left to do here (W updates; round 4: an
+// iteration of a rank is four launches instead of six).
+static bool multi_exchange(snmf_multi* m, int g, int par, unsigned xs, int& seq, int& rc, std::string& err, bool fused = false) {
     hipStream_t st = m->ctx[g]->stream;
     auto note = [&](int s) {
         if (rc == SNMF_OK && s != SNMF_OK) {
@@ -373,7 +377,9 @@ static bool multi_exchange(snmf_multi* m, int g, int par, unsigned xs, int& seq,
     };
     const bool flags = m->mode == SNMF_EXCHANGE_FLAGS;
     const int grid = (int)std::max<size_t>(1, std::min<size_t>((m->xlen + 255) / 256, 512));
-    if (m->n > 1 && rc == SNMF_OK) {
+    if (fused) {
+        if (m->n > 1 && rc == SNMF_OK && !flags && hipEventRecord(m->ev[par][g], st) != hipSuccess) note(fail(SNMF_ERR_NO_DEVICE, "hipEventRecord failed"));
+    } else if (m->n > 1 && rc == SNMF_OK) {
         PushArgs pa{};
         pa.src = m->stats[g] + m->xoff;
         pa.len = m->xlen;
@@ -394,7 +400,7 @@ static bool multi_exchange(snmf_multi* m, int g, int par, unsigned xs, int& seq,
         if (!flags)
             for (int q = 0; q < m->n; ++q)
                 if (q != g && hipStreamWaitEvent(st, m->ev[par][q], 0) != hipSuccess) note(fail(SNMF_ERR_NO_DEVICE, "hipStreamWaitEvent failed"));
-        if (rc == SNMF_OK) {
+        if (rc == SNMF_OK && !fused) {
             hipLaunchKernelGGL(k_sum_ranks, dim3(grid), dim3(256), 0, st, (const double*)(m->slots[g] + (size_t)par * m->n * m->xlen),
                                m->n, m->xlen, m->stats[g] + m->xoff, flags ? (const unsigned*)(m->flags[g] + (size_t)par * m->n) : nullptr,
                                xs, &m->plan[g]->st->fault);
@@ -419,13 +425,35 @@ static void multi_rank_loop(snmf_multi* m, int g, int it0, int target, bool fina
     unsigned xs = m->xseq;
     const bool flags = m->mode == SNMF_EXCHANGE_FLAGS;
     bool all_ok = true;
+    // W updates: the exchange rides on the iteration's own launches (k_reduce pushes, k_wapply sums); SNMF_MULTI_UNFUSED=1
+    // keeps the separate k_push_stats / k_sum_ranks launches (tests compare the two: bit-identical)
+    const char* uf = getenv("SNMF_MULTI_UNFUSED");
+    const bool fused = m->upd_w && m->n > 1 && m->xoff == 0 && !(uf && atoi(uf) != 0);
     for (int it = it0; it < target && all_ok; ++it) {
         if (rc == SNMF_OK) step(snmf_plan_hstep(m->plan[g]));
+        snmf_plan::Exchange X;
+        ++xs;
+        if (fused) {
+            X.n = m->n;
+            X.len = m->xlen;
+            X.seq = xs;
+            for (int q = 0; q < m->n; ++q) {
+                X.push_dst[q] = m->slots[q] + ((size_t)par * m->n + g) * m->xlen;
+                X.push_flag[q] = flags ? m->flags[q] + (size_t)par * m->n + g : nullptr;
+            }
+            X.push_done = flags ? m->flags[g] + (size_t)2 * m->n : nullptr;
+            X.gather = m->slots[g] + (size_t)par * m->n * m->xlen;
+            X.gflags = flags ? (const unsigned*)(m->flags[g] + (size_t)par * m->n) : nullptr;
+            m->plan[g]->xpush = &X;
+        }
         if (rc == SNMF_OK) step(snmf_plan_wstats(m->plan[g], m->stats[g]));
-        all_ok = multi_exchange(m, g, par, ++xs, seq, rc, err);
+        m->plan[g]->xpush = nullptr;
+        all_ok = multi_exchange(m, g, par, xs, seq, rc, err, fused);
         if (!all_ok) break;
         par ^= 1;
+        if (fused) m->plan[g]->xgather = &X;
         if (rc == SNMF_OK) step(snmf_plan_wapply(m->plan[g], m->stats[g]));
+        m->plan[g]->xgather = nullptr;
         if (m->can_stop && ++since >= 4) {  // same poll schedule and (bit-identical statistics) same answer on every rank
             since = 0;
             int32_t sflag = 0;

@@ -62,7 +62,8 @@ def test_device_list_solve_matches_oracle_and_unsharded(gpu_ctx, case):
 
 @pytest.mark.parametrize("mode,two_devices", [("events", False), ("flags", False), ("flags", True), ("events", True)],
                          ids=["events-one-device", "flags-one-device", "flags-two-devices", "events-two-devices"])
-def test_handle_api_replicas_are_bit_identical_and_equal_the_step_api(gpu_ctx, lib, mode, two_devices):
+@pytest.mark.parametrize("unfused", [False, True], ids=["fused", "unfused"])
+def test_handle_api_replicas_are_bit_identical_and_equal_the_step_api(gpu_ctx, lib, mode, two_devices, unfused, monkeypatch):
     """snmf_multi_* with 2 ranks against a hand-driven pair of plans over the step API (hstep -> wstats -> host-side fp64
     sum in rank order -> wapply): the one-shot exchange adds the slots in rank order too, so W, H and every cost must
     agree BIT FOR BIT; and the two W replicas of the multi handle must be identical.  Both orderings of the exchange
@@ -74,6 +75,9 @@ def test_handle_api_replicas_are_bit_identical_and_equal_the_step_api(gpu_ctx, l
     from se_snmf_nat_amd.api import _make_params
     if two_devices and lib.snmf_device_count() < 2:
         pytest.skip("needs two HIP devices")
+    # round 4: the exchange rides on the iteration's own launches (k_reduce pushes into the peers' slots, k_wapply sums them:
+    # four launches per iteration and rank instead of six); SNMF_MULTI_UNFUSED=1 keeps k_push_stats / k_sum_ranks -- same bits
+    monkeypatch.setenv("SNMF_MULTI_UNFUSED", "1" if unfused else "0")
     F, T, r, iters = 257, 1300, 48, 9
     V, W0, H0 = synth_problem(F, T, r)
     V32, H32 = V.astype(np.float32), H0.astype(np.float32)

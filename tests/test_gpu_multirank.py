@@ -151,7 +151,7 @@ def test_bench_launches_its_own_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(SNMF_DIST_BACKEND="gloo", SNMF_FORCE_DEVICE="0")
     pr = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-                         "--T", "6400", "--r", "64", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE,
+                         "--T", "6400", "--r", "64", "--no-cpu-baseline", "--c5-T", "12800"], env=env, stdout=subprocess.PIPE,
                         stderr=subprocess.PIPE, text=True, timeout=900)
     assert pr.returncode == 0, pr.stderr[-2000:]
     lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
@@ -167,6 +167,10 @@ def test_bench_launches_its_own_ranks():
     assert "error" not in one, one
     assert one["ms_per_step"] > 0 and one["devices"] == [0, 0] and one["steps"] == 4
     assert abs(one["final_cost"] - d["final_cost"]) <= 1e-6 * d["final_cost"]
+    # the extra strong-scaling leg on BASELINE configs[4] (beta = 2, r = 512; here with few frames), beside `value`
+    c5 = d["c5_strong"]
+    assert "error" not in c5, c5
+    assert c5["ms_per_step"] > 0 and c5["steps"] == 10 and c5["final_cost"] > 0 and "r=512" in c5["workload"]
 
 
 def test_bench_single_gpu_line_keeps_the_contract():
