@@ -2547,6 +2547,30 @@ __global__ __launch_bounds__(512, 2) void k_hsolve_small(StepArgs a, SmallArgs s
 // solve instead of twice per iteration.  The extra row (F = 64*FB + 1) is a wave-level dot product.
 // Loop semantics, objective recording and the stop test are those of k_hsolve_small.
 // ============================================================================================
+// P1 of k_hsolve_frame: this thread's FB x KB register block times the wave's KB entries of hv -> the wave's partial Lam
+// (lamp[kb][Fm]) and, with the extra row, its partial of W[Fm,:] * hv.  Shared by the solve's loop and the reconstruction passes.
+template <int FB, int KB>
+__device__ __forceinline__ void hsolve_frame_p1(const f32x2 (&wr)[FB / 2][KB], const float* hv, const float* wxs, float* lamp, float* xlam,
+                                                int Fm, bool xr, int kb, int fb, int lane) {
+    f32x2 lp[FB / 2];
+#pragma unroll
+    for (int i2 = 0; i2 < FB / 2; ++i2) lp[i2] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk) {
+        const float hk = hv[kb * KB + kk];  // wave-uniform address: LDS broadcast
+        const f32x2 hk2 = f32x2{hk, hk};
+#pragma unroll
+        for (int i2 = 0; i2 < FB / 2; ++i2) lp[i2] = __builtin_elementwise_fma(wr[i2][kk], hk2, lp[i2]);
+    }
+#pragma unroll
+    for (int i2 = 0; i2 < FB / 2; ++i2) *reinterpret_cast<f32x2*>(lamp + kb * Fm + fb * FB + 2 * i2) = lp[i2];
+    if (xr) {  // extra row: this wave's KB columns of W[Fm,:] * hv, lanes 0..KB-1
+        static_assert(KB <= 64, "one lane per column");
+        const float px = wave_sum_f(lane < KB ? wxs[kb * KB + lane] * hv[kb * KB + lane] : 0.f);
+        if (lane == 0) xlam[kb] = px;
+    }
+}
+
 template <int FB, int KB, int BM, bool OBJ, bool RECON = false>
 __global__ __launch_bounds__(512, 2) void k_hsolve_frame(StepArgs a, SmallArgs sa, const float* __restrict__ Wcf) {
     constexpr int NTHR = 512, RB = 8 * KB, LDP = RB + 1;  // LDP odd: the partial rows hit distinct banks
@@ -2633,26 +2657,7 @@ __global__ __launch_bounds__(512, 2) void k_hsolve_frame(StepArgs a, SmallArgs s
         if (j > sa.max_iter && !(OBJ && sa.max_iter >= 1)) break;
         const bool upd = j <= sa.max_iter;
         // ---- P1: Lam = W * h ---------------------------------------------------------------------
-        {
-            f32x2 lp[FB / 2];
-#pragma unroll
-            for (int i2 = 0; i2 < FB / 2; ++i2) lp[i2] = f32x2{0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < KB; ++kk) {
-                const float hk = hs[kb * KB + kk];  // wave-uniform address: LDS broadcast
-                const f32x2 hk2 = f32x2{hk, hk};
-#pragma unroll
-                for (int i2 = 0; i2 < FB / 2; ++i2) lp[i2] = __builtin_elementwise_fma(wr[i2][kk], hk2, lp[i2]);
-            }
-#pragma unroll
-            for (int i2 = 0; i2 < FB / 2; ++i2)
-                *reinterpret_cast<f32x2*>(lamp + kb * Fm + fb * FB + 2 * i2) = lp[i2];
-            if (xr) {  // extra row: this wave's KB columns of W[Fm,:] * h, lanes 0..KB-1
-                static_assert(KB <= 64, "one lane per column");
-                const float px = wave_sum_f(lane < KB ? wxs[kb * KB + lane] * hs[kb * KB + lane] : 0.f);
-                if (lane == 0) xlam[kb] = px;
-            }
-        }
+        hsolve_frame_p1<FB, KB>(wr, hs, wxs, lamp, xlam, Fm, xr, kb, fb, lane);
         __syncthreads();
         float dterm = 0.f;
         for (int f = tid; f < Fm; f += NTHR) {
@@ -2779,36 +2784,21 @@ __global__ __launch_bounds__(512, 2) void k_hsolve_frame(StepArgs a, SmallArgs s
     }
     for (int k = tid; k < rp; k += NTHR) a.Hout[k] = k < RB ? hs[k] : 0.f;
     if (RECON) {
-        // Xm_hat_sum = B_x*A_x and Dm_hat_sum = B_d*A_d: two more passes of the P1 shape with h .* wn, the first
-        // over the columns k < Rx, the second over the rest
+        // Xm_hat_sum = B_x*A_x and Dm_hat_sum = B_d*A_d: two more passes of P1 ITSELF (the same inlined code, so the register
+        // block keeps the allocation of the solve's loop: with the class select inside the unrolled products this variant --
+        // the one the online loop launches -- had 32 spilled VGPRs and 36 B of scratch) over two masked copies of h .* wn,
+        // the first with the columns k < Rx, the second with the rest; they live in sps / dps, which are dead by now.
         float* out = sa.recon + (size_t)blockIdx.x * 2 * F;
-        __syncthreads();  // H has been copied out: h <- h .* wn in place
+        __syncthreads();  // H has been copied out and nobody reads sps / dps any more
         if (lane < KB) {
             const int k = kb * KB + lane;
-            hs[k] = k < a.rp ? (float)((double)hs[k] * sa.wn[k]) : 0.f;
+            const float hw = k < a.rp ? (float)((double)hs[k] * sa.wn[k]) : 0.f;
+            sps[k] = k < sa.Rx ? hw : 0.f;
+            dps[k] = k < sa.Rx ? 0.f : hw;
         }
         __builtin_amdgcn_wave_barrier();
         for (int part = 0; part < 2; ++part) {
-            f32x2 lp[FB / 2];
-#pragma unroll
-            for (int i2 = 0; i2 < FB / 2; ++i2) lp[i2] = f32x2{0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < KB; ++kk) {
-                const int k = kb * KB + kk;
-                const float hk = ((k < sa.Rx) == (part == 0)) ? hs[k] : 0.f;
-                const f32x2 hk2 = f32x2{hk, hk};
-#pragma unroll
-                for (int i2 = 0; i2 < FB / 2; ++i2) lp[i2] = __builtin_elementwise_fma(wr[i2][kk], hk2, lp[i2]);
-            }
-#pragma unroll
-            for (int i2 = 0; i2 < FB / 2; ++i2)
-                *reinterpret_cast<f32x2*>(lamp + kb * Fm + fb * FB + 2 * i2) = lp[i2];
-            if (xr) {
-                const int k = kb * KB + lane;
-                const bool mine = lane < KB && (k < sa.Rx) == (part == 0);
-                const float px = wave_sum_f(mine ? wxs[k] * hs[k] : 0.f);
-                if (lane == 0) xlam[kb] = px;
-            }
+            hsolve_frame_p1<FB, KB>(wr, part ? dps : sps, wxs, lamp, xlam, Fm, xr, kb, fb, lane);
             __syncthreads();
             for (int f = tid; f < Fm && f < F; f += NTHR) {
                 float s = lamp[f];
