@@ -228,7 +228,7 @@ def test_full_size_c2_golden_is_consistent_with_the_oracle_on_a_frame_block():
     H12_head at a point where one more H-only iteration moves it exactly as the full solve would -- checked through
     the cheap invariants instead: costs strictly decreasing, 12-iteration vectors equal to the head of the long run,
     W12 unit-norm and non-negative, H slices non-negative and finite."""
-    g = np.load(os.path.join(GOLD, "c2_full_257x100000_r256.npz", "basis_v73_small_expected.npz"))
+    g = np.load(os.path.join(GOLD, "c2_full_257x100000_r256.npz"))
     assert g["W12"].shape == (257, 256) and g["H12_head"].shape == (256, 64) and g["H12_tail"].shape == (256, 64)
     np.testing.assert_array_equal(g["cost"][:12], g["cost12"])
     np.testing.assert_array_equal(g["div"][:12], g["div12"])
