@@ -282,7 +282,7 @@ def main():
         traffic, traffic_source = None, None
         if (F, T, r) == (F_, T_, R_):
             import glob
-            for fn in sorted(glob.glob(os.path.join(_ROOT, "profiles", "r*_traffic.json")))[-1:]:
+            for fn in sorted(glob.glob(os.path.join(_ROOT, "profiles", "r[0-9][0-9]_traffic.json")))[-1:]:
                 tj = json.load(open(fn))
                 # the launch that runs in the timed region: the KL update + objective variant of the dominant kernel
                 keys = [k for k in tj if k.startswith("k_" + dom)]
