@@ -111,7 +111,11 @@ int snmf_sparse_nmf_oop_f32(snmf_ctx* ctx, const snmf_params* p, const float* V,
 /* A plan owns fp32 device copies of V (F x T), W (F x r), H (r x T) in the engine's padded
  * layouts plus all workspaces.  Call order: create -> set_v/set_w/set_h[/set_sparsity] ->
  * init -> run (or the step functions) -> get_*.  `p->T` is the LOCAL column count of this
- * shard when the frame axis is sharded across ranks. */
+ * shard when the frame axis is sharded across ranks.
+ * One documented deviation from the reference's expression: a Euclidean (beta = 2) FULL update with r < 2F forms the W step's
+ * P = max(W*H, 1e-9) * H' (src/sparse_nmf.m:166, :228-233) as W * (H*H'), i.e. without the floor on W*H.  The two differ only
+ * where W*H < 1e-9 (silent rows / frames), by at most 1e-9 * sum(h) per entry of P.  Environment SNMF_GRAM_P=0 at plan creation
+ * selects the reference's expression (one more Lam' pass per iteration); tests/test_gpu_parity.py pins both. */
 int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan** out);
 void snmf_plan_destroy(snmf_plan* plan);
 

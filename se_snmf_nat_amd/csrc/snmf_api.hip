@@ -385,7 +385,10 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     }
     // Euclidean full updates: P through the Gram matrix (launch_gram_p) wherever it is the cheaper form (2 r^2 T against
     // 4 F T r; W-only solves take their objective from the P launch's Lam' and keep it)
-    if (pl->bm == BM_EUC && pl->upd_w && pl->upd_h && pl->TTW == 32 && r < 2 * F) {
+    // SNMF_GRAM_P=0 opts out: P = max(W*H, flr)*H' is then formed from the Lam' pass exactly as src/sparse_nmf.m:228-233 writes
+    // it (the two forms differ only where W*H sits below the 1e-9 floor, by at most flr * sum(h) per entry: include/snmf.h)
+    const char* gp_env = getenv("SNMF_GRAM_P");
+    if (pl->bm == BM_EUC && pl->upd_w && pl->upd_h && pl->TTW == 32 && r < 2 * F && !(gp_env && atoi(gp_env) == 0)) {
         pl->gram_p = true;
         const int nfg_g = (pl->rp / 32 + pl->NWB - 1) / pl->NWB;
         pl->gram_chunks = pl->kq_kg ? pl->kq_chunks

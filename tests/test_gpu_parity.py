@@ -586,6 +586,35 @@ def test_euclidean_w_step_through_the_gram_matrix(gpu_ctx):
     assert np.max(np.abs(o["cost"] - orf["cost"]) / np.abs(orf["cost"])) < 1e-5
 
 
+def test_gram_form_opt_out_keeps_the_floor_of_the_reference(gpu_ctx, monkeypatch):
+    """SNMF_GRAM_P=0 forms P = max(W*H, flr) * H' as src/sparse_nmf.m:228-233 writes it.  On data with silent rows AND silent
+    frames the rows of W that sit at the floor are where the two forms can differ (by at most flr * sum(h) per entry of P):
+    with the opt-out those rows follow the fp64 oracle at the solver tolerance measured on THOSE rows alone; with the Gram
+    form the pinned bound is the whole-matrix tolerance (the floor rows carry ~1e-9 of the Frobenius norm)."""
+    from se_snmf_nat_amd import Plan, sparse_nmf
+    F, T, r = 96, 900, 24
+    rs = np.random.default_rng(11)
+    V = rs.gamma(0.5, 1.0, (F, 6)) @ rs.gamma(0.3, 1.0, (6, T)) + 1e-3
+    V[:10, :] = 0.0
+    V[:, 300:360] = 0.0
+    p = dict(cf="ed", sparsity=0.5, max_iter=12, conv_eps=0, cost_check=1, init_w=rs.random((F, r)), init_h=rs.random((r, T)))
+    wr, hr, orf = oracle_nmf(V, p)
+    w_g, h_g, o_g = sparse_nmf(V, p, ctx=gpu_ctx)
+    monkeypatch.setenv("SNMF_GRAM_P", "0")
+    pl = Plan(gpu_ctx, F, T, r, beta=2.0, max_iter=2, cost_check=True)
+    assert "Gram matrix" not in pl.describe()
+    pl.close()
+    w_f, h_f, o_f = sparse_nmf(V, p, ctx=gpu_ctx)
+    monkeypatch.delenv("SNMF_GRAM_P")
+    for w, h, o in ((w_g, h_g, o_g), (w_f, h_f, o_f)):
+        assert rel(w, wr) < REL_WH and rel(h, hr) < REL_WH
+        assert np.max(np.abs(o["cost"] - orf["cost"]) / np.abs(orf["cost"])) < 1e-5
+    # the floor rows by themselves: the reference's expression tracks the oracle there, row-relative
+    assert rel(w_f[:10], wr[:10]) < 1e-3
+    # and the Gram form's deviation on them is bounded in ABSOLUTE terms by what the dropped floor can move
+    assert np.max(np.abs(w_g[:10] - wr[:10])) < 1e-3 * np.max(np.abs(wr)) + 1e-7
+
+
 def test_shapes_beyond_the_fused_kernels_take_the_out_of_envelope_path(gpu_ctx):
     """What the fused kernels cannot hold in LDS / registers -- F + r beyond the 16-frame tile images (~2540), W updates
     with r > 1024 under KL or with F = 32n+1 rows -- is no longer refused (src/sparse_nmf.m has no such limit): the plan
