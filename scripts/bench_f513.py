@@ -49,7 +49,7 @@ def synth(F, T, r, seed=0):
 
 for name in which:
     c = SHAPES[name]
-    F, T, r = c["F"], c["T"], c["r"]
+    F, T, r = c["F"], int(os.environ.get("SNMF_BENCH_T", c["T"])), c["r"]  # (SNMF_BENCH_T: the same shape on another frame count)
     iters = K or c["iters"]
     V, W0, H0 = synth(F, T, r)
     kw = {}

@@ -28,6 +28,7 @@ _TU_HDRS = {
     "snmf_tu_online.hip": ["snmf_online.h"],
     "snmf_tu_multi.hip": ["snmf_multi.h"],
     "snmf_tu_dnmf.hip": ["snmf_frontend.h"],
+    "snmf_tu_smallf.hip": ["snmf_smallf.h"],
 }
 HDRS = sorted(_glob.glob(os.path.join(_HERE, "csrc", "*.h"))) + [os.path.join(_ROOT, "include", "snmf.h")]
 

@@ -295,6 +295,19 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
             }
         }
     }
+    // At most two row tiles and four column tiles (the Mel solves): a tile per WAVE, nothing handed between waves
+    // (snmf_smallf.h).  Follows SNMF_HSTEP_RP (tests compare against the barrier-phased kernels); SNMF_HSTEP_SF=0 keeps the
+    // role pipeline.
+    {
+        const char* e = getenv("SNMF_HSTEP_RP");
+        const char* e2 = getenv("SNMF_HSTEP_SF");
+        pl->sf = pl->bm == BM_KL && pl->upd_h && !pl->xr && pl->nf <= 2 && pl->nk <= 4 && !pl->generic && !(e && atoi(e) == 0) &&
+                 !(e2 && atoi(e2) == 0);
+        pl->lds_sf = ((size_t)pl->nf * pl->rp * 32 + (size_t)pl->nk * pl->Fq * 32 + 2 * (size_t)pl->rp) * 4 + 2 * 8 * sizeof(double);
+        pl->sf_grid = std::max(1, std::min((T + 31) / 32, ctx->n_cu));
+        pl->sf_stagger = 8000;
+        if (const char* e3 = getenv("SNMF_SF_STAG")) pl->sf_stagger = atoi(e3);
+    }
     // k_wstats geometry: 4-wave workgroups, each wave owns one 32-row tile x NKT 32-column tiles of
     // the statistics in registers.  NKT <= 8 (128 accumulator VGPRs): two workgroups per CU.
     if (pl->nk <= 4) { pl->NKT = 4; pl->WPS = 2; }
@@ -336,6 +349,18 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         pl->lds_w = std::max<size_t>(std::max<size_t>((pl->NLW ? pl->nbw * buf_ld : buf) + tail,
                                                       (size_t)std::max(4, pl->NWB) * pl->rp * 4),
                                      (size_t)(pl->NWB + pl->NLW) * 64 * sizeof(double));
+    }
+    // Fewer row tiles than consumer waves (F = 64, a Mel spectrogram: two): the consumer waves form teams that take the chunk's
+    // tiles in turn (StepArgs::til) instead of leaving half the SIMDs without an MFMA wave.  Needs the loader geometry (the
+    // teams' partial statistics meet in the tile buffers at the end), one row group, one kappa-group, no extra row.
+    pl->til = 1;
+    if (pl->NLW && pl->TTW == 32 && !pl->xr && pl->n_fg == 1 && pl->n_kg == 1 && pl->upd_w && pl->NKT <= 8) {
+        int til = 1;
+        while (til * 2 * pl->nf <= pl->NWB) til *= 2;
+        const size_t per_wave = (size_t)(pl->NKT * 16 + 8) * 64 * 4;
+        while (til > 1 && (size_t)(til - 1) * (pl->NWB / til) * per_wave > pl->lds_w) til /= 2;
+        if (const char* e = getenv("SNMF_WSTATS_TIL")) if (atoi(e) == 1) til = 1;
+        pl->til = til;
     }
     const int wg_w = pl->NLW ? 1 : pl->WPS;  // workgroups per CU
     pl->n_chunks = std::max(1, std::min(n_tiles_w, ctx->n_cu * wg_w / std::max(1, pl->n_fg * pl->n_kg)));
@@ -540,7 +565,10 @@ extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
     const bool kl_pipe = pl->NWH == 8 && pl->NLH == 4 && pl->bm == BM_KL && pl->upd_h && !pl->M && pl->hstep_rp;
     char hs[256];
     const bool rh_pipe = pl->rh && pl->upd_h && !pl->M;
-    if (rh_pipe)
+    const bool sf_pipe = pl->sf && !pl->M;
+    if (sf_pipe)
+        snprintf(hs, sizeof hs, "k_hstep_sf (a tile per wave from first load to last store, 8 waves per workgroup; %d tiles, grid %d)", pl->rp_tiles, pl->sf_grid);
+    else if (rh_pipe)
         snprintf(hs, sizeof hs, "k_hstep_rh (4 P1 + 4 P2 + 4 loader waves on half tiles%s; %d of %d tiles pipelined, last round split %d ways, grid %d)",
                  pl->rh_lxh == 1 ? ", P2 cut four ways over the contraction + leftover columns as 4x4x1 MFMAs" : (pl->rh_lxh == 2 ? ", P2 in wave pairs cut over the contraction + leftover columns as 4x4x1 MFMAs" : ""), pl->rp_full, pl->rp_tiles, pl->rp_S, pl->rp_grid);
     else if (kl_pipe)
@@ -557,9 +585,9 @@ extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
              "F=%d T=%d r=%d beta=%g | Fm=%d(+%d VALU row) rp=%d Tp=%d | hstep: %s, tile=%d frames, grid=%d x %d thr, lds=%zu B | "
              "wstats: NK=%d waves=%d+%d grid=(%d chunks,%d fgroups,%d kgroups; group-1 chunks %d) lds=%zu B%s | W finish (run loop): %s | n_cu=%d",
              pl->p.F, pl->p.T, pl->p.r, pl->p.beta, pl->Fm, pl->xr, pl->rp, pl->Tp, hs, pl->TTH * pl->NT,
-             (kl_pipe || rh_pipe) ? pl->rp_grid : pl->grid_h, rh_pipe ? 768 : (pl->NWH + pl->NLH) * 64,
-             rh_pipe ? pl->lds_rh : pl->lds_h, pl->NKT, pl->NWB, pl->NLW, pl->n_chunks, pl->n_fg, pl->n_kg, pl->n_ch1 ? pl->n_ch1 : pl->n_chunks, pl->lds_w,
-             pl->gram_p ? ", P = W*(H*H') through the Gram matrix" : "", pl->wfin ? "k_wfin" : (pl->upd_w ? "k_reduce + k_wapply" : "none"), pl->ctx->n_cu);
+             sf_pipe ? pl->sf_grid : ((kl_pipe || rh_pipe) ? pl->rp_grid : pl->grid_h), sf_pipe ? 512 : (rh_pipe ? 768 : (pl->NWH + pl->NLH) * 64),
+             sf_pipe ? pl->lds_sf : (rh_pipe ? pl->lds_rh : pl->lds_h), pl->NKT, pl->NWB, pl->NLW, pl->n_chunks, pl->n_fg, pl->n_kg, pl->n_ch1 ? pl->n_ch1 : pl->n_chunks, pl->lds_w,
+             pl->gram_p ? ", P = W*(H*H') through the Gram matrix" : (pl->til > 1 ? (pl->til == 2 ? ", 2 consumer teams take the tiles in turn" : ", 4+ consumer teams take the tiles in turn") : ""), pl->wfin ? "k_wfin" : (pl->upd_w ? "k_reduce + k_wapply" : "none"), pl->ctx->n_cu);
     return SNMF_OK;
 }
 
@@ -709,6 +737,7 @@ StepArgs make_args(snmf_plan* pl) {
     a.stop = &pl->st->stop;
     a.stagger_shift = -1;
     a.nbuf = 2;
+    a.til = 1;
     a.prof = pl->prof;
     a.wx = pl->wx;
     a.Fm = pl->Fm;
@@ -1004,6 +1033,7 @@ static bool hupd_is_rp(const snmf_plan* pl) {
 static int hupd_parts(const snmf_plan* pl) {
     if (pl->generic) return kGBlocks;
     if (pl->M) return pl->grid_mdi;
+    if (pl->sf) return pl->sf_grid;
     if (hupd_is_rp(pl)) return pl->rp_grid;
     return pl->grid_h;
 }

@@ -110,6 +110,11 @@ struct snmf_plan {
     int NKT = 8, NWB = 4, WPS = 2, NLW = 0;  // k_wstats template geometry (NLW loader waves)
     int nbw = 2;                             // k_wstats tile buffers in LDS with loader waves (3 where they fit)
     int n_fg = 1, n_kg = 1, n_chunks = 1;
+    bool sf = false;      // KL H-update launches through k_hstep_sf (F <= 64, r <= 128: snmf_smallf.h)
+    int sf_grid = 1;
+    int sf_stagger = 0;   // cycles by which the second wave of each SIMD starts late (k_hstep_sf)
+    size_t lds_sf = 0;
+    int til = 1;  // k_wstats: consumer teams that share a chunk's tiles (StepArgs::til)
     int n_ch1 = 0;  // k_wstats: chunks of row group 1 when the two row groups are split unevenly (else 0)
     // beta = 2, r > 256: the V*H^T launch (needs no Lam') runs the loader-wave geometry <8,4,4,2> once per 256-column
     // kappa-group, each staging only its own columns of H (kq_chunks frame chunks, kq_kg kappa-groups; 0 = off)
@@ -231,6 +236,7 @@ int xfer_sync(snmf_ctx* c);
 int launch_hstep(snmf_plan* pl, bool obj, bool upd);
 int launch_hstep_rp(snmf_plan* pl, StepArgs a, bool obj);  // snmf_tu_hstep_rp.hip
 int launch_hstep_rh(snmf_plan* pl, StepArgs a, bool obj);  // snmf_tu_hstep_rh.hip
+int launch_hstep_sf(snmf_plan* pl, StepArgs a, bool obj);  // snmf_tu_smallf.hip
 int launch_wstats(snmf_plan* pl, bool obj);
 int launch_wstats_nk4(snmf_plan* pl, const StepArgs& a, bool obj);  // snmf_tu_wstats4.hip
 int launch_wstats_nk8(snmf_plan* pl, const StepArgs& a, bool obj);  // snmf_tu_wstats8.hip

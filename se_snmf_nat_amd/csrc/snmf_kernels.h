@@ -148,6 +148,9 @@ struct StepArgs {
     int n_ch1;            // k_wstats: > 0 = row group 1 has its own, smaller, number of frame chunks (1-D grid)
     int lxh;              // k_hstep_rh: P2 cut over the contraction, leftover columns on the VALU (nk = 4, r = 97..100)
     int kc;               // k_wstats, WM = 3 (V * H^T needs no Lam'): each kappa-group stages only ITS 32*NK columns of H
+    int til;              // k_wstats with loader waves, FEWER row tiles than consumer waves (nf <= NWB / 2, no extra row): the consumers
+                          // are til teams of NWB / til waves; team p takes the tiles it % til == p of the chunk and the teams' partial
+                          // statistics are added through LDS at the end (fixed order).  0 / 1: every consumer wave on every tile
     int nbuf;             // k_wstats with loader waves: tile buffers in LDS (2, or 3 where they fit: the loaders then run two tiles ahead)
     int F, T, Fp, rp, Tp, nf, nk;
     int nqk;              // 8-deep k-blocks of the contractions over the components = ceil(r / 8): W's columns / H's rows
@@ -1553,6 +1556,23 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
     }
     if (threadIdx.x < 25) cnt[threadIdx.x] = 0u;
     __syncthreads();
+    // A wave WITHOUT work -- an A wave past the last row tile, a B wave without a column tile -- used to walk the tile list
+    // anyway, waiting for and posting every signal: a wave that polls LDS takes issue slots from the MFMA wave of its SIMD
+    // (F = 64: two of four A waves, r <= 32: three of four B waves).  Where nothing else needs it (no split last round, whose
+    // parts are dealt to all four waves of a team; no extra row, which the A waves share) its progress words are set to
+    // "done with every tile" once and it waits at the final barrier instead.
+    bool idle = false;
+    if (a.part_S == 0) {
+        const bool bs = a.nf <= 2 && a.nk >= 2;  // (b_shift: see the B team)
+        const bool idle_a = w < NA && w >= a.nf && !a.xr;
+        const bool idle_b = w >= NA && w < NA + NB && (bs ? w - NA < 2 : w - NA >= a.nk);
+        if (lane == 0) {
+            if (idle_a) p1a[w] = p1b[w] = xdone[w] = 0xffffffffu;
+            if (idle_b) p2done[w - NA] = 0xffffffffu;
+        }
+        idle = idle_a || idle_b;
+    }
+    __syncthreads();
     // Tiles [0, n_full) go through the pipeline, dealt out round-robin.  The tiles of the last PARTIAL round,
     // [n_full, n_tiles), are split over part_S workgroups each: workgroup u < (n_tiles - n_full) * part_S
     // takes part u % part_S of tile n_full + u / part_S as one more staged tile AFTER its pipelined ones.
@@ -1687,6 +1707,8 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                 rp_post(vready, lw, (unsigned)(j + 3), lane);
             }
         }
+    } else if (idle) {
+        // (nothing: straight to the final reduction)
     } else if (w < NA) {
         // ================================ A team: P1 ================================================
         SNMF_STAMP_DECL
@@ -1723,9 +1745,11 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     f32x16 acc[1] = {zero16()};
                     const int so[1] = {phi * rp * 128};
                     contract_shared_buf<1>(acc, wimage_rsrc(a.Wt4, (size_t)a.nf * rp * 32), lane * 16, so, sp, a.nqk, gate_ready);
+                    SNMF_STAMP(4);
                     gate_v();
                     rp_p1_epilogue<OBJ>(a, acc[0], Rs, phi, t0, lane, dsum);
                     if (phi == w) rp_post(p1a, w, (unsigned)(j + 1), lane);
+                    SNMF_STAMP(5);
                 }
             }
             gate_ready();  // (a wave without a row tile has not waited yet)
@@ -1756,11 +1780,18 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
         const int wb = w - NA;
         SNMF_STAMP_DECL
         // 1 ./ dph of this wave's columns: constants of the launch when the wave owns one pair of column tiles (nk <= 8)
-        const bool one_group = a.nk <= 2 * NB;
+        // Which column tiles this wave owns: tile wb and wb + NB, ... -- unless the A team has work for two waves only
+        // (nf <= 2: a Mel spectrogram of 64 bands): A waves 0 and 1 share their SIMDs with B waves 0 and 1, and with P1 AND P2
+        // of a tile on SIMDs 0 / 1 while SIMDs 2 / 3 carry a quarter of P2 each, the tile period was the loaded SIMDs' (Mel
+        // 64 x 72000 r = 100: 84 of a tile's 232 MFMAs on each of them).  Then B waves 2 and 3 take ALL column tiles in pairs
+        // (kb, kb + 2): P1 on SIMDs 0 / 1, P2 on SIMDs 2 / 3.
+        const bool b_shift = a.nf <= 2 && a.nk >= 2;
+        const int kb = b_shift ? wb - 2 : wb, kpair = b_shift ? 2 : NB;
+        const bool one_group = a.nk <= 2 * kpair;
         f32x4 dp0[4], dp1[4];
-        if (one_group && wb < a.nk) {
-            rp_p2_consts(a, wb, lane, dp0);
-            if (wb + NB < a.nk) rp_p2_consts(a, wb + NB, lane, dp1);
+        if (one_group && kb >= 0 && kb < a.nk) {
+            rp_p2_consts(a, kb, lane, dp0);
+            if (kb + kpair < a.nk) rp_p2_consts(a, kb + kpair, lane, dp1);
         }
         auto b_item = [&](const int j) {  // P2 of the whole tile in place j of the list
             const int t0 = tile_of(j) * Tt;
@@ -1776,16 +1807,16 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             const int nqm = a.xr ? nq - 1 : nq;  // k-blocks over the ratio rows proper; the extra row's is a phase of its own, gated by xdone
             auto gate_p1b = [&]() { rp_await(p1b, (unsigned)(j + 1), a.stop); };
             auto gate_x = [&]() { rp_await(xdone, (unsigned)(j + 1), a.stop); };
-            for (int kap = wb; kap < a.nk; kap += 2 * NB) {
-                if (kap + NB < a.nk) {
+            for (int kap = kb < 0 ? a.nk : kb; kap < a.nk; kap += 2 * kpair) {
+                if (kap + kpair < a.nk) {
                     f32x16 acc[2] = {zero16(), zero16()};
                     if (!one_group) {
                         rp_p2_consts(a, kap, lane, dp0);
-                        rp_p2_consts(a, kap + NB, lane, dp1);
+                        rp_p2_consts(a, kap + kpair, lane, dp1);
                     }
                     {
                         const __amdgpu_buffer_rsrc_t rsk = wimage_rsrc(a.Wk4, (size_t)a.nk * a.Fq * 32);
-                        const int so[2] = {kap * a.Fq * 128, (kap + NB) * a.Fq * 128};
+                        const int so[2] = {kap * a.Fq * 128, (kap + kpair) * a.Fq * 128};
                         contract_shared_buf<2>(acc, rsk, lane * 16, so, sp, nq1, gate_p1a);
                         if (nqm > nq1) {
                             const int so2[2] = {so[0] + nq1 * 1024, so[1] + nq1 * 1024};
@@ -1800,7 +1831,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     }
                     SNMF_STAMP(9);
                     rp_p2_epilogue<OBJ>(a, acc[0], Hs, kap, t0, lane, dp0, shsum);
-                    rp_p2_epilogue<OBJ>(a, acc[1], Hs, kap + NB, t0, lane, dp1, shsum);
+                    rp_p2_epilogue<OBJ>(a, acc[1], Hs, kap + kpair, t0, lane, dp1, shsum);
                     SNMF_STAMP(10);
                 } else {
                     f32x16 acc[1] = {zero16()};
@@ -2896,8 +2927,12 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         for (int k = threadIdx.x; k < rp; k += NTHR) wxs[k] = a.wx[k];
     if (GXL && do_x)  // (the consumers' partial extra rows start at zero; a barrier separates this from their first use)
         for (int k = threadIdx.x; k < NWB * gxw; k += NTHR) (lds + NBUF * TT * (ldh + 32 * NWB) + a.rp + 128)[k] = 0.f;
-    const int phi = by * NWB + w;
-    const int fc = w * 32 + fl;  // this lane's column of the staged V image
+    // F = 64 (a Mel spectrogram) has two row tiles: two of four consumer waves -- two of four SIMDs -- would carry the whole
+    // chunk.  With a.til > 1 the consumers form til TEAMS of nfl = NWB / til waves; wave w is row tile w % nfl of team w / nfl.
+    const int til = (NL > 0 && a.til > 1) ? a.til : 1, nfl = NWB / til;
+    const int wl = til > 1 ? w % nfl : w, tph = til > 1 ? w / nfl : 0;
+    const int phi = by * NWB + wl;
+    const int fc = wl * 32 + fl;  // this lane's column of the staged V image
     const bool active = !is_loader && phi < a.nf;
     const int kap_base = blockIdx.z * NK;  // kappa-group (r > 32*NK: P3 is recomputed per group)
     const bool do_obj = OBJ && blockIdx.z == 0;
@@ -2942,9 +2977,14 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     // (the read-modify-write is inline assembly: as C++ stores into the LDS array inside the tile loop they alias every
     //  tile read as far as the compiler knows, and the 168-VGPR geometries went from 16 to 211 spilled registers)
     const unsigned gxa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(gxs + w * gxw + 4 * lane);
+    // A consumer wave without a row tile (and without a share of the extra row) has nothing to do in the tile loop but wait
+    // and report -- polling LDS beside the MFMA wave of its SIMD: its progress word is set to "done with every tile" instead.
+    const bool idle_c = NL > 0 && !is_loader && !active && !do_x;
     if (NL > 0) {
         if (threadIdx.x < 4 + NWB) ready[threadIdx.x] = 0u;
         __syncthreads();  // slots and wxs are set
+        if (idle_c && lane == 0) done[w] = 0xffffffffu;
+        __syncthreads();
     }
 
     // The extra row of one tile (row group 0 only): ratio_x[t] for this wave's CPW columns, then gx[k] += ratio_x[t] * H[k,t].
@@ -3090,7 +3130,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     }
     SNMF_STAMP_DECL
     int cb = NL > 0 ? NBUF - 1 : 0;  // buffer of the consumers' current tile (advanced at the loop top)
-    for (int tile = tb, it = 0; tile < te && !is_loader; ++tile, ++it) {
+    for (int tile = tb, it = 0; tile < te && !is_loader && !idle_c; ++tile, ++it) {
         const int t0 = tile * TT;
         SNMF_STAMP(0);
         if (NL > 0) cb = cb + 1 == NBUF ? 0 : cb + 1;
@@ -3137,7 +3177,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         }
         if (do_x) xrow_tile(Hs, t0, w, vx + cb * 32);
         SNMF_STAMP(2);
-        if (!active) {
+        if (!active || (til > 1 && it % til != tph)) {  // (another team's tile: only the progress report)
             if (NL > 0) rp_post(done, w, (unsigned)(it + 1), lane);
             continue;
         }
@@ -3275,8 +3315,42 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     }
 #endif
 
+    if (NL > 0 && til > 1) {
+        // the teams' partial statistics -> team 0, through the tile buffers (every consumer is past its last tile and the
+        // loaders past their last DMA at the first barrier), added in team order
+        float* xs = lds;  // [(til - 1) * nfl][NK * 16 + 4 * LX][64]
+        constexpr int NV = NK * 16 + (LX ? 4 * LX : 0);
+        __syncthreads();
+        if (active && tph > 0) {
+            float* dst = xs + (size_t)((tph - 1) * nfl + wl) * NV * 64 + lane;
+#pragma unroll
+            for (int k = 0; k < NK; ++k)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dst[(k * 16 + i) * 64] = G[k][i];
+            if constexpr (LX > 0) {
+#pragma unroll
+                for (int j = 0; j < 4 * LX; ++j) dst[(NK * 16 + j) * 64] = gl[j];
+            }
+        }
+        __syncthreads();
+        if (active && tph == 0) {
+            for (int p = 1; p < til; ++p) {
+                const float* src = xs + (size_t)((p - 1) * nfl + wl) * NV * 64 + lane;
+#pragma unroll
+                for (int k = 0; k < NK; ++k)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) G[k][i] += src[(k * 16 + i) * 64];
+                if constexpr (LX > 0) {
+#pragma unroll
+                    for (int j = 0; j < 4 * LX; ++j) gl[j] += src[(NK * 16 + j) * 64];
+                }
+            }
+        }
+        __syncthreads();  // (the row-sum reduction below reuses the same memory)
+    }
+    const bool writes = active && tph == 0;
     // ---- write the partial slab: D tile lane (k = fl, h), reg -> f = 32*phi + drow(reg,h)
-    if (active) {
+    if (writes) {
         float* slab = a.slabs + ((size_t)chunk * n_mat + mat_index) * rp * Fp;
 #pragma unroll
         for (int kap = 0; kap < NK; ++kap) {
@@ -3290,7 +3364,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
             }
         }
     }
-    if (active && LX > 0) {  // leftover columns: slab[k0 + j][f] = the two lane halves' partial sums (fixed order: h = 0, then h = 1)
+    if (writes && LX > 0) {  // leftover columns: slab[k0 + j][f] = the two lane halves' partial sums (fixed order: h = 0, then h = 1)
         float* slab = a.slabs + ((size_t)chunk * n_mat + mat_index) * rp * Fp;
         const int k0 = (a.nk - 1) * 32;
 #pragma unroll

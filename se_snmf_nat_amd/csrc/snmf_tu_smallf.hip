@@ -1,0 +1,24 @@
+// snmf_tu_smallf.hip -- launches of the small-F kernels (snmf_smallf.h: spectrograms of at most two 32-row tiles, the Mel solves).
+#include "snmf_internal.h"
+#include "snmf_smallf.h"
+
+template <int NF, int NK>
+static int launch_hstep_sf_n(snmf_plan* pl, const StepArgs& a, bool obj) {
+    dim3 g(pl->sf_grid), b(snmf::kSfWaves * 64);
+    return obj ? launch_big(snmf::k_hstep_sf<NF, NK, true>, g, b, pl->lds_sf, pl->ctx->stream, a)
+               : launch_big(snmf::k_hstep_sf<NF, NK, false>, g, b, pl->lds_sf, pl->ctx->stream, a);
+}
+template <int NF>
+static int launch_hstep_sf_f(snmf_plan* pl, const StepArgs& a, bool obj) {
+    switch (pl->nk) {
+        case 1: return launch_hstep_sf_n<NF, 1>(pl, a, obj);
+        case 2: return launch_hstep_sf_n<NF, 2>(pl, a, obj);
+        case 3: return launch_hstep_sf_n<NF, 3>(pl, a, obj);
+        default: return launch_hstep_sf_n<NF, 4>(pl, a, obj);
+    }
+}
+int launch_hstep_sf(snmf_plan* pl, StepArgs a, bool obj) {
+    a.stagger = pl->sf_stagger;
+    a.n_tiles = pl->rp_tiles;  // only tiles that hold a frame (the pad tiles of both H buffers are zero and stay zero)
+    return pl->nf == 1 ? launch_hstep_sf_f<1>(pl, a, obj) : launch_hstep_sf_f<2>(pl, a, obj);
+}

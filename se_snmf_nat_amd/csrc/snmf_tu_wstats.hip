@@ -12,6 +12,7 @@ int launch_wstats(snmf_plan* pl, bool obj) {
     a.ldh = pl->ldhw;
     a.stagger = pl->stagger_w;
     a.nbuf = pl->nbw;
+    a.til = pl->til;
 
     ScopedTimer tm(pl->ctx, FAM_WSTATS);
     if (pl->NKT == 4) return launch_wstats_nk4(pl, a, obj);

@@ -32,6 +32,7 @@ static int launch_gram_p(snmf_plan* pl, const StepArgs& a) {
     ag.nf = pl->rp / 32;
     ag.xr = 0;
     ag.n_ch1 = 0;
+    ag.til = 1;  // (the consumer teams are a property of the plan's F: here the rows are H's)
     ag.slabs = pl->gram_slabs;
     if (pl->kq_kg) {  // r > 256: by kappa-groups on the loader-wave geometry, like the Q launch
         ag.ldh = 260;
@@ -90,6 +91,7 @@ static int launch_wstats_geo(snmf_plan* pl, const StepArgs& a, bool obj) {
             aq.kc = 1;
             aq.nbuf = 2;
             aq.n_ch1 = 0;
+            aq.til = 1;
             auto kern = k_wstats<8, 4, 4, 2, 3, BM_EUC, false, 32>;
             SN_TRY(ensure_dyn_lds(pl->ctx->device, (const void*)kern, pl->kq_lds));
             hipLaunchKernelGGL(kern, dim3(pl->kq_chunks, pl->n_fg, pl->kq_kg), dim3(512), pl->kq_lds, pl->ctx->stream, aq, pl->kq_chunks, 0,

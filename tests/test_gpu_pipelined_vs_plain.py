@@ -30,7 +30,11 @@ SHAPES = [(65, 70, 12000), (129, 70, 12000), (65, 32, 12000), (64, 70, 12000), (
           # compact V image -- the reference's shipped F = 513 at R = 100 / 200 (settings/initial_setting_SNMF_NAT.m:21-29,48-49)
           (513, 100, 12000), (513, 200, 9000), (513, 256, 5000), (385, 100, 12000), (449, 250, 9000), (512, 128, 8000),
           (289, 40, 20000), (513, 200, 100), (513, 100, 9000), (512, 256, 10000), (513, 97, 12000), (512, 99, 9000),
-          (513, 194, 12000), (512, 200, 16500)]
+          (513, 194, 12000), (512, 200, 16500),
+          # at most two row tiles (a Mel spectrogram: run_basis_train.m:91 on 64 bands): k_hstep_rp with P2 on the B waves of
+          # the SIMDs the A team leaves free, k_wstats with consumer TEAMS that take the tiles of a chunk in turn
+          (64, 100, 20000), (64, 40, 12000), (32, 100, 12000), (64, 200, 12000), (128, 100, 12000), (64, 100, 9000),
+          (64, 128, 70000), (40, 20, 33000), (64, 100, 3000), (32, 8, 100)]
 
 
 def _run(ctx, V, W0, H0, r, *, h_only, iters):
@@ -54,25 +58,29 @@ def test_pipelined_kernels_equal_plain_kernels(gpu_ctx, shape, monkeypatch):
     for k in ("SNMF_HSTEP_RP", "SNMF_HSTEP_SPLIT", "SNMF_WSTATS_NL"):
         monkeypatch.delenv(k, raising=False)
     h_new, _, geo, obj_new = _run(gpu_ctx, V, W0, H0, r, h_only=True, iters=2)
-    _, w_new, _, _ = _run(gpu_ctx, V, W0, H0, r, h_only=False, iters=3)
+    _, w_new, geo_full, _ = _run(gpu_ctx, V, W0, H0, r, h_only=False, iters=3)
     n_cu = int(re.search(r"n_cu=(\d+)", geo).group(1))
-    if (T + 31) // 32 <= n_cu:
+    if (T + 31) // 32 <= n_cu and "k_hstep_sf" not in geo:
         # one tile per workgroup: nothing to pipeline, the plan takes the barrier-phased kernels by itself (C1's case)
         assert "k_hstep_rp" not in geo and "k_hstep_rh" not in geo  # (k_wstats keeps its loader waves while a workgroup has several tiles)
         n_full, n_tiles, S = (T + 31) // 32, (T + 31) // 32, 0
     else:
-        assert "k_hstep_rp" in geo or "k_hstep_rh" in geo  # the pipelined path is what ran
+        assert "k_hstep_rp" in geo or "k_hstep_rh" in geo or "k_hstep_sf" in geo  # the pipelined path is what ran
         m = re.search(r"(\d+) of (\d+) tiles pipelined, last round split (\d+) ways", geo)
-        n_full, n_tiles, S = (int(x) for x in m.groups())
+        if "k_hstep_sf" in geo:  # (F <= 64, r <= 128: a tile per wave, never split)
+            assert F <= 64 and r <= 128
+            n_full, n_tiles, S = (T + 31) // 32, (T + 31) // 32, 0
+        else:
+            n_full, n_tiles, S = (int(x) for x in m.groups())
     monkeypatch.setenv("SNMF_HSTEP_SPLIT", "0")
     h_ns, _, geo_ns, _ = _run(gpu_ctx, V, W0, H0, r, h_only=True, iters=2)
     _, w_ns, _, _ = _run(gpu_ctx, V, W0, H0, r, h_only=False, iters=3)
-    assert "split 0 ways" in geo_ns or "k_hstep," in geo_ns
+    assert "split 0 ways" in geo_ns or "k_hstep," in geo_ns or "k_hstep_sf" in geo_ns
     monkeypatch.setenv("SNMF_HSTEP_RP", "0")
     monkeypatch.setenv("SNMF_WSTATS_NL", "0")
     h_old, _, geo_old, obj_old = _run(gpu_ctx, V, W0, H0, r, h_only=True, iters=2)
     _, w_old, _, _ = _run(gpu_ctx, V, W0, H0, r, h_only=False, iters=3)
-    assert "k_hstep_rp" not in geo_old and "k_hstep_rh" not in geo_old
+    assert "k_hstep_rp" not in geo_old and "k_hstep_rh" not in geo_old and "k_hstep_sf" not in geo_old
     # every tile in the pipeline: the plain kernels bit for bit -- except where k_hstep_rh cuts P2 over the contraction
     # (r = 97..100 on 16 row tiles: four partial sums per numerator instead of one chain), which is a summation order of its own
     lxh = "over the contraction" in geo  # (r = 97..100 four ways, r = 193..200 in wave pairs)
@@ -95,5 +103,7 @@ def test_pipelined_kernels_equal_plain_kernels(gpu_ctx, shape, monkeypatch):
         assert (d <= 2e-5 * np.abs(h_old[:, t_split:]) + 1e-30).all(), d.max()
         assert not np.array_equal(h_new[:, t_split:], h_old[:, t_split:]) or T - t_split < 64  # (another order: not the same bits)
     assert np.abs(w_new - w_old).max() <= 2e-6 * np.abs(w_old).max()
+    if F in (32, 64) and (T + 31) // 32 > n_cu:
+        assert "consumer teams take the tiles in turn" in geo_full
     for a, b in zip(obj_new, obj_old):
         assert abs(a - b) <= 1e-6 * abs(b)
