@@ -641,7 +641,9 @@ struct WAdaptArgs {
 };
 
 constexpr int kWaRB = 8, kWaRP = 64;    // rows of W per workgroup (32 threads each), padded rank (32 rows x 1024 threads: 2261 instead of 2743 frames/s)
-constexpr int kWaNT = kWaRB * 32;         // threads per workgroup
+constexpr int kWaLPR = 32;                // threads per row of W (64 -- a wave per row, eight waves per workgroup -- made the products no
+                                          // faster and both exchanges slower: 3434 against 3620 frames/s)
+constexpr int kWaNT = kWaRB * kWaLPR;     // threads per workgroup
 
 // Grid barrier on a monotonic device counter (zeroed before the launch).  cooperative_groups' grid.sync()
 // measured ~20 us per call here, and an agent-scope release/acquire pair costs a write-back plus an
@@ -655,8 +657,11 @@ constexpr int kWaNT = kWaRB * 32;         // threads per workgroup
 // is the flag".  Correct, but 256 pollers per workgroup flood the coherent path: 2090 instead of 2790 frames/s.
 // Tried: 16 / 32 rows per workgroup: the exchange does not get cheaper with fewer workgroups, the products do
 // get slower: 2650 / 2400 frames/s.)
-__device__ __forceinline__ bool grid_bar(unsigned* ctr, unsigned nwg, unsigned& gen) {
-    __shared__ int ok_s;
+// `ok_sp`: one int of the caller's DYNAMIC LDS.  (A static __shared__ here preceded the dynamic region and shifted its base
+// by 4 bytes: every 8- / 16-byte LDS access of the kernel was then off its natural alignment and replayed at 64 cycles per
+// wave-instruction -- /opt/skills/guides/cdna_hip_programming.md, "statics totalling != 0 (mod 16) shift the base".)
+__device__ __forceinline__ bool grid_bar(unsigned* ctr, unsigned nwg, unsigned& gen, int* ok_sp) {
+    int& ok_s = *ok_sp;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's exchange stores are acknowledged ...
     __syncthreads();                                   // ... and so are everybody's in the workgroup
     ++gen;
@@ -672,7 +677,17 @@ __device__ __forceinline__ bool grid_bar(unsigned* ctr, unsigned nwg, unsigned& 
     return ok_s != 0;
 }
 
+#ifdef SNMF_PROF_WA  // diagnostic builds only: cycles of workgroup 0 by phase, summed over the solves of a run
+__device__ unsigned long long g_wa_prof[10];
+#define WA_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    atomicAdd(&g_wa_prof[i], t_ - wa_t_); wa_t_ = t_; } } while (0)
+#else
+#define WA_STAMP(i)
+#endif
 __global__ __launch_bounds__(kWaNT) void k_wadapt(WAdaptArgs a) {
+#ifdef SNMF_PROF_WA
+    unsigned long long wa_t_ = __builtin_amdgcn_s_memtime();
+#endif
     constexpr int RB = kWaRB, RP = kWaRP, NT = kWaNT, NWV = kWaNT / 64;
     unsigned gen = 0;
     bool bar_ok = true;
@@ -683,6 +698,7 @@ __global__ __launch_bounds__(kWaNT) void k_wadapt(WAdaptArgs a) {
     double* cq = Wd + RB * RP;                            // [RP] reduced column quantities
     double* cs = cq + RP;                                 // [RP] colsum(W)
     double* red = cs + RP;                                // [NWV + 1] (padded to 32)
+    int* oks = reinterpret_cast<int*>(red + 31);          // the grid barrier's verdict (red is padded to 32 doubles)
     double* scr = red + 32;                               // [2][128] cross_sum scratch
     double* tmp = scr + 256;                              // [2*RP] reduced quantities of one exchange
     float* Wf = reinterpret_cast<float*>(tmp + 2 * RP);   // [RB][RP]
@@ -692,32 +708,49 @@ __global__ __launch_bounds__(kWaNT) void k_wadapt(WAdaptArgs a) {
     float* Rs = Vs + RB * ma;                             // [RB][ma]
     float* Hs = Rs + RB * ma;                             // [Ra][ma]
     float* HT = Hs + Ra * ma;                             // [ma][RP + 1]
-    const int f = tid >> 5, l32 = tid & 31;               // row of the block, lane within the row's 32 threads
+    // the operand images of the two products: what ONE lane needs for one k (its four frames l, l + 32, l + 64, l + 96) resp.
+    // one frame (its two columns l, l + 32) side by side, so that it is ONE wide read instead of four / two (ma <= 128)
+    float* Hp = HT + ma * (RP + 1);                       // [Ra][128]: Hp[k][4 l + j] = h[k][l + 32 j]  (0 past ma)
+    float* HTp = Hp + Ra * 128;                           // [ma][RP]:  HTp[t][2 l + c] = h[l + 32 c][t] (0 past Ra)
+    static_assert(kWaLPR == 32 && RP == 64, "operand images of k_wadapt's products");
+    const bool wide = a.ma <= 128 && (a.ma & 3) == 0;    // (16-byte reads of rows of ma floats)
+    const int f = tid / kWaLPR, l32 = tid % kWaLPR;       // row of the block, lane within the row's threads
+    static_assert(RP % kWaLPR == 0 && 128 % kWaLPR == 0, "whole columns of G / frames per lane");
     const bool row_ok = f0 + f < F;
 
     // ---- load + src/sparse_nmf.m:157-169 ------------------------------------------------------
+    // (consecutive threads take consecutive ROWS of one column / frame: the block's 8 rows are one 64- / 32-byte piece of memory)
     for (int i = tid; i < RB * RP; i += NT) {
-        const int ff = i / RP, k = i - ff * RP;
-        Wd[i] = (k < Ra && f0 + ff < F) ? a.W0[(size_t)k * F + f0 + ff] : 0.0;
+        const int k = i / RB, ff = i - k * RB;
+        Wd[ff * RP + k] = (k < Ra && f0 + ff < F) ? a.W0[(size_t)k * F + f0 + ff] : 0.0;
     }
     for (int i = tid; i < RB * ma; i += NT) {
-        const int ff = i / ma, t = i - ff * ma;
-        Vs[i] = (f0 + ff < F) ? fmaxf(a.V[(size_t)t * F + f0 + ff], a.flr) : 0.f;   // :169
+        const int t = i / RB, ff = i - t * RB;
+        Vs[ff * ma + t] = (f0 + ff < F) ? fmaxf(a.V[(size_t)t * F + f0 + ff], a.flr) : 0.f;   // :169
     }
     for (int i = tid; i < Ra * ma; i += NT) {
         const int t = i / Ra, k = i - t * Ra;
         Hs[k * ma + t] = a.H[i];
     }
     __syncthreads();
-    // wn = sqrt(sum(w.^2)): partial over this block's rows
+    // wn = sqrt(sum(w.^2)) and colsum(w): partials over this block's rows, ONE exchange (the column sums of the normalised
+    // W are colsum(w) ./ wn, as after every update below)
     if (tid < RP) {
-        double s = 0.0;
-        for (int ff = 0; ff < RB; ++ff) s += Wd[ff * RP + tid] * Wd[ff * RP + tid];
-        xstore(a.part2 + (size_t)wg * 2 * RP + tid, s);
+        double s2 = 0.0, s1 = 0.0;
+        for (int ff = 0; ff < RB; ++ff) {
+            const double w = Wd[ff * RP + tid];
+            s2 += w * w;
+            s1 += w;
+        }
+        xstore(a.part2 + (size_t)wg * 2 * RP + tid, s2);
+        xstore(a.part2 + (size_t)wg * 2 * RP + RP + tid, s1);
     }
-    bar_ok &= grid_bar(a.bar, (unsigned)nwg, gen);
-    cross_sum(a.part2, 2 * RP, RP, nwg, scr, tmp);
-    if (tid < RP) cq[tid] = tid < Ra ? sqrt(tmp[tid]) : 1.0;  // wn
+    bar_ok &= grid_bar(a.bar, (unsigned)nwg, gen, oks);
+    cross_sum(a.part2, 2 * RP, 2 * RP, nwg, scr, tmp);
+    if (tid < RP) {
+        cq[tid] = tid < Ra ? sqrt(tmp[tid]) : 1.0;  // wn
+        cs[tid] = tmp[RP + tid] / cq[tid];
+    }
     __syncthreads();
     for (int i = tid; i < RB * RP; i += NT) {
         const int k = i % RP;
@@ -734,24 +767,26 @@ __global__ __launch_bounds__(kWaNT) void k_wadapt(WAdaptArgs a) {
         const int t = i / (RP + 1), k = i - t * (RP + 1);
         HT[i] = k < Ra ? Hs[k * ma + t] : 0.f;
     }
+    if (wide) {
+        for (int i = tid; i < Ra * 128; i += NT) {
+            const int k = i >> 7, l = (i & 127) >> 2, j = i & 3, t = l + 32 * j;
+            Hp[i] = t < ma ? Hs[k * ma + t] : 0.f;
+        }
+        for (int i = tid; i < ma * RP; i += NT) {
+            const int t = i / RP, l = (i % RP) >> 1, c = i & 1, k = l + 32 * c;
+            HTp[i] = k < Ra ? Hs[k * ma + t] : 0.f;
+        }
+    }
     if (tid < RP) {
         float s = 0.f;
         if (tid < Ra)
             for (int t = 0; t < ma; ++t) s += Hs[tid * ma + t];
         sk[tid] = s;                                     // sum(h,2)
     }
-    // colsum(w) partial (first use: iteration 1)
-    if (tid < RP) {
-        double s = 0.0;
-        for (int ff = 0; ff < RB; ++ff) s += Wd[ff * RP + tid];
-        xstore(a.part2 + (size_t)wg * 2 * RP + RP + tid, s);
-    }
-    bar_ok &= grid_bar(a.bar, (unsigned)nwg, gen);
-    cross_sum(a.part2, 2 * RP, 2 * RP, nwg, scr, tmp);
-    if (tid < RP) cs[tid] = tmp[RP + tid];
     __syncthreads();
     double sh_const = 0.0;                               // sum(sum(sparsity .* h)) (:261), constant: H is fixed
     for (int k = 0; k < Ra; ++k) sh_const += (double)a.sparsity * (double)sk[k];
+    WA_STAMP(0);
 
     double last_cost = 0.0;
     int n_rec = 0;
@@ -759,21 +794,92 @@ __global__ __launch_bounds__(kWaNT) void k_wadapt(WAdaptArgs a) {
     for (int j = 1; j <= a.max_iter + 1; ++j) {
         if (j > a.max_iter && !a.cost_check) break;
         // ---- Lam' = max(W*H, flr), ratio, divergence of iterate j-1 ------------------------------
+        // Both products keep the summation order of the plain loops (one fma chain per output element, k resp. t ascending), but
+        // as written before -- one output at a time, its LDS operands read inside the chain, the result stored into the same
+        // LDS array the next chain reads from -- every fma waited for an LDS round trip (18 k cycles per product on a wave that
+        // has its SIMD to itself: 115 cycles per fma; phase stamps of the diagnostic build).  Here a thread's outputs (four
+        // frames, two columns) advance together and nothing is stored inside the loops, so the reads pipeline.
         float dterm = 0.f;
-        for (int t = l32; t < ma; t += 32) {
-            float acc = 0.f;
-            for (int k = 0; k < Ra; ++k) acc = fmaf(Wf[f * RP + k], Hs[k * ma + t], acc);
-            const float lam = fmaxf(acc, a.flr), v = Vs[f * ma + t];
-            Rs[f * ma + t] = row_ok ? v * fast_rcp(lam) : 0.f;
-            if (row_ok) dterm += div_term<BM_KL>(v, lam, 1.f, 0.f);
+        if (wide) {
+            constexpr int NJ = 4;
+            f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+            const float* wr = Wf + f * RP;        // (columns k >= Ra of Wf are zero)
+            const float* hp = Hp + 4 * l32;
+            // four k per step: one 16-byte read of the W row + four 16-byte reads of the lane's frames; the chains are the plain
+            // loop's (per frame, k ascending; a padded k adds fma(0, h, acc) = acc)
+            const int n4 = (Ra + 3) >> 2;
+            for (int g = 0; g < n4; ++g) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + 4 * g);
+                f32x4 h4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = 4 * g + u < Ra ? 4 * g + u : Ra - 1;  // (w = 0 there)
+                    h4[u] = *reinterpret_cast<const f32x4*>(hp + k * 128);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) a4[jj] = fmaf(w4[u], h4[u][jj], a4[jj]);
+            }
+            float ac[NJ] = {a4[0], a4[1], a4[2], a4[3]};
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int t = l32 + kWaLPR * j;
+                if (t < ma) {
+                    const float lam = fmaxf(ac[j], a.flr), v = Vs[f * ma + t];
+                    Rs[f * ma + t] = row_ok ? v * fast_rcp(lam) : 0.f;
+                    if (row_ok) dterm += div_term<BM_KL>(v, lam, 1.f, 0.f);
+                }
+            }
+        } else {
+            for (int t = l32; t < ma; t += kWaLPR) {
+                float acc = 0.f;
+                for (int k = 0; k < Ra; ++k) acc = fmaf(Wf[f * RP + k], Hs[k * ma + t], acc);
+                const float lam = fmaxf(acc, a.flr), v = Vs[f * ma + t];
+                Rs[f * ma + t] = row_ok ? v * fast_rcp(lam) : 0.f;
+                if (row_ok) dterm += div_term<BM_KL>(v, lam, 1.f, 0.f);
+            }
         }
         __syncthreads();
+        WA_STAMP(1);
         // ---- G = (V./Lam') * H' -----------------------------------------------------------------
-        for (int k = l32; k < RP; k += 32) {
-            float acc = 0.f;
-            if (k < Ra)
-                for (int t = 0; t < ma; ++t) acc = fmaf(Rs[f * ma + t], HT[t * (RP + 1) + k], acc);
-            Gs[f * RP + k] = acc;
+        {
+            constexpr int NC = RP / kWaLPR;  // columns l32 + kWaLPR * c of this lane (HT's columns k >= Ra are zero)
+            float g[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) g[c] = 0.f;
+            const float* rr = Rs + f * ma;
+            if (wide) {
+                // four frames per step: one 16-byte read of the ratio row + four 8-byte reads of the lane's two columns
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                const float* xp = HTp + 2 * l32;
+                const int m4 = ma >> 2;
+                for (int q = 0; q < m4; ++q) {
+                    const f32x4 r4 = *reinterpret_cast<const f32x4*>(rr + 4 * q);
+                    f32x2 x2[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) x2[u] = *reinterpret_cast<const f32x2*>(xp + (4 * q + u) * RP);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        g[0] = fmaf(r4[u], x2[u][0], g[0]);
+                        g[1] = fmaf(r4[u], x2[u][1], g[1]);
+                    }
+                }
+                for (int t = 4 * m4; t < ma; ++t) {
+                    const float r = rr[t];
+                    g[0] = fmaf(r, xp[t * RP], g[0]);
+                    g[1] = fmaf(r, xp[t * RP + 1], g[1]);
+                }
+            } else {
+                const float* hc = HT + l32;
+                for (int t = 0; t < ma; ++t) {
+                    const float r = rr[t];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) g[c] = fmaf(r, hc[t * (RP + 1) + kWaLPR * c], g[c]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) Gs[f * RP + l32 + kWaLPR * c] = l32 + kWaLPR * c < Ra ? g[c] : 0.f;
         }
         const float dw = wave_sum_f(dterm);
         if ((tid & 63) == 0) red[tid >> 6] = (double)dw;
@@ -789,11 +895,13 @@ __global__ __launch_bounds__(kWaNT) void k_wadapt(WAdaptArgs a) {
             for (int q = 0; q < NWV; ++q) dsum += red[q];
             xstore(a.part1 + (size_t)wg * (RP + 1) + RP, dsum);
         }
-        bar_ok &= grid_bar(a.bar, (unsigned)nwg, gen);
+        WA_STAMP(2);
+        bar_ok &= grid_bar(a.bar, (unsigned)nwg, gen, oks);
         cross_sum(a.part1, RP + 1, RP + 1, nwg, scr, tmp);     // colsum(G .* W) | div
         if (tid < RP) cq[tid] = tmp[tid];
         if (tid == RP) red[NWV] = tmp[RP];
         __syncthreads();
+        WA_STAMP(3);
         if (a.cost_check && j > 1) {                      // cost of iterate j-1 (:260-284)
             const double cost = red[NWV] + sh_const;
             const int it = j - 1;
@@ -831,7 +939,8 @@ __global__ __launch_bounds__(kWaNT) void k_wadapt(WAdaptArgs a) {
             xstore(a.part2 + (size_t)wg * 2 * RP + tid, s2);
             xstore(a.part2 + (size_t)wg * 2 * RP + RP + tid, s1);
         }
-        bar_ok &= grid_bar(a.bar, (unsigned)nwg, gen);
+        WA_STAMP(4);
+        bar_ok &= grid_bar(a.bar, (unsigned)nwg, gen, oks);
         cross_sum(a.part2, 2 * RP, 2 * RP, nwg, scr, tmp);
         if (tid < RP) {
             const double nrm = tid < Ra ? sqrt(tmp[tid]) : 1.0;
@@ -839,6 +948,7 @@ __global__ __launch_bounds__(kWaNT) void k_wadapt(WAdaptArgs a) {
             cs[tid] = tmp[RP + tid] / nrm;               // colsum of the normalised W
         }
         __syncthreads();
+        WA_STAMP(5);
         for (int i = tid; i < RB * RP; i += NT) {
             const int k = i % RP;
             const double w = k < Ra ? Wd[i] / cq[k] : 0.0;   // :242, ALL columns
@@ -846,13 +956,21 @@ __global__ __launch_bounds__(kWaNT) void k_wadapt(WAdaptArgs a) {
             Wf[i] = (float)w;
         }
         __syncthreads();
+        WA_STAMP(6);
+#ifdef SNMF_PROF_WA
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_wa_prof[8], 1ull);
+#endif
     }
     __syncthreads();
     for (int i = tid; i < RB * RP; i += NT) {
-        const int ff = i / RP, k = i - ff * RP;
-        if (k < Ra && f0 + ff < F) a.Wout[(size_t)k * F + f0 + ff] = Wd[i];
+        const int k = i / RB, ff = i - k * RB;
+        if (k < Ra && f0 + ff < F) a.Wout[(size_t)k * F + f0 + ff] = Wd[ff * RP + k];
     }
     if (wg == 0 && tid == 0) *a.n_iter_out = !bar_ok ? -1 : (stopped ? n_rec : a.max_iter);
+    WA_STAMP(7);
+#ifdef SNMF_PROF_WA
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_wa_prof[9], 1ull);
+#endif
 }
 
 }  // namespace snmf

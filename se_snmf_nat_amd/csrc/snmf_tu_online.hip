@@ -79,6 +79,20 @@ extern "C" void snmf_online_destroy(snmf_online* o) {
     if (!o) return;
     hipSetDevice(o->ctx->device);
     hipStreamSynchronize(o->ctx->stream);
+#ifdef SNMF_PROF_WA
+    {
+        unsigned long long pf[10] = {0};
+        hipMemcpyFromSymbol(pf, HIP_SYMBOL(g_wa_prof), sizeof pf);
+        if (pf[9]) {
+            static const char* nm[8] = {"setup", "product Lam'", "product G + partial sums", "exchange A", "W update + partial sums", "exchange B", "normalise", "store"};
+            fprintf(stderr, "[SNMF_PROF_WA] %llu solves, %.2f loops per solve; k cycles per solve:", pf[9], (double)pf[8] / pf[9]);
+            for (int i = 0; i < 8; ++i) fprintf(stderr, " %s=%.1f", nm[i], (double)pf[i] / pf[9] * 1e-3);
+            fprintf(stderr, "\n");
+            unsigned long long z[10] = {0};
+            hipMemcpyToSymbol(HIP_SYMBOL(g_wa_prof), z, sizeof z);
+        }
+    }
+#endif
     if (o->hp) snmf_plan_destroy(o->hp);
     if (o->ap) snmf_plan_destroy(o->ap);
     if (o->hsemi) snmf_plan_destroy(o->hsemi);
@@ -164,7 +178,8 @@ static int online_make_solvers(snmf_online* o) {
         hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, ctx->device);
         o->wa_nwg = (F + kWaRB - 1) / kWaRB;
         o->wa_lds = (size_t)(kWaRB * kWaRP + 4 * kWaRP + 32 + 256) * 8 +
-                    (size_t)(2 * kWaRB * kWaRP + kWaRP + 2 * kWaRB * p->m_a + p->R_a * p->m_a + p->m_a * (kWaRP + 1)) * 4;
+                    (size_t)(2 * kWaRB * kWaRP + kWaRP + 2 * kWaRB * p->m_a + p->R_a * p->m_a + p->m_a * (kWaRP + 1) +
+                             ((p->m_a <= 128 && p->m_a % 4 == 0) ? p->R_a * 128 + p->m_a * kWaRP : 0)) * 4;  // (+ the products' operand images)
         o->wadapt = coop != 0 && o->wa_nwg <= ctx->n_cu && o->wa_nwg <= 2 * kWaQ && o->wa_lds <= 160 * 1024;
         if (o->wadapt) {
             D(&o->wa_W, (size_t)p->R_a * F);
