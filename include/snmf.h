@@ -71,7 +71,10 @@ const char* snmf_last_error(void);
 int snmf_device_count(void); /* number of HIP devices visible, 0 if none (never fails) */
 
 /* ---- context ---------------------------------------------------------------------------- */
-/* Replaces the implicit gpuArray device state of src/sparse_nmf_GPU.m:161-166. */
+/* Replaces the implicit gpuArray device state of src/sparse_nmf_GPU.m:161-166.
+ * A context keeps the device blocks of destroyed plans for the next plan of the same sizes (a caller that solves problem after
+ * problem of one shape -- every call site of sparse_nmf in the reference -- does not pay hipMalloc / hipFree per call): at most
+ * SNMF_DEVCACHE_MB megabytes (environment, read at creation; default 4096, 0 = off), released by snmf_ctx_destroy. */
 int snmf_ctx_create(snmf_ctx** out, int device);
 /* Use a caller-owned hipStream_t; NULL = the context's own (non-blocking) stream.  The legacy
  * default stream has handle 0 == NULL and therefore cannot be selected: a caller that must order

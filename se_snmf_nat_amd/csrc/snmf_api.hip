@@ -63,6 +63,7 @@ extern "C" int snmf_ctx_create(snmf_ctx** out, int device) {
     snmf_ctx* c = new snmf_ctx();
     c->device = device;
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char* e = getenv("SNMF_DEVCACHE_MB")) c->cache_cap = (size_t)std::max(0, atoi(e)) << 20;
     c->lds_max = prop.sharedMemPerBlock > 0 ? (size_t)prop.sharedMemPerBlock : 64 * 1024;
     {
         int v = 0;
@@ -103,11 +104,37 @@ extern "C" int snmf_ctx_sync(snmf_ctx* c) {
     return SNMF_OK;
 }
 
+void* ctx_take(snmf_ctx* c, size_t bytes) {
+    for (size_t i = 0; i < c->cache.size(); ++i)
+        if (c->cache[i].second == bytes) {
+            void* p = c->cache[i].first;
+            c->cache.erase(c->cache.begin() + i);
+            c->cache_bytes -= bytes;
+            return p;
+        }
+    return nullptr;
+}
+void ctx_give(snmf_ctx* c, void* p, size_t bytes) {
+    if (bytes > c->cache_cap) {
+        hipFree(p);
+        return;
+    }
+    while (c->cache_bytes + bytes > c->cache_cap || c->cache.size() >= 256) {  // oldest first
+        hipFree(c->cache.front().first);
+        c->cache_bytes -= c->cache.front().second;
+        c->cache.erase(c->cache.begin());
+    }
+    c->cache.emplace_back(p, bytes);
+    c->cache_bytes += bytes;
+}
+
 extern "C" void snmf_ctx_destroy(snmf_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     drain_timers(c);
     if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto& b : c->cache) hipFree(b.first);
+    c->cache.clear();
     if (c->aux) snmf_ctx_destroy(c->aux);
     xfer_destroy(c);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -171,7 +198,11 @@ extern "C" void snmf_plan_destroy(snmf_plan* pl) {
                     pl->w_ind, pl->staging, pl->wx, pl->Wcf, pl->M, pl->part_buf, pl->part_cnt,
                     pl->gLam,  pl->gR,    pl->gD,   pl->gNum, pl->gDen, pl->gram_slabs, pl->gram32};
     for (void* q : ptrs)
-        if (q) hipFree(q);
+        if (q) {
+            auto it = pl->blocks.find(q);
+            if (it != pl->blocks.end()) ctx_give(pl->ctx, q, it->second);
+            else hipFree(q);
+        }
     delete pl;
 }
 
@@ -471,52 +502,59 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     const size_t nWt = (size_t)pl->Fm * pl->rp, nWk = (size_t)pl->Fq * pl->rp;
     int s = SNMF_OK;
     auto A = [&](int st) { if (s == SNMF_OK) s = st; };
-    A(dalloc(&pl->V, nV));
-    A(dalloc(&pl->H[0], nH));
-    A(dalloc(&pl->H[1], nH));
-    A(dalloc(&pl->Wc, nW));
-    A(dalloc(&pl->Wcf, nW));
-    A(dalloc(&pl->Wt4, nWt));
-    A(dalloc(&pl->Wk4, nWk));
-    A(dalloc(&pl->wx, (size_t)pl->rp));
-    A(dalloc(&pl->dphv, (size_t)pl->rp));
-    A(dalloc(&pl->colsum, (size_t)pl->rp));
-    A(dalloc(&pl->lamk, (size_t)pl->rp));
-    if (p->sparsity_kind == SNMF_SPARSITY_FULL) A(dalloc(&pl->S, nH));
+    // (through the context's block cache; the plan remembers the sizes so that snmf_plan_destroy can hand the blocks back)
+    auto palloc = [&](auto** p, size_t n) {
+        size_t bytes = 0;
+        const int st = dalloc(p, n, ctx, &bytes);
+        if (st == SNMF_OK) pl->blocks[(void*)*p] = bytes;
+        return st;
+    };
+    A(palloc(&pl->V, nV));
+    A(palloc(&pl->H[0], nH));
+    A(palloc(&pl->H[1], nH));
+    A(palloc(&pl->Wc, nW));
+    A(palloc(&pl->Wcf, nW));
+    A(palloc(&pl->Wt4, nWt));
+    A(palloc(&pl->Wk4, nWk));
+    A(palloc(&pl->wx, (size_t)pl->rp));
+    A(palloc(&pl->dphv, (size_t)pl->rp));
+    A(palloc(&pl->colsum, (size_t)pl->rp));
+    A(palloc(&pl->lamk, (size_t)pl->rp));
+    if (p->sparsity_kind == SNMF_SPARSITY_FULL) A(palloc(&pl->S, nH));
     if (pl->upd_w) {
-        A(dalloc(&pl->slabs, (size_t)pl->n_chunks * pl->n_mat * nW));
-        A(dalloc(&pl->spart, (size_t)pl->n_chunks * pl->rp));
+        A(palloc(&pl->slabs, (size_t)pl->n_chunks * pl->n_mat * nW));
+        A(palloc(&pl->spart, (size_t)pl->n_chunks * pl->rp));
     }
     if (pl->gram_p) {
-        A(dalloc(&pl->gram_slabs, (size_t)pl->gram_chunks * pl->rp * pl->rp));
-        A(dalloc(&pl->gram32, (size_t)pl->rp * pl->rp));
+        A(palloc(&pl->gram_slabs, (size_t)pl->gram_chunks * pl->rp * pl->rp));
+        A(palloc(&pl->gram32, (size_t)pl->rp * pl->rp));
     }
     if (pl->generic) {
-        A(dalloc(&pl->gLam, nV));
-        A(dalloc(&pl->gR, nV));
-        if (pl->bm != BM_KL) A(dalloc(&pl->gD, nV));
+        A(palloc(&pl->gLam, nV));
+        A(palloc(&pl->gR, nV));
+        if (pl->bm != BM_KL) A(palloc(&pl->gD, nV));
         if (pl->upd_h) {
-            A(dalloc(&pl->gNum, nH));
-            if (pl->bm != BM_KL) A(dalloc(&pl->gDen, nH));
+            A(palloc(&pl->gNum, nH));
+            if (pl->bm != BM_KL) A(palloc(&pl->gDen, nH));
         }
     }
     if (pl->rp_S) {
-        A(dalloc(&pl->part_buf, (size_t)pl->rp_grid * 32 * pl->rp));
-        A(dalloc(&pl->part_cnt, (size_t)(pl->rp_tiles - pl->rp_full)));
+        A(palloc(&pl->part_buf, (size_t)pl->rp_grid * 32 * pl->rp));
+        A(palloc(&pl->part_cnt, (size_t)(pl->rp_tiles - pl->rp_full)));
     }
     pl->n_part = std::max(std::max(pl->grid_h, pl->grid_mdi), pl->n_chunks * pl->n_fg);
     pl->n_part = std::max(pl->n_part, pl->rp_grid);
     pl->n_part = std::max(pl->n_part, 1024);
     if (pl->generic) pl->n_part = kGBlocks + 256;  // (+ the slots of k_sum_sh behind the Lam pass's)
-    A(dalloc(&pl->part, (size_t)2 * pl->n_part));
-    A(dalloc(&pl->stats, (size_t)pl->n_mat * nW + pl->rp + 2));
-    A(dalloc(&pl->divh, (size_t)std::max(1, p->max_iter)));
-    A(dalloc(&pl->costh, (size_t)std::max(1, p->max_iter)));
-    A(dalloc(&pl->wn, (size_t)pl->rp));
-    A(dalloc(&pl->st, (size_t)1));
-    A(dalloc(&pl->w_ind, (size_t)pl->rp));
+    A(palloc(&pl->part, (size_t)2 * pl->n_part));
+    A(palloc(&pl->stats, (size_t)pl->n_mat * nW + pl->rp + 2));
+    A(palloc(&pl->divh, (size_t)std::max(1, p->max_iter)));
+    A(palloc(&pl->costh, (size_t)std::max(1, p->max_iter)));
+    A(palloc(&pl->wn, (size_t)pl->rp));
+    A(palloc(&pl->st, (size_t)1));
+    A(palloc(&pl->w_ind, (size_t)pl->rp));
 #ifdef SNMF_PROF
-    A(dalloc(&pl->prof, (size_t)1024 * 8 * 12 + 3 * 8192 + 16384));  // phase slots, then (cycles, 100 MHz ticks) and start tick per wave
+    A(palloc(&pl->prof, (size_t)1024 * 8 * 12 + 3 * 8192 + 16384));  // phase slots, then (cycles, 100 MHz ticks) and start tick per wave
     hipMemset(pl->prof, 0, ((size_t)1024 * 8 * 12 + 3 * 8192 + 16384) * 8);
 #endif
     if (s != SNMF_OK) {

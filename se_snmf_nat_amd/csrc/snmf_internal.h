@@ -68,7 +68,14 @@ struct snmf_ctx {
     HostXfer* xf = nullptr;  // created by the first host-array transfer
     snmf_ctx* aux = nullptr; // a second stream + transfer pipeline on the same device (uploads under a running solve: snmf_tu_dnmf.hip)
     XferStats xs;
+    // Device blocks of destroyed plans, kept for the next plan of this context (a caller that solves problem after problem of one
+    // shape -- every MATLAB call site of sparse_nmf -- otherwise pays hipMalloc + hipFree of ~30 buffers per call: 3-5 ms).  Exact
+    // size matches only; at most cache_cap bytes (SNMF_DEVCACHE_MB, default 4096; 0 = off); released with the context.
+    std::vector<std::pair<void*, size_t>> cache;
+    size_t cache_bytes = 0, cache_cap = (size_t)4096 << 20;
 };
+void* ctx_take(snmf_ctx* c, size_t bytes);          // a cached block of exactly `bytes`, or nullptr
+void ctx_give(snmf_ctx* c, void* p, size_t bytes);   // hand a block back (cached, or freed when the cache is full)
 
 struct ScopedTimer {
     snmf_ctx* c;
@@ -185,14 +192,22 @@ struct snmf_plan {
     bool final_done = false;
     double sh_const = 0.0;
     std::vector<uint8_t> h_w_ind;
+    std::map<void*, size_t> blocks;  // device blocks of this plan by size (handed back to the context's cache on destruction)
 };
 
 static inline size_t roundup(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
 template <typename T>
-static int dalloc(T** p, size_t n) {
+static int dalloc(T** p, size_t n, snmf_ctx* cache_of = nullptr, size_t* bytes_out = nullptr) {
     *p = nullptr;
-    hipError_t e = hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T));
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    if (bytes_out) *bytes_out = bytes;
+    if (cache_of)
+        if (void* q = ctx_take(cache_of, bytes)) {
+            *p = (T*)q;
+            return SNMF_OK;
+        }
+    hipError_t e = hipMalloc((void**)p, bytes);
     if (e != hipSuccess) return fail(SNMF_ERR_NOMEM, "hipMalloc(%zu bytes): %s", n * sizeof(T), hipGetErrorString(e));
     return SNMF_OK;
 }
