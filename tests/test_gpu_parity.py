@@ -566,6 +566,31 @@ def test_h_step_cut_over_the_contraction(gpu_ctx, F, r, T, mode):
     check(sparse_nmf(V, p, ctx=gpu_ctx), oracle_nmf(V, p))
 
 
+@pytest.mark.parametrize("F,r,T,mode,spk", [(64, 100, 9000, "full", "scalar"), (64, 100, 8210, "h", "rvec"), (64, 100, 8500, "full", "matrix"),
+                                            (40, 100, 12000, "full", "rvec"), (64, 128, 9000, "semi", "scalar"), (32, 20, 9000, "full", "matrix"),
+                                            (64, 40, 300, "full", "rvec"), (64, 100, 8600, "w", "scalar"), (48, 70, 33, "h", "matrix")])
+def test_small_f_kernels_against_oracle(gpu_ctx, F, r, T, mode, spk):
+    """The Mel solves (run_basis_train.m:90-91: 64 bands, R = 100; run_basis_DNMF_Mel.m:75-88): F <= 64 and r <= 128 take
+    k_hstep_sf for the KL H update (a tile per wave, operands loaded straight into MFMA layout, csrc/snmf_smallf.h) and k_wstats with
+    consumer teams; every sparsity form (src/sparse_nmf.m:150-155), every update mode, edge tiles in F and in T."""
+    from se_snmf_nat_amd import Plan, sparse_nmf
+    rs = np.random.default_rng(F * 7 + r + T)
+    V = rs.gamma(0.5, 1.0, (F, 12)) @ rs.gamma(0.3, 1.0, (12, T)) + 1e-3
+    sp = {"scalar": 3.0, "rvec": rs.random(r) * 4, "matrix": np.abs(rs.standard_normal((r, T))) * 3}[spk]
+    p = dict(cf="kl", sparsity=sp, max_iter=5, conv_eps=0, cost_check=1, init_w=rs.random((F, r)), init_h=rs.random((r, T)))
+    kw = {}
+    if mode == "h":
+        p["w_update_ind"] = kw["w_update_ind"] = np.zeros(r, bool)
+    if mode == "w":
+        p["h_update_ind"] = kw["h_update_ind"] = np.zeros(r, bool)
+    if mode == "semi":
+        p["w_update_ind"] = kw["w_update_ind"] = np.arange(r) >= r // 2
+    pl = Plan(gpu_ctx, F, T, r, beta=1.0, max_iter=2, cost_check=True, **kw)
+    assert ("k_hstep_sf" in pl.describe()) == (mode != "w")
+    pl.close()
+    check(sparse_nmf(V, p, ctx=gpu_ctx), oracle_nmf(V, p))
+
+
 def test_euclidean_w_step_through_the_gram_matrix(gpu_ctx):
     """beta = 2, r > 256, full update: P = max(W*H, flr) * H' (src/sparse_nmf.m:224-231) is formed as W * (H*H'), which
     differs from the reference's expression only where W*H sits at the 1e-9 floor.  Silent rows of V (exact zeros, floored
