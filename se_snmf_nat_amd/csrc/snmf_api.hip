@@ -326,15 +326,15 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
             }
         }
     }
-    // At most two row tiles and four column tiles (the Mel solves): a tile per WAVE, nothing handed between waves
+    // At most two row tiles and eight column tiles (the Mel solves, r <= 256): a tile per WAVE, nothing handed between waves
     // (snmf_smallf.h).  Follows SNMF_HSTEP_RP (tests compare against the barrier-phased kernels); SNMF_HSTEP_SF=0 keeps the
     // role pipeline.
     {
         const char* e = getenv("SNMF_HSTEP_RP");
         const char* e2 = getenv("SNMF_HSTEP_SF");
-        pl->sf = pl->bm == BM_KL && pl->upd_h && !pl->xr && pl->nf <= 2 && pl->nk <= 4 && !pl->generic && !(e && atoi(e) == 0) &&
-                 !(e2 && atoi(e2) == 0);
         pl->lds_sf = ((size_t)pl->nf * pl->rp * 32 + (size_t)pl->nk * pl->Fq * 32 + 2 * (size_t)pl->rp) * 4 + 2 * 8 * sizeof(double);
+        pl->sf = pl->bm == BM_KL && pl->upd_h && !pl->xr && pl->nf <= 2 && pl->nk <= 8 && pl->lds_sf <= lds_cap && !pl->generic &&
+                 !(e && atoi(e) == 0) && !(e2 && atoi(e2) == 0);
         pl->sf_grid = std::max(1, std::min((T + 31) / 32, ctx->n_cu));
         pl->sf_stagger = 8000;
         if (const char* e3 = getenv("SNMF_SF_STAG")) pl->sf_stagger = atoi(e3);

@@ -1,5 +1,5 @@
 // snmf_smallf.h -- the KL half-steps for spectrograms of at most two 32-row tiles (F <= 64: the Mel solves,
-// run_basis_train.m:90-91 and run_basis_DNMF_Mel.m:75-88 on p.Mel_bands = 64 rows) with r <= 128 components.
+// run_basis_train.m:90-91 and run_basis_DNMF_Mel.m:75-88 on p.Mel_bands = 64 rows) with r <= 256 components.
 //
 // Why a family of its own.  With F = 64 a 32-frame tile is 232 MFMAs for a whole compute unit; the role pipelines
 // (k_hstep_rp, k_wstats with loader waves) pay a fixed hand-off chain per tile -- loader -> A team -> B team -> loader, one
@@ -25,7 +25,7 @@ namespace snmf {
 
 constexpr int kSfWaves = 8;  // waves per workgroup (two per SIMD), one workgroup per CU
 
-// NF row tiles (1..2), NK column tiles of H (1..4).  Dynamic LDS: Wt4 image [NF][rp/8][2][32][4], Wk4 image [NK][Fq/8][2][32][4],
+// NF row tiles (1..2), NK column tiles of H (1..8; 254 VGPRs at 8, no scratch).  Dynamic LDS: Wt4 image [NF][rp/8][2][32][4], Wk4 image [NK][Fq/8][2][32][4],
 // 1 ./ dph [rp], lambda_k [rp], then [2][kSfWaves] doubles for the objective partials.
 template <int NF, int NK, bool OBJ>
 __global__ __launch_bounds__(kSfWaves * 64, 2) void k_hstep_sf(StepArgs a) {

@@ -14,7 +14,11 @@ static int launch_hstep_sf_f(snmf_plan* pl, const StepArgs& a, bool obj) {
         case 1: return launch_hstep_sf_n<NF, 1>(pl, a, obj);
         case 2: return launch_hstep_sf_n<NF, 2>(pl, a, obj);
         case 3: return launch_hstep_sf_n<NF, 3>(pl, a, obj);
-        default: return launch_hstep_sf_n<NF, 4>(pl, a, obj);
+        case 4: return launch_hstep_sf_n<NF, 4>(pl, a, obj);
+        case 5: return launch_hstep_sf_n<NF, 5>(pl, a, obj);
+        case 6: return launch_hstep_sf_n<NF, 6>(pl, a, obj);
+        case 7: return launch_hstep_sf_n<NF, 7>(pl, a, obj);
+        default: return launch_hstep_sf_n<NF, 8>(pl, a, obj);
     }
 }
 int launch_hstep_sf(snmf_plan* pl, StepArgs a, bool obj) {

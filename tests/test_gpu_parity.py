@@ -568,9 +568,11 @@ def test_h_step_cut_over_the_contraction(gpu_ctx, F, r, T, mode):
 
 @pytest.mark.parametrize("F,r,T,mode,spk", [(64, 100, 9000, "full", "scalar"), (64, 100, 8210, "h", "rvec"), (64, 100, 8500, "full", "matrix"),
                                             (40, 100, 12000, "full", "rvec"), (64, 128, 9000, "semi", "scalar"), (32, 20, 9000, "full", "matrix"),
-                                            (64, 40, 300, "full", "rvec"), (64, 100, 8600, "w", "scalar"), (48, 70, 33, "h", "matrix")])
+                                            (64, 40, 300, "full", "rvec"), (64, 100, 8600, "w", "scalar"), (48, 70, 33, "h", "matrix"),
+                                            # R_x + R_d = 200 on Mel bands: solve 1 of run_basis_DNMF_Mel.m:75
+                                            (64, 200, 9000, "h", "scalar"), (64, 256, 8300, "full", "rvec"), (64, 161, 8400, "h", "matrix")])
 def test_small_f_kernels_against_oracle(gpu_ctx, F, r, T, mode, spk):
-    """The Mel solves (run_basis_train.m:90-91: 64 bands, R = 100; run_basis_DNMF_Mel.m:75-88): F <= 64 and r <= 128 take
+    """The Mel solves (run_basis_train.m:90-91: 64 bands, R = 100; run_basis_DNMF_Mel.m:75-88): F <= 64 and r <= 256 take
     k_hstep_sf for the KL H update (a tile per wave, operands loaded straight into MFMA layout, csrc/snmf_smallf.h) and k_wstats with
     consumer teams; every sparsity form (src/sparse_nmf.m:150-155), every update mode, edge tiles in F and in T."""
     from se_snmf_nat_amd import Plan, sparse_nmf
