@@ -23,7 +23,7 @@ def rel(a, b):
 
 
 def draw():
-    F = int(rs.choice([257, 513, 129, 65, 64, 128, 512, 385, 97, int(rs.integers(8, 600)), int(rs.integers(8, 200))]))
+    F = int(rs.choice([257, 513, 129, 65, 64, 128, 512, 385, 97, 64, 40, 32, int(rs.integers(8, 65)), int(rs.integers(8, 600)), int(rs.integers(8, 200))]))
     r = int(rs.choice([int(rs.integers(1, 40)), int(rs.integers(90, 132)), int(rs.integers(190, 260)), 100, 200, 256, 40,
                        int(rs.integers(257, 700)), int(rs.integers(1, 300))]))
     kind = rs.integers(0, 4)
