@@ -385,7 +385,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     // tiles in turn (StepArgs::til) instead of leaving half the SIMDs without an MFMA wave.  Needs the loader geometry (the
     // teams' partial statistics meet in the tile buffers at the end), one row group, one kappa-group, no extra row.
     pl->til = 1;
-    if (pl->NLW && pl->TTW == 32 && !pl->xr && pl->n_fg == 1 && pl->n_kg == 1 && pl->upd_w && pl->NKT <= 8) {
+    if (pl->NLW && pl->TTW == 32 && !pl->xr && pl->n_fg == 1 && pl->n_kg == 1 && pl->upd_w && pl->NKT == 4 && pl->bm == BM_KL) {
         int til = 1;
         while (til * 2 * pl->nf <= pl->NWB) til *= 2;
         const size_t per_wave = (size_t)(pl->NKT * 16 + 8) * 64 * 4;

@@ -148,9 +148,6 @@ struct StepArgs {
     int n_ch1;            // k_wstats: > 0 = row group 1 has its own, smaller, number of frame chunks (1-D grid)
     int lxh;              // k_hstep_rh: P2 cut over the contraction, leftover columns on the VALU (nk = 4, r = 97..100)
     int kc;               // k_wstats, WM = 3 (V * H^T needs no Lam'): each kappa-group stages only ITS 32*NK columns of H
-    int til;              // k_wstats with loader waves, FEWER row tiles than consumer waves (nf <= NWB / 2, no extra row): the consumers
-                          // are til teams of NWB / til waves; team p takes the tiles it % til == p of the chunk and the teams' partial
-                          // statistics are added through LDS at the end (fixed order).  0 / 1: every consumer wave on every tile
     int nbuf;             // k_wstats with loader waves: tile buffers in LDS (2, or 3 where they fit: the loaders then run two tiles ahead)
     int F, T, Fp, rp, Tp, nf, nk;
     int nqk;              // 8-deep k-blocks of the contractions over the components = ceil(r / 8): W's columns / H's rows
@@ -172,6 +169,11 @@ struct StepArgs {
     int lam_is_u;         // scalar sparsity: every real row has the same lambda (pad rows of H are zero anyway)
     float lam_u;          // ... that lambda
     float beta, inv_bb1;
+    int til;              // (LAST: a field in the middle moves the kernel-argument offsets of everything behind it, and the 168-VGPR
+                          // geometries of k_wstats answered the different scalar loads with 176 spilled VGPRs)
+                          // k_wstats with loader waves, FEWER row tiles than consumer waves (nf <= NWB / 2, no extra row): the consumers
+                          // are til teams of NWB / til waves; team p takes the tiles it % til == p of the chunk and the teams' partial
+                          // statistics are added through LDS at the end (fixed order).  0 / 1: every consumer wave on every tile
 };
 
 
@@ -2867,9 +2869,11 @@ __global__ __launch_bounds__(512, 2) void k_hsolve_frame(StepArgs a, SmallArgs s
 // LX: 16-byte groups (1 or 2) of statistics columns past the last FULL 32-column tile that are accumulated on the VALU
 // instead of a nearly empty MFMA tile (r = 100: 4 columns, r = 200: 8); 0 = every column tile through the MFMAs.  A template
 // parameter: as a run-time branch the extra code cost the 8+4-wave geometry 113 spilled VGPRs.
-template <int NK, int NWB, int NL, int WPS, int WM, int BM, bool OBJ, int TT = 32, int LX = 0>
-__global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int n_chunks, int mat_index,
-                                                                 int n_mat) {
+// TIL: the consumer teams of StepArgs::til.  A compile-time switch, and a kernel of its own (k_wstats_teams): the eight-consumer
+// geometries of the F = 513 shapes sit at their 168-VGPR limit, and the team indices as run-time values in their tile loop cost them
+// 19 spilled VGPRs (the reference's 513 x 72000 r = 100 W step 0.1350 -> 0.1407 ms); profiles/r04_resources.csv is the check.
+template <int NK, int NWB, int NL, int WPS, int WM, int BM, bool OBJ, int TT, int LX, bool TIL>
+__device__ __forceinline__ void wstats_body(StepArgs a, int n_chunks, int mat_index, int n_mat) {
     static_assert(TT == 32 || (TT == 16 && NL == 0), "narrow tiles: 16 frames, synchronous staging");
     constexpr int NTHR = (NWB + NL) * 64;
     // Tile buffers: 1 without loader waves; with them 2, or 3 where the LDS has room (host: a.nbuf).  With two buffers the DMA
@@ -2929,10 +2933,15 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         for (int k = threadIdx.x; k < NWB * gxw; k += NTHR) (lds + NBUF * TT * (ldh + 32 * NWB) + a.rp + 128)[k] = 0.f;
     // F = 64 (a Mel spectrogram) has two row tiles: two of four consumer waves -- two of four SIMDs -- would carry the whole
     // chunk.  With a.til > 1 the consumers form til TEAMS of nfl = NWB / til waves; wave w is row tile w % nfl of team w / nfl.
-    const int til = (NL > 0 && a.til > 1) ? a.til : 1, nfl = NWB / til;
-    const int wl = til > 1 ? w % nfl : w, tph = til > 1 ? w / nfl : 0;
-    const int phi = by * NWB + wl;
-    const int fc = wl * 32 + fl;  // this lane's column of the staged V image
+    int til = 1, nfl = NWB, wl = w, tph = 0;
+    if constexpr (TIL) {
+        til = (NL > 0 && a.til > 1) ? a.til : 1;
+        nfl = NWB / til;
+        wl = til > 1 ? w % nfl : w;
+        tph = til > 1 ? w / nfl : 0;
+    }
+    const int phi = by * NWB + (TIL ? wl : w);
+    const int fc = (TIL ? wl : w) * 32 + fl;  // this lane's column of the staged V image
     const bool active = !is_loader && phi < a.nf;
     const int kap_base = blockIdx.z * NK;  // kappa-group (r > 32*NK: P3 is recomputed per group)
     const bool do_obj = OBJ && blockIdx.z == 0;
@@ -2979,12 +2988,15 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     const unsigned gxa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(gxs + w * gxw + 4 * lane);
     // A consumer wave without a row tile (and without a share of the extra row) has nothing to do in the tile loop but wait
     // and report -- polling LDS beside the MFMA wave of its SIMD: its progress word is set to "done with every tile" instead.
-    const bool idle_c = NL > 0 && !is_loader && !active && !do_x;
+    // (NWB = 4 geometries only: in the eight-consumer kernels of the F = 513 shapes the extra loop condition cost 0.7 %)
+    const bool idle_c = NL > 0 && NWB == 4 && !is_loader && !active && !do_x;
     if (NL > 0) {
         if (threadIdx.x < 4 + NWB) ready[threadIdx.x] = 0u;
         __syncthreads();  // slots and wxs are set
-        if (idle_c && lane == 0) done[w] = 0xffffffffu;
-        __syncthreads();
+        if constexpr (NWB == 4) {  // (the eight-consumer kernels sit at their register limit: this code as dead code cost them 176 spilled VGPRs)
+            if (idle_c && lane == 0) done[w] = 0xffffffffu;
+            __syncthreads();
+        }
     }
 
     // The extra row of one tile (row group 0 only): ratio_x[t] for this wave's CPW columns, then gx[k] += ratio_x[t] * H[k,t].
@@ -3130,7 +3142,13 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     }
     SNMF_STAMP_DECL
     int cb = NL > 0 ? NBUF - 1 : 0;  // buffer of the consumers' current tile (advanced at the loop top)
-    for (int tile = tb, it = 0; tile < te && !is_loader && !idle_c; ++tile, ++it) {
+    // (an idle consumer's loop is empty.  Through the loop's END, not one more term in its condition: as `&& !(NWB == 4 && idle_c)`
+    //  -- constant true in the eight-consumer kernels -- it still cost THEM 176 spilled VGPRs at their 168-register limit)
+    int te_c = te;
+    if constexpr (NWB == 4) {
+        if (idle_c) te_c = tb;
+    }
+    for (int tile = tb, it = 0; tile < te_c && !is_loader; ++tile, ++it) {
         const int t0 = tile * TT;
         SNMF_STAMP(0);
         if (NL > 0) cb = cb + 1 == NBUF ? 0 : cb + 1;
@@ -3177,7 +3195,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         }
         if (do_x) xrow_tile(Hs, t0, w, vx + cb * 32);
         SNMF_STAMP(2);
-        if (!active || (til > 1 && it % til != tph)) {  // (another team's tile: only the progress report)
+        if (!active || (TIL && til > 1 && it % til != tph)) {  // (another team's tile: only the progress report)
             if (NL > 0) rp_post(done, w, (unsigned)(it + 1), lane);
             continue;
         }
@@ -3315,7 +3333,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
     }
 #endif
 
-    if (NL > 0 && til > 1) {
+    if constexpr (TIL && NL > 0) if (til > 1) {
         // the teams' partial statistics -> team 0, through the tile buffers (every consumer is past its last tile and the
         // loaders past their last DMA at the first barrier), added in team order
         float* xs = lds;  // [(til - 1) * nfl][NK * 16 + 4 * LX][64]
@@ -3348,7 +3366,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
         }
         __syncthreads();  // (the row-sum reduction below reuses the same memory)
     }
-    const bool writes = active && tph == 0;
+    const bool writes = TIL ? (active && tph == 0) : active;
     // ---- write the partial slab: D tile lane (k = fl, h), reg -> f = 32*phi + drow(reg,h)
     if (writes) {
         float* slab = a.slabs + ((size_t)chunk * n_mat + mat_index) * rp * Fp;
@@ -3445,6 +3463,18 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int
             a.part[2 * slot + 1] = 0.0;
         }
     }
+}
+
+template <int NK, int NWB, int NL, int WPS, int WM, int BM, bool OBJ, int TT = 32, int LX = 0>
+__global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats(StepArgs a, int n_chunks, int mat_index,
+                                                                 int n_mat) {
+    wstats_body<NK, NWB, NL, WPS, WM, BM, OBJ, TT, LX, false>(a, n_chunks, mat_index, n_mat);
+}
+// the same with consumer TEAMS (StepArgs::til): a kernel of its own, see the note on TIL above
+template <int NK, int NWB, int NL, int WPS, int WM, int BM, bool OBJ, int TT = 32, int LX = 0>
+__global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats_teams(StepArgs a, int n_chunks, int mat_index,
+                                                                       int n_mat) {
+    wstats_body<NK, NWB, NL, WPS, WM, BM, OBJ, TT, LX, true>(a, n_chunks, mat_index, n_mat);
 }
 
 // Convergence test of src/sparse_nmf.m:260-285 for iteration `it` (1-based) whose (div, sh) sit

@@ -6,15 +6,27 @@
 #include "snmf_generic.h"
 
 // k_wstats dispatch
-template <int NK, int NWB, int NL, int WPS, int WM, int BM, bool OBJ, int TT = 32, int LX = 0>
+template <int NK, int NWB, int NL, int WPS, int WM, int BM, bool OBJ, int TT = 32, int LX = 0, bool TIL = false>
 static int launch_wstats_one(snmf_plan* pl, const StepArgs& a, int mat_index) {
+    // consumer teams (plan->til > 1: fewer row tiles than consumer waves) are instantiated for the KL statistics of the NK = 4
+    // loader geometries only -- the Mel solves; other divergences at such shapes keep every consumer wave on every tile
+    if constexpr (!TIL && NK == 4 && NL > 0 && WM == 0 && BM == BM_KL && TT == 32) {
+        if (pl->til > 1) return launch_wstats_one<NK, NWB, NL, WPS, WM, BM, OBJ, TT, LX, true>(pl, a, mat_index);
+    }
     const bool split = pl->n_ch1 > 0;  // uneven row-group split: 1-D grid, group 0's chunks first
     dim3 g(split ? pl->n_chunks + (pl->n_fg - 1) * pl->n_ch1 : pl->n_chunks, split ? 1 : pl->n_fg, pl->n_kg), b((NWB + NL) * 64);
     StepArgs as = a;
     as.n_ch1 = split ? pl->n_ch1 : 0;
-    auto kern = k_wstats<NK, NWB, NL, WPS, WM, BM, OBJ, TT, LX>;
-    SN_TRY(ensure_dyn_lds(pl->ctx->device, (const void*)kern, pl->lds_w));
-    hipLaunchKernelGGL(kern, g, b, pl->lds_w, pl->ctx->stream, as, pl->n_chunks, mat_index, pl->n_mat);
+    if (!TIL) as.til = 1;
+    if constexpr (TIL) {
+        auto kern = k_wstats_teams<NK, NWB, NL, WPS, WM, BM, OBJ, TT, LX>;
+        SN_TRY(ensure_dyn_lds(pl->ctx->device, (const void*)kern, pl->lds_w));
+        hipLaunchKernelGGL(kern, g, b, pl->lds_w, pl->ctx->stream, as, pl->n_chunks, mat_index, pl->n_mat);
+    } else {
+        auto kern = k_wstats<NK, NWB, NL, WPS, WM, BM, OBJ, TT, LX>;
+        SN_TRY(ensure_dyn_lds(pl->ctx->device, (const void*)kern, pl->lds_w));
+        hipLaunchKernelGGL(kern, g, b, pl->lds_w, pl->ctx->stream, as, pl->n_chunks, mat_index, pl->n_mat);
+    }
     HIP_TRY(hipGetLastError());
     return SNMF_OK;
 }
