@@ -393,6 +393,17 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         if (const char* e = getenv("SNMF_WSTATS_TIL")) if (atoi(e) == 1) til = 1;
         pl->til = til;
     }
+    // ... and the KL statistics of the same shapes (r <= 128) through k_wstats_sf; follows SNMF_WSTATS_NL (tests compare against
+    // the synchronously staging kernels); SNMF_WSTATS_SF=0 keeps k_wstats_teams
+    {
+        const char* e = getenv("SNMF_WSTATS_NL");
+        const char* e2 = getenv("SNMF_WSTATS_SF");
+        const int ncl = 8 / std::max(1, pl->nf);
+        pl->lds_wsf = ((size_t)(ncl - 1) * pl->nf * pl->nk * 1024 + (size_t)ncl * pl->rp) * 4 + 8 * sizeof(double) + 64;
+        pl->wsf = pl->bm == BM_KL && pl->upd_w && !pl->xr && pl->nf <= 2 && pl->nk <= 4 && pl->TTW == 32 && pl->n_kg == 1 && pl->n_fg == 1 &&
+                  pl->NLW && !pl->generic && pl->lds_wsf <= lds_cap && !(e && atoi(e) == 0) && !(e2 && atoi(e2) == 0);
+        if (pl->wsf) pl->til = 1;
+    }
     const int wg_w = pl->NLW ? 1 : pl->WPS;  // workgroups per CU
     pl->n_chunks = std::max(1, std::min(n_tiles_w, ctx->n_cu * wg_w / std::max(1, pl->n_fg * pl->n_kg)));
     // Two row groups, only group 0 carries the extra row: deal the workgroups out so that both finish together.
@@ -625,7 +636,7 @@ extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
              pl->p.F, pl->p.T, pl->p.r, pl->p.beta, pl->Fm, pl->xr, pl->rp, pl->Tp, hs, pl->TTH * pl->NT,
              sf_pipe ? pl->sf_grid : ((kl_pipe || rh_pipe) ? pl->rp_grid : pl->grid_h), sf_pipe ? 512 : (rh_pipe ? 768 : (pl->NWH + pl->NLH) * 64),
              sf_pipe ? pl->lds_sf : (rh_pipe ? pl->lds_rh : pl->lds_h), pl->NKT, pl->NWB, pl->NLW, pl->n_chunks, pl->n_fg, pl->n_kg, pl->n_ch1 ? pl->n_ch1 : pl->n_chunks, pl->lds_w,
-             pl->gram_p ? ", P = W*(H*H') through the Gram matrix" : (pl->til > 1 ? (pl->til == 2 ? ", 2 consumer teams take the tiles in turn" : ", 4+ consumer teams take the tiles in turn") : ""), pl->wfin ? "k_wfin" : (pl->upd_w ? "k_reduce + k_wapply" : "none"), pl->ctx->n_cu);
+             pl->gram_p ? ", P = W*(H*H') through the Gram matrix" : (pl->wsf ? ", k_wstats_sf: a tile per wave" : (pl->til > 1 ? (pl->til == 2 ? ", 2 consumer teams take the tiles in turn" : ", 4+ consumer teams take the tiles in turn") : "")), pl->wfin ? "k_wfin" : (pl->upd_w ? "k_reduce + k_wapply" : "none"), pl->ctx->n_cu);
     return SNMF_OK;
 }
 

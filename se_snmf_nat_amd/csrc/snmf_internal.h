@@ -119,6 +119,8 @@ struct snmf_plan {
     int n_fg = 1, n_kg = 1, n_chunks = 1;
     bool sf = false;      // KL H-update launches through k_hstep_sf (F <= 64, r <= 128: snmf_smallf.h)
     int sf_grid = 1;
+    bool wsf = false;     // KL statistics through k_wstats_sf (F <= 64, r <= 128)
+    size_t lds_wsf = 0;
     int sf_stagger = 0;   // cycles by which the second wave of each SIMD starts late (k_hstep_sf)
     size_t lds_sf = 0;
     int til = 1;  // k_wstats: consumer teams that share a chunk's tiles (StepArgs::til)
@@ -252,6 +254,7 @@ int launch_hstep(snmf_plan* pl, bool obj, bool upd);
 int launch_hstep_rp(snmf_plan* pl, StepArgs a, bool obj);  // snmf_tu_hstep_rp.hip
 int launch_hstep_rh(snmf_plan* pl, StepArgs a, bool obj);  // snmf_tu_hstep_rh.hip
 int launch_hstep_sf(snmf_plan* pl, StepArgs a, bool obj);  // snmf_tu_smallf.hip
+int launch_wstats_sf(snmf_plan* pl, const StepArgs& a, bool obj);  // snmf_tu_smallf.hip
 int launch_wstats(snmf_plan* pl, bool obj);
 int launch_wstats_nk4(snmf_plan* pl, const StepArgs& a, bool obj);  // snmf_tu_wstats4.hip
 int launch_wstats_nk8(snmf_plan* pl, const StepArgs& a, bool obj);  // snmf_tu_wstats8.hip

@@ -246,4 +246,186 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_hstep_sf(StepArgs a) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------------------------
+// k_wstats_sf: the KL statistics of the W half-step (src/sparse_nmf.m:215-222: G = (V ./ Lam') * H', s = sum(H, 2)) in the same
+// style: nothing is staged for anybody else.  Wave w of a workgroup is row tile phi = w / NCL of "chunk lane" c = w % NCL
+// (NCL = 8 / NF): it walks the tiles tb + c, tb + c + NCL, ... of the workgroup's frame range with its NK accumulator tiles of G
+// in registers.  Per tile:
+//   P3  Lam'^T[t, f] = sum_k H[k, t] W[f, k]: A = the lane's H pieces (lane (t, h), loaded as in k_hstep_sf), B = W fragment
+//       (LDS); the D tile has frames in registers and rows in lanes -- the A-operand layout of
+//   P4  G[f, k] += sum_t ratio[t, f] H[k, t]: A = ratio registers, B = H[32 kap + lane][t] as 4-byte loads (the tile's rows were
+//       fetched a moment ago by this wave: L2 hits), one column tile ahead of its MFMAs; the same reads give the row sums.
+// At the end the chunk lanes' accumulators meet in LDS (fixed order) and the workgroup writes ONE slab, so k_wfin / k_reduce see
+// what k_wstats would have written for n_chunks = gridDim.x.
+// Dynamic LDS: max(Wt4 image NF * rp * 32 floats, (NCL - 1) * NF partial tiles of NK * 16 * 64 floats) + [rp] row sums + doubles.
+template <int NF, int NK, bool OBJ>
+__global__ __launch_bounds__(kSfWaves * 64, 2) void k_wstats_sf(StepArgs a, int n_chunks, int mat_index, int n_mat) {
+    if (a.stop && *a.stop) return;
+    constexpr int NCL = kSfWaves / NF;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, w = wave_index();
+    const int rp = a.rp, Fp = a.Fp, nq8 = rp / 8;
+    const int fl = lane & 31, h = lane >> 5;
+    const int phi = w / NCL, c = w % NCL;
+    const int chunk = blockIdx.x;
+    const int tb = (int)(((long long)a.n_tiles * chunk) / n_chunks), te = (int)(((long long)a.n_tiles * (chunk + 1)) / n_chunks);
+    {
+        const int n4 = NF * rp * 32 / 4;
+        for (int i = threadIdx.x; i < n4; i += kSfWaves * 64) reinterpret_cast<f32x4*>(lds)[i] = reinterpret_cast<const f32x4*>(a.Wt4)[i];
+    }
+    __syncthreads();
+    const f32x4* const wtl = reinterpret_cast<const f32x4*>(lds) + lane + (size_t)phi * nq8 * 64;
+
+    f32x16 G[NK];
+    float ssum[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        G[k] = zero16();
+        ssum[k] = 0.f;
+    }
+    double acc_div = 0.0;
+    const bool do_s = phi == 0;
+
+    for (int tile = tb + c; tile < te; tile += NCL) {
+        const int t0 = tile * 32;
+        // this lane's H pieces (operand layout, as k_hstep_sf), its V values in the D layout of P3, the first column tile of P4
+        f32x4 hq[NK * 4];
+        float v[16], b0[16], b1[16];
+        {
+            const float* hp = a.Hin + ((size_t)t0 + fl) * rp + 4 * h;
+#pragma unroll
+            for (int q = 0; q < NK * 4; ++q) hq[q] = *reinterpret_cast<const f32x4*>(hp + 8 * q);
+            // (buffer loads: ONE lane offset per array, the register's row as a scalar offset -- sixteen 64-bit lane addresses per
+            //  array were what spilled)
+            const __amdgpu_buffer_rsrc_t rv =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.V + (size_t)t0 * Fp), 0, 32 * Fp * 4, 0x00020000);
+            const int vo = ((4 * h) * Fp + phi * 32 + fl) * 4;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, vo, drow(i, 0) * Fp * 4, 0));
+        }
+        // H[32 kap + fl][t0 + drow(i, h)]: lane offset (4 h) * rp + fl, scalar offset drow(i, 0) * rp + 32 kap
+        const __amdgpu_buffer_rsrc_t rh =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Hin + (size_t)t0 * rp), 0, 32 * rp * 4, 0x00020000);
+        const int ho = ((4 * h) * rp + fl) * 4;
+        auto ldb = [&](float (&b)[16], int kap) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                b[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rh, ho, (drow(i, 0) * rp + kap * 32) * 4, 0));
+        };
+        ldb(b0, 0);
+        // ---- P3 ----
+        f32x16 acc = zero16();
+        {
+            f32x4 wa = wtl[0], wb;
+#pragma unroll
+            for (int q = 0; q < NK * 4; ++q) {
+                if (q > 4 * (NK - 1) && q >= a.nqk) break;  // (zero padding past ceil(r / 8): see k_hstep_sf)
+                if (q + 1 < NK * 4) wb = wtl[(q + 1) * 64];
+                SNMF_PIN();
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = mfma32(hq[q][e], wa[e], acc);
+                wa = wb;
+            }
+        }
+        // ---- ratio (and the objective of a W-only solve): lane (f = fl, h), register i <-> frame t0 + drow(i, h) ----
+        float R[16];
+        {
+            const int f = phi * 32 + fl;
+            const bool edge = OBJ && !(phi * 32 + 32 <= a.F && t0 + 32 <= a.T);
+            float dsum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float lam = fmaxf(acc[i], kFlr);
+                if (OBJ) {
+                    const float d = div_term<BM_KL>(v[i], lam, a.beta, a.inv_bb1);
+                    if (edge) dsum += (f < a.F && t0 + drow(i, h) < a.T) ? d : 0.f;
+                    else dsum += d;
+                }
+                R[i] = v[i] * fast_rcp(lam);
+            }
+            if (OBJ) acc_div += (double)dsum;
+        }
+        // ---- P4, the row sums riding on its operand reads ----
+        auto ktile = [&](f32x16& g, float& ss, const float (&b)[16]) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) g = mfma32(R[i], b[i], g);
+            if (do_s) {
+                float s4 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s4 += b[i];
+                ss += s4;
+            }
+        };
+#pragma unroll
+        for (int kap = 0; kap < NK; kap += 2) {
+            if (kap + 1 < NK) ldb(b1, kap + 1);
+            SNMF_PIN();
+            ktile(G[kap], ssum[kap], b0);
+            if (kap + 1 < NK) {
+                if (kap + 2 < NK) ldb(b0, kap + 2);
+                SNMF_PIN();
+                ktile(G[kap + 1], ssum[kap + 1], b1);
+            }
+        }
+    }
+
+    // ---- the chunk lanes' partial statistics -> lane 0 of each row tile, through LDS, in lane order ----
+    __syncthreads();  // (every wave is through with the W image)
+    float* xs = lds;                                             // [(NCL - 1) * NF][NK * 16][64]
+    float* sred = lds + (size_t)(NCL - 1) * NF * NK * 16 * 64;   // [NCL][rp] row sums
+    double* dred = reinterpret_cast<double*>(sred + NCL * rp);   // [kSfWaves]
+    if (c > 0) {
+        float* dst = xs + (size_t)((c - 1) * NF + phi) * NK * 16 * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dst[(k * 16 + i) * 64] = G[k][i];
+    }
+    if (do_s) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const float other = __shfl_xor(ssum[k], 32, 64);  // the two lane halves hold the two halves of a tile's frames
+            if (h == 0) sred[c * rp + k * 32 + fl] = ssum[k] + other;
+        }
+    }
+    if (OBJ) {
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) acc_div += __shfl_xor(acc_div, s, 64);
+        if (lane == 0) dred[w] = acc_div;
+    }
+    __syncthreads();
+    if (c == 0) {
+        for (int p = 1; p < NCL; ++p) {
+            const float* src = xs + (size_t)((p - 1) * NF + phi) * NK * 16 * 64 + lane;
+#pragma unroll
+            for (int k = 0; k < NK; ++k)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) G[k][i] += src[(k * 16 + i) * 64];
+        }
+        // slab: D tile lane (k = fl, h), register -> f = 32 phi + drow(reg, h)  (k_wstats' layout)
+        float* slab = a.slabs + ((size_t)chunk * n_mat + mat_index) * rp * Fp;
+#pragma unroll
+        for (int kap = 0; kap < NK; ++kap) {
+            float* dst = slab + (size_t)(kap * 32 + fl) * Fp + phi * 32 + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 o = {G[kap][4 * g], G[kap][4 * g + 1], G[kap][4 * g + 2], G[kap][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(dst + 8 * g) = o;
+            }
+        }
+    }
+    for (int k = threadIdx.x; k < rp; k += kSfWaves * 64) {
+        float sk = 0.f;
+        for (int p = 0; p < NCL; ++p) sk += sred[p * rp + k];
+        a.spart[(size_t)chunk * rp + k] = sk;
+    }
+    if (OBJ && threadIdx.x == 0) {
+        double d = 0.0;
+        for (int i = 0; i < kSfWaves; ++i) d += dred[i];
+        a.part[2 * chunk] = d;
+        a.part[2 * chunk + 1] = 0.0;
+    }
+}
+
 }  // namespace snmf

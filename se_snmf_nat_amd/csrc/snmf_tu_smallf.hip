@@ -26,3 +26,32 @@ int launch_hstep_sf(snmf_plan* pl, StepArgs a, bool obj) {
     a.n_tiles = pl->rp_tiles;  // only tiles that hold a frame (the pad tiles of both H buffers are zero and stay zero)
     return pl->nf == 1 ? launch_hstep_sf_f<1>(pl, a, obj) : launch_hstep_sf_f<2>(pl, a, obj);
 }
+
+template <int NF, int NK>
+static int launch_wstats_sf_n(snmf_plan* pl, const StepArgs& a, bool obj) {
+    dim3 g(pl->n_chunks), b(snmf::kSfWaves * 64);
+    hipStream_t st = pl->ctx->stream;
+    if (obj) {
+        auto kern = snmf::k_wstats_sf<NF, NK, true>;
+        SN_TRY(ensure_dyn_lds(pl->ctx->device, (const void*)kern, pl->lds_wsf));
+        hipLaunchKernelGGL(kern, g, b, pl->lds_wsf, st, a, pl->n_chunks, 0, pl->n_mat);
+    } else {
+        auto kern = snmf::k_wstats_sf<NF, NK, false>;
+        SN_TRY(ensure_dyn_lds(pl->ctx->device, (const void*)kern, pl->lds_wsf));
+        hipLaunchKernelGGL(kern, g, b, pl->lds_wsf, st, a, pl->n_chunks, 0, pl->n_mat);
+    }
+    HIP_TRY(hipGetLastError());
+    return SNMF_OK;
+}
+template <int NF>
+static int launch_wstats_sf_f(snmf_plan* pl, const StepArgs& a, bool obj) {
+    switch (pl->nk) {
+        case 1: return launch_wstats_sf_n<NF, 1>(pl, a, obj);
+        case 2: return launch_wstats_sf_n<NF, 2>(pl, a, obj);
+        case 3: return launch_wstats_sf_n<NF, 3>(pl, a, obj);
+        default: return launch_wstats_sf_n<NF, 4>(pl, a, obj);
+    }
+}
+int launch_wstats_sf(snmf_plan* pl, const StepArgs& a, bool obj) {
+    return pl->nf == 1 ? launch_wstats_sf_f<1>(pl, a, obj) : launch_wstats_sf_f<2>(pl, a, obj);
+}
