@@ -165,6 +165,18 @@ int snmf_plan_objstats(snmf_plan* plan, double* stats_dev);
 int snmf_plan_objapply(snmf_plan* plan, const double* stats_dev);
 /* 1 when the device-side convergence test has fired (synchronises the stream). */
 int snmf_plan_stopped(snmf_plan* plan, int32_t* stopped);
+/* The loop above in ONE call for a process-per-GPU host: up to n_iters iterations of
+ *     hstep -> wstats(stats) -> all_reduce(stats, len, user) -> wapply(stats)
+ * with the caller's collective as a callback (it must enqueue an in-place SUM of the `len` doubles at `stats` over the ranks on
+ * the context's stream, or order its own stream against it; it returns 0, anything else aborts the loop with
+ * SNMF_ERR_INVALID).  `len` is the whole buffer, or 2 (the two cost scalars at the tail: `stats + stats_len - 2`) when no
+ * column of W is updated.  all_reduce = NULL: a single rank.  poll_every > 0: the convergence flag is read every poll_every
+ * iterations when conv_eps > 0 (every rank reads the same value).  finalize != 0: after the last iteration of the SOLVE
+ * (max_iter reached, no early stop) the objective of the last iterate is formed (objstats -> all_reduce -> objapply).
+ * iters_done: iterations this call ran.  src/sparse_nmf.m:186-286 per rank. */
+typedef int (*snmf_allreduce_fn)(double* stats_dev, int64_t len, void* user);
+int snmf_plan_run_sharded(snmf_plan* plan, int32_t n_iters, double* stats_dev, snmf_allreduce_fn all_reduce, void* user,
+                          int32_t poll_every, int32_t finalize, int32_t* iters_done);
 
 /* Online separation stream (src/NTF_sep_event_RT.m:67-107 -> src/bnmf_sep_event_RT_IS16.m:138-154):
  * the SAME dictionary W and the SAME initial activations H0 (the reference re-seeds its generator

@@ -20,6 +20,9 @@ SRC = sorted(_glob.glob(os.path.join(_HERE, "csrc", "*.hip")))
 OBJ_DIR = os.path.join(_ROOT, "build", "obj")
 # headers each translation unit includes beyond the ones every unit does (an edit to a header rebuilds only its users)
 _COMMON_HDRS = ["snmf_internal.h", "snmf_kernels.h", os.path.join(_ROOT, "include", "snmf.h")]
+# int (*snmf_allreduce_fn)(double* stats_dev, int64_t len, void* user)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p)
+
 _TU_HDRS = {
     "snmf_api.hip": ["snmf_frontend.h", "snmf_generic.h", "snmf_prof.h"],
     "snmf_tu_wstats.hip": ["snmf_generic.h", "snmf_wstats_dispatch.h"],
@@ -42,7 +45,7 @@ SYMBOLS = [
     "snmf_plan_set_h_f64", "snmf_plan_set_h_f32", "snmf_plan_set_sparsity_f64", "snmf_plan_set_sparsity_f32",
     "snmf_plan_init", "snmf_plan_run", "snmf_plan_stats_len",
     "snmf_plan_hstep", "snmf_plan_wstats", "snmf_plan_wapply", "snmf_plan_objstats", "snmf_plan_objapply",
-    "snmf_plan_stopped",
+    "snmf_plan_stopped", "snmf_plan_run_sharded",
     "snmf_plan_get_w_f64", "snmf_plan_get_w_f32", "snmf_plan_get_h_f64", "snmf_plan_get_h_f32",
     "snmf_plan_get_objective", "snmf_plan_solve_frames_f64", "snmf_plan_solve_frames_f32",
     "snmf_ctx_timing", "snmf_ctx_timing_get", "snmf_plan_describe",
@@ -274,6 +277,7 @@ def load():
     sig["snmf_run_basis_dnmf_audio_f64"] = (C.c_int, [vp, PP, SP, i32, i32, vp, i64, vp, i64, vp, i32, vp, i64, vp, u64, vp, i64, vp, i64, vp])
     sig["snmf_run_basis_train_audio_f64"] = (C.c_int, [vp, PP, SP, dbl, vp, i32, vp, i64, vp, i32, vp, u64, vp, vp, vp, vp, vp])
     sig["snmf_ctx_xfer_stats"] = (C.c_int, [vp, vp, C.c_int])
+    sig["snmf_plan_run_sharded"] = (C.c_int, [vp, i32, vp, ALLREDUCE_FN, vp, i32, i32, C.POINTER(i32)])
     for ty in ("f64", "f32"):
         sig[f"snmf_sparse_nmf_oop_{ty}"] = (C.c_int, [vp, PP, vp, i64, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i32)])
     lib.snmf_abi_version.restype = C.c_int

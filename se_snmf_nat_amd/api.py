@@ -535,6 +535,29 @@ class Plan:
         _lib.check(self._lib.snmf_plan_stopped(self._h, C.byref(s)))
         return bool(s.value)
 
+    def run_sharded(self, n_iters, stats_ptr, all_reduce=None, *, poll_every=4, finalize=True):
+        """snmf_plan_run_sharded: up to n_iters iterations of hstep -> wstats -> all_reduce -> wapply in ONE library call.
+        all_reduce(ptr, n_doubles): in-place SUM over the ranks of the n_doubles doubles at device address ptr (None: one rank).
+        Returns the iterations run."""
+        err = []
+
+        def _cb(ptr, n, _user):
+            try:
+                all_reduce(int(ptr), int(n))
+                return 0
+            except BaseException as e:  # (must not propagate through the C frame)
+                err.append(e)
+                return 1
+
+        cb = _lib.ALLREDUCE_FN(_cb) if all_reduce is not None else _lib.ALLREDUCE_FN()
+        done = C.c_int32()
+        rc = self._lib.snmf_plan_run_sharded(self._h, int(n_iters), C.c_void_p(stats_ptr), cb, None, int(poll_every),
+                                             1 if finalize else 0, C.byref(done))
+        if err:
+            raise err[0]
+        _lib.check(rc)
+        return int(done.value)
+
     # -- results ------------------------------------------------------------------------------
     def get_w(self, dtype=np.float64):
         out = np.empty((self.F, self.r), dtype=dtype, order="F")

@@ -1187,6 +1187,44 @@ extern "C" int snmf_plan_stopped(snmf_plan* pl, int32_t* stopped) {
     return SNMF_OK;
 }
 
+extern "C" int snmf_plan_run_sharded(snmf_plan* pl, int32_t n_iters, double* stats, snmf_allreduce_fn all_reduce, void* user,
+                                     int32_t poll_every, int32_t finalize, int32_t* iters_done) {
+    PLAN_CHECK(pl);
+    if (!pl->inited) return fail(SNMF_ERR_STATE, "plan not initialised");
+    if (!stats) return fail(SNMF_ERR_INVALID, "stats is NULL");
+    if (iters_done) *iters_done = 0;
+    const int64_t full = snmf_plan_stats_len(pl);
+    const bool w_any = pl->upd_w;
+    double* ar_ptr = w_any ? stats : stats + full - 2;  // H-only solves exchange nothing but the two cost scalars
+    const int64_t ar_len = w_any ? full : 2;
+    const bool can_stop = pl->p.cost_check && pl->p.conv_eps > 0 && poll_every > 0;
+    int since = 0, ran = 0;
+    bool stopped = false;
+    while (ran < n_iters && pl->it_done < pl->p.max_iter) {
+        SN_TRY(snmf_plan_hstep(pl));
+        SN_TRY(snmf_plan_wstats(pl, stats));
+        if (all_reduce && all_reduce(ar_ptr, ar_len, user) != 0) return fail(SNMF_ERR_INVALID, "all_reduce callback failed");
+        SN_TRY(snmf_plan_wapply(pl, stats));
+        ++ran;
+        if (can_stop && ++since >= poll_every) {
+            since = 0;
+            int32_t st = 0;
+            SN_TRY(snmf_plan_stopped(pl, &st));
+            if (st) {
+                stopped = true;
+                break;
+            }
+        }
+    }
+    if (iters_done) *iters_done = ran;
+    if (finalize && !stopped && pl->it_done >= pl->p.max_iter && pl->p.cost_check && !pl->final_done && pl->it_done > 0) {
+        SN_TRY(snmf_plan_objstats(pl, stats));
+        if (all_reduce && all_reduce(stats + full - 2, 2, user) != 0) return fail(SNMF_ERR_INVALID, "all_reduce callback failed");
+        SN_TRY(snmf_plan_objapply(pl, stats));
+    }
+    return SNMF_OK;
+}
+
 // final objective (iterate max_iter): objective-only pass + sum(S.*H) + check
 static int finalize_objective(snmf_plan* pl) {
     if (pl->final_done || !pl->p.cost_check || pl->it_done < 1) return SNMF_OK;

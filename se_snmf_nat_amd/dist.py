@@ -58,6 +58,18 @@ class ShardedLoop:
 
     def run(self, n_iters=None):
         target = self.max_iter if n_iters is None else min(self.max_iter, self.it + int(n_iters))
+        if hasattr(self.e, "run_sharded") and hasattr(self.stats, "data_ptr"):
+            # the product engine: the loop runs inside the library (snmf_plan_run_sharded), one call for all the iterations;
+            # the collective comes back as a callback on the (whole or two-scalar) statistics buffer
+            def ar(ptr, n):
+                self.all_reduce(self.stats)
+            last = target >= self.max_iter
+            ran = self.e.run_sharded(target - self.it, self._ptr(), ar, poll_every=self.poll_every if self.can_stop else 0,
+                                     finalize=last and self.cost_check and not self.finalized)
+            self.it += ran
+            if last and self.it >= self.max_iter and self.cost_check and self.it > 0:
+                self.finalized = True
+            return self.it
         since = 0
         stopped = False
         while self.it < target:
