@@ -252,3 +252,62 @@ def test_sharded_dnmf_loop_world2_equals_the_unsharded_call(gpu_ctx):
     assert np.array_equal(A, A1)
     rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
     assert rel(res[0][1], B1) < 5e-6
+
+
+def test_run_sharded_in_the_library_equals_the_step_api(gpu_ctx):
+    """snmf_plan_run_sharded (the process-per-GPU loop inside the library, the collective as a callback) against the same loop
+    driven call by call over the step API: identical W, H and objective vectors; the callback is called once per iteration on
+    the whole statistics buffer (+ once on the two cost scalars for the final objective); an exception raised inside the
+    callback comes back as that exception, not as a crash in the C frame.  src/sparse_nmf.m:186-286 per rank."""
+    import torch
+    from se_snmf_nat_amd import Plan
+    F, T, r, iters = 129, 3000, 24, 7
+    V, W0, H0 = synth_problem(F, T, r)
+
+    def make():
+        pl = Plan(gpu_ctx, F, T, r, beta=1.0, max_iter=iters, conv_eps=0.0, cost_check=True, sparsity=2.0)
+        pl.set_v(V); pl.set_w(W0); pl.set_h(H0); pl.init()
+        return pl, torch.zeros(pl.stats_len(), dtype=torch.float64, device="cuda:0")
+
+    a, sa = make()
+    torch.cuda.synchronize()
+    for _ in range(iters):
+        a.hstep(); a.wstats(sa.data_ptr()); a.wapply(sa.data_ptr())
+    a.objstats(sa.data_ptr()); a.objapply(sa.data_ptr())
+    b, sb = make()
+    torch.cuda.synchronize()
+    calls = []
+    ran = b.run_sharded(iters, sb.data_ptr(), lambda ptr, n: calls.append((ptr - sb.data_ptr(), n)))
+    assert ran == iters
+    assert calls == [(0, b.stats_len())] * iters + [((b.stats_len() - 2) * 8, 2)]
+    assert np.array_equal(a.get_w(), b.get_w()) and np.array_equal(a.get_h(), b.get_h())
+    assert np.array_equal(a.get_objective()[1], b.get_objective()[1])
+    a.close(); b.close()
+    c, sc = make()
+
+    def boom(ptr, n):
+        raise RuntimeError("collective failed")
+    with pytest.raises(RuntimeError, match="collective failed"):
+        c.run_sharded(3, sc.data_ptr(), boom)
+    c.close()
+
+
+def test_device_block_cache_does_not_leak_state(monkeypatch):
+    """A context hands the device blocks of a destroyed plan to the next plan of the same sizes (SNMF_DEVCACHE_MB): the second
+    solve must not see anything of the first -- same results as on a context with the cache off."""
+    from se_snmf_nat_amd import Context, sparse_nmf
+    V, W0, H0 = synth_problem(129, 2500, 24)
+    V2, W2, H2 = synth_problem(129, 2500, 24, seed=7) if "seed" in synth_problem.__code__.co_varnames else (V[:, ::-1].copy(), W0[::-1].copy(), H0[:, ::-1].copy())
+    p1 = dict(cf="kl", sparsity=3.0, max_iter=6, conv_eps=0, cost_check=1, init_w=W0, init_h=H0)
+    p2 = dict(cf="kl", sparsity=1.0, max_iter=6, conv_eps=0, cost_check=1, init_w=W2, init_h=H2)
+    monkeypatch.setenv("SNMF_DEVCACHE_MB", "0")
+    c0 = Context(0)
+    ref = sparse_nmf(V2, p2, ctx=c0)
+    c0.close()
+    monkeypatch.delenv("SNMF_DEVCACHE_MB")
+    c1 = Context(0)
+    sparse_nmf(V, p1, ctx=c1)          # fills the cache with this solve's blocks
+    got = sparse_nmf(V2, p2, ctx=c1)   # same sizes: every block is a reused one
+    c1.close()
+    assert np.array_equal(ref[0], got[0]) and np.array_equal(ref[1], got[1])
+    assert np.array_equal(ref[2]["cost"], got[2]["cost"])
