@@ -98,6 +98,70 @@ def cpu_baseline(F, T, r, budget_iters=8, repeats=3):
                       + ", ".join(f"{x:.1f}" for x in dts) + " s"}
 
 
+def algorithmic_bytes(family, F, T, r):
+    """SURVEY.md section 8d's per-launch HBM bytes of a half-step (fp32): the H step reads V and H and writes H
+    (4(FT + 2rT)); the W statistics read V and H once (4(FT + rT); their split-T slabs are extra and not counted)."""
+    return 4.0 * (F * T + 2.0 * r * T) if family == "hstep" else 4.0 * (F * T + r * T)
+
+
+def csrc_digest():
+    """sha256 over the kernel sources (names + bytes, sorted): what scripts/summarize_prof.py stamps into the traffic file
+    on the box that measured it, so that a later bench can tell whether the kernels changed since (`traffic_stale`)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(_ROOT, "se_snmf_nat_amd", "csrc", "*"))):
+        if os.path.isfile(fn) and fn.endswith((".h", ".hip", ".cpp")):
+            h.update(os.path.basename(fn).encode())
+            h.update(open(fn, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pick_traffic_key(tj, kname):
+    """The entry of a profiles/*_traffic.json that belongs to the launch of `kname` the timed region runs: the key must BE
+    an instantiation of that kernel (`kname<...>`, never a substring match of another family); among those the one launched
+    most often in the profiled command (`calls`, stamped by summarize_prof.py), else -- older files -- the objective
+    variant (`<true` first template argument of the role pipelines), else the one that moved the most bytes (warm-up and
+    drop-in launches of the same family run on a few thousand frames)."""
+    keys = [k for k in tj if not k.startswith("_") and (k == kname or k.startswith(kname + "<"))]
+    if not keys:
+        return None
+    if all("calls" in tj[k] for k in keys):
+        return max(keys, key=lambda k: (tj[k]["calls"], tj[k]["total_bytes"]))
+    obj = [k for k in keys if k.startswith(kname + "<true")]
+    return max(obj or keys, key=lambda k: tj[k]["total_bytes"])
+
+
+def committed_traffic(kname, flops, alg_bytes, root=_ROOT):
+    """(traffic, traffic_source, frac_rocprof) from the newest committed rocprofv3 summaries of this command."""
+    import csv
+    import glob
+    fns = sorted(glob.glob(os.path.join(root, "profiles", "r[0-9][0-9]_traffic.json")))
+    if not fns:
+        return None, None, None
+    fn = fns[-1]
+    tj = json.load(open(fn))
+    key = pick_traffic_key(tj, kname)
+    if key is None:
+        return None, None, None
+    traffic = tj[key]["total_bytes"]
+    stamp = tj.get("_csrc_digest")
+    src = {"file": "profiles/" + os.path.basename(fn), "kernel": key, "commit": tj.get("_source_commit"),
+           "csrc_digest": stamp, "traffic_stale": (stamp != csrc_digest()) if stamp else None,
+           "note": "quoted from the committed rocprofv3 --pmc passes of this command (a profiler cannot run inside bench.py); "
+                   "traffic_stale = a file under se_snmf_nat_amd/csrc changed since those passes (null: the file predates the stamp)"}
+    frac = None
+    ks = fn.replace("_traffic.json", "_kernel_stats.csv")
+    if os.path.exists(ks):
+        for row in csv.reader(ln for ln in open(ks) if not ln.startswith("#")):
+            if row and row[0] == key:
+                avg_ns = float(row[3])
+                frac = flops / (avg_ns * 1e-9) / 1e12 / PEAK_F32_MFMA_TFLOPS
+                src["rocprof_avg_ms"] = avg_ns * 1e-6
+                src["rocprof_calls"] = int(row[1])
+    return traffic, src, frac
+
+
 def cost_vs_oracle(F, T, r, n_it, final_cost):
     """|final_cost - oracle cost after the same number of iterations| / oracle cost, from the committed full-size
     golden (tests/golden/make_golden_c2.py: the fp64 oracle on exactly make_problem's inputs).  None when the run is
@@ -279,27 +343,12 @@ def main():
         # HBM bytes per launch of the dominant kernel: from the SEPARATE rocprofv3 --pmc passes of the
         # same command (scripts/prof.sh -> scripts/summarize_prof.py -> profiles/*_traffic.json);
         # a profiler cannot run inside this process, so the committed measurement is quoted.
-        traffic, traffic_source = None, None
+        alg_bytes = algorithmic_bytes(dom, F, T, r)
+        traffic, traffic_source, frac_rocprof = None, None, None
         if (F, T, r) == (F_, T_, R_):
-            import glob
-            for fn in sorted(glob.glob(os.path.join(_ROOT, "profiles", "r[0-9][0-9]_traffic.json")))[-1:]:
-                tj = json.load(open(fn))
-                # the launch that runs in the timed region: the KL update + objective variant of the dominant kernel
-                keys = [k for k in tj if k.startswith("k_" + dom)]
-                pref = [k for k in keys if k.startswith("k_hstep_rp<true") or "true, true" in k] or keys
-                if pref:
-                    traffic = tj[pref[0]]["total_bytes"]
-                    traffic_source = {"file": "profiles/" + os.path.basename(fn), "kernel": pref[0],
-                                      "commit": tj.get("_source_commit"),
-                                      "note": "quoted from the committed rocprofv3 --pmc passes of this command (a profiler cannot run "
-                                              "inside bench.py); stale if the kernel changed after that commit"}
+            traffic, traffic_source, frac_rocprof = committed_traffic(kname, flops_half, alg_bytes)
         last_cost = [c for c in cost if c != 0.0]
         ach = flops_half / (fam[dom][0] * 1e-3) / 1e12 if fam[dom][0] > 0 else 0.0
-        # the kernel(s) actually launched for the dominant half-step (from the plan's own description)
-        if dom == "hstep":
-            kname = "k_hstep_rh" if "k_hstep_rh" in desc else ("k_hstep_rp" if "k_hstep_rp" in desc else "k_hstep")
-        else:
-            kname = "k_wstats"
         out = {
             "metric": "NMF multiplicative-update iterations/sec (FxTxr)", "value": K / dt, "unit": "iterations/s",
             "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
@@ -311,6 +360,9 @@ def main():
                          "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE/WRITE_SIZE passes)",
                          "traffic_source": traffic_source,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "traffic_ratio": (traffic / alg_bytes) if traffic else None,
+                         "frac_rocprof": frac_rocprof,
                          "algorithmic_flops_per_launch": flops_half,
                          "kernel_ms": {f: fam[f][0] for f in fam if fam[f][1]}, "launches": {f: fam[f][1] for f in fam if fam[f][1]},
                          "kernel_ms_note": "HIP events on the engine's stream around every launch of a family, from a SEPARATE "

@@ -53,7 +53,13 @@ with open(f"profiles/{tag}_pmc.csv", "w") as f:
         wr = d.get("WRITE_SIZE", 0) * 1024
         traffic[k] = {"read_bytes": rd, "write_bytes": wr, "total_bytes": rd + wr}
         f.write(f"\"{k}\"," + ",".join(f"{d.get(c, float('nan')):.6g}" for c in cols) + f",{rd:.6g},{wr:.6g}\n")
+calls = {short(r["Name"]): int(r["Calls"]) for r in rows}
+for k in traffic:  # launches of each instantiation in the TRACE pass: what bench.pick_traffic_key selects by
+    traffic[k]["calls"] = calls.get(k, 0)
 traffic["_command"] = cmd
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (csrc_digest: the sources this box's library was built from travel with the snapshot)
+traffic["_csrc_digest"] = bench.csrc_digest()
 if os.environ.get("SNMF_SOURCE_COMMIT"):
     traffic["_source_commit"] = os.environ["SNMF_SOURCE_COMMIT"]
 json.dump(traffic, open(f"profiles/{tag}_traffic.json", "w"), indent=1)

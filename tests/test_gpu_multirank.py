@@ -199,6 +199,14 @@ def test_bench_single_gpu_line_keeps_the_contract():
     assert rf["kernel_ms"]["hstep"] > 0 and rf["kernel_ms"]["wstats"] > 0
     assert rf["kernel"] in ("k_hstep_rp", "k_hstep_rh", "k_hstep", "k_wstats") and rf["kernel"] in d["config"]["geometry"] + " k_wstats"
     assert "separate" in rf["kernel_ms_note"].lower() and "traffic_source" in rf
+    # sense, not only keys: the dominant kernel's own time fits inside a step; a quoted traffic figure belongs to the kernel
+    # the line names and is at least that kernel's algorithmic bytes
+    dom = "hstep" if rf["kernel"].startswith("k_hstep") else "wstats"
+    assert rf["kernel_ms"][dom] <= 1.05 * d["ms_per_step"]
+    assert rf["algorithmic_bytes_per_launch"] > 0
+    if rf["traffic"] is not None:
+        assert rf["traffic_source"]["kernel"].startswith(rf["kernel"] + "<")
+        assert rf["traffic"] >= rf["algorithmic_bytes_per_launch"] and rf["traffic_ratio"] == pytest.approx(rf["traffic"] / rf["algorithmic_bytes_per_launch"])
     cb = d["cpu_baseline"]
     assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("port", "reference") and cb["sample"]
 
