@@ -326,6 +326,13 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
             }
         }
     }
+    // k_hstep_m (merged roles: one wave per SIMD runs P1, both epilogues and P2 of its own rows / columns, snmf_hstep_m.h): the
+    // double-buffered geometry with exactly 8 row tiles and 8 column tiles (C2).  SNMF_HSTEP_M=1 selects it (A/B against k_hstep_rp).
+    {
+        const char* e = getenv("SNMF_HSTEP_M");
+        pl->hm = e && atoi(e) != 0 && pl->hstep_rp && pl->NWH == 8 && pl->NLH == 4 && pl->bm == BM_KL && pl->nf == 8 && pl->nk == 8 && !pl->generic;
+        pl->hm_grid = std::max(1, std::min(pl->rp_tiles, ctx->n_cu));
+    }
     // At most two row tiles and eight column tiles (the Mel solves, r <= 256): a tile per WAVE, nothing handed between waves
     // (snmf_smallf.h).  Follows SNMF_HSTEP_RP (tests compare against the barrier-phased kernels); SNMF_HSTEP_SF=0 keeps the
     // role pipeline.
@@ -620,6 +627,9 @@ extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
     else if (rh_pipe)
         snprintf(hs, sizeof hs, "k_hstep_rh (4 P1 + 4 P2 + 4 loader waves on half tiles%s; %d of %d tiles pipelined, last round split %d ways, grid %d)",
                  pl->rh_lxh == 1 ? ", P2 cut four ways over the contraction + leftover columns as 4x4x1 MFMAs" : (pl->rh_lxh == 2 ? ", P2 in wave pairs cut over the contraction + leftover columns as 4x4x1 MFMAs" : ""), pl->rp_full, pl->rp_tiles, pl->rp_S, pl->rp_grid);
+    else if (kl_pipe && pl->hm && !pl->S)
+        snprintf(hs, sizeof hs, "k_hstep_m (merged roles: 4 waves, one per SIMD, each P1 + P2 of its own row / column tiles; %d tiles whole, grid %d)",
+                 pl->rp_tiles, pl->hm_grid);
     else if (kl_pipe)
         snprintf(hs, sizeof hs, "k_hstep_rp (4 P1 + 4 P2 + 4 loader waves; %d of %d tiles pipelined, last round split %d ways, grid %d)",
                  pl->rp_full, pl->rp_tiles, pl->rp_S, pl->rp_grid);
@@ -1083,7 +1093,7 @@ static int hupd_parts(const snmf_plan* pl) {
     if (pl->generic) return kGBlocks;
     if (pl->M) return pl->grid_mdi;
     if (pl->sf) return pl->sf_grid;
-    if (hupd_is_rp(pl)) return pl->rp_grid;
+    if (hupd_is_rp(pl)) return (pl->hm && !pl->rh && !pl->S) ? pl->hm_grid : pl->rp_grid;
     return pl->grid_h;
 }
 

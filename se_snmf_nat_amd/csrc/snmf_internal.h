@@ -110,6 +110,8 @@ struct snmf_plan {
     // k_hstep_rp launch geometry: tiles [0, rp_full) through the pipeline on rp_grid workgroups, the tiles of the last
     // partial round [rp_full, rp_tiles) cut into rp_S row parts, one workgroup each (rp_S = 0: no split)
     int rp_tiles = 0, rp_full = 0, rp_S = 0, rp_grid = 1;
+    bool hm = false;               // KL update launches run k_hstep_m (merged roles, one wave per SIMD: snmf_hstep_m.h); SNMF_HSTEP_M=0/1
+    int hm_grid = 1;
     bool rh = false;               // KL update launches run k_hstep_rh (9..16 row tiles, e.g. F = 513: one ratio image, pipelined by half tiles)
     size_t lds_rh = 0;
     float* part_buf = nullptr;     // partial numerators of the split tiles [rp_grid][32][rp]
@@ -253,6 +255,7 @@ int xfer_sync(snmf_ctx* c);
 int launch_hstep(snmf_plan* pl, bool obj, bool upd);
 int launch_hstep_rp(snmf_plan* pl, StepArgs a, bool obj);  // snmf_tu_hstep_rp.hip
 int launch_hstep_rh(snmf_plan* pl, StepArgs a, bool obj);  // snmf_tu_hstep_rh.hip
+int launch_hstep_m(snmf_plan* pl, StepArgs a, bool obj);   // snmf_tu_hstep_m.hip
 int launch_hstep_sf(snmf_plan* pl, StepArgs a, bool obj);  // snmf_tu_smallf.hip
 int launch_wstats_sf(snmf_plan* pl, const StepArgs& a, bool obj);  // snmf_tu_smallf.hip
 int launch_wstats(snmf_plan* pl, bool obj);

@@ -2890,8 +2890,9 @@ __device__ __forceinline__ void wstats_body(StepArgs a, int n_chunks, int mat_in
     // NK = 4 (r <= 128) with full tiles: the H image's leading dimension is always 128 + 4 (host: ldhw), a COMPILE-TIME constant
     // here -- P4's sixteen row bases become one base + immediate offsets (15 VGPRs less: the LX variants of the 8+4-wave
     // geometry spilled 1..4 registers into scratch, which costs a kernel ~4 us per launch, and carried the adds per tile)
-    constexpr bool LDHC = NK == 4 && TT == 32;
-    const int ldh = LDHC ? 132 : a.ldh;
+    // (NK = 8, r <= 256, one kappa-group: always 256 + 4 -- the host's ldhw and the kappa-group launches' 260)
+    constexpr bool LDHC = (NK == 4 || NK == 8) && TT == 32;
+    const int ldh = LDHC ? (NK == 4 ? 132 : 260) : a.ldh;
     const int bufsz = TT * (ldh + ldv);     // floats per buffer: Hs [TT][ldh] then Vs [TT][ldv]
     float* wxs = lds + NBUF * bufsz;        // [rp] extra row of W
     const int lane = threadIdx.x & 63, w = wave_index();
