@@ -32,6 +32,8 @@ _TU_HDRS = {
     "snmf_tu_multi.hip": ["snmf_multi.h"],
     "snmf_tu_dnmf.hip": ["snmf_frontend.h"],
     "snmf_tu_smallf.hip": ["snmf_smallf.h"],
+    "snmf_tu_itersf.hip": ["snmf_smallf.h"],
+    "snmf_tu_hstep_m.hip": ["snmf_hstep_m.h"],
 }
 HDRS = sorted(_glob.glob(os.path.join(_HERE, "csrc", "*.h"))) + [os.path.join(_ROOT, "include", "snmf.h")]
 

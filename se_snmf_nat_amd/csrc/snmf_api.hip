@@ -411,6 +411,16 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
                   pl->NLW && !pl->generic && pl->lds_wsf <= lds_cap && !(e && atoi(e) == 0) && !(e2 && atoi(e2) == 0);
         if (pl->wsf) pl->til = 1;
     }
+    // ... and, for FULL updates of those shapes, both half-steps in one launch (k_iter_sf; the run loop only: the step API keeps
+    // the two launches, between which a multi-rank caller sums nothing but could).  SNMF_ITER_SF=0 keeps two launches.
+    {
+        const char* e = getenv("SNMF_ITER_SF");
+        const int ncl = 4;  // SIMD pairs (H wave + W wave) per workgroup = chunk lanes of k_wstats_sf at two row tiles
+        const size_t body = ((size_t)pl->nf * pl->rp * 32 + (size_t)pl->nk * pl->Fq * 32 + 2 * (size_t)pl->rp + (size_t)(ncl + 1) * 32 * (32 * pl->nk + 4) + 2 * ncl + 1) * 4;
+        const size_t tail = ((size_t)ncl * pl->nf * pl->nk * 1024 + (size_t)ncl * pl->rp) * 4 + 2 * ncl * sizeof(double);
+        pl->lds_isf = std::max(body, tail) + 64;
+        pl->isf = pl->sf && pl->wsf && pl->nf == 2 && pl->nk >= 3 && pl->upd_h && pl->upd_w && pl->lds_isf <= lds_cap && !(e && atoi(e) == 0);
+    }
     const int wg_w = pl->NLW ? 1 : pl->WPS;  // workgroups per CU
     pl->n_chunks = std::max(1, std::min(n_tiles_w, ctx->n_cu * wg_w / std::max(1, pl->n_fg * pl->n_kg)));
     // Two row groups, only group 0 carries the extra row: deal the workgroups out so that both finish together.
@@ -622,7 +632,9 @@ extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
     char hs[256];
     const bool rh_pipe = pl->rh && pl->upd_h && !pl->M;
     const bool sf_pipe = pl->sf && !pl->M;
-    if (sf_pipe)
+    if (sf_pipe && pl->isf && pl->wfin)
+        snprintf(hs, sizeof hs, "k_iter_sf (H step + W statistics of a full update in ONE launch, 4 SIMD pairs of an H wave and a W wave per workgroup; %d tiles, grid %d; step API: k_hstep_sf)", pl->rp_tiles, pl->n_chunks);
+    else if (sf_pipe)
         snprintf(hs, sizeof hs, "k_hstep_sf (a tile per wave from first load to last store, 8 waves per workgroup; %d tiles, grid %d)", pl->rp_tiles, pl->sf_grid);
     else if (rh_pipe)
         snprintf(hs, sizeof hs, "k_hstep_rh (4 P1 + 4 P2 + 4 loader waves on half tiles%s; %d of %d tiles pipelined, last round split %d ways, grid %d)",
@@ -1263,6 +1275,15 @@ extern "C" int snmf_plan_run(snmf_plan* pl, int32_t n_iters, int32_t* iters_done
     int since_poll = 0;
     bool stopped = false;
     while (pl->it_done < target) {
+        if (pl->isf && pl->wfin && !pl->M && pl->n_chunks == std::max(1, std::min((pl->p.T + 31) / 32, pl->ctx->n_cu))) {
+            // F <= 64, r <= 128, full KL update: H step + W statistics in ONE launch (k_iter_sf), then the reduction + W update
+            const int j = pl->it_done + 1;
+            const bool obj = want_obj(pl, j);
+            SN_TRY(launch_iter_sf(pl, obj));
+            pl->cur ^= 1;
+            SN_TRY(launch_wfin(pl, pl->stats, obj, pl->n_chunks, false, obj ? j - 1 : 0));
+            pl->it_done = j;
+        } else {
         SN_TRY(snmf_plan_hstep(pl));
         if (pl->wfin) {
             // (what snmf_plan_wstats + snmf_plan_wapply do for a W update, the reduction and the update in one launch)
@@ -1280,6 +1301,7 @@ extern "C" int snmf_plan_run(snmf_plan* pl, int32_t n_iters, int32_t* iters_done
         } else {
             SN_TRY(snmf_plan_wstats(pl, pl->stats));
             SN_TRY(snmf_plan_wapply(pl, pl->stats));
+        }
         }
         if (can_stop && ++since_poll >= 4) {
             since_poll = 0;

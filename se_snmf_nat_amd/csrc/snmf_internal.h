@@ -123,6 +123,8 @@ struct snmf_plan {
     int sf_grid = 1;
     bool wsf = false;     // KL statistics through k_wstats_sf (F <= 64, r <= 128)
     size_t lds_wsf = 0;
+    bool isf = false;     // full KL updates of those shapes: H step + W statistics in ONE launch (k_iter_sf); SNMF_ITER_SF=0 keeps two
+    size_t lds_isf = 0;
     int sf_stagger = 0;   // cycles by which the second wave of each SIMD starts late (k_hstep_sf)
     size_t lds_sf = 0;
     int til = 1;  // k_wstats: consumer teams that share a chunk's tiles (StepArgs::til)
@@ -258,6 +260,7 @@ int launch_hstep_rh(snmf_plan* pl, StepArgs a, bool obj);  // snmf_tu_hstep_rh.h
 int launch_hstep_m(snmf_plan* pl, StepArgs a, bool obj);   // snmf_tu_hstep_m.hip
 int launch_hstep_sf(snmf_plan* pl, StepArgs a, bool obj);  // snmf_tu_smallf.hip
 int launch_wstats_sf(snmf_plan* pl, const StepArgs& a, bool obj);  // snmf_tu_smallf.hip
+int launch_iter_sf(snmf_plan* pl, bool obj);  // snmf_tu_smallf.hip: H step + W statistics of one full KL iteration, H[cur] -> H[cur ^ 1]
 int launch_wstats(snmf_plan* pl, bool obj);
 int launch_wstats_nk4(snmf_plan* pl, const StepArgs& a, bool obj);  // snmf_tu_wstats4.hip
 int launch_wstats_nk8(snmf_plan* pl, const StepArgs& a, bool obj);  // snmf_tu_wstats8.hip

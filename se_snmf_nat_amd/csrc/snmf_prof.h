@@ -8,6 +8,12 @@ static void snmf_prof_report(snmf_plan* pl) {
         const int nw = wlast ? pl->n_chunks * pl->n_fg * pl->NWB : pl->grid_h * pl->NWH;
         std::vector<unsigned long long> hp((size_t)nw * 12);
         hipMemcpy(hp.data(), pl->prof + (wlast ? (size_t)4096 * 12 : 0), hp.size() * 8, hipMemcpyDeviceToHost);
+        if (const char* dump = getenv("SNMF_PROF_DUMP")) {  // raw per-wave phase cycles [nw][12] for offline analysis
+            if (FILE* f = fopen(dump, "wb")) {
+                fwrite(hp.data(), 8, hp.size(), f);
+                fclose(f);
+            }
+        }
         double tot[12] = {0};
         for (int i = 0; i < nw; ++i)
             for (int j = 0; j < 12; ++j) tot[j] += (double)hp[(size_t)i * 12 + j];

@@ -286,7 +286,16 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_wstats_sf(StepArgs a, int 
     double acc_div = 0.0;
     const bool do_s = phi == 0;
 
-    for (int tile = tb + c; tile < te; tile += NCL) {
+    // Whole rounds of NCL tiles, then the remainder of m = n % NCL tiles: remainder tile j goes to chunk lane (j + m) % NCL -- the
+    // deal of k_iter_sf's W tasks (whose H task of that tile sits on pair j, so that no SIMD gets an extra tile of both kinds);
+    // the two kernels accumulate the same tiles in the same order, which keeps their slabs bit for bit the same.
+    const int n_my = te - tb, n_rnd = n_my / NCL, n_rem = n_my - n_rnd * NCL;
+    const int jx = (c - n_rem + NCL) % NCL;  // the remainder tile of this lane, if jx < n_rem
+    const int n_it = n_rnd + (jx < n_rem ? 1 : 0);
+    const bool x_first = n_rem == 1 && jx == 0;  // (a single remainder tile is its lane's FIRST tile: see k_iter_sf)
+    for (int itx = 0; itx < n_it; ++itx) {
+        const int itr = x_first ? itx - 1 : itx;  // index among the whole rounds (-1 / n_rnd: the remainder tile)
+        const int tile = (itr >= 0 && itr < n_rnd) ? tb + c + itr * NCL : tb + n_rnd * NCL + jx;
         const int t0 = tile * 32;
         // this lane's H pieces (operand layout, as k_hstep_sf), its V values in the D layout of P3, the first column tile of P4
         f32x4 hq[NK * 4];
@@ -425,6 +434,464 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_wstats_sf(StepArgs a, int 
         for (int i = 0; i < kSfWaves; ++i) d += dred[i];
         a.part[2 * chunk] = d;
         a.part[2 * chunk + 1] = 0.0;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// k_iter_sf (round 5): the H half-step AND the W statistics of a full KL update in ONE launch, for spectrograms of two 32-row
+// tiles (F = 33..64: run_basis_train.m:90-91 on 64 Mel bands) and three or four column tiles (r = 65..128: R = 100).
+// V and H cross HBM once per iteration instead of twice, the W images are filled once, and one launch with its ramp, its
+// final reduction and its drain disappears.
+//
+// Eight waves, two per SIMD, in four PAIRS (waves c and 4 + c: SIMD partners under the cyclic wave placement):
+//   H wave c      the tile body of k_hstep_sf: operand loads straight into the MFMA layout, P1, ratio, P2, the H update in
+//                 registers, H_new stored the way it came -- and written once more into the pair's LDS hand-off buffer
+//                 ([32 frames][32 NK + 4], 16-byte writes in the layout it was computed in);
+//   W wave 4 + c  the tile body of k_wstats_sf on the tile its partner has just finished: P3's A operand (H_new pieces, lane
+//                 (t, h)) comes out of the hand-off buffer with the 16-byte reads that mirror the writes, P4's B operand (H_new
+//                 with the components in lanes) with 4-byte reads of the same buffer -- no second trip to L2 for H, nothing of
+//                 it in the wave's vmcnt queue; V once more with the rows in lanes (4-byte loads of lines its partner fetched
+//                 a tile earlier).  It owns the statistics of BOTH row tiles: NF * NK accumulator tiles, pinned to a[0:127].
+// Why pairs and not one wave that does everything: the statistics of both row tiles are 128 registers and a tile's other state
+// ~240, so a do-everything wave is alone on its SIMD -- built first, 68.8 us against 73.0 for the two launches (Mel 64 x 72000,
+// r = 100): with one wave per SIMD every latency of the tile (the operand loads' HBM round trip first of all) is exposed.
+// Here each wave stays under 256 registers, both waves of a SIMD carry 232 MFMAs per tile, and one wave's loads, LDS round
+// trips and epilogues run beside the other's MFMA loops.  The hand-off is ONE-WAY and per SIMD pair -- `full` (H wave: tile i
+// is in the buffer) / `empty` (W wave: tile i is read) -- not the workgroup-wide chain the role pipelines paid per tile.
+// Work split: pair c walks the tiles tb + c, tb + c + 4, ... of the workgroup's contiguous frame range: exactly the tiles, in
+// exactly the order, in which waves (phi, c) of k_wstats_sf accumulate them, and the pairs' statistics meet in LDS in the
+// same order -- with n_chunks workgroups the slabs, the row sums and therefore W equal the two-launch path BIT FOR BIT, and H_new
+// is per tile the same arithmetic (tests/test_gpu_parity.py::test_fused_small_f_iteration_equals_the_two_launches).
+// Dynamic LDS: Wt4 image (P1 and P3), Wk4 image (P2), 1 ./ dph and lambda_k [rp] each, 4 hand-off buffers, 8 progress words; the
+// end of the kernel reuses it for the pairs' partial statistics as k_wstats_sf does.
+
+// G += a (x) b with the accumulator tile PINNED to the accumulation registers ("a" constraint).  The NF * NK statistics tiles live
+// across the whole kernel; left to the allocator they are ordinary values that move between the two register classes around
+// every phase (hundreds of v_accvgpr moves per tile).  As operands of this statement their home is a[...].
+__device__ __forceinline__ void mfma32_acc_agpr(f32x16& g, float a, float b) {
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(g) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void sf_post(unsigned* word, unsigned val, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    if (lane == 0) __hip_atomic_store(word, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// The H wave's side of the hand-off WITHOUT compiler-visible memory effects: a fence (or a "memory" clobber) inside the tile loop
+// orders every LDS access of the tile around it as far as the compiler knows, and the H waves' code went from 206 registers
+// to 256 + 11 spilled (either of the two fences alone did it).  The hardware needs none of that: LDS operations of a wave
+// complete in order, the data written behind the wait and ahead of the post are registers of this wave.
+__device__ __forceinline__ void sf_post_raw(unsigned word_addr, unsigned val) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(word_addr), "v"(val));
+}
+__device__ __forceinline__ void sf_await_raw(unsigned word_addr, unsigned target, const int* stop) {
+    int spin = 0;
+    for (;;) {
+        unsigned x;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(x) : "v"(word_addr));
+        if (__builtin_amdgcn_readfirstlane((int)x) >= (int)target) break;
+        if (++spin > kSpinLimit) {
+            raise_fault(stop);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+__device__ __forceinline__ void sf_await(const unsigned* word, unsigned target, const int* stop) {
+    int spin = 0;
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+        if (++spin > kSpinLimit) {
+            raise_fault(stop);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// SK: the sparsity kind (0: one lambda for every row, 1: a lambda per row, 2: an r x T matrix in H's layout) -- a parameter of the
+// KERNEL here, not of a tile-loop lambda as in k_hstep_sf (three loops in one function: the register allocation of the worst).
+template <int NK, bool OBJ, int SK>
+__global__ __launch_bounds__(kSfWaves * 64, 2) void k_iter_sf(StepArgs a, int n_chunks, int n_mat) {
+    if (a.stop && *a.stop) return;
+    constexpr int NF = 2, NP = kSfWaves / 2, NTHR = kSfWaves * 64, LDT = 32 * NK + 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, w = wave_index();
+    const bool is_w = w >= NP;          // W wave of pair c
+    const int c = is_w ? w - NP : w;
+    const int rp = a.rp, Fp = a.Fp;
+    const int nq8 = rp / 8, nqf = a.Fq / 8;
+    float* const wt = lds;                                    // Wt4: NF * rp * 32 floats
+    float* const wk = wt + (size_t)NF * rp * 32;              // Wk4: NK * Fq * 32 floats
+    float* const rdp = wk + (size_t)NK * a.Fq * 32;           // 1 ./ dph [rp]
+    float* const lmk = rdp + rp;                              // lambda_k [rp]
+    float* const hb = lmk + rp + (size_t)c * 32 * LDT;        // this pair's hand-off buffer [32][LDT]
+    float* const xb = lmk + rp + (size_t)NP * 32 * LDT;       // one more buffer: a chunk's single remainder tile (below)
+    unsigned* const sig = reinterpret_cast<unsigned*>(xb + 32 * LDT);  // full[NP], empty[NP], xfull
+    unsigned* const full = sig + c;
+    unsigned* const empty = sig + NP + c;
+    const unsigned full_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)full;
+    const unsigned empty_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)empty;
+    const unsigned xfull_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(sig + 2 * NP);
+    const int t = lane & 31, h = lane >> 5;                   // (as a frame index: lane (t, h); as a row / component index: fl = t)
+    const int chunk = blockIdx.x;
+    const int tb = (int)(((long long)a.n_tiles * chunk) / n_chunks), te = (int)(((long long)a.n_tiles * (chunk + 1)) / n_chunks);
+    {
+        const int n4 = (NF * rp * 32 + NK * a.Fq * 32) / 4, nt4 = NF * rp * 32 / 4;
+        for (int i = threadIdx.x; i < n4; i += NTHR) {
+            const f32x4 x = i < nt4 ? reinterpret_cast<const f32x4*>(a.Wt4)[i] : reinterpret_cast<const f32x4*>(a.Wk4)[i - nt4];
+            reinterpret_cast<f32x4*>(lds)[i] = x;
+        }
+        for (int k = threadIdx.x; k < rp; k += NTHR) {
+            rdp[k] = a.S ? 0.f : fast_rcp(a.dphv[k]);
+            lmk[k] = a.S ? 0.f : a.lamk[k];
+        }
+        if (threadIdx.x < 2 * NP + 1) sig[threadIdx.x] = 0u;
+    }
+    __syncthreads();
+    const f32x4* const wtl = reinterpret_cast<const f32x4*>(wt) + lane;  // fragment (phi, q): wtl[(phi * nq8 + q) * 64]
+    const f32x4* const wkl = reinterpret_cast<const f32x4*>(wk) + lane;  // fragment (kap, q): wkl[(kap * nqf + q) * 64]
+
+    // (the end of the kernel -- barrier, partial statistics into LDS, barrier -- is written out in BOTH role branches: the statistics
+    //  tiles must not be live in the H waves' code, whose registers they would take: 128 of the 256 a wave has at two per SIMD)
+    float* const xs = lds;                                            // [NP][NF * NK][16][64]   (after the first barrier)
+    float* const sred = lds + (size_t)NP * NF * NK * 16 * 64;         // [NP][rp] row sums
+    double* const dred = reinterpret_cast<double*>(sred + NP * rp);   // [2][NP]
+
+    if (!is_w) {
+        double acc_div = 0.0, acc_sh = 0.0;
+        // ================================ H wave: k_hstep_sf's tile body + the hand-off ================================
+        // this pair's H tasks: tile c of every whole round of NP tiles and remainder tile c (if there is one).  A SINGLE remainder tile
+        // (n = 4 R + 1: Mel 64 x 72000 is 9 tiles a chunk) is pair 0's FIRST task and goes into the extra buffer, which nobody has to
+        // release: pair 1's W wave takes it while it would otherwise wait for its own partner's second tile, and no SIMD carries an
+        // extra task of both kinds behind a chain of hand-offs (5 tasks on the two busiest SIMDs instead of 6 on one).
+        const int n_my = te - tb, n_rnd = n_my / NP, n_rem = n_my - n_rnd * NP;
+        const bool x_first = n_rem == 1 && c == 0;
+        const unsigned n_h = (unsigned)(n_rnd + (c < n_rem ? 1 : 0));
+        SNMF_STAMP_DECL
+        for (unsigned ith = 0; ith < n_h; ++ith) {
+            const bool is_x = x_first && ith == 0;                  // the remainder tile, into the extra buffer
+            const unsigned it = x_first ? ith - 1u : ith;           // index among the tiles that go through this pair's own buffer
+            const int tile = is_x ? tb + n_rnd * NP : tb + c + (int)it * NP;
+            const int t0 = tile * 32;
+            f32x4 hq[NK * 4], vq[NF * 4];
+            {
+                const float* hp = a.Hin + ((size_t)t0 + t) * rp + 4 * h;
+                const float* vp = a.V + ((size_t)t0 + t) * Fp + 4 * h;
+#pragma unroll
+                for (int q = 0; q < NK * 4; ++q) hq[q] = *reinterpret_cast<const f32x4*>(hp + 8 * q);
+#pragma unroll
+                for (int q = 0; q < NF * 4; ++q) vq[q] = *reinterpret_cast<const f32x4*>(vp + 8 * q);
+            }
+            // ---- P1 + ratio ----
+            float dsum = 0.f;
+            {
+                f32x16 acc[NF];
+                f32x4 wa[NF], wb[NF];
+#pragma unroll
+                for (int phi = 0; phi < NF; ++phi) {
+                    acc[phi] = zero16();
+                    wa[phi] = wtl[(phi * nq8) * 64];
+                }
+#pragma unroll
+                for (int q = 0; q < NK * 4; ++q) {
+                    if (q > 4 * (NK - 1) && q >= a.nqk) break;
+                    if (q + 1 < NK * 4) {
+#pragma unroll
+                        for (int phi = 0; phi < NF; ++phi) wb[phi] = wtl[(phi * nq8 + q + 1) * 64];
+                    }
+                    SNMF_PIN();
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int phi = 0; phi < NF; ++phi) acc[phi] = mfma32(wa[phi][e], hq[q][e], acc[phi]);
+#pragma unroll
+                    for (int phi = 0; phi < NF; ++phi) wa[phi] = wb[phi];
+                }
+                SNMF_STAMP(0);
+#pragma unroll
+                for (int phi = 0; phi < NF; ++phi) {
+                    const bool edge = OBJ && !(phi * 32 + 32 <= a.F && t0 + 32 <= a.T);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float v = vq[phi * 4 + g][j];
+                            const float lam = fmaxf(acc[phi][4 * g + j], kFlr);
+                            if (OBJ) {
+                                const float d = div_term<BM_KL>(v, lam, a.beta, a.inv_bb1);
+                                if (edge) dsum += (phi * 32 + 8 * g + 4 * h + j < a.F && t0 + t < a.T) ? d : 0.f;
+                                else dsum += d;
+                            }
+                            vq[phi * 4 + g][j] = v * fast_rcp(lam);
+                        }
+                        if (OBJ) __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            if (OBJ) acc_div += (double)dsum;
+            SNMF_STAMP(1);
+            // ---- P2 + the H update ----
+            float shsum = 0.f;
+            auto p2_update = [&](const f32x16& acc, const int kap) {
+                float hs = 0.f;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int k0 = kap * 32 + 8 * g + 4 * h;
+                    const f32x4 ho = hq[kap * 4 + g];
+                    f32x4 sp, dp;
+                    if constexpr (SK == 2) {
+                        sp = *reinterpret_cast<const f32x4*>(a.S + ((size_t)t0 + t) * rp + k0);
+                        const f32x4 cs = *reinterpret_cast<const f32x4*>(a.colsum + k0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) dp[j] = fast_rcp(fmaxf(cs[j] + sp[j], kFlr));
+                    } else {
+                        dp = *reinterpret_cast<const f32x4*>(rdp + k0);
+                        if constexpr (OBJ && SK == 1) sp = *reinterpret_cast<const f32x4*>(lmk + k0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hq[kap * 4 + g][j] = ho[j] * acc[4 * g + j] * dp[j];
+                    if constexpr (OBJ) {
+                        if constexpr (SK == 0) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) hs += ho[j];
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) shsum += sp[j] * ho[j];
+                        }
+                    }
+                }
+                if constexpr (OBJ && SK == 0) shsum += a.lam_u * hs;
+            };
+#pragma unroll
+            for (int kap = 0; kap < NK; kap += 2) {
+                constexpr int NQ = NF * 4;
+                if (kap + 1 < NK) {
+                    f32x16 acc0 = zero16(), acc1 = zero16();
+                    f32x4 wa0 = wkl[(kap * nqf) * 64], wa1 = wkl[((kap + 1) * nqf) * 64], wb0, wb1;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        if (q + 1 < NQ) {
+                            wb0 = wkl[(kap * nqf + q + 1) * 64];
+                            wb1 = wkl[((kap + 1) * nqf + q + 1) * 64];
+                        }
+                        SNMF_PIN();
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            acc0 = mfma32(wa0[e], vq[q][e], acc0);
+                            acc1 = mfma32(wa1[e], vq[q][e], acc1);
+                        }
+                        wa0 = wb0;
+                        wa1 = wb1;
+                    }
+                    p2_update(acc0, kap);
+                    p2_update(acc1, kap + 1);
+                } else {
+                    f32x16 acc0 = zero16();
+                    f32x4 wa0 = wkl[(kap * nqf) * 64], wb0;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        if (q + 1 < NQ) wb0 = wkl[(kap * nqf + q + 1) * 64];
+                        SNMF_PIN();
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc0 = mfma32(wa0[e], vq[q][e], acc0);
+                        wa0 = wb0;
+                    }
+                    p2_update(acc0, kap);
+                }
+            }
+            if (OBJ) acc_sh += (double)shsum;
+            SNMF_STAMP(2);
+            // ---- H_new leaves the way it came ... ----
+            {
+                float* op = a.Hout + ((size_t)t0 + t) * rp + 4 * h;
+#pragma unroll
+                for (int q = 0; q < NK * 4; ++q) *reinterpret_cast<f32x4*>(op + 8 * q) = hq[q];
+            }
+            // ---- ... and goes to the partner: [frame][component], once the partner has read the previous tile ----
+            // (the writes are inline assembly: as C++ stores into the LDS array inside the tile loop they alias every W-fragment read of
+            //  the tile as far as the compiler knows, and the H waves' code went from 206 registers to 256 + 11 spilled.  LDS operations
+            //  of a wave complete in order, so the progress word posted behind them cannot overtake them)
+            SNMF_STAMP(3);
+            if (!is_x && it > 0) sf_await_raw(empty_a, it, a.stop);
+            SNMF_STAMP(4);
+            {
+                const unsigned tpa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)((is_x ? xb : hb) + t * LDT + 4 * h);
+#pragma unroll
+                for (int q = 0; q < NK * 4; ++q) asm volatile("ds_write_b128 %0, %1" ::"v"(tpa + 32u * q), "v"(hq[q]));
+            }
+            sf_post_raw(is_x ? xfull_a : full_a, is_x ? 1u : it + 1);
+            SNMF_STAMP(3);
+        }
+        __syncthreads();  // (every wave is through with the W images and the hand-off buffers)
+        SNMF_STAMP(10);
+        if (OBJ) {
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) {
+                acc_div += __shfl_xor(acc_div, s, 64);
+                acc_sh += __shfl_xor(acc_sh, s, 64);
+            }
+            if (lane == 0) {
+                dred[c] = acc_div;
+                dred[NP + c] = acc_sh;
+            }
+        }
+        __syncthreads();
+        SNMF_STAMP(11);
+        SNMF_STAMP_OUT(a.prof + ((size_t)blockIdx.x * 8 + w) * 12, 12);
+        SNMF_STAMP_CLK(a.prof, (size_t)blockIdx.x * 8 + w);
+    } else {
+        // ================================ W wave: k_wstats_sf's tile body on the partner's tile ================================
+        f32x16 G[NF][NK];
+        float ssum[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+#pragma unroll
+            for (int phi = 0; phi < NF; ++phi) G[phi][k] = zero16();
+            ssum[k] = 0.f;
+        }
+        SNMF_STAMP_DECL
+        // One W task: the statistics of `tile` out of hand-off buffer `hbx`, once its H wave has posted `target` on `fullx`.
+        auto w_tile = [&](const int tile, const float* const hbx, const unsigned* const fullx, const unsigned target) {
+            const int t0 = tile * 32;
+            // V with the rows in lanes (lane (f, h): frames drow(i, h)): lines the partner fetched a tile ago.  ONE row tile's values
+            // at a time: those of the second are loaded into the same registers in front of its P3.
+            float vt[16];
+            const __amdgpu_buffer_rsrc_t rv =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.V + (size_t)t0 * Fp), 0, 32 * Fp * 4, 0x00020000);
+            auto ld_vt = [&](int phi) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    vt[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, ((4 * h) * Fp + phi * 32 + t) * 4, drow(i, 0) * Fp * 4, 0));
+            };
+            ld_vt(0);
+            SNMF_STAMP(9);
+            sf_await(fullx, target, a.stop);
+            SNMF_STAMP(5);
+            // One row tile after the other (the statistics take 128 of the wave's 256 registers: the ratio of ONE row tile at a time,
+            // and the 4-byte operand reads of P4 once per row tile -- LDS reads are what this wave has to spare):
+#pragma unroll
+            for (int phi = 0; phi < NF; ++phi) {
+                // ---- P3: Lam'^T[t, f]; A = H_new pieces of lane (t, h) (hand-off buffer), B = W fragment ----
+                if (phi > 0) ld_vt(phi);  // (P3's 52 MFMAs are between these loads and their use)
+                float R[16];
+                {
+                    const float* ap = hbx + t * LDT + 4 * h;
+                    f32x16 acc = zero16();
+                    f32x4 wa = wtl[(phi * nq8) * 64], wb, ha = *reinterpret_cast<const f32x4*>(ap), hn;
+#pragma unroll
+                    for (int q = 0; q < NK * 4; ++q) {
+                        if (q > 4 * (NK - 1) && q >= a.nqk) break;
+                        if (q + 1 < NK * 4) {
+                            wb = wtl[(phi * nq8 + q + 1) * 64];
+                            hn = *reinterpret_cast<const f32x4*>(ap + 8 * (q + 1));
+                        }
+                        SNMF_PIN();
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc = mfma32(ha[e], wa[e], acc);
+                        wa = wb;
+                        ha = hn;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) R[i] = vt[i] * fast_rcp(fmaxf(acc[i], kFlr));
+                }
+                SNMF_STAMP(6);
+
+                // ---- P4: G[f, k] += sum_t ratio'[t, f] H_new[k, t]; B = H_new with the components in lanes (frame drow(i, h),
+                // component 32 kap + fl), one column tile ahead; the row sums ride on the reads of the first row tile ----
+                {
+                    const float* bp = hbx + (4 * h) * LDT + t;
+                    float b0[16];
+                    auto ldb = [&](float (&b)[16], int kap) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) b[i] = bp[drow(i, 0) * LDT + kap * 32];
+                    };
+                    auto ktile = [&](const float (&b)[16], int kap) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) G[phi][kap] = mfma32(R[i], b[i], G[phi][kap]);
+                        if (phi == 0) {
+                            float s4 = 0.f;
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) s4 += b[i];
+                            ssum[kap] += s4;
+                        }
+                    };
+                    // (one operand set, read right in front of its MFMAs: the partner wave's MFMAs cover the LDS round trip of the first
+                    //  read, and a second set in flight cost this wave 16 of the registers it does not have)
+#pragma unroll
+                    for (int kap = 0; kap < NK; ++kap) {
+                        ldb(b0, kap);
+                        ktile(b0, kap);
+                    }
+                }
+                SNMF_STAMP(7);
+            }
+        };
+        // this pair's W tasks: the tiles its own H wave hands over (whole rounds) and -- so that no SIMD carries an extra tile of BOTH kinds --
+        // the remainder tile whose H task sits on pair jx = (c - m) mod NP.  A single remainder tile comes FIRST, out of the extra
+        // buffer (see the H waves); two or three come last, out of their pairs' own buffers.  k_wstats_sf deals its tiles the same way.
+        const int n_my = te - tb, n_rnd = n_my / NP, n_rem = n_my - n_rnd * NP;
+        const int jx = (c - n_rem + NP) % NP;
+        if (n_rem == 1 && jx == 0) w_tile(tb + n_rnd * NP, xb, sig + 2 * NP, 1u);
+        for (int it = 0; it < n_rnd; ++it) {
+            w_tile(tb + c + it * NP, hb, full, (unsigned)(it + 1));
+            sf_post(empty, (unsigned)(it + 1), lane);  // (the last reads of the buffer have returned: the MFMAs consumed them)
+        }
+        if (n_rem > 1 && jx < n_rem)  // (the last tile of pair jx's buffer: nobody waits for `empty` behind it)
+            w_tile(tb + n_rnd * NP + jx, lmk + rp + (size_t)jx * 32 * LDT, sig + jx, (unsigned)(n_rnd + 1));
+        SNMF_STAMP(8);
+        __syncthreads();  // (every wave is through with the W images and the hand-off buffers)
+        SNMF_STAMP(10);
+        // Every W wave writes its NF * NK tiles; tile j = phi * NK + kap is then summed over the pairs IN PAIR ORDER (the order in which
+        // k_wstats_sf's lane 0 adds them) by wave j % NP, which writes that tile's rows of the slab: the four waves share the
+        // reduction instead of waiting for pair 0's W wave (its 384 dependent LDS reads were ~4 us at the end of the kernel).
+#pragma unroll
+        for (int phi = 0; phi < NF; ++phi)
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                float* dst = xs + (size_t)(c * NF * NK + phi * NK + k) * 16 * 64 + lane;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dst[i * 64] = G[phi][k][i];
+            }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const float other = __shfl_xor(ssum[k], 32, 64);  // the two lane halves hold the two halves of a tile's frames
+            if (h == 0) sred[c * rp + k * 32 + t] = ssum[k] + other;
+        }
+        __syncthreads();
+        for (int j = c; j < NF * NK; j += NP) {
+            const int phi = j / NK, kap = j - phi * NK;
+            float g[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) g[i] = xs[(size_t)j * 16 * 64 + i * 64 + lane];
+            for (int p = 1; p < NP; ++p) {
+                const float* src = xs + (size_t)(p * NF * NK + j) * 16 * 64 + lane;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) g[i] += src[i * 64];
+            }
+            // slab: D tile lane (k = fl, h), register -> f = 32 phi + drow(reg, h)  (k_wstats' layout)
+            float* dst = a.slabs + ((size_t)chunk * n_mat) * rp * Fp + (size_t)(kap * 32 + t) * Fp + phi * 32 + 4 * h;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const f32x4 o = {g[4 * gq], g[4 * gq + 1], g[4 * gq + 2], g[4 * gq + 3]};
+                *reinterpret_cast<f32x4*>(dst + 8 * gq) = o;
+            }
+        }
+        SNMF_STAMP(11);
+        SNMF_STAMP_OUT(a.prof + ((size_t)blockIdx.x * 8 + w) * 12, 12);
+        SNMF_STAMP_CLK(a.prof, (size_t)blockIdx.x * 8 + w);
+    }
+    for (int k = threadIdx.x; k < rp; k += NTHR) {
+        float sk = 0.f;
+        for (int p = 0; p < NP; ++p) sk += sred[p * rp + k];
+        a.spart[(size_t)chunk * rp + k] = sk;
+    }
+    if (OBJ && threadIdx.x == 0) {
+        double d = 0.0, s2 = 0.0;
+        for (int i = 0; i < NP; ++i) {
+            d += dred[i];
+            s2 += dred[NP + i];
+        }
+        a.part[2 * chunk] = d;
+        a.part[2 * chunk + 1] = s2;
     }
 }
 

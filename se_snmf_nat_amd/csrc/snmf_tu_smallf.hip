@@ -55,3 +55,4 @@ static int launch_wstats_sf_f(snmf_plan* pl, const StepArgs& a, bool obj) {
 int launch_wstats_sf(snmf_plan* pl, const StepArgs& a, bool obj) {
     return pl->nf == 1 ? launch_wstats_sf_f<1>(pl, a, obj) : launch_wstats_sf_f<2>(pl, a, obj);
 }
+

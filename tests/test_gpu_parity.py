@@ -10,6 +10,7 @@ and the early-stop iteration index must match EXACTLY.
 """
 import glob
 import os
+import re
 
 import numpy as np
 import pytest
@@ -655,3 +656,37 @@ def test_shapes_beyond_the_fused_kernels_take_the_out_of_envelope_path(gpu_ctx):
     pl = Plan(gpu_ctx, 512, 64, 1100, beta=1.0, max_iter=2, cost_check=True, w_update_ind=np.zeros(1100, bool))  # H-only: fused
     assert "out-of-envelope" not in pl.describe() and "k_hstep" in pl.describe()
     pl.close()
+
+
+@pytest.mark.parametrize("shape", [(64, 100, 20000, 1.0), (64, 128, 9000, 5.0), (40, 70, 33000, 1.0), (64, 96, 8231, "rvec"), (64, 100, 72000, 5.0),
+                                   (48, 65, 300 * 32 + 5, 2.0)], ids=lambda s: "F%d_r%d_T%d" % s[:3])
+def test_fused_small_f_iteration_equals_the_two_launches(gpu_ctx, shape, monkeypatch):
+    """k_iter_sf (csrc/snmf_smallf.h: the H half-step and the W statistics of a full KL update in one launch, SIMD pairs of an H
+    wave and a W wave; run_basis_train.m:90-91 on 64 Mel bands at R = 100) against k_hstep_sf + k_wstats_sf: the same arithmetic
+    per tile and the same tiles in the same order on every chunk lane, so W and H agree in EVERY BIT after several iterations
+    (chunks of 4 R, 4 R + 1 -- the remainder tile through the extra hand-off buffer -- and 4 R + 2 / 3 tiles), and the objective
+    to the grouping of its fp64 partials."""
+    from se_snmf_nat_amd import Plan
+    F, r, T, sp = shape
+    rs = np.random.default_rng(F * 1000 + r)
+    V = (rs.gamma(0.5, 1.0, (F, 16)) @ rs.gamma(0.3, 1.0, (16, T)) + 1e-3).astype(np.float32)
+    W0 = rs.random((F, r))
+    H0 = rs.random((r, T)).astype(np.float32)
+    sparsity = np.linspace(0.5, 2.0, r) if sp == "rvec" else sp
+
+    def run(fused):
+        monkeypatch.setenv("SNMF_ITER_SF", "1" if fused else "0")
+        pl = Plan(gpu_ctx, F, T, r, beta=1.0, max_iter=4, conv_eps=0.0, cost_check=True, sparsity=sparsity)
+        pl.set_v(V); pl.set_w(W0); pl.set_h(H0); pl.init(); pl.run()
+        out = (pl.get_h(np.float32), pl.get_w(), pl.describe(), pl.get_objective())
+        pl.close()
+        return out
+
+    a, b = run(True), run(False)
+    n_cu = int(re.search(r"n_cu=(\d+)", a[2]).group(1)) if "n_cu=" in a[2] else 256
+    assert ("k_iter_sf" in a[2]) == ((T + 31) // 32 > n_cu), a[2]
+    assert "k_iter_sf" not in b[2]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert a[3][2] == b[3][2]
+    for x, y in zip(a[3][1], b[3][1]):
+        assert abs(x - y) <= 1e-9 * abs(y)

@@ -107,3 +107,31 @@ def test_pipelined_kernels_equal_plain_kernels(gpu_ctx, shape, monkeypatch):
         assert "k_wstats_sf" in geo_full or "consumer teams take the tiles in turn" in geo_full
     for a, b in zip(obj_new, obj_old):
         assert abs(a - b) <= 1e-6 * abs(b)
+
+
+@pytest.mark.parametrize("shape", [(257, 256, 30000), (256, 230, 17000), (257, 225, 40007), (257, 256, 9000)], ids=lambda s: "F%d_r%d_T%d" % s)
+def test_merged_role_h_step_equals_plain(gpu_ctx, shape, monkeypatch):
+    """k_hstep_m (csrc/snmf_hstep_m.h: one wave per SIMD runs P1, both epilogues and P2 of its own row / column tiles; opt-in,
+    SNMF_HSTEP_M=1) against the barrier-phased k_hstep: the same MFMA order per output tile, so H after H-only iterations
+    agrees in every bit, W after full iterations to the summation order of the row sums (src/sparse_nmf.m:189-208)."""
+    F, r, T = shape
+    rs = np.random.default_rng(F * 1000 + r)
+    V = (rs.gamma(0.5, 1.0, (F, 16)) @ rs.gamma(0.3, 1.0, (16, T)) + 1e-3).astype(np.float32)
+    W0 = rs.random((F, r))
+    H0 = rs.random((r, T)).astype(np.float32)
+    for k in ("SNMF_HSTEP_RP", "SNMF_HSTEP_SPLIT", "SNMF_WSTATS_NL"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("SNMF_HSTEP_M", "1")
+    h_m, _, geo, obj_m = _run(gpu_ctx, V, W0, H0, r, h_only=True, iters=2)
+    _, w_m, _, _ = _run(gpu_ctx, V, W0, H0, r, h_only=False, iters=3)
+    n_cu = int(re.search(r"n_cu=(\d+)", geo).group(1))
+    assert ("k_hstep_m" in geo) == ((T + 31) // 32 > n_cu)
+    monkeypatch.setenv("SNMF_HSTEP_M", "0")
+    monkeypatch.setenv("SNMF_HSTEP_RP", "0")
+    h_p, _, geo_p, obj_p = _run(gpu_ctx, V, W0, H0, r, h_only=True, iters=2)
+    _, w_p, _, _ = _run(gpu_ctx, V, W0, H0, r, h_only=False, iters=3)
+    assert "k_hstep_m" not in geo_p and "k_hstep_rp" not in geo_p
+    assert np.array_equal(h_m, h_p)
+    assert np.abs(w_m - w_p).max() <= 2e-6 * np.abs(w_p).max()
+    for a, b in zip(obj_m, obj_p):
+        assert abs(a - b) <= 1e-6 * abs(b)
