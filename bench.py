@@ -340,6 +340,11 @@ def main():
         div, cost, n_it = plan2.get_objective()
         ms = dt / K * 1e3
         dom = max(("hstep", "wstats"), key=lambda f: fam[f][0])
+        # the kernel(s) actually launched for the dominant half-step (from the plan's own description)
+        if dom == "hstep":
+            kname = next((k for k in ("k_hstep_rh", "k_hstep_rp", "k_hstep_m", "k_iter_sf", "k_hstep_sf") if k in desc), "k_hstep")
+        else:
+            kname = "k_wstats_sf" if "k_wstats_sf" in desc else "k_wstats"
         # HBM bytes per launch of the dominant kernel: from the SEPARATE rocprofv3 --pmc passes of the
         # same command (scripts/prof.sh -> scripts/summarize_prof.py -> profiles/*_traffic.json);
         # a profiler cannot run inside this process, so the committed measurement is quoted.

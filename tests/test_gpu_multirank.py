@@ -197,7 +197,7 @@ def test_bench_single_gpu_line_keeps_the_contract():
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == pytest.approx(157.3)
     assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"]) and 0 < rf["frac"] < 1 and "traffic" in rf
     assert rf["kernel_ms"]["hstep"] > 0 and rf["kernel_ms"]["wstats"] > 0
-    assert rf["kernel"] in ("k_hstep_rp", "k_hstep_rh", "k_hstep", "k_wstats") and rf["kernel"] in d["config"]["geometry"] + " k_wstats"
+    assert rf["kernel"] in ("k_hstep_rp", "k_hstep_rh", "k_hstep_m", "k_hstep", "k_wstats") and rf["kernel"] in d["config"]["geometry"] + " k_wstats"
     assert "separate" in rf["kernel_ms_note"].lower() and "traffic_source" in rf
     # sense, not only keys: the dominant kernel's own time fits inside a step; a quoted traffic figure belongs to the kernel
     # the line names and is at least that kernel's algorithmic bytes
