@@ -192,7 +192,7 @@ def self_launch(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
            "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--dim-F", str(args.F), "--dim-T", str(args.T), "--dim-r", str(args.r), "--c5-T", str(args.c5_T)]
+           "--dim-F", str(args.F), "--dim-T", str(args.T), "--dim-r", str(args.r), "--c5-T", str(args.c5_T), "--c4-T", str(args.c4_T)]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
     pr = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
@@ -293,6 +293,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--oneshot-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--c5-T", dest="c5_T", type=int, default=500_000, help=argparse.SUPPRESS)  # frames of the extra C5 leg (tests shrink it)
+    ap.add_argument("--c4-T", dest="c4_T", type=int, default=100_000, help=argparse.SUPPRESS)  # frames PER RANK of the extra C4 leg
     # --dim-*: the spellings self_launch() passes on (torch.distributed.run's own parser prefix-matches a bare --r)
     ap.add_argument("--F", "--dim-F", dest="F", type=int, default=F_)
     ap.add_argument("--T", "--dim-T", dest="T", type=int, default=T_)
@@ -493,6 +494,11 @@ def main():
         c5 = c5_strong_leg(world, rank, local_rank, torch, dist, T=args.c5_T)
         if rank == 0:
             out["c5_strong"] = c5
+        # BASELINE configs[3], the config north_star's ">= 6x at 8 GPUs" names: the sharded basis-training path run_basis_DNMF.m:36-55
+        # (3 solves x 50 iterations, 513 x 100000 frames PER RANK, R_x = R_d = 100), A_hat resident between the solves
+        c4 = c4_dnmf_leg(world, rank, local_rank, torch, dist, T_per=args.c4_T)
+        if rank == 0:
+            out["c4_dnmf"] = c4
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
@@ -527,6 +533,8 @@ def c5_strong_leg(world, rank, local_rank, torch, dist, F=513, T=500_000, r=512,
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if float(ok.item()) < 1.0:
         return {"error": err or "another rank could not set the C5 shard up"}
+    # (a rank that raises INSIDE the loop leaves its peers in the loop's collective until the process group's time-out: nothing
+    #  short of that can release them; what CAN be guaranteed is that no rank reports a number unless every rank finished)
     try:
         tr.run(warm)
         tr.sync()
@@ -540,6 +548,10 @@ def c5_strong_leg(world, rank, local_rank, torch, dist, F=513, T=500_000, r=512,
         dt = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device="cuda")
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         dt = float(dt.item())
+        fin = torch.tensor([1.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(fin, op=dist.ReduceOp.MIN)
+        if float(fin.item()) < 1.0:
+            return {"error": "a rank did not finish the C5 loop"}
         _d, cost, _n = tr.plan.get_objective()
         last = [c for c in cost if c != 0.0]
         desc = tr.plan.describe()
@@ -551,6 +563,80 @@ def c5_strong_leg(world, rank, local_rank, torch, dist, F=513, T=500_000, r=512,
                 "value": steps / dt, "unit": "iterations/s", "steps": steps, "warmup": warm, "scaling": "strong",
                 "executed_TFLOPs": fl * steps / dt / 1e12, "frac_of_peak": fl * steps / dt / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
                 "final_cost": float(last[-1]) if last else None, "geometry": desc}
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+def c4_dnmf_leg(world, rank, local_rank, torch, dist, F=513, T_per=100_000, R_x=100, R_d=100, iters=50):
+    """BASELINE configs[3] on the process-per-GPU path: run_basis_DNMF.m:36-55 -- H-only on Y (r = R_x + R_d), W-only on X and on D
+    with the activations of solve 1 -- with the frames sharded over the ranks (T_per frames EACH: weak scaling, more utterances per
+    GPU), one all-reduce of the W statistics per iteration of solves 2 / 3, A_hat handed from solve 1 to solves 2 / 3 on the
+    device.  The three feature blocks are resident (torch CUDA tensors) when the timed region starts; plan creation is inside it.
+    Timed like the headline leg: barrier + synchronize on both sides, MAX over ranks."""
+    from se_snmf_nat_amd.dist import ShardedTrainer
+    err, dev = None, torch.device("cuda", local_rank)
+    try:
+        g = np.random.default_rng([4, rank])
+        Wx = np.random.default_rng(41).gamma(0.5, 1.0, size=(F, 24)).astype(np.float32)
+        Wd = np.random.default_rng(42).gamma(0.5, 1.0, size=(F, 16)).astype(np.float32)
+        Xh = np.empty((F, T_per), np.float32, order="F")
+        Dh = np.empty((F, T_per), np.float32, order="F")
+        for a in range(0, T_per, 50000):
+            b = min(T_per, a + 50000)
+            Xh[:, a:b] = Wx @ g.gamma(0.3, 1.0, size=(24, b - a)).astype(np.float32) + 1e-9
+            Dh[:, a:b] = Wd @ g.gamma(0.3, 1.0, size=(16, b - a)).astype(np.float32) + 1e-9
+        # column-major F x T_per = torch (T_per, F) contiguous
+        Xd = torch.from_numpy(np.ascontiguousarray(Xh.T)).to(dev)
+        Dd = torch.from_numpy(np.ascontiguousarray(Dh.T)).to(dev)
+        Yd = Xd + Dd
+        H0 = torch.from_numpy(np.ascontiguousarray(g.random((T_per, R_x + R_d), dtype=np.float32))).to(dev)
+        B = np.random.default_rng(43).random((F, R_x + R_d)) + 0.05
+        del Xh, Dh
+        torch.cuda.synchronize()
+    except Exception as e:  # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    ok = torch.tensor([0.0 if err else 1.0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if float(ok.item()) < 1.0:
+        return {"error": err or "another rank could not set the C4 shard up"}
+    try:
+        r = R_x + R_d
+        common = dict(beta=1.0, sparsity=5.0, max_iter=iters, conv_eps=0.0, cost_check=True, device=local_rank)
+
+        def three_solves():
+            t1 = ShardedTrainer(Yd, B, H0, w_update_ind=np.zeros(r, bool), h_update_ind=np.ones(r, bool), **common)
+            t1.run()
+            A = t1.plan.get_h_device()
+            t2 = ShardedTrainer(Xd, B[:, :R_x], A[:, :R_x].contiguous(), w_update_ind=np.ones(R_x, bool), h_update_ind=np.zeros(R_x, bool), **common)
+            t2.run()
+            t3 = ShardedTrainer(Dd, B[:, R_x:], A[:, R_x:].contiguous(), w_update_ind=np.ones(R_d, bool), h_update_ind=np.zeros(R_d, bool), **common)
+            t3.run()
+            t3.sync()
+            c3 = [c for c in t3.plan.get_objective()[1] if c != 0.0]
+            return float(c3[-1]) if c3 else None, t1.plan.describe(), t2.plan.describe()
+
+        three_solves()  # warm-up: code objects, cached device blocks, the clock
+        dist.barrier()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        cost3, d1, d2 = three_solves()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device="cuda")
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        dt = float(dt.item())
+        fin = torch.tensor([1.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(fin, op=dist.ReduceOp.MIN)
+        if float(fin.item()) < 1.0:
+            return {"error": "a rank did not finish the C4 loop"}
+        T = T_per * world
+        fl = iters * (4.0 * F * T * r + 2 * 4.0 * F * T * R_x)  # H-only: Lam + contraction at r; W-only (x2): the same at R_x (= R_d)
+        return {"workload": f"{world}xMI355X run_basis_DNMF (BASELINE configs[3]): 513 x {T} frames ({T_per} per rank), R_x = R_d = {R_x}, "
+                            f"3 solves x {iters} iterations, A_hat resident between the solves", "seconds": dt,
+                "value": 3 * iters / dt, "unit": "solver iterations/s", "scaling": "weak", "frames_per_rank": T_per,
+                "algorithmic_TFLOPs": fl / dt / 1e12, "frac_of_peak": fl / dt / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
+                "final_cost_solve3": cost3, "geometry_solve1": d1, "geometry_solve2": d2}
     except Exception as e:  # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"}
 

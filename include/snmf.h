@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SNMF_ABI_VERSION 3  /* 3: snmf_run_basis_dnmf_*, snmf_run_basis_train_audio_f64, snmf_sparse_nmf_oop_*, snmf_plan_set_h_random, snmf_ctx_xfer_stats; 2: snmf_multi_* */
+#define SNMF_ABI_VERSION 4  /* 4: snmf_run_basis_dnmf_multi_*; 3: snmf_run_basis_dnmf_*, snmf_run_basis_train_audio_f64, snmf_sparse_nmf_oop_*, snmf_plan_set_h_random, snmf_ctx_xfer_stats; 2: snmf_multi_* */
 
 typedef enum snmf_status {
     SNMF_OK = 0,
@@ -249,7 +249,7 @@ int snmf_tf_dd_f32(snmf_ctx* ctx, double alpha_eta, int32_t F, int32_t T, const 
 
 /* ---- the training callers, device-resident ------------------------------------------------------- */
 /* h = rand(r, n) of src/sparse_nmf.m:133-134 for a caller that supplies no init_h: Philox-4x32-10 keyed by `seed`, counter =
- * column-major element index / 4, value = ((x >> 8) + 0.5) * 2^-24 in (0, 1), written straight into the plan's resident H
+ * column-major element index / 4, value = ((x >> 9) + 0.5) * 2^-23 (exactly representable, strictly inside (0, 1)), written straight into the plan's resident H
  * (MATLAB's legacy rand('seed', s) stream is not reproducible; a wrapper that wants ITS draws passes them to snmf_plan_set_h).
  * Every entry below that takes `H0` uses this generator when H0 is NULL. */
 int snmf_plan_set_h_random(snmf_plan* plan, uint64_t seed);
@@ -394,7 +394,8 @@ void snmf_online_destroy(snmf_online* o);
  * peer, every rank sums the slots in rank order, so the W replicas and the stop decision (:272-284) are bit-identical everywhere.
  * H-only solves exchange only the two cost scalars.  Call order as for a plan: create -> set_v / set_w / set_h
  * [/ set_sparsity] -> init -> run -> get_*.  Matrices are HOST buffers of the WHOLE problem (V: F x T, H: r x T,
- * column-major); params->T is the total frame count.  snmf_multi_run creates its rank threads per call and restores
+ * column-major; every rank's shard moves through its own pinned pipeline, all ranks at once); params->T is the total frame
+ * count.  snmf_multi_run creates its rank threads per call and restores
  * the calling thread's current HIP device before it returns; the one-shot entries use min(n_dev, T) ranks.
  *   col_begin: n_dev + 1 ascending column offsets (col_begin[0] = 0, col_begin[n_dev] = T), or NULL = balanced. */
 typedef struct snmf_multi snmf_multi;
@@ -436,6 +437,22 @@ int snmf_sparse_nmf_multi_f64(const int32_t* devices, int32_t n_dev, const snmf_
 int snmf_sparse_nmf_multi_f32(const int32_t* devices, int32_t n_dev, const snmf_params* p, const float* V, int64_t ldV,
                               float* W, float* H, const float* sparsity, double* div_out, double* cost_out,
                               int32_t* n_iter_out);
+/* B_hat = run_basis_DNMF(x, d, B, p) with a device list (run_basis_DNMF.m:36-55; BASELINE config 4): snmf_run_basis_dnmf_f64 / _f32
+ * with the frames of all three solves sharded over `n_dev` ranks of this process -- the same arguments, `devices` in place of the
+ * context.  Y, X, D cross PCIe once each (every rank its shard, all ranks at once, X and D under solve 1), each rank keeps ITS
+ * columns of A_hat in HBM for solves 2 / 3, one exchange of the W statistics per iteration, only B_hat (and A_hat when asked
+ * for) comes back.  H0 == NULL: rank g draws columns [col_g, col_g+1) of the (R_x + R_d) x T Philox draw, so the result does not
+ * depend on the number of ranks beyond the order in which the ranks' statistics are summed (a few fp32 ulp on B_hat; A_hat
+ * bit for bit).  The ranks' contexts, gather buffers and peer-access grants are built once per device list and kept for the
+ * life of the process (csrc/snmf_multi.h: teams). */
+int snmf_run_basis_dnmf_multi_f64(const int32_t* devices, int32_t n_dev, const snmf_params* p, int32_t R_x, int32_t R_d,
+                                  const double* Y, int64_t ldY, const double* X, int64_t ldX, const double* D, int64_t ldD,
+                                  const double* B, int64_t ldB, const double* H0, uint64_t seed, double* B_hat, int64_t ldBh,
+                                  double* A_hat, int64_t ldA, int32_t* n_iter_out);
+int snmf_run_basis_dnmf_multi_f32(const int32_t* devices, int32_t n_dev, const snmf_params* p, int32_t R_x, int32_t R_d,
+                                  const float* Y, int64_t ldY, const float* X, int64_t ldX, const float* D, int64_t ldD,
+                                  const float* B, int64_t ldB, const float* H0, uint64_t seed, float* B_hat, int64_t ldBh,
+                                  float* A_hat, int64_t ldA, int32_t* n_iter_out);
 
 /* ---- instrumentation (bench.py: HIP-event timing on the engine's own stream) ------------ */
 /* Average device time in milliseconds per launch of the named kernel family over the launches

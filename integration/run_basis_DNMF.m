@@ -18,5 +18,17 @@ else
     if p.random_seed > 0, rand('seed', p.random_seed); end %#ok<RAND>
     H0 = rand(p.R_x + p.R_d, n);
 end
+if isfield(p, 'snmf_devices') && numel(p.snmf_devices) > 1
+    % BASELINE config 4: the frames of all three solves sharded over the GPUs of this node (zero-based device ordinals), one
+    % MEX call (snmf_run_basis_dnmf_multi_f64): the three feature sets are formed on device 0 (snmf_frontend_mex), every rank
+    % then takes its shard of each through its own PCIe link, A_hat stays in HBM between the solves, only B_hat comes back.
+    m = min(length(x), length(d));
+    x = double(x(1:m)); d = double(d(1:m));
+    Y = snmf_frontend_mex('stft', x(:) + d(:), p, p.DCbin);
+    X = snmf_frontend_mex('stft', x(:), p, p.DCbin);
+    D = snmf_frontend_mex('stft', d(:), p, p.DCbin);
+    B_hat = snmf_dnmf_mex('dnmf_multi', Y, X, D, double(B), H0, p, double(p.snmf_devices(:)'));
+    return
+end
 B_hat = snmf_dnmf_mex('dnmf', double(x(:)), double(d(:)), double(B), H0, p, []);
 end

@@ -9,6 +9,7 @@
 //
 //     n           = snmf_dnmf_mex('nframes', n_samples, p)
 //     [B_hat, ni] = snmf_dnmf_mex('dnmf',  x, d, B, H0, p, melmat)      melmat: [] (DFT) or F_order x (fftlength/2+1) = mel_matrix(...)'
+//     [B_hat, ni] = snmf_dnmf_mex('dnmf_multi', Y, X, D, B, H0, p, devices)   formed features, frames sharded over the devices (snmf_run_basis_dnmf_multi_f64)
 //     [B_DFT, B_Mel, A_DFT, A_Mel, ni] = snmf_dnmf_mex('train', s_full, sample_idx, H0, p, melmat, DC_bin)
 //   H0: (R_x+R_d) x n_frames (resp. r x n_frames) double -- rand(r, n) drawn by the wrapper with MATLAB's generator exactly as
 //       src/sparse_nmf.m:112-114,:133-134 would -- or [] to let the engine draw it on the device (snmf_plan_set_h_random).
@@ -102,6 +103,16 @@ static void fill_solver(const mxArray* p, snmf_params* q) {
     q->sparsity_scalar = field_or(p, "sparsity", 0.0);
 }
 
+// p.random_seed as the key of the device generator.  src/sparse_nmf.m:112 re-seeds only for random_seed > 0 ("<= 0: keep the
+// generator's state"), which a stateless counter-based generator cannot mean: with H0 = [] such a seed is an error here, and the
+// double is converted through int64 (a negative double -> uint64 is undefined behaviour).
+static uint64_t device_seed(const mxArray* p, bool h0_given) {
+    const double sd = field_or(p, "random_seed", 1);
+    if (h0_given) return 1;  // (not used: the caller's own draws are the initial activations)
+    if (!(sd >= 1.0)) mexErrMsgIdAndTxt("snmf:field", "H0 = [] needs p.random_seed >= 1: the device generator is keyed by it (src/sparse_nmf.m:112: <= 0 means 'do not re-seed')");
+    return (uint64_t)(int64_t)sd;
+}
+
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     if (snmf_abi_version() != SNMF_ABI_VERSION)  // a stale libsnmf_hip.so must not be driven through newer prototypes
         mexErrMsgIdAndTxt("snmf:abi", "libsnmf_hip.so has ABI version %d, this MEX file was built against %d", snmf_abi_version(), SNMF_ABI_VERSION);
@@ -114,6 +125,44 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         if (nrhs != 3 || !mxIsStruct(prhs[2])) mexErrMsgIdAndTxt("snmf:nargin", "usage: n = snmf_dnmf_mex('nframes', n_samples, p)");
         fill_stft(prhs[2], win, &sp, field_or(prhs[2], "DCbin", 1));
         plhs[0] = mxCreateDoubleScalar((double)snmf_stft_num_frames(&sp, (int64_t)mxGetScalar(prhs[1])));
+        return;
+    }
+    if (!std::strcmp(cmd, "dnmf_multi")) {  // (no context of this file's own: the library keeps one team of contexts per device list)
+        if (nrhs != 8 || !mxIsStruct(prhs[6])) mexErrMsgIdAndTxt("snmf:nargin", "usage: [B_hat, n_iter] = snmf_dnmf_mex('dnmf_multi', Y, X, D, B, H0, p, devices)");
+        const mxArray *Y = prhs[1], *X = prhs[2], *D = prhs[3], *B = prhs[4], *H0 = prhs[5], *p = prhs[6], *dv = prhs[7];
+        const int R_x = (int)field(p, "R_x"), R_d = (int)field(p, "R_d");
+        snmf_params q;
+        fill_solver(p, &q);
+        q.F = (int32_t)mxGetM(Y);
+        q.T = (int32_t)mxGetN(Y);
+        q.r = R_x + R_d;
+        const mxArray* mats[3] = {Y, X, D};
+        for (const mxArray* M_ : mats)
+            if (!mxIsDouble(M_) || mxIsComplex(M_) || (int)mxGetM(M_) != q.F || (int)mxGetN(M_) != q.T)
+                mexErrMsgIdAndTxt("snmf:dim", "Y, X and D must be real double matrices of one size");
+        if (!mxIsDouble(B) || mxIsComplex(B) || (int)mxGetM(B) != q.F || (int)mxGetN(B) != q.r)
+            mexErrMsgIdAndTxt("snmf:dim", "B must be %d x (R_x + R_d = %d) double", q.F, q.r);
+        const double* h0 = nullptr;
+        if (!mxIsEmpty(H0)) {
+            if (!mxIsDouble(H0) || (int)mxGetM(H0) != q.r || (int)mxGetN(H0) != q.T) mexErrMsgIdAndTxt("snmf:dim", "H0 must be %d x %d double or []", q.r, q.T);
+            h0 = mxGetDoubles(H0);
+        }
+        const size_t nd = mxGetNumberOfElements(dv);
+        if (!mxIsDouble(dv) || nd < 1 || nd > 16) mexErrMsgIdAndTxt("snmf:dim", "devices must be a double vector of 1..16 zero-based device ordinals");
+        std::vector<int32_t> devs(nd);
+        for (size_t i = 0; i < nd; ++i) devs[i] = (int32_t)mxGetDoubles(dv)[i];
+        const double seed_d = field_or(p, "random_seed", 1);
+        if (!h0 && !(seed_d >= 1.0)) mexErrMsgIdAndTxt("snmf:field", "the device generator needs p.random_seed >= 1 (src/sparse_nmf.m:112: <= 0 means 'do not re-seed', which a stateless generator cannot mean)");
+        plhs[0] = mxCreateDoubleMatrix((mwSize)q.F, (mwSize)q.r, mxREAL);
+        int32_t nit[3] = {0, 0, 0};
+        const int st = snmf_run_basis_dnmf_multi_f64(devs.data(), (int32_t)nd, &q, R_x, R_d, mxGetDoubles(Y), q.F, mxGetDoubles(X), q.F,
+                                                     mxGetDoubles(D), q.F, mxGetDoubles(B), q.F, h0, (uint64_t)(int64_t)(seed_d >= 1.0 ? seed_d : 1.0),
+                                                     mxGetDoubles(plhs[0]), q.F, nullptr, q.r, nit);
+        if (st != SNMF_OK) mexErrMsgIdAndTxt("snmf:solve", "%s", snmf_last_error());
+        if (nlhs > 1) {
+            plhs[1] = mxCreateDoubleMatrix(1, 3, mxREAL);
+            for (int i = 0; i < 3; ++i) mxGetDoubles(plhs[1])[i] = nit[i];
+        }
         return;
     }
     need_ctx();
@@ -142,7 +191,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         int32_t nit[3] = {0, 0, 0};
         const int st = snmf_run_basis_dnmf_audio_f64(g_ctx, &q, &sp, R_x, R_d, x.data(), (int64_t)x.size(), d.data(), (int64_t)d.size(),
                                                      M ? mel.data() : nullptr, M, mxGetDoubles(B), q.F, h0,
-                                                     (uint64_t)field_or(p, "random_seed", 1), mxGetDoubles(plhs[0]), q.F, nullptr, q.r, nit);
+                                                     device_seed(p, h0 != nullptr), mxGetDoubles(plhs[0]), q.F, nullptr, q.r, nit);
         if (st != SNMF_OK) mexErrMsgIdAndTxt("snmf:solve", "%s", snmf_last_error());
         if (nlhs > 1) {
             plhs[1] = mxCreateDoubleMatrix(1, 3, mxREAL);
@@ -187,7 +236,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         int32_t nit[2] = {0, 0};
         const double dd = field_or(p, "domain_DD", 0) != 0.0 ? field(p, "alpha_eta") : -1.0;  // :64-67
         const int st = snmf_run_basis_train_audio_f64(g_ctx, &q, &sp, dd, mel.data(), M, s.data(), (int64_t)s.size(), i0.data(), exemplar ? 1 : 0,
-                                                      h0, (uint64_t)field_or(p, "random_seed", 1), mxGetDoubles(plhs[0]),
+                                                      h0, device_seed(p, h0 != nullptr || exemplar), mxGetDoubles(plhs[0]),
                                                       exemplar ? nullptr : mxGetDoubles(AD), mxGetDoubles(BM), exemplar ? nullptr : mxGetDoubles(AM), nit);
         if (st != SNMF_OK) {
             mxDestroyArray(BM);

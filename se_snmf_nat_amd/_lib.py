@@ -62,8 +62,9 @@ SYMBOLS = [
     "snmf_sparse_nmf_multi_f64", "snmf_sparse_nmf_multi_f32", "snmf_multi_set_exchange",
     "snmf_plan_set_h_random", "snmf_run_basis_dnmf_f64", "snmf_run_basis_dnmf_f32", "snmf_run_basis_dnmf_audio_f64",
     "snmf_run_basis_train_audio_f64", "snmf_ctx_xfer_stats", "snmf_sparse_nmf_oop_f64", "snmf_sparse_nmf_oop_f32",
+    "snmf_run_basis_dnmf_multi_f64", "snmf_run_basis_dnmf_multi_f32",
 ]
-ABI_VERSION = 3  # include/snmf.h: SNMF_ABI_VERSION this binding was written against
+ABI_VERSION = 4  # include/snmf.h: SNMF_ABI_VERSION this binding was written against
 EXCHANGE_AUTO, EXCHANGE_FLAGS, EXCHANGE_EVENTS = 0, 1, 2
 
 SNMF_OK = 0
@@ -276,6 +277,7 @@ def load():
     sig["snmf_plan_set_h_random"] = (C.c_int, [vp, u64])
     for ty in ("f64", "f32"):
         sig[f"snmf_run_basis_dnmf_{ty}"] = (C.c_int, [vp, PP, i32, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp, u64, vp, i64, vp, i64, vp])
+        sig[f"snmf_run_basis_dnmf_multi_{ty}"] = (C.c_int, [vp, i32, PP, i32, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp, u64, vp, i64, vp, i64, vp])
     sig["snmf_run_basis_dnmf_audio_f64"] = (C.c_int, [vp, PP, SP, i32, i32, vp, i64, vp, i64, vp, i32, vp, i64, vp, u64, vp, i64, vp, i64, vp])
     sig["snmf_run_basis_train_audio_f64"] = (C.c_int, [vp, PP, SP, dbl, vp, i32, vp, i64, vp, i32, vp, u64, vp, vp, vp, vp, vp])
     sig["snmf_ctx_xfer_stats"] = (C.c_int, [vp, vp, C.c_int])

@@ -304,14 +304,14 @@ def philox4x32_10(ctr, key0, key1):
 def philox_uniform(seed, r, n):
     """The r x n uniforms the engine draws on the device for an initial H the caller does not supply (include/snmf.h:
     snmf_plan_set_h_random; csrc/snmf_tu_dnmf.hip): Philox-4x32-10 keyed by `seed`, counter = column-major element index // 4,
-    value = ((x >> 8) + 0.5) * 2^-24.  NumPy restatement, so that a host can reproduce the device's draws bit for bit."""
+    value = ((x >> 9) + 0.5) * 2^-23 (exactly representable, strictly inside (0, 1)).  NumPy restatement, so that a host can reproduce the device's draws bit for bit."""
     tot = int(r) * int(n)
     n4 = (tot + 3) // 4
     q = np.arange(n4, dtype=np.uint64)
     c = philox4x32_10([q & np.uint64(0xFFFFFFFF), q >> np.uint64(32), np.zeros(n4, np.uint64), np.zeros(n4, np.uint64)],
                       int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF)
     x = np.stack(c, axis=1).reshape(-1)[:tot]
-    u = ((x >> np.uint64(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    u = ((x >> np.uint64(9)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 8388608.0)
     return u.reshape((int(n), int(r))).T  # element (k, t) = draw k + r*t
 
 
@@ -340,9 +340,9 @@ def run_basis_dnmf(Y, X, D, B, R_x, R_d, p, *, ctx=None, dtype=np.float64, devic
     p = dict(p)
     B = np.asarray(B, dtype=np.float64)
     if resident is None:
-        resident = devices is None
-    if resident and devices is None:
-        return _run_basis_dnmf_resident(Y, X, D, B, int(R_x), int(R_d), p, ctx=ctx, dtype=dtype, h0=h0)
+        resident = True
+    if resident:  # (with a device list: snmf_run_basis_dnmf_multi_*, every rank's shard resident on its device)
+        return _run_basis_dnmf_resident(Y, X, D, B, int(R_x), int(R_d), p, ctx=ctx, dtype=dtype, h0=h0, devices=devices)
     p["w_update_ind"] = np.zeros(R_x + R_d, bool)  # :37
     p["h_update_ind"] = np.ones(R_x + R_d, bool)  # :38
     p["init_w"] = B  # :39
@@ -366,7 +366,7 @@ def run_basis_dnmf(Y, X, D, B, R_x, R_d, p, *, ctx=None, dtype=np.float64, devic
     return np.concatenate([B_hat_x, B_hat_d], axis=1), A_hat  # :55
 
 
-def _run_basis_dnmf_resident(Y, X, D, B, R_x, R_d, p, *, ctx, dtype, h0, want_a=True):
+def _run_basis_dnmf_resident(Y, X, D, B, R_x, R_d, p, *, ctx, dtype, h0, want_a=True, devices=None):
     dt = np.dtype(dtype)
     if dt not in (np.dtype(np.float64), np.dtype(np.float32)):
         raise SnmfError(1, "dtype must be float64 or float32")
@@ -393,11 +393,17 @@ def _run_basis_dnmf_resident(Y, X, D, B, R_x, R_d, p, *, ctx, dtype, h0, want_a=
     A_hat = np.empty((r, T), dtype=dt, order="F") if want_a else None
     nit = np.zeros(3, np.int32)
     lib = _lib.load()
-    ctx = ctx or default_context()
-    fn = lib.snmf_run_basis_dnmf_f64 if dt == np.float64 else lib.snmf_run_basis_dnmf_f32
     ldc = lambda M: M.strides[1] // dt.itemsize if M.shape[1] > 1 else M.shape[0]
-    _lib.check(fn(ctx._h, C.byref(sp), R_x, R_d, _ptr(Y), ldc(Y), _ptr(X), ldc(X), _ptr(D), ldc(D), _ptr(Bc), F,
-                  _ptr(H0) if H0 is not None else None, seed, _ptr(B_hat), F, _ptr(A_hat) if want_a else None, r, _ptr(nit)))
+    tail = (C.byref(sp), R_x, R_d, _ptr(Y), ldc(Y), _ptr(X), ldc(X), _ptr(D), ldc(D), _ptr(Bc), F,
+            _ptr(H0) if H0 is not None else None, seed, _ptr(B_hat), F, _ptr(A_hat) if want_a else None, r, _ptr(nit))
+    if devices is not None:  # the frames of all three solves sharded over a device list, inside this process
+        dv = np.ascontiguousarray(devices, dtype=np.int32)
+        fn = lib.snmf_run_basis_dnmf_multi_f64 if dt == np.float64 else lib.snmf_run_basis_dnmf_multi_f32
+        _lib.check(fn(_ptr(dv), int(dv.size), *tail))
+    else:
+        ctx = ctx or default_context()
+        fn = lib.snmf_run_basis_dnmf_f64 if dt == np.float64 else lib.snmf_run_basis_dnmf_f32
+        _lib.check(fn(ctx._h, *tail))
     return B_hat, A_hat
 
 
@@ -569,6 +575,16 @@ class Plan:
         out = np.empty((self.r, self.T), dtype=dtype, order="F")
         fn = self._lib.snmf_plan_get_h_f64 if out.dtype == np.float64 else self._lib.snmf_plan_get_h_f32
         _lib.check(fn(self._h, _ptr(out), self.r, 0))
+        return out
+
+    def get_h_device(self):
+        """The activations as a torch CUDA tensor of shape (T, r), float32 (= column-major r x T) on the plan's device: what
+        Plan.set_h of another plan takes without a host round trip (dist.run_basis_dnmf_sharded hands solve 1's H to solves 2 / 3)."""
+        import torch
+        out = torch.empty((self.T, self.r), dtype=torch.float32, device=torch.device("cuda", self.ctx.device))
+        torch.cuda.current_stream(out.device).synchronize()
+        _lib.check(self._lib.snmf_plan_get_h_f32(self._h, C.c_void_p(out.data_ptr()), self.r, 1))
+        self.ctx.sync()
         return out
 
     def solve_frames(self, v, h0, dtype=np.float64):

@@ -242,6 +242,7 @@ int validate_stft(const snmf_stft_params* sp);
 int stft_to_device(snmf_ctx* ctx, const snmf_stft_params* sp, const float* samples, int64_t n_samples, int samples_on_device,
                    float* dst, int64_t ld, int64_t n_frames);
 int result_h_index(snmf_plan* pl, int* idx);
+int rand_h(snmf_plan* pl, uint64_t seed, int64_t col0);  // snmf_tu_dnmf.hip: Philox draw of an initial H, columns [col0, col0 + T) of the r x n draw
 template <typename T> int set_v(snmf_plan* pl, const T* V, int64_t ld, int dev);
 template <typename T> int set_w(snmf_plan* pl, const T* W, int64_t ld, int dev);
 template <typename T> int set_h(snmf_plan* pl, const T* H, int64_t ld, int dev);

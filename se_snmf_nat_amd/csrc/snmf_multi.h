@@ -97,29 +97,51 @@ __global__ __launch_bounds__(256) void k_sum_ranks(const double* __restrict__ sl
 
 }  // namespace snmf
 
+// What a device list owns for as long as the process runs (round 5): the ranks' contexts (stream, transfer pipeline, cached device
+// blocks) with a second context each (uploads under a running solve), the fine-grained gather buffers and arrival words, the
+// events, the peer-access grants.  Creating these per CALL (round 4: every snmf_sparse_nmf_multi_* call, three times per
+// run_basis_DNMF) cost milliseconds of hipExtMalloc / hipHostMalloc / stream creation per rank; a team is built once per
+// device list, handed to one user at a time (team_acquire / team_release) and kept when released.  The handles of one user
+// (the three solves of snmf_run_basis_dnmf_multi_*) may SHARE a team as long as they never run at the same time: exchange
+// number and parity live in the team, so consecutive exchanges of different handles never reuse an arrival value.
+struct MultiTeam {
+    int n = 0;
+    std::vector<int> dev;
+    std::vector<snmf_ctx*> ctx;       // [n] (ctx[g]->aux: the second context of rank g's device)
+    std::vector<double*> slots;       // [n] gather buffers, slots_cap doubles each (fine-grained device memory)
+    size_t slots_cap = 0;
+    std::vector<unsigned*> flags;     // [n] arrival words: [2 parities][n ranks], then the push launch's workgroup counter
+    std::vector<hipEvent_t> ev[2];    // ev[parity][rank]: "rank has pushed"  (EVENTS mode)
+    bool fine_grained = true;         // every gather buffer / arrival word is fine-grained (else only EVENTS ordering is safe)
+    bool shared_dev = false;          // two ranks on one device
+    unsigned xseq = 0;                // exchanges issued so far (the next one is number xseq + 1)
+    int par = 0;                      // parity of the next exchange
+    int refs = 0;                     // 0: idle in the cache
+};
+
 struct snmf_multi {
     int n = 0;
     snmf_params p{};
+    MultiTeam* team = nullptr;
+    bool team_owner = true;           // this handle took the team out of the cache (and gives it back)
+    bool use_aux = false;             // the ranks' plans live on the second contexts
     std::vector<int> dev;
     std::vector<int64_t> col;         // n + 1 column offsets
-    std::vector<snmf_ctx*> ctx;
+    std::vector<snmf_ctx*> ctx;       // [n] borrowed from the team (ctx or aux)
     std::vector<snmf_plan*> plan;
     std::vector<double*> stats;       // [n] device statistics buffer of each rank
-    std::vector<double*> slots;       // [n] gather buffers: [2 parities][n ranks][xlen]  (fine-grained device memory)
-    std::vector<unsigned*> flags;     // [n] arrival words: [2 parities][n ranks], then the push launch's workgroup counter
-    std::vector<hipEvent_t> ev[2];    // ev[parity][rank]: "rank has pushed"  (EVENTS mode)
+    std::vector<double*> slots;       // [n] borrowed: the team's gather buffers, used as [2 parities][n ranks][xlen]
+    std::vector<unsigned*> flags;     // [n] borrowed
     int mode = 0;                     // SNMF_EXCHANGE_FLAGS / _EVENTS (resolved from AUTO at creation)
     bool shared_dev = false;          // two ranks on one device: submissions of push and sum are ordered by the host in every mode
     // every gather buffer and arrival word is fine-grained (coherent) device memory.  If the runtime refused one of them the
     // buffers are coarse-grained: a kernel that POLLS them while peers write (FLAGS) could see the flag and still read stale
     // slot lines from its L2, so only EVENTS ordering -- a kernel boundary between push and sum -- is allowed then.
     bool fine_grained = true;
-    unsigned xseq = 0;                // exchanges issued so far (the next one is number xseq + 1)
     std::vector<uint8_t> w_ind, h_ind;
     size_t len = 0, xoff = 0, xlen = 0;  // statistics length; the exchanged part [xoff, xoff + xlen)
     bool upd_w = true, can_stop = false;
     int it = 0;                       // iterations issued
-    int par = 0;                      // parity of the next exchange
     bool inited = false, finalized = false, stopped = false;
     // host barrier of the rank threads (sense reversing)
     std::atomic<int> bar_count{0};
@@ -149,6 +171,133 @@ static bool multi_barrier(snmf_multi* m, int seq, bool i_failed) {
     return m->failed_at.load(std::memory_order_acquire) > seq;
 }
 
+// ---- teams ---------------------------------------------------------------------------------------------------------
+static std::mutex g_team_mu;
+static std::vector<MultiTeam*> g_teams;   // every team of the process (idle ones have refs == 0)
+constexpr int kMaxIdleTeams = 4;
+
+static void team_destroy(MultiTeam* t) {
+    for (int g = 0; g < (int)t->ctx.size(); ++g) {
+        if (!t->ctx[g]) continue;
+        hipSetDevice(t->dev[g]);
+        hipStreamSynchronize(t->ctx[g]->stream);
+        for (int q = 0; q < 2; ++q)
+            if (g < (int)t->ev[q].size() && t->ev[q][g]) hipEventDestroy(t->ev[q][g]);
+        if (g < (int)t->slots.size() && t->slots[g]) hipFree(t->slots[g]);
+        if (g < (int)t->flags.size() && t->flags[g]) hipFree(t->flags[g]);
+        snmf_ctx_destroy(t->ctx[g]);
+    }
+    delete t;
+}
+
+static int team_create(const int32_t* devices, int n_dev, MultiTeam** out) {
+    MultiTeam* t = new MultiTeam();
+    t->n = n_dev;
+    t->dev.assign(devices, devices + n_dev);
+    t->ctx.assign(n_dev, nullptr);
+    t->slots.assign(n_dev, nullptr);
+    t->flags.assign(n_dev, nullptr);
+    t->ev[0].assign(n_dev, nullptr);
+    t->ev[1].assign(n_dev, nullptr);
+    for (int g = 0; g < n_dev; ++g)
+        for (int q = 0; q < g; ++q) t->shared_dev = t->shared_dev || devices[g] == devices[q];
+    int s = SNMF_OK;
+    for (int g = 0; g < n_dev && s == SNMF_OK; ++g) {
+        s = snmf_ctx_create(&t->ctx[g], t->dev[g]);
+        if (s == SNMF_OK) s = snmf_ctx_create(&t->ctx[g]->aux, t->dev[g]);
+    }
+    for (int g = 0; g < n_dev && s == SNMF_OK; ++g) {
+        if (hipSetDevice(t->dev[g]) != hipSuccess) s = fail(SNMF_ERR_NO_DEVICE, "hipSetDevice(%d)", t->dev[g]);
+        // arrival words are written by PEERS while this device may hold lines of them: fine-grained (coherent) device memory;
+        // plain hipMalloc only if the runtime refuses (then kernel boundaries must do)
+        const size_t fb = ((size_t)2 * n_dev + 1) * sizeof(unsigned);
+        if (s == SNMF_OK && hipExtMallocWithFlags((void**)&t->flags[g], fb, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            t->fine_grained = false;
+            s = dalloc(&t->flags[g], (size_t)2 * n_dev + 1);
+        }
+        if (s == SNMF_OK) hipMemset(t->flags[g], 0, fb);
+        for (int q = 0; q < 2 && s == SNMF_OK; ++q)
+            if (hipEventCreateWithFlags(&t->ev[q][g], hipEventDisableTiming) != hipSuccess)
+                s = fail(SNMF_ERR_NO_DEVICE, "hipEventCreate failed on device %d", t->dev[g]);
+        // peer stores into every other device's gather buffer
+        for (int q = 0; q < n_dev && s == SNMF_OK; ++q) {
+            if (t->dev[q] == t->dev[g]) continue;
+            int can = 0;
+            hipDeviceCanAccessPeer(&can, t->dev[g], t->dev[q]);
+            if (!can) {
+                s = fail(SNMF_ERR_UNSUPPORTED, "device %d cannot access device %d as a peer", t->dev[g], t->dev[q]);
+                break;
+            }
+            const hipError_t e = hipDeviceEnablePeerAccess(t->dev[q], 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                s = fail(SNMF_ERR_NO_DEVICE, "hipDeviceEnablePeerAccess(%d -> %d): %s", t->dev[g], t->dev[q], hipGetErrorString(e));
+            (void)hipGetLastError();
+        }
+    }
+    if (s != SNMF_OK) {
+        const std::string keep = g_err;
+        team_destroy(t);
+        g_err = keep;
+        return s;
+    }
+    *out = t;
+    return SNMF_OK;
+}
+
+// gather buffers for exchanges of xlen doubles per rank (grown, never shrunk; contents are zeroed by snmf_multi_init)
+static int team_reserve(MultiTeam* t, size_t xlen) {
+    const size_t need = (size_t)2 * t->n * xlen;
+    if (need <= t->slots_cap) return SNMF_OK;
+    for (int g = 0; g < t->n; ++g) {
+        if (hipSetDevice(t->dev[g]) != hipSuccess) return fail(SNMF_ERR_NO_DEVICE, "hipSetDevice(%d)", t->dev[g]);
+        hipStreamSynchronize(t->ctx[g]->stream);
+        hipStreamSynchronize(t->ctx[g]->aux->stream);
+        if (t->slots[g]) hipFree(t->slots[g]);
+        t->slots[g] = nullptr;
+        if (hipExtMallocWithFlags((void**)&t->slots[g], need * sizeof(double), hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            t->fine_grained = false;  // (coarse-grained memory: only EVENTS ordering is safe, see snmf_multi_set_exchange)
+            SN_TRY(dalloc(&t->slots[g], need));
+        }
+    }
+    t->slots_cap = need;
+    return SNMF_OK;
+}
+
+static int team_acquire(const int32_t* devices, int n_dev, MultiTeam** out) {
+    {
+        std::lock_guard<std::mutex> lk(g_team_mu);
+        for (MultiTeam* t : g_teams)
+            if (t->refs == 0 && t->n == n_dev && std::equal(t->dev.begin(), t->dev.end(), devices)) {
+                t->refs = 1;
+                *out = t;
+                return SNMF_OK;
+            }
+    }
+    MultiTeam* t = nullptr;
+    SN_TRY(team_create(devices, n_dev, &t));
+    t->refs = 1;
+    std::lock_guard<std::mutex> lk(g_team_mu);
+    g_teams.push_back(t);
+    *out = t;
+    return SNMF_OK;
+}
+static void team_release(MultiTeam* t) {
+    MultiTeam* kill = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_team_mu);
+        if (--t->refs > 0) return;
+        int idle = 0;
+        for (MultiTeam* q : g_teams) idle += q->refs == 0;
+        if (idle > kMaxIdleTeams) {
+            g_teams.erase(std::find(g_teams.begin(), g_teams.end(), t));
+            kill = t;
+        }
+    }
+    if (kill) team_destroy(kill);
+}
+
 extern "C" void snmf_multi_destroy(snmf_multi* m) {
     if (!m) return;
     for (int g = 0; g < (int)m->plan.size(); ++g) {
@@ -158,22 +307,18 @@ extern "C" void snmf_multi_destroy(snmf_multi* m) {
         }
     }
     for (int g = 0; g < (int)m->plan.size(); ++g) {
-        if (g >= (int)m->ctx.size() || !m->ctx[g]) continue;  // a rank that never came up (e.g. a bad device ordinal) owns nothing
+        if (g >= (int)m->ctx.size() || !m->ctx[g]) continue;
         hipSetDevice(m->dev[g]);
-        for (int q = 0; q < 2; ++q)
-            if (g < (int)m->ev[q].size() && m->ev[q][g]) hipEventDestroy(m->ev[q][g]);
         if (g < (int)m->stats.size() && m->stats[g]) hipFree(m->stats[g]);
-        if (g < (int)m->slots.size() && m->slots[g]) hipFree(m->slots[g]);
-        if (g < (int)m->flags.size() && m->flags[g]) hipFree(m->flags[g]);
         if (m->plan[g]) snmf_plan_destroy(m->plan[g]);
     }
-    for (snmf_ctx* c : m->ctx)
-        if (c) snmf_ctx_destroy(c);
+    if (m->team && m->team_owner) team_release(m->team);
     delete m;
 }
 
-extern "C" int snmf_multi_create(const int32_t* devices, int32_t n_dev, const snmf_params* p, const int64_t* col_begin,
-                                 snmf_multi** out) {
+// the handle on a team the caller holds (team == nullptr: take one out of the cache for this handle's lifetime)
+static int multi_create_on(MultiTeam* team, bool use_aux, const int32_t* devices, int32_t n_dev, const snmf_params* p,
+                           const int64_t* col_begin, snmf_multi** out) {
     if (!devices || !p || !out) return fail(SNMF_ERR_INVALID, "NULL argument");
     *out = nullptr;
     if (n_dev < 1 || n_dev > 16) return fail(SNMF_ERR_INVALID, "n_dev = %d outside [1, 16]", n_dev);
@@ -204,26 +349,27 @@ extern "C" int snmf_multi_create(const int32_t* devices, int32_t n_dev, const sn
     if (p->h_update_ind) m->h_ind.assign(p->h_update_ind, p->h_update_ind + p->r);
     m->p.w_update_ind = m->w_ind.empty() ? nullptr : m->w_ind.data();
     m->p.h_update_ind = m->h_ind.empty() ? nullptr : m->h_ind.data();
-    m->ctx.assign(n_dev, nullptr);
     m->plan.assign(n_dev, nullptr);
     m->stats.assign(n_dev, nullptr);
-    m->slots.assign(n_dev, nullptr);
-    m->flags.assign(n_dev, nullptr);
-    {   // AUTO: device-side ordering when every rank has a device of its own
-        bool distinct = true;
-        for (int g = 0; g < n_dev; ++g)
-            for (int q = 0; q < g; ++q) distinct = distinct && devices[g] != devices[q];
-        m->mode = distinct ? SNMF_EXCHANGE_FLAGS : SNMF_EXCHANGE_EVENTS;
-        m->shared_dev = !distinct;
-    }
-    m->ev[0].assign(n_dev, nullptr);
-    m->ev[1].assign(n_dev, nullptr);
     m->rc.assign(n_dev, SNMF_OK);
     m->err.assign(n_dev, std::string());
+    m->use_aux = use_aux;
     int s = SNMF_OK;
+    if (team) {
+        m->team = team;
+        m->team_owner = false;
+    } else {
+        s = team_acquire(devices, n_dev, &m->team);
+        if (s != SNMF_OK) {
+            delete m;
+            return s;
+        }
+    }
+    MultiTeam* t = m->team;
+    m->ctx.assign(n_dev, nullptr);
+    for (int g = 0; g < n_dev; ++g) m->ctx[g] = use_aux ? t->ctx[g]->aux : t->ctx[g];
+    m->shared_dev = t->shared_dev;
     for (int g = 0; g < n_dev && s == SNMF_OK; ++g) {
-        s = snmf_ctx_create(&m->ctx[g], m->dev[g]);
-        if (s != SNMF_OK) break;
         snmf_params pg = m->p;
         pg.T = (int32_t)(m->col[g + 1] - m->col[g]);
         s = snmf_plan_create(m->ctx[g], &pg, &m->plan[g]);
@@ -234,47 +380,12 @@ extern "C" int snmf_multi_create(const int32_t* devices, int32_t n_dev, const sn
         m->len = (size_t)snmf_plan_stats_len(m->plan[0]);
         m->xoff = m->upd_w ? 0 : m->len - 2;  // H-only solves exchange nothing but (div, sum S.*H)
         m->xlen = m->len - m->xoff;
+        s = team_reserve(t, m->xlen);
     }
     for (int g = 0; g < n_dev && s == SNMF_OK; ++g) {
         if (hipSetDevice(m->dev[g]) != hipSuccess) s = fail(SNMF_ERR_NO_DEVICE, "hipSetDevice(%d)", m->dev[g]);
         if (s == SNMF_OK) s = dalloc(&m->stats[g], m->len);
-        // gather buffer and arrival words are written by PEERS while this device may hold lines of them: fine-grained
-        // (coherent) device memory; plain hipMalloc only if the runtime refuses (then kernel boundaries must do)
-        if (s == SNMF_OK) {
-            const size_t sb = (size_t)2 * n_dev * m->xlen * sizeof(double), fb = ((size_t)2 * n_dev + 1) * sizeof(unsigned);
-            if (hipExtMallocWithFlags((void**)&m->slots[g], sb, hipDeviceMallocFinegrained) != hipSuccess) {
-                (void)hipGetLastError();
-                m->fine_grained = false;  // (coarse-grained memory: only EVENTS ordering is safe, see snmf_multi_set_exchange)
-                s = dalloc(&m->slots[g], (size_t)2 * n_dev * m->xlen);
-            }
-            if (s == SNMF_OK && hipExtMallocWithFlags((void**)&m->flags[g], fb, hipDeviceMallocFinegrained) != hipSuccess) {
-                (void)hipGetLastError();
-                m->fine_grained = false;
-                s = dalloc(&m->flags[g], (size_t)2 * n_dev + 1);
-            }
-            if (s == SNMF_OK) hipMemset(m->flags[g], 0, fb);
-            if (s == SNMF_OK) hipMemset(m->slots[g], 0, sb);  // (the fused push writes the r real rows only: the pad rows stay zero)
-        }
-        if (s == SNMF_OK) {
-            hipMemset(m->stats[g], 0, m->len * sizeof(double));
-            for (int q = 0; q < 2 && s == SNMF_OK; ++q)
-                if (hipEventCreateWithFlags(&m->ev[q][g], hipEventDisableTiming) != hipSuccess)
-                    s = fail(SNMF_ERR_NO_DEVICE, "hipEventCreate failed on device %d", m->dev[g]);
-        }
-        // peer stores into every other device's gather buffer
-        for (int q = 0; q < n_dev && s == SNMF_OK; ++q) {
-            if (m->dev[q] == m->dev[g]) continue;
-            int can = 0;
-            hipDeviceCanAccessPeer(&can, m->dev[g], m->dev[q]);
-            if (!can) {
-                s = fail(SNMF_ERR_UNSUPPORTED, "device %d cannot access device %d as a peer", m->dev[g], m->dev[q]);
-                break;
-            }
-            const hipError_t e = hipDeviceEnablePeerAccess(m->dev[q], 0);
-            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
-                s = fail(SNMF_ERR_NO_DEVICE, "hipDeviceEnablePeerAccess(%d -> %d): %s", m->dev[g], m->dev[q], hipGetErrorString(e));
-            (void)hipGetLastError();
-        }
+        if (s == SNMF_OK) hipMemset(m->stats[g], 0, m->len * sizeof(double));
     }
     if (s != SNMF_OK) {
         const std::string keep = g_err;
@@ -282,9 +393,18 @@ extern "C" int snmf_multi_create(const int32_t* devices, int32_t n_dev, const sn
         g_err = keep;
         return s;
     }
-    if (!m->fine_grained) m->mode = SNMF_EXCHANGE_EVENTS;  // (AUTO resolved above before the allocations were known)
+    m->slots = t->slots;
+    m->flags = t->flags;
+    m->fine_grained = t->fine_grained;
+    // AUTO: device-side ordering when every rank has a device of its own and the buffers are coherent
+    m->mode = (!t->shared_dev && t->fine_grained) ? SNMF_EXCHANGE_FLAGS : SNMF_EXCHANGE_EVENTS;
     *out = m;
     return SNMF_OK;
+}
+
+extern "C" int snmf_multi_create(const int32_t* devices, int32_t n_dev, const snmf_params* p, const int64_t* col_begin,
+                                 snmf_multi** out) {
+    return multi_create_on(nullptr, false, devices, n_dev, p, col_begin, out);
 }
 
 extern "C" int snmf_multi_set_exchange(snmf_multi* m, int32_t mode) {
@@ -292,12 +412,7 @@ extern "C" int snmf_multi_set_exchange(snmf_multi* m, int32_t mode) {
     if (mode != SNMF_EXCHANGE_AUTO && mode != SNMF_EXCHANGE_FLAGS && mode != SNMF_EXCHANGE_EVENTS)
         return fail(SNMF_ERR_INVALID, "unknown exchange mode %d", mode);
     if (m->it != 0 && m->inited) return fail(SNMF_ERR_STATE, "the exchange mode can only change between solves (before snmf_multi_run)");
-    if (mode == SNMF_EXCHANGE_AUTO) {
-        bool distinct = true;
-        for (int g = 0; g < m->n; ++g)
-            for (int q = 0; q < g; ++q) distinct = distinct && m->dev[g] != m->dev[q];
-        mode = (distinct && m->fine_grained) ? SNMF_EXCHANGE_FLAGS : SNMF_EXCHANGE_EVENTS;
-    }
+    if (mode == SNMF_EXCHANGE_AUTO) mode = (!m->shared_dev && m->fine_grained) ? SNMF_EXCHANGE_FLAGS : SNMF_EXCHANGE_EVENTS;
     if (mode == SNMF_EXCHANGE_FLAGS && !m->fine_grained)
         return fail(SNMF_ERR_UNSUPPORTED, "FLAGS ordering needs fine-grained gather buffers, which this runtime refused to allocate (EVENTS is in use)");
     m->mode = mode;
@@ -307,14 +422,38 @@ extern "C" int snmf_multi_set_exchange(snmf_multi* m, int32_t mode) {
 #define MULTI_CHECK(m) \
     if (!(m)) return fail(SNMF_ERR_INVALID, "multi handle is NULL")
 
+// Run fn(g) for every rank, ranks 1.. on threads of their own (each GPU has its own PCIe link, each context its own pinned
+// pipeline; the host-side narrowing pool takes jobs from several threads at once): round 4 walked the ranks one after another
+// from the calling thread.  Returns the first failure with its message.
+template <typename Fn>
+static int multi_for_ranks(snmf_multi* m, Fn fn) {
+    std::vector<int> rc(m->n, SNMF_OK);
+    std::vector<std::string> er(m->n);
+    int dev_before = -1;
+    (void)hipGetDevice(&dev_before);
+    auto one = [&](int g) {
+        if (hipSetDevice(m->dev[g]) != hipSuccess) rc[g] = fail(SNMF_ERR_NO_DEVICE, "hipSetDevice(%d) failed", m->dev[g]);
+        else rc[g] = fn(g);
+        if (rc[g] != SNMF_OK) er[g] = g_err;
+    };
+    std::vector<std::thread> th;
+    for (int g = 1; g < m->n; ++g) th.emplace_back(one, g);
+    one(0);
+    for (auto& t : th) t.join();
+    if (dev_before >= 0) (void)hipSetDevice(dev_before);
+    for (int g = 0; g < m->n; ++g)
+        if (rc[g] != SNMF_OK) return fail(rc[g], "rank %d (device %d): %s", g, m->dev[g], er[g].c_str());
+    return SNMF_OK;
+}
+
 template <typename T>
 static int multi_set_cols(snmf_multi* m, const T* A, int64_t ld, int which) {
     MULTI_CHECK(m);
     if (!A) return fail(SNMF_ERR_INVALID, "NULL matrix");
-    for (int g = 0; g < m->n; ++g) {
+    SN_TRY(multi_for_ranks(m, [&](int g) {
         const T* Ag = A + (size_t)m->col[g] * ld;
-        SN_TRY(which == 0 ? set_v<T>(m->plan[g], Ag, ld, 0) : set_h<T>(m->plan[g], Ag, ld, 0));
-    }
+        return which == 0 ? set_v<T>(m->plan[g], Ag, ld, 0) : set_h<T>(m->plan[g], Ag, ld, 0);
+    }));
     m->inited = false;
     return SNMF_OK;
 }
@@ -326,7 +465,7 @@ template <typename T>
 static int multi_set_w(snmf_multi* m, const T* W, int64_t ld) {
     MULTI_CHECK(m);
     if (!W) return fail(SNMF_ERR_INVALID, "NULL matrix");
-    for (int g = 0; g < m->n; ++g) SN_TRY(set_w<T>(m->plan[g], W, ld, 0));
+    SN_TRY(multi_for_ranks(m, [&](int g) { return set_w<T>(m->plan[g], W, ld, 0); }));
     m->inited = false;
     return SNMF_OK;
 }
@@ -349,9 +488,14 @@ extern "C" int snmf_multi_set_sparsity_f32(snmf_multi* m, const float* S) { retu
 extern "C" int snmf_multi_init(snmf_multi* m) {
     MULTI_CHECK(m);
     for (int g = 0; g < m->n; ++g) SN_TRY(snmf_plan_init(m->plan[g]));
+    // this handle's view of the team's gather buffers starts from zeros (the fused push writes the r real rows only: the pad
+    // rows must be zero, and another handle of the team may have used the memory with another layout)
+    for (int g = 0; g < m->n; ++g) {
+        HIP_TRY(hipSetDevice(m->dev[g]));
+        HIP_TRY(hipMemsetAsync(m->slots[g], 0, (size_t)2 * m->n * m->xlen * sizeof(double), m->ctx[g]->stream));
+    }
     for (int g = 0; g < m->n; ++g) SN_TRY(snmf_ctx_sync(m->ctx[g]));
     m->it = 0;
-    m->par = 0;
     m->inited = true;
     m->finalized = false;
     m->stopped = false;
@@ -378,7 +522,7 @@ static bool multi_exchange(snmf_multi* m, int g, int par, unsigned xs, int& seq,
     const bool flags = m->mode == SNMF_EXCHANGE_FLAGS;
     const int grid = (int)std::max<size_t>(1, std::min<size_t>((m->xlen + 255) / 256, 512));
     if (fused) {
-        if (m->n > 1 && rc == SNMF_OK && !flags && hipEventRecord(m->ev[par][g], st) != hipSuccess) note(fail(SNMF_ERR_NO_DEVICE, "hipEventRecord failed"));
+        if (m->n > 1 && rc == SNMF_OK && !flags && hipEventRecord(m->team->ev[par][g], st) != hipSuccess) note(fail(SNMF_ERR_NO_DEVICE, "hipEventRecord failed"));
     } else if (m->n > 1 && rc == SNMF_OK) {
         PushArgs pa{};
         pa.src = m->stats[g] + m->xoff;
@@ -392,14 +536,14 @@ static bool multi_exchange(snmf_multi* m, int g, int par, unsigned xs, int& seq,
         pa.done_ctr = flags ? m->flags[g] + (size_t)2 * m->n : nullptr;
         hipLaunchKernelGGL(k_push_stats, dim3(grid), dim3(256), 0, st, pa);
         if (hipGetLastError() != hipSuccess) note(fail(SNMF_ERR_NO_DEVICE, "k_push_stats launch failed"));
-        else if (!flags && hipEventRecord(m->ev[par][g], st) != hipSuccess) note(fail(SNMF_ERR_NO_DEVICE, "hipEventRecord failed"));
+        else if (!flags && hipEventRecord(m->team->ev[par][g], st) != hipSuccess) note(fail(SNMF_ERR_NO_DEVICE, "hipEventRecord failed"));
     }
     // every rank has recorded (EVENTS) / submitted its push (FLAGS on a shared device) -- or somebody failed: all leave
     if ((!flags || m->shared_dev) && !multi_barrier(m, seq++, rc != SNMF_OK)) return false;
     if (m->n > 1) {
         if (!flags)
             for (int q = 0; q < m->n; ++q)
-                if (q != g && hipStreamWaitEvent(st, m->ev[par][q], 0) != hipSuccess) note(fail(SNMF_ERR_NO_DEVICE, "hipStreamWaitEvent failed"));
+                if (q != g && hipStreamWaitEvent(st, m->team->ev[par][q], 0) != hipSuccess) note(fail(SNMF_ERR_NO_DEVICE, "hipStreamWaitEvent failed"));
         if (rc == SNMF_OK && !fused) {
             hipLaunchKernelGGL(k_sum_ranks, dim3(grid), dim3(256), 0, st, (const double*)(m->slots[g] + (size_t)par * m->n * m->xlen),
                                m->n, m->xlen, m->stats[g] + m->xoff, flags ? (const unsigned*)(m->flags[g] + (size_t)par * m->n) : nullptr,
@@ -421,8 +565,8 @@ static void multi_rank_loop(snmf_multi* m, int g, int it0, int target, bool fina
         }
     };
     step(hipSetDevice(m->dev[g]) == hipSuccess ? SNMF_OK : fail(SNMF_ERR_NO_DEVICE, "hipSetDevice(%d) failed", m->dev[g]));
-    int par = m->par, since = 0, stopped = 0;
-    unsigned xs = m->xseq;
+    int par = m->team->par, since = 0, stopped = 0;
+    unsigned xs = m->team->xseq;
     const bool flags = m->mode == SNMF_EXCHANGE_FLAGS;
     bool all_ok = true;
     // W updates: the exchange rides on the iteration's own launches (k_reduce pushes, k_wapply sums); SNMF_MULTI_UNFUSED=1
@@ -480,8 +624,8 @@ static void multi_rank_loop(snmf_multi* m, int g, int it0, int target, bool fina
     m->rc[g] = rc;
     m->err[g] = err;
     if (g == 0) {
-        m->par = par;
-        m->xseq = xs;
+        m->team->par = par;
+        m->team->xseq = xs;
         *stopped_out = stopped;
     }
 }
@@ -539,13 +683,11 @@ extern "C" int snmf_multi_get_w_rank_f64(snmf_multi* m, int32_t rank, double* W,
 }
 extern "C" int snmf_multi_get_h_f64(snmf_multi* m, double* H, int64_t ld) {
     MULTI_CHECK(m);
-    for (int g = 0; g < m->n; ++g) SN_TRY(snmf_plan_get_h_f64(m->plan[g], H + (size_t)m->col[g] * ld, ld, 0));
-    return SNMF_OK;
+    return multi_for_ranks(m, [&](int g) { return snmf_plan_get_h_f64(m->plan[g], H + (size_t)m->col[g] * ld, ld, 0); });
 }
 extern "C" int snmf_multi_get_h_f32(snmf_multi* m, float* H, int64_t ld) {
     MULTI_CHECK(m);
-    for (int g = 0; g < m->n; ++g) SN_TRY(snmf_plan_get_h_f32(m->plan[g], H + (size_t)m->col[g] * ld, ld, 0));
-    return SNMF_OK;
+    return multi_for_ranks(m, [&](int g) { return snmf_plan_get_h_f32(m->plan[g], H + (size_t)m->col[g] * ld, ld, 0); });
 }
 extern "C" int snmf_multi_get_objective(snmf_multi* m, double* div_out, double* cost_out, int32_t* n_iter_out) {
     MULTI_CHECK(m);
@@ -593,4 +735,131 @@ extern "C" int snmf_sparse_nmf_multi_f32(const int32_t* devices, int32_t n_dev, 
                                          float* W, float* H, const float* sparsity, double* div_out, double* cost_out,
                                          int32_t* n_iter_out) {
     return sparse_nmf_multi_impl<float>(devices, n_dev, p, V, ldV, W, H, sparsity, div_out, cost_out, n_iter_out);
+}
+
+// ---- B_hat = run_basis_DNMF(x, d, B, p) over a device list, device-resident (round 5) ---------------------------------------
+// run_basis_DNMF.m:36-55 with the frames of all three solves sharded over the ranks of ONE team: Y, X, D cross PCIe once each --
+// every rank's shard through its own pinned pipeline, all ranks at once, X and D on the second contexts under solve 1 -- A_hat
+// never leaves HBM (each rank hands ITS columns of solve 1's H to its plans of solves 2 / 3), only B_hat (and A_hat when asked
+// for) comes back.  Round 4 ran this as three snmf_sparse_nmf_multi_* calls: three handle constructions, serial shard uploads
+// from the calling thread, A_hat device -> host -> device twice.
+template <typename T>
+static int dnmf_multi_impl(const int32_t* devices, int32_t n_dev, const snmf_params* p, int R_x, int R_d, const T* Y, int64_t ldY,
+                           const T* X, int64_t ldX, const T* D, int64_t ldD, const T* B, int64_t ldB, const T* H0, uint64_t seed,
+                           T* B_hat, int64_t ldBh, T* A_hat, int64_t ldA, int32_t* n_iter3) {
+    if (!devices || !p || !Y || !X || !D || !B || !B_hat) return fail(SNMF_ERR_INVALID, "devices, p, Y, X, D, B and B_hat must be non-NULL");
+    if (R_x < 1 || R_d < 1 || p->r != R_x + R_d) return fail(SNMF_ERR_DIM, "params->r = %d must equal R_x + R_d = %d + %d", p->r, R_x, R_d);
+    if (p->sparsity_kind != SNMF_SPARSITY_SCALAR)
+        return fail(SNMF_ERR_DIM, "run_basis_DNMF needs a scalar p.sparsity (its W-only solves have R_x / R_d rows)");
+    if (ldB < p->F || ldBh < p->F) return fail(SNMF_ERR_INVALID, "leading dimension of B / B_hat < F");
+    if (A_hat && ldA < p->r) return fail(SNMF_ERR_INVALID, "leading dimension of A_hat < R_x + R_d");
+    if (n_dev < 1 || n_dev > 16) return fail(SNMF_ERR_INVALID, "n_dev = %d outside [1, 16]", n_dev);
+    if (p->T >= 1 && n_dev > p->T) n_dev = p->T;
+    (void)hipGetLastError();
+    int dev_before = -1;
+    (void)hipGetDevice(&dev_before);
+    struct Cleanup {
+        MultiTeam* team = nullptr;
+        snmf_multi *m1 = nullptr, *m2 = nullptr, *m3 = nullptr;
+        int dev = -1;
+        ~Cleanup() {
+            const std::string keep = g_err;
+            if (m3) snmf_multi_destroy(m3);
+            if (m2) snmf_multi_destroy(m2);
+            if (m1) snmf_multi_destroy(m1);
+            if (team) team_release(team);
+            if (dev >= 0) (void)hipSetDevice(dev);
+            g_err = keep;
+        }
+    } C;
+    C.dev = dev_before;
+    SN_TRY(team_acquire(devices, n_dev, &C.team));
+    std::vector<uint8_t> on(p->r, 1), off(p->r, 0);
+    snmf_params q = *p;
+    q.w_update_ind = off.data();  // run_basis_DNMF.m:37
+    q.h_update_ind = on.data();   // :38
+    SN_TRY(multi_create_on(C.team, false, devices, n_dev, &q, nullptr, &C.m1));
+    q.r = R_x;
+    q.w_update_ind = on.data();   // :43
+    q.h_update_ind = off.data();  // :44
+    SN_TRY(multi_create_on(C.team, true, devices, n_dev, &q, nullptr, &C.m2));
+    q.r = R_d;                    // :49-50
+    SN_TRY(multi_create_on(C.team, true, devices, n_dev, &q, nullptr, &C.m3));
+    snmf_multi *m1 = C.m1, *m2 = C.m2, *m3 = C.m3;
+    // solve 1's operands: every rank its shard of Y, B, and ITS columns of the initial activations
+    SN_TRY(multi_for_ranks(m1, [&](int g) {
+        snmf_plan* pl = m1->plan[g];
+        SN_TRY(set_v<T>(pl, Y + (size_t)m1->col[g] * ldY, ldY, 0));
+        SN_TRY(set_w<T>(pl, B, ldB, 0));  // p.init_w = B   (:39)
+        if (H0) SN_TRY(set_h<T>(pl, H0 + (size_t)m1->col[g] * p->r, p->r, 0));
+        else SN_TRY(rand_h(pl, seed, m1->col[g]));
+        return (int)SNMF_OK;
+    }));
+    // X, D and the two halves of B go up on the second contexts while solve 1 runs
+    int rc_up = SNMF_OK;
+    std::string err_up;
+    std::thread up([&] {
+        rc_up = multi_for_ranks(m2, [&](int g) {
+            SN_TRY(set_v<T>(m2->plan[g], X + (size_t)m2->col[g] * ldX, ldX, 0));
+            SN_TRY(set_v<T>(m3->plan[g], D + (size_t)m3->col[g] * ldD, ldD, 0));
+            SN_TRY(set_w<T>(m2->plan[g], B, ldB, 0));                      // p.init_w = B(:,1:R_x)            (:45)
+            SN_TRY(set_w<T>(m3->plan[g], B + (size_t)R_x * ldB, ldB, 0));  // p.init_w = B(:,R_x+1:R_x+R_d)    (:51)
+            return (int)SNMF_OK;
+        });
+        if (rc_up != SNMF_OK) err_up = g_err;
+    });
+    int32_t n1 = 0, n2 = 0, n3 = 0;
+    int s = snmf_multi_init(m1);
+    SN_STEP(s, snmf_multi_run(m1, p->max_iter, &n1));  // [~, A_hat] = sparse_nmf(Y, p)   (:40)
+    up.join();
+    if (s != SNMF_OK) return s;
+    if (rc_up != SNMF_OK) return fail(rc_up, "%s", err_up.c_str());
+    // p.init_h = A_hat(1:R_x,:) / A_hat(R_x+1:end,:)   (:46, :52): rows of each rank's resident fp32 H, device to device
+    SN_TRY(multi_for_ranks(m2, [&](int g) {
+        int idx = 0;
+        SN_TRY(result_h_index(m1->plan[g], &idx));
+        const float* A = m1->plan[g]->H[idx];
+        SN_TRY(set_h<float>(m2->plan[g], A, m1->plan[g]->rp, 1));
+        SN_TRY(set_h<float>(m3->plan[g], A + R_x, m1->plan[g]->rp, 1));
+        return (int)SNMF_OK;
+    }));
+    int rc_a = SNMF_OK;
+    std::string err_a;
+    std::thread dl;
+    if (A_hat) dl = std::thread([&] {  // A_hat -> host under solves 2 / 3 (solve 1's contexts are idle now)
+        rc_a = sizeof(T) == 8 ? snmf_multi_get_h_f64(m1, (double*)A_hat, ldA) : snmf_multi_get_h_f32(m1, (float*)A_hat, ldA);
+        if (rc_a != SNMF_OK) err_a = g_err;
+    });
+    s = snmf_multi_init(m2);
+    SN_STEP(s, snmf_multi_run(m2, p->max_iter, &n2));  // [B_hat_x, ~] = sparse_nmf(X, p)  (:47)
+    SN_STEP(s, snmf_multi_init(m3));
+    SN_STEP(s, snmf_multi_run(m3, p->max_iter, &n3));  // [B_hat_d, ~] = sparse_nmf(D, p)  (:53)
+    if (sizeof(T) == 8) {
+        SN_STEP(s, snmf_multi_get_w_f64(m2, (double*)B_hat, ldBh));  // B_hat = [B_hat_x, B_hat_d]   (:55)
+        SN_STEP(s, snmf_multi_get_w_f64(m3, (double*)B_hat + (size_t)R_x * ldBh, ldBh));
+    } else {
+        SN_STEP(s, snmf_multi_get_w_f32(m2, (float*)B_hat, ldBh));
+        SN_STEP(s, snmf_multi_get_w_f32(m3, (float*)B_hat + (size_t)R_x * ldBh, ldBh));
+    }
+    if (dl.joinable()) dl.join();
+    if (s != SNMF_OK) return s;
+    if (rc_a != SNMF_OK) return fail(rc_a, "%s", err_a.c_str());
+    if (n_iter3) {
+        n_iter3[0] = n1;
+        n_iter3[1] = n2;
+        n_iter3[2] = n3;
+    }
+    return SNMF_OK;
+}
+extern "C" int snmf_run_basis_dnmf_multi_f64(const int32_t* devices, int32_t n_dev, const snmf_params* p, int32_t R_x, int32_t R_d,
+                                             const double* Y, int64_t ldY, const double* X, int64_t ldX, const double* D, int64_t ldD,
+                                             const double* B, int64_t ldB, const double* H0, uint64_t seed, double* B_hat, int64_t ldBh,
+                                             double* A_hat, int64_t ldA, int32_t* n_iter_out) {
+    return dnmf_multi_impl<double>(devices, n_dev, p, R_x, R_d, Y, ldY, X, ldX, D, ldD, B, ldB, H0, seed, B_hat, ldBh, A_hat, ldA, n_iter_out);
+}
+extern "C" int snmf_run_basis_dnmf_multi_f32(const int32_t* devices, int32_t n_dev, const snmf_params* p, int32_t R_x, int32_t R_d,
+                                             const float* Y, int64_t ldY, const float* X, int64_t ldX, const float* D, int64_t ldD,
+                                             const float* B, int64_t ldB, const float* H0, uint64_t seed, float* B_hat, int64_t ldBh,
+                                             float* A_hat, int64_t ldA, int32_t* n_iter_out) {
+    return dnmf_multi_impl<float>(devices, n_dev, p, R_x, R_d, Y, ldY, X, ldX, D, ldD, B, ldB, H0, seed, B_hat, ldBh, A_hat, ldA, n_iter_out);
 }

@@ -32,15 +32,23 @@ __device__ __host__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-// H[t * rp + k] = u(k + r * t) for k < r, t < T; pads zero
-static __global__ __launch_bounds__(256) void k_rand_h(float* __restrict__ H, int rp, int r, int T, uint64_t seed) {
-    const size_t n4 = ((size_t)r * T + 3) / 4;
-    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (size_t)gridDim.x * 256) {
+// H[t * rp + k] = u(k + r * (t_off + t)) for k < r, t < T; pads zero.  t_off: this plan's first column in the r x n matrix the draw
+// is defined on (a shard of the frames starts from ITS columns of the unsharded draw: dist.h0_columns, snmf_run_basis_dnmf_multi_*).
+// value = ((x >> 9) + 0.5) * 2^-23: every one of the 2^23 results is exactly representable and lies strictly inside (0, 1)
+// (with 24 bits and + 0.5 the sum needed 25 bits: ties rounded to even, the largest draw came out as 1.0 -- round 4's advisor).
+static __global__ __launch_bounds__(256) void k_rand_h(float* __restrict__ H, int rp, int r, int T, uint64_t seed, uint64_t t_off) {
+    const uint64_t e_lo = (uint64_t)r * t_off, e_hi = e_lo + (uint64_t)r * (uint64_t)T;
+    const uint64_t q_lo = e_lo / 4, n4 = (e_hi + 3) / 4 - q_lo;
+    for (uint64_t qi = (uint64_t)blockIdx.x * 256 + threadIdx.x; qi < n4; qi += (uint64_t)gridDim.x * 256) {
+        const uint64_t q = q_lo + qi;
         uint32_t o[4];
         philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
         for (int j = 0; j < 4; ++j) {
-            const size_t e = 4 * q + j;
-            if (e < (size_t)r * T) H[(e / r) * rp + (e % r)] = ((float)(o[j] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+            const uint64_t e = 4 * q + j;
+            if (e >= e_lo && e < e_hi) {
+                const uint64_t le = e - e_lo;
+                H[(le / r) * rp + (le % r)] = ((float)(o[j] >> 9) + 0.5f) * (1.0f / 8388608.0f);
+            }
         }
     }
 }
@@ -67,12 +75,13 @@ static int aux_ctx(snmf_ctx* c, snmf_ctx** out) {
     return SNMF_OK;
 }
 
-static int rand_h(snmf_plan* pl, uint64_t seed) {
+int rand_h(snmf_plan* pl, uint64_t seed, int64_t col0) {
     HIP_TRY(hipSetDevice(pl->ctx->device));
     hipStream_t st = pl->ctx->stream;
     const size_t nH = (size_t)pl->rp * pl->Tp;
     HIP_TRY(hipMemsetAsync(pl->H[0], 0, nH * 4, st));
-    hipLaunchKernelGGL(k_rand_h, dim3(grid_for(((size_t)pl->p.r * pl->p.T + 3) / 4)), dim3(256), 0, st, pl->H[0], pl->rp, pl->p.r, pl->p.T, seed);
+    hipLaunchKernelGGL(k_rand_h, dim3(grid_for(((size_t)pl->p.r * pl->p.T + 3) / 4 + 1)), dim3(256), 0, st, pl->H[0], pl->rp, pl->p.r, pl->p.T, seed,
+                       (uint64_t)std::max<int64_t>(0, col0));
     HIP_TRY(hipGetLastError());
     pl->have_h = true;
     pl->inited = false;
@@ -82,7 +91,7 @@ static int rand_h(snmf_plan* pl, uint64_t seed) {
 
 extern "C" int snmf_plan_set_h_random(snmf_plan* pl, uint64_t seed) {
     PLAN_CHECK(pl);
-    return rand_h(pl, seed);
+    return rand_h(pl, seed, 0);
 }
 
 namespace {
@@ -190,7 +199,7 @@ int dnmf_impl(snmf_ctx* ctx, const snmf_params* p, int R_x, int R_d, const T* Y,
     SN_TRY(set_v<T>(L.p1, Y, ldY, 0));
     SN_TRY(set_w<T>(L.p1, B, ldB, 0));  // p.init_w = B   (:39)
     if (H0) SN_TRY(set_h<T>(L.p1, H0, p->r, 0));
-    else SN_TRY(rand_h(L.p1, seed));
+    else SN_TRY(rand_h(L.p1, seed, 0));
     auto upload23 = [&]() -> int {
         SN_TRY(set_v<T>(L.p2, X, ldX, 0));
         SN_TRY(set_v<T>(L.p3, D, ldD, 0));
@@ -288,7 +297,7 @@ extern "C" int snmf_run_basis_dnmf_audio_f64(snmf_ctx* ctx, const snmf_params* p
     SN_TRY(features_to_plan(L.p1, sp, dy, n, mel, mel_M, scr1));
     SN_TRY(set_w<double>(L.p1, B, ldB, 0));
     if (H0) SN_TRY(set_h<double>(L.p1, H0, p->r, 0));
-    else SN_TRY(rand_h(L.p1, seed));
+    else SN_TRY(rand_h(L.p1, seed, 0));
     auto upload23 = [&]() -> int {
         HIP_TRY(hipSetDevice(ctx->device));
         SN_TRY(features_to_plan(L.p2, sp, dx, n, mel, mel_M, scr2));
@@ -379,7 +388,7 @@ extern "C" int snmf_run_basis_train_audio_f64(snmf_ctx* ctx, const snmf_params* 
         pl->mdi_v_fresh = true;
         SN_TRY(set_w<float>(pl, w0, rows, 1));  // p.init_w = B_*_init   (:87, :90)
         if (H0) SN_TRY(set_h<double>(pl, H0, r, 0));
-        else SN_TRY(rand_h(pl, seed));          // the reference re-seeds per call (:112-114): both solves start from the SAME h
+        else SN_TRY(rand_h(pl, seed, 0));       // the reference re-seeds per call (:112-114): both solves start from the SAME h
         SN_TRY(snmf_plan_init(pl));
         SN_TRY(snmf_plan_run(pl, pl->p.max_iter, ni));
         SN_TRY(snmf_plan_get_w_f64(pl, Bo, rows, 0));

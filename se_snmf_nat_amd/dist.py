@@ -32,12 +32,14 @@ def shard_bounds(T, world_size, rank):
 class ShardedLoop:
     """for it = 1:max_iter of src/sparse_nmf.m:186 with the frame axis sharded over ranks."""
 
-    def __init__(self, engine, stats, all_reduce, *, max_iter, can_stop, cost_check, poll_every=4):
+    def __init__(self, engine, stats, all_reduce, *, max_iter, can_stop, cost_check, poll_every=4, step_view=None):
         """engine: step interface; stats: buffer object the engine fills (torch tensor or numpy);
-        all_reduce(stats): in-place sum over ranks (no-op for world_size 1)."""
+        all_reduce(view): in-place sum over ranks of the given slice of `stats` (no-op for world_size 1);
+        step_view: the slice one iteration exchanges (default: all of it; H-only solves: the two cost scalars at the tail)."""
         self.e = engine
         self.stats = stats
         self.all_reduce = all_reduce
+        self.step_view = stats if step_view is None else step_view
         self.max_iter = int(max_iter)
         self.can_stop = bool(can_stop)
         self.cost_check = bool(cost_check)
@@ -52,7 +54,7 @@ class ShardedLoop:
     def step(self):
         self.e.hstep()
         self.e.wstats(self._ptr())
-        self.all_reduce(self.stats)
+        self.all_reduce(self.step_view)
         self.e.wapply(self._ptr())
         self.it += 1
 
@@ -61,8 +63,13 @@ class ShardedLoop:
         if hasattr(self.e, "run_sharded") and hasattr(self.stats, "data_ptr"):
             # the product engine: the loop runs inside the library (snmf_plan_run_sharded), one call for all the iterations;
             # the collective comes back as a callback on the (whole or two-scalar) statistics buffer
-            def ar(ptr, n):
-                self.all_reduce(self.stats)
+            base, esz = self.stats.data_ptr(), self.stats.element_size()
+
+            def ar(ptr, n):  # exactly the `n` doubles at `ptr` the library asks for (include/snmf.h: snmf_allreduce_fn)
+                off = (int(ptr) - base) // esz
+                if off < 0 or off + int(n) > self.stats.numel() or (int(ptr) - base) % esz:
+                    raise ValueError("collective asked for a range outside the statistics buffer")
+                self.all_reduce(self.stats[off:off + int(n)])
             last = target >= self.max_iter
             ran = self.e.run_sharded(target - self.it, self._ptr(), ar, poll_every=self.poll_every if self.can_stop else 0,
                                      finalize=last and self.cost_check and not self.finalized)
@@ -82,7 +89,7 @@ class ShardedLoop:
                     break
         if not stopped and self.it >= self.max_iter and self.cost_check and not self.finalized and self.it > 0:
             self.e.objstats(self._ptr())
-            self.all_reduce(self.stats)
+            self.all_reduce(self.stats[-2:])  # (div, sum S.*H): all the final objective needs
             self.e.objapply(self._ptr())
             self.finalized = True
         return self.it
@@ -129,22 +136,23 @@ class ShardedTrainer:
         torch.cuda.current_stream(self.device).synchronize()  # the zero fill ran on torch's current stream
         # H-only solves exchange nothing but the two cost scalars at the tail of the buffer
         w_any = True if w_update_ind is None else bool(np.asarray(w_update_ind).any())
-        self._ar_view = self.stats if w_any else self.stats[-2:]
         self.loop = ShardedLoop(self.plan, self.stats, self._all_reduce, max_iter=max_iter,
-                                can_stop=bool(cost_check) and conv_eps > 0, cost_check=cost_check)
+                                can_stop=bool(cost_check) and conv_eps > 0, cost_check=cost_check,
+                                step_view=self.stats if w_any else self.stats[-2:])
 
     def _all_reduce(self, t):
+        """In-place sum over the ranks of `t`, a slice of the statistics buffer."""
         if self.world > 1:
             if self.stream is None:
                 self.ctx.sync()  # engine on its private stream: order by hand
-                self.dist.all_reduce(self._ar_view, op=self.dist.ReduceOp.SUM, group=self.group)
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
                 self.torch.cuda.current_stream(self.device).synchronize()
                 return
             with self.torch.cuda.stream(self.stream):
                 if self.dist.get_backend(self.group) != "nccl":
                     # host-staged backends (gloo dry runs) read the buffer from the host side
                     self.stream.synchronize()
-                self.dist.all_reduce(self._ar_view, op=self.dist.ReduceOp.SUM, group=self.group)
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def run(self, n_iters=None):
         return self.loop.run(n_iters)
@@ -197,13 +205,16 @@ def run_basis_dnmf_sharded(Y_local, X_local, D_local, B, R_x, R_d, p, *, device=
     H0 = h0_columns(int(p.get("random_seed", 1)), r, int(t0), T_loc, int(T_total))
     t1 = ShardedTrainer(Y_local, B, H0, w_update_ind=np.zeros(r, bool), h_update_ind=np.ones(r, bool), **common)
     t1.run()
-    _, A_hat, _ = t1.result()
-    t2 = ShardedTrainer(X_local, B[:, :R_x], A_hat[:R_x, :], w_update_ind=np.ones(R_x, bool),
+    # A_hat stays on the device between the solves (round 5): p.init_h = A_hat(1:R_x,:) / A_hat(R_x+1:end,:) (:46, :52) are
+    # slices of solve 1's resident H, copied device to device -- no NumPy round trip of the r x T activations
+    A_dev = t1.plan.get_h_device()  # torch (T_loc, r) float32 = column-major r x T_loc
+    t2 = ShardedTrainer(X_local, B[:, :R_x], A_dev[:, :R_x].contiguous(), w_update_ind=np.ones(R_x, bool),
                         h_update_ind=np.zeros(R_x, bool), **common)
     t2.run()
     B_hat_x, _, _ = t2.result()
-    t3 = ShardedTrainer(D_local, B[:, R_x:r], A_hat[R_x:r, :], w_update_ind=np.ones(R_d, bool),
+    t3 = ShardedTrainer(D_local, B[:, R_x:r], A_dev[:, R_x:r].contiguous(), w_update_ind=np.ones(R_d, bool),
                         h_update_ind=np.zeros(R_d, bool), **common)
     t3.run()
     B_hat_d, _, _ = t3.result()
+    A_hat = np.asfortranarray(A_dev.cpu().numpy().T.astype(np.float64))  # (what the caller gets back: r x T_loc)
     return np.concatenate([B_hat_x, B_hat_d], axis=1), A_hat

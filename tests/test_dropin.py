@@ -204,3 +204,48 @@ def test_training_entry_in_exemplar_mode(gpu_ctx):
         ref = ref / np.sqrt((ref ** 2).sum(0)) + 1e-9
         assert rel(out[key], ref) < 1e-5, key
     assert out["A_DFT_sub"] == 0 and out["A_Mel_sub"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_ranks", [2, 3])
+@pytest.mark.parametrize("conv_eps", [0.0, 1e-3])
+def test_resident_dnmf_over_a_device_list_equals_the_single_device_call(gpu_ctx, n_ranks, conv_eps):
+    """snmf_run_basis_dnmf_multi_f64 (run_basis_DNMF.m:36-55 with the frames of all three solves sharded over a device list, every
+    rank's A_hat columns resident between the solves; csrc/snmf_multi.h) against the single-device resident call: frames are
+    independent given W, so A_hat -- nothing but the two cost scalars is exchanged in solve 1 -- comes out BIT FOR BIT, early
+    stops included; B_hat's statistics are summed per rank and then across the ranks (fp64), which moves it by a few fp32 ulp.
+    The ranks share the one device of the test box (EVENTS ordering)."""
+    from se_snmf_nat_amd import run_basis_dnmf
+    Y, X, D, B = _dnmf_problem(F=513, T=900, R_x=12, R_d=9, seed=8)
+    p = dict(cf="kl", sparsity=5, max_iter=40, conv_eps=conv_eps, cost_check=1, random_seed=1)
+    B1, A1 = run_basis_dnmf(Y, X, D, B, 12, 9, p, ctx=gpu_ctx)
+    Bm, Am = run_basis_dnmf(Y, X, D, B, 12, 9, p, devices=[0] * n_ranks)
+    assert np.array_equal(Am, A1)
+    assert rel(Bm, B1) < 5e-6
+    # a second call reuses the device list's team (contexts, gather buffers): the same bits again
+    Bm2, Am2 = run_basis_dnmf(Y, X, D, B, 12, 9, p, devices=[0] * n_ranks)
+    assert np.array_equal(Bm2, Bm) and np.array_equal(Am2, Am)
+    # ... and the three-call path over the same device list (round 4's form) agrees with the resident one bit for bit
+    B3, A3 = run_basis_dnmf(Y, X, D, B, 12, 9, p, devices=[0] * n_ranks, resident=False)
+    assert np.array_equal(B3, Bm) and np.array_equal(A3, Am)
+
+
+@pytest.mark.gpu
+def test_resident_multi_dnmf_golden_loop_and_device_rng(gpu_ctx):
+    """The committed oracle run of run_basis_DNMF.m:36-55 through the device-list entry (two ranks), and the device generator:
+    rank g draws ITS columns of the (R_x + R_d) x T Philox draw, so h0 = "device" gives the single-device A_hat bit for bit."""
+    from se_snmf_nat_amd import run_basis_dnmf
+    ref = dict(np.load(os.path.join(GOLD, "ref_data.npz")))
+    d = dict(np.load(os.path.join(GOLD, "dnmf_loop_513x64_r20_20.npz")))
+    Y = ref["Y"]
+    X = (Y * d["mask"] + 1e-9).astype(np.float32)
+    D = (Y - X + 2e-9).astype(np.float32)
+    Bs = np.concatenate([ref["B"][:, :20], ref["B"][:, 100:120]], axis=1)
+    p = dict(cf="kl", sparsity=5, max_iter=30, conv_eps=1e-3, cost_check=1)
+    B_hat, A_hat = run_basis_dnmf(Y, X, D, Bs, 20, 20, p, devices=[0, 0])
+    assert rel(B_hat, d["B_hat"]) < REL_WH and rel(A_hat, d["A_hat"]) < REL_WH
+    Y2, X2, D2, B2 = _dnmf_problem(F=257, T=403, R_x=8, R_d=7)
+    q = dict(cf="kl", sparsity=5, max_iter=10, conv_eps=0, cost_check=1, random_seed=4)
+    B1, A1 = run_basis_dnmf(Y2, X2, D2, B2, 8, 7, q, ctx=gpu_ctx, h0="device")
+    Bm, Am = run_basis_dnmf(Y2, X2, D2, B2, 8, 7, q, devices=[0, 0, 0], h0="device")
+    assert np.array_equal(Am, A1) and rel(Bm, B1) < 5e-6

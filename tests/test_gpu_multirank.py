@@ -151,7 +151,7 @@ def test_bench_launches_its_own_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(SNMF_DIST_BACKEND="gloo", SNMF_FORCE_DEVICE="0")
     pr = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-                         "--T", "6400", "--r", "64", "--no-cpu-baseline", "--c5-T", "12800"], env=env, stdout=subprocess.PIPE,
+                         "--T", "6400", "--r", "64", "--no-cpu-baseline", "--c5-T", "12800", "--c4-T", "9600"], env=env, stdout=subprocess.PIPE,
                         stderr=subprocess.PIPE, text=True, timeout=900)
     assert pr.returncode == 0, pr.stderr[-2000:]
     lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
@@ -171,6 +171,10 @@ def test_bench_launches_its_own_ranks():
     c5 = d["c5_strong"]
     assert "error" not in c5, c5
     assert c5["ms_per_step"] > 0 and c5["steps"] == 10 and c5["final_cost"] > 0 and "r=512" in c5["workload"]
+    # ... and the sharded basis-training path of BASELINE configs[3] (run_basis_DNMF.m:36-55: three solves, A_hat resident)
+    c4 = d["c4_dnmf"]
+    assert "error" not in c4, c4
+    assert c4["seconds"] > 0 and c4["value"] > 0 and c4["scaling"] == "weak" and c4["frames_per_rank"] == 9600 and c4["final_cost_solve3"] > 0
 
 
 def test_bench_single_gpu_line_keeps_the_contract():
