@@ -130,8 +130,6 @@ struct snmf_multi {
     std::vector<snmf_ctx*> ctx;       // [n] borrowed from the team (ctx or aux)
     std::vector<snmf_plan*> plan;
     std::vector<double*> stats;       // [n] device statistics buffer of each rank
-    std::vector<double*> slots;       // [n] borrowed: the team's gather buffers, used as [2 parities][n ranks][xlen]
-    std::vector<unsigned*> flags;     // [n] borrowed
     int mode = 0;                     // SNMF_EXCHANGE_FLAGS / _EVENTS (resolved from AUTO at creation)
     bool shared_dev = false;          // two ranks on one device: submissions of push and sum are ordered by the host in every mode
     // every gather buffer and arrival word is fine-grained (coherent) device memory.  If the runtime refused one of them the
@@ -393,8 +391,6 @@ static int multi_create_on(MultiTeam* team, bool use_aux, const int32_t* devices
         g_err = keep;
         return s;
     }
-    m->slots = t->slots;
-    m->flags = t->flags;
     m->fine_grained = t->fine_grained;
     // AUTO: device-side ordering when every rank has a device of its own and the buffers are coherent
     m->mode = (!t->shared_dev && t->fine_grained) ? SNMF_EXCHANGE_FLAGS : SNMF_EXCHANGE_EVENTS;
@@ -487,12 +483,16 @@ extern "C" int snmf_multi_set_sparsity_f32(snmf_multi* m, const float* S) { retu
 
 extern "C" int snmf_multi_init(snmf_multi* m) {
     MULTI_CHECK(m);
+    // (the team's gather buffers may have been re-allocated for a later handle with longer statistics: the handle always goes
+    //  through the team's pointers, and falls back to EVENTS ordering if that allocation came out coarse-grained)
+    m->fine_grained = m->team->fine_grained;
+    if (!m->fine_grained) m->mode = SNMF_EXCHANGE_EVENTS;
     for (int g = 0; g < m->n; ++g) SN_TRY(snmf_plan_init(m->plan[g]));
     // this handle's view of the team's gather buffers starts from zeros (the fused push writes the r real rows only: the pad
     // rows must be zero, and another handle of the team may have used the memory with another layout)
     for (int g = 0; g < m->n; ++g) {
         HIP_TRY(hipSetDevice(m->dev[g]));
-        HIP_TRY(hipMemsetAsync(m->slots[g], 0, (size_t)2 * m->n * m->xlen * sizeof(double), m->ctx[g]->stream));
+        HIP_TRY(hipMemsetAsync(m->team->slots[g], 0, (size_t)2 * m->n * m->xlen * sizeof(double), m->ctx[g]->stream));
     }
     for (int g = 0; g < m->n; ++g) SN_TRY(snmf_ctx_sync(m->ctx[g]));
     m->it = 0;
@@ -530,10 +530,10 @@ static bool multi_exchange(snmf_multi* m, int g, int par, unsigned xs, int& seq,
         pa.n = m->n;
         pa.seq = xs;
         for (int q = 0; q < m->n; ++q) {
-            pa.dst[q] = m->slots[q] + ((size_t)par * m->n + g) * m->xlen;
-            pa.flag[q] = flags ? m->flags[q] + (size_t)par * m->n + g : nullptr;
+            pa.dst[q] = m->team->slots[q] + ((size_t)par * m->n + g) * m->xlen;
+            pa.flag[q] = flags ? m->team->flags[q] + (size_t)par * m->n + g : nullptr;
         }
-        pa.done_ctr = flags ? m->flags[g] + (size_t)2 * m->n : nullptr;
+        pa.done_ctr = flags ? m->team->flags[g] + (size_t)2 * m->n : nullptr;
         hipLaunchKernelGGL(k_push_stats, dim3(grid), dim3(256), 0, st, pa);
         if (hipGetLastError() != hipSuccess) note(fail(SNMF_ERR_NO_DEVICE, "k_push_stats launch failed"));
         else if (!flags && hipEventRecord(m->team->ev[par][g], st) != hipSuccess) note(fail(SNMF_ERR_NO_DEVICE, "hipEventRecord failed"));
@@ -545,8 +545,8 @@ static bool multi_exchange(snmf_multi* m, int g, int par, unsigned xs, int& seq,
             for (int q = 0; q < m->n; ++q)
                 if (q != g && hipStreamWaitEvent(st, m->team->ev[par][q], 0) != hipSuccess) note(fail(SNMF_ERR_NO_DEVICE, "hipStreamWaitEvent failed"));
         if (rc == SNMF_OK && !fused) {
-            hipLaunchKernelGGL(k_sum_ranks, dim3(grid), dim3(256), 0, st, (const double*)(m->slots[g] + (size_t)par * m->n * m->xlen),
-                               m->n, m->xlen, m->stats[g] + m->xoff, flags ? (const unsigned*)(m->flags[g] + (size_t)par * m->n) : nullptr,
+            hipLaunchKernelGGL(k_sum_ranks, dim3(grid), dim3(256), 0, st, (const double*)(m->team->slots[g] + (size_t)par * m->n * m->xlen),
+                               m->n, m->xlen, m->stats[g] + m->xoff, flags ? (const unsigned*)(m->team->flags[g] + (size_t)par * m->n) : nullptr,
                                xs, &m->plan[g]->st->fault);
             if (hipGetLastError() != hipSuccess) note(fail(SNMF_ERR_NO_DEVICE, "k_sum_ranks launch failed"));
         }
@@ -582,12 +582,12 @@ static void multi_rank_loop(snmf_multi* m, int g, int it0, int target, bool fina
             X.len = m->xlen;
             X.seq = xs;
             for (int q = 0; q < m->n; ++q) {
-                X.push_dst[q] = m->slots[q] + ((size_t)par * m->n + g) * m->xlen;
-                X.push_flag[q] = flags ? m->flags[q] + (size_t)par * m->n + g : nullptr;
+                X.push_dst[q] = m->team->slots[q] + ((size_t)par * m->n + g) * m->xlen;
+                X.push_flag[q] = flags ? m->team->flags[q] + (size_t)par * m->n + g : nullptr;
             }
-            X.push_done = flags ? m->flags[g] + (size_t)2 * m->n : nullptr;
-            X.gather = m->slots[g] + (size_t)par * m->n * m->xlen;
-            X.gflags = flags ? (const unsigned*)(m->flags[g] + (size_t)par * m->n) : nullptr;
+            X.push_done = flags ? m->team->flags[g] + (size_t)2 * m->n : nullptr;
+            X.gather = m->team->slots[g] + (size_t)par * m->n * m->xlen;
+            X.gflags = flags ? (const unsigned*)(m->team->flags[g] + (size_t)par * m->n) : nullptr;
             m->plan[g]->xpush = &X;
         }
         if (rc == SNMF_OK) step(snmf_plan_wstats(m->plan[g], m->stats[g]));
