@@ -8,6 +8,8 @@ MATLAB doubles), split into host->device / solve / device->host, next to the bar
         as three sparse_nmf calls (round 3's path), as ONE resident call on features (fp64 and fp32 host arrays), and from the
         two waveforms (audio in, B_hat out)
   mel   run_basis_train.m:91: the Mel solve (64 x 72000, r = 100) -- the HBM-side shape
+  c4m   BASELINE configs[3] behind a DEVICE LIST (snmf_run_basis_dnmf_multi_f64): n = 2, 4, 8 ranks that share device 0 (the box
+        has one GPU: EVENTS ordering), the whole 513 x 100000 problem sharded; beside it n x (one shard's three resident solves)
 
 All random draws and host-side array preparation happen OUTSIDE the timed regions.  One JSON line per measurement:
   python scripts/bench_dropin.py [pcie a11 c2 c4 mel] > profiles/r04_dropin.jsonl
@@ -171,3 +173,35 @@ if "c4" in which:
         t = time.perf_counter(); Bh = train.run_basis_DNMF(xs, ds, B, fp, ctx=ctx, h0="device"); best = min(best, time.perf_counter() - t)
     emit(config=f"C4 run_basis_DNMF(x, d, B, p) from the waveforms ({n} samples -> {F}x{T}), B_hat out", call_s=best,
          solver_iterations_per_s=150 / best, audio_MB=2 * n * 4 / 1e6)
+
+if "c4m" in which:
+    # The device-list entry of run_basis_DNMF (round 5): every rank's shard through its own pinned pipeline, A_hat resident per rank.
+    # With n ranks on ONE device the shards' kernels serialise, so the yardstick is n x (the three solves of one shard, data resident).
+    from se_snmf_nat_amd.api import _run_basis_dnmf_resident
+    F, T, Rx, Rd = 513, 100_000, 100, 100
+    X, _, _ = synth(F, T, Rx, 1); D, _, _ = synth(F, T, Rd, 2)
+    Y = np.asfortranarray(X + D + 1e-9)
+    B = np.asfortranarray(np.random.default_rng(3).random((F, Rx + Rd)))
+    p = dict(cf="kl", sparsity=5, max_iter=50, conv_eps=0, cost_check=1, random_seed=1)
+    _, _, H0 = synth(F, T, Rx + Rd, 5, np.float32)
+    for n in (2, 4, 8):
+        devs = [0] * n
+        Ts = T // n
+        shard = resident_solve_s(F, Ts, Rx + Rd, 50, Y[:, :Ts], B, H0[:, :Ts], beta=1.0, sparsity=5.0, w_update_ind=np.zeros(Rx + Rd, bool))
+        for M, r0 in ((X, 0), (D, Rx)):
+            shard += resident_solve_s(F, Ts, Rx, 50, M[:, :Ts], B[:, r0:r0 + Rx], H0[r0:r0 + Rx, :Ts], beta=1.0, sparsity=5.0, h_update_ind=np.zeros(Rx, bool))
+        _run_basis_dnmf_resident(Y[:, :8192], X[:, :8192], D[:, :8192], B, Rx, Rd, p, ctx=None, dtype=np.float64, h0="device", want_a=False, devices=devs)  # the team exists
+        best = {}
+        for want_a in (False, True):
+            b = 1e9
+            for _ in range(2):
+                t = time.perf_counter()
+                _run_basis_dnmf_resident(Y, X, D, B, Rx, Rd, p, ctx=None, dtype=np.float64, h0="device", want_a=want_a, devices=devs)
+                b = min(b, time.perf_counter() - t)
+            best[want_a] = b
+        # round 4's form of the same call: three snmf_sparse_nmf_multi_* calls, A_hat through the host in between
+        t = time.perf_counter(); run_basis_dnmf(Y, X, D, B, Rx, Rd, p, devices=devs, resident=False, h0="device"); three = time.perf_counter() - t
+        emit(config=f"C4 run_basis_DNMF over a device list: {n} ranks on device 0, {F}x{T} sharded, 3 solves x 50 it, fp64 host arrays",
+             ranks=n, call_s_B_hat_only=best[False], call_s_with_A_hat=best[True], three_multi_calls_s=three,
+             n_times_one_shard_resident_s=n * shard, one_shard_resident_s=shard, call_over_n_shards=best[False] / (n * shard),
+             solver_iterations_per_s=150 / best[False])

@@ -1471,6 +1471,45 @@ extern "C" int snmf_plan_solve_frames_f32(snmf_plan* pl, int32_t tps, const floa
 }
 
 // ---- one-shot drop-in ------------------------------------------------------------------------
+// The pages of a result array that was allocated a moment ago (mxCreateDoubleMatrix, np.empty: MATLAB's value semantics) do not
+// exist yet: the first write to each is a page fault, and at 205 MB (C2's activations) those faults -- 50 000 of them when the
+// allocation did not get huge pages -- were up to 7 ms INSIDE the download of a one-shot call (round 5: Plan.get_h 3.4 ms into
+// an array with huge pages, 10-11 ms behind a solve in the same process).  The out-of-place entries know the destination from the
+// start, so a few host threads make its pages exist WHILE the device solves: madvise(MADV_POPULATE_WRITE) (Linux 5.14: faults the
+// range in without writing to it), else one write per page -- joined before the download, so nothing can be overwritten.
+#include <sys/mman.h>
+#include <unistd.h>
+#include <thread>
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
+namespace {
+struct Prefault {
+    std::vector<std::thread> th;
+    void start(void* ptr, size_t bytes, int n_thr = 4) {
+        if (!ptr || bytes < ((size_t)8 << 20)) return;
+        const size_t pg = (size_t)sysconf(_SC_PAGESIZE);
+        const uintptr_t lo = ((uintptr_t)ptr + pg - 1) & ~(uintptr_t)(pg - 1), hi = ((uintptr_t)ptr + bytes) & ~(uintptr_t)(pg - 1);
+        if (hi <= lo) return;
+        const size_t n_pg = (hi - lo) / pg;
+        for (int i = 0; i < n_thr; ++i) {
+            const uintptr_t a = lo + (n_pg * i / n_thr) * pg, b = lo + (n_pg * (i + 1) / n_thr) * pg;
+            if (b <= a) continue;
+            th.emplace_back([a, b, pg] {
+                (void)madvise((void*)a, b - a, MADV_HUGEPAGE);  // (a hint where transparent huge pages are opt-in: 100 faults instead of 50 000)
+                if (madvise((void*)a, b - a, MADV_POPULATE_WRITE) == 0) return;
+                for (uintptr_t q = a; q < b; q += pg) *(volatile char*)q = 0;  // (older kernels: EINVAL)
+            });
+        }
+    }
+    void join() {
+        for (auto& t : th) t.join();
+        th.clear();
+    }
+    ~Prefault() { join(); }
+};
+}  // namespace
+
 template <typename T>
 static int sparse_nmf_impl(snmf_ctx* ctx, const snmf_params* p, const T* V, int64_t ldV, const T* W0, const T* H0, T* W, T* H,
                            const T* sparsity, double* div_out, double* cost_out, int32_t* n_iter_out) {
@@ -1486,8 +1525,11 @@ static int sparse_nmf_impl(snmf_ctx* ctx, const snmf_params* p, const T* V, int6
         if (!sparsity) SN_STEP(s, fail(SNMF_ERR_INVALID, "sparsity array required for this sparsity_kind"));
         else SN_STEP(s, set_s<T>(pl, sparsity, 0));
     }
+    Prefault pf;
+    if (s == SNMF_OK && (const T*)H != H0) pf.start(H, (size_t)p->r * p->T * sizeof(T));  // out-of-place: H holds nothing yet
     SN_STEP(s, snmf_plan_init(pl));
     if (s == SNMF_OK) SN_STEP(s, snmf_plan_run(pl, p->max_iter, nullptr));
+    pf.join();
     if (s == SNMF_OK) {
         if (sizeof(T) == 8) {
             SN_STEP(s, snmf_plan_get_w_f64(pl, (double*)W, p->F, 0));

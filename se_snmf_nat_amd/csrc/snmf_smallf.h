@@ -566,6 +566,7 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_iter_sf(StepArgs a, int n_
         const int n_my = te - tb, n_rnd = n_my / NP, n_rem = n_my - n_rnd * NP;
         const bool x_first = n_rem == 1 && c == 0;
         const unsigned n_h = (unsigned)(n_rnd + (c < n_rem ? 1 : 0));
+        const int hlo = (t * rp + 4 * h) * 4, vlo = (t * Fp + 4 * h) * 4;  // this lane's byte offsets inside a tile of H / V
         SNMF_STAMP_DECL
         for (unsigned ith = 0; ith < n_h; ++ith) {
             const bool is_x = x_first && ith == 0;                  // the remainder tile, into the extra buffer
@@ -573,13 +574,16 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_iter_sf(StepArgs a, int n_
             const int tile = is_x ? tb + n_rnd * NP : tb + c + (int)it * NP;
             const int t0 = tile * 32;
             f32x4 hq[NK * 4], vq[NF * 4];
-            {
-                const float* hp = a.Hin + ((size_t)t0 + t) * rp + 4 * h;
-                const float* vp = a.V + ((size_t)t0 + t) * Fp + 4 * h;
+            {   // (buffer loads: descriptor + ONE lane offset per array + immediates -- as 64-bit lane pointers the three tile bases were
+                //  six long-lived VGPRs that this kernel does not have: they were what the H waves spilled)
+                const __amdgpu_buffer_rsrc_t rhi =
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Hin + (size_t)t0 * rp), 0, 32 * rp * 4, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rvi =
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.V + (size_t)t0 * Fp), 0, 32 * Fp * 4, 0x00020000);
 #pragma unroll
-                for (int q = 0; q < NK * 4; ++q) hq[q] = *reinterpret_cast<const f32x4*>(hp + 8 * q);
+                for (int q = 0; q < NK * 4; ++q) hq[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rhi, hlo, 32 * q, 0));
 #pragma unroll
-                for (int q = 0; q < NF * 4; ++q) vq[q] = *reinterpret_cast<const f32x4*>(vp + 8 * q);
+                for (int q = 0; q < NF * 4; ++q) vq[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rvi, vlo, 32 * q, 0));
             }
             // ---- P1 + ratio ----
             float dsum = 0.f;
@@ -702,9 +706,9 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_iter_sf(StepArgs a, int n_
             SNMF_STAMP(2);
             // ---- H_new leaves the way it came ... ----
             {
-                float* op = a.Hout + ((size_t)t0 + t) * rp + 4 * h;
+                const __amdgpu_buffer_rsrc_t rho = __builtin_amdgcn_make_buffer_rsrc(a.Hout + (size_t)t0 * rp, 0, 32 * rp * 4, 0x00020000);
 #pragma unroll
-                for (int q = 0; q < NK * 4; ++q) *reinterpret_cast<f32x4*>(op + 8 * q) = hq[q];
+                for (int q = 0; q < NK * 4; ++q) buf_store_b128(rho, hlo, 32 * q, hq[q]);
             }
             // ---- ... and goes to the partner: [frame][component], once the partner has read the previous tile ----
             // (the writes are inline assembly: as C++ stores into the LDS array inside the tile loop they alias every W-fragment read of
@@ -771,7 +775,9 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_iter_sf(StepArgs a, int n_
 #pragma unroll
             for (int phi = 0; phi < NF; ++phi) {
                 // ---- P3: Lam'^T[t, f]; A = H_new pieces of lane (t, h) (hand-off buffer), B = W fragment ----
+                SNMF_PIN();               // (not earlier: hoisted into the previous row tile's P4 the sixteen values were spilled at once)
                 if (phi > 0) ld_vt(phi);  // (P3's 52 MFMAs are between these loads and their use)
+                SNMF_PIN();
                 float R[16];
                 {
                     const float* ap = hbx + t * LDT + 4 * h;
@@ -867,12 +873,14 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_iter_sf(StepArgs a, int n_
 #pragma unroll
                 for (int i = 0; i < 16; ++i) g[i] += src[i * 64];
             }
-            // slab: D tile lane (k = fl, h), register -> f = 32 phi + drow(reg, h)  (k_wstats' layout)
-            float* dst = a.slabs + ((size_t)chunk * n_mat) * rp * Fp + (size_t)(kap * 32 + t) * Fp + phi * 32 + 4 * h;
+            // slab: D tile lane (k = fl, h), register -> f = 32 phi + drow(reg, h)  (k_wstats' layout).  Buffer stores: the 64-bit
+            // lane pointers of these few stores were computed at the top of the kernel and carried (spilled) through the tile loop
+            const __amdgpu_buffer_rsrc_t rsl =
+                __builtin_amdgcn_make_buffer_rsrc(a.slabs + ((size_t)chunk * n_mat) * rp * Fp, 0, rp * Fp * 4, 0x00020000);
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const f32x4 o = {g[4 * gq], g[4 * gq + 1], g[4 * gq + 2], g[4 * gq + 3]};
-                *reinterpret_cast<f32x4*>(dst + 8 * gq) = o;
+                buf_store_b128(rsl, (t * Fp + 4 * h) * 4, ((kap * 32) * Fp + phi * 32 + 8 * gq) * 4, o);
             }
         }
         SNMF_STAMP(11);
