@@ -21,8 +21,8 @@ OUT = os.path.join(ROOT, "profiles", f"{TAG}_resources.csv")
 
 # kernel (demangled prefix) -> the configs / shapes that launch it (from plan.describe() of those shapes and the committed traces)
 LAUNCHED = [
-    ("snmf::k_hstep_rp<true>", "C2 257x100000 r=256 KL (headline): H step, iterations with the objective"),
-    ("snmf::k_hstep_rp<false>", "C2: H step of iteration 1 / cost_check = 0"),
+    ("snmf::k_hstep_rp<true, false>", "C2 257x100000 r=256 KL (headline): H step, iterations with the objective"),
+    ("snmf::k_hstep_rp<false, false>", "C2: H step of iteration 1 / cost_check = 0"),
     ("snmf::k_wstats<8, 4, 4, 2, 0, 1, false, 32, 0>", "C2: W statistics (full update: the objective rides on the H step)"),
     ("snmf::k_wfin<1>", "C2 / a11 / C4 W-only: chunk reduction + W update (snmf_plan_run)"),
     ("snmf::k_hstep_rh<true, 1>", "a11 513x72000 r=100 KL full (run_basis_train.m:88): H step"),
@@ -117,7 +117,9 @@ if reach:
     # k_iter_sf<4, *, 0> (Mel 64 bands, R = 100): the W waves carry the statistics of both row tiles (128 registers) beside a tile's
     # state; what is spilled are loop-invariant addresses and the second row tile's sixteen V values (profiles/r05_experiments.md,
     # section 2): 15 400 iterations/s with them against 12 600-13 100 for the spill-free two-launch path
-    KNOWN = {"snmf::k_iter_sf<4, true, 0>", "snmf::k_iter_sf<4, false, 0>"}
+    # k_hstep_rp<true, true> (r <= 64 with the objective): ONE value, stored once and reloaded once per loader wave at the role's entry,
+    # outside every loop
+    KNOWN = {"snmf::k_iter_sf<4, true, 0>", "snmf::k_iter_sf<4, false, 0>", "snmf::k_hstep_rp<true, true>"}
     new = [o for o in offenders if o[0] not in KNOWN]
     if new:
         raise SystemExit("reachable instantiations with spilled VGPRs that are not documented exceptions: " + ", ".join(o[0] for o in new))

@@ -294,6 +294,14 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     }
     pl->lds_h = std::max<size_t>(pl->NLH ? 2 * lds1 - lds_extra : (pl->NT == 1 ? (size_t)pl->TTH * per_col + lds_extra : lds2),
                                  2 * kMaxNW * 64 * sizeof(double));
+    // one or two column tiles (r <= 64) on the double-buffered role pipeline: P2 cut over the contraction (k_hstep_rp<., CUT>):
+    // 32 KB of partial tiles + 1 ./ dph + two more signals behind the buffers
+    {
+        const char* e = getenv("SNMF_RP_CUT");
+        const size_t more = 32 + (size_t)4 * pl->nk * 1024 * 4 + (size_t)pl->rp * 4;
+        pl->rp_cut = pl->NLH == 4 && pl->NWH == 8 && pl->bm == BM_KL && pl->nk <= 2 && pl->nf >= 4 && pl->lds_h + more <= lds_cap && !(e && atoi(e) == 0);
+        if (pl->rp_cut) pl->lds_h += more;
+    }
     pl->lds_mdi = std::max<size_t>(lds1, 2 * kMaxNW * 64 * sizeof(double));  // MDI pass: (NW=8, NT=1, NL=0)
     pl->grid_mdi = std::max(1, std::min(pl->Tp / 32, ctx->n_cu));
     const int n_tiles_h = pl->Tp / (pl->TTH * pl->NT);
@@ -312,7 +320,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         pl->rp_S = 0;
         const char* e = getenv("SNMF_HSTEP_SPLIT");
         // (k_hstep_rh splits by CONTIGUOUS row tiles within a half: 16 row tiles only, F = 505..513)
-        if ((pl->NLH == 4 || (pl->rh && pl->nf == 16)) && !(e && atoi(e) == 0)) {
+        if ((pl->NLH == 4 || (pl->rh && pl->nf == 16)) && !pl->rp_cut && !(e && atoi(e) == 0)) {
             // (only a partial round BEHIND whole ones: a problem of fewer tiles than workgroups is latency-bound, and there
             //  the split's extra steps -- partial stores, the arrival counter, the finishing pass -- cost more than the
             //  shorter MFMA loops save: C1, 257 x 2000 r = 40, ran 23.3 k iterations/s split against 26.7 k whole)
@@ -643,8 +651,8 @@ extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
         snprintf(hs, sizeof hs, "k_hstep_m (merged roles: 4 waves, one per SIMD, each P1 + P2 of its own row / column tiles; %d tiles whole, grid %d)",
                  pl->rp_tiles, pl->hm_grid);
     else if (kl_pipe)
-        snprintf(hs, sizeof hs, "k_hstep_rp (4 P1 + 4 P2 + 4 loader waves; %d of %d tiles pipelined, last round split %d ways, grid %d)",
-                 pl->rp_full, pl->rp_tiles, pl->rp_S, pl->rp_grid);
+        snprintf(hs, sizeof hs, "k_hstep_rp (4 P1 + 4 P2 + 4 loader waves%s; %d of %d tiles pipelined, last round split %d ways, grid %d)",
+                 pl->rp_cut ? ", P2 cut four ways over the contraction" : "", pl->rp_full, pl->rp_tiles, pl->rp_S, pl->rp_grid);
     else
         snprintf(hs, sizeof hs, "k_hstep");
     if (pl->generic) {

@@ -1250,6 +1250,36 @@ __device__ __forceinline__ void rh_cut_epilogue(const StepArgs& a, const f32x16&
     }
     if (OBJ && a.lam_is_u && !a.S) shsum += a.lam_u * hs;
 }
+// ... and for ONE register group g chosen at run time (wave-uniform), the group's four numerators in `num`: k_hstep_rp<., CUT>, where
+// wave w finishes group w of every column tile.
+template <bool OBJ>
+__device__ __forceinline__ void rp_cut_group_epilogue(const StepArgs& a, const f32x4& num, float* Hs, int kap, int g, int t0, int lane,
+                                                      const float* rdph, float& shsum) {
+    const int fl = lane & 31, h = lane >> 5;
+    const int t = t0 + fl, k0 = kap * 32 + 8 * g + 4 * h;
+    float* hsp = Hs + fl * a.ldh + k0;
+    const f32x4 hov = *reinterpret_cast<f32x4*>(hsp);
+    f32x4 dp, spv = {0.f, 0.f, 0.f, 0.f};
+    if (a.S) {
+        const f32x4 cs = *reinterpret_cast<const f32x4*>(a.colsum + k0);
+        spv = *reinterpret_cast<const f32x4*>(a.S + (size_t)t * a.rp + k0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dp[j] = fast_rcp(fmaxf(cs[j] + spv[j], kFlr));
+    } else {
+        dp = *reinterpret_cast<const f32x4*>(rdph + k0);
+        if (OBJ && !a.lam_is_u) spv = *reinterpret_cast<const f32x4*>(a.lamk + k0);
+    }
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = hov[j] * num[j] * dp[j];
+    *reinterpret_cast<f32x4*>(hsp) = o;
+    if (OBJ) {
+        if (a.lam_is_u && !a.S) shsum += a.lam_u * (((hov[0] + hov[1]) + hov[2]) + hov[3]);
+        else
+#pragma unroll
+            for (int j = 0; j < 4; ++j) shsum += spv[j] * hov[j];
+    }
+}
 __device__ __forceinline__ void rp_p2_consts(const StepArgs& a, int kap, int lane, f32x4 (&dpf)[4]) {
     const int h = lane >> 5;
     if (!a.S) {
@@ -1525,7 +1555,13 @@ __device__ __forceinline__ double rp_part_finish(const StepArgs& a, const float*
     return (double)shsum;
 }
 
-template <bool OBJ>
+// CUT (round 5; r <= 64: one or two column tiles -- settings/bak_IS16_results/initial_setting_SNMF_Techwin_201603_RT.m:47-48 R_x = 20,
+// R_d = 10, initial_setting_IMCRA.m:47-48 R = 50): P2's column tiles were ONE B wave's work (nk = 1: 4 (nf + ..) k-blocks x 4 MFMAs
+// on one SIMD -- at F = 513 260 MFMAs beside 64 of P1 -- while three B waves idled).  Here every B wave contracts a quarter of the
+// k-blocks for ALL column tiles, the partial tiles meet in LDS (k_hstep_rh<., 1>'s exchange: wdone / rdone) and wave w finishes
+// register group w (rows 8 w .. 8 w + 7 of each 32-column tile) summed in wave order, so both orders of arrival give the same
+// bits.  A template parameter: the instantiation the headline runs (CUT = false) is the code it was.
+template <bool OBJ, bool CUT = false>
 __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
     constexpr int NA = 4, NB = 4, NL = 4, NTHR = (NA + NB + NL) * 64, NLT = NL * 64, Tt = 32;
     constexpr int PA = 10, PB = 10;  // f32x4 per loader thread of the H / V block held in registers (as stage_in2)
@@ -1547,7 +1583,12 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
     // vready: "the tile's V block is staged" -- a signal of its own because the A team needs V only in its epilogues: the
     // loaders commit the H block first and post `ready`, so the V commit is off the path the A team's next loop waits for.
     unsigned *ready = cnt, *p1a = cnt + 4, *p1b = cnt + 8, *p2done = cnt + 12, *xdone = cnt + 16, *vready = cnt + 20;
+    unsigned *wdone = cnt + 28, *rdone = cnt + 32;               // CUT: partial tiles written / read (B team internal)
+    float* const Ps = reinterpret_cast<float*>(cnt + 40);        // CUT: [4 waves][nk <= 2 tiles][4 g][64 lanes][4] partial numerators
+    float* const rdph = Ps + 4 * a.nk * 1024;                    // CUT: [rp] 1 ./ dph (rp_cut_group_epilogue)
     double acc_div = 0.0, acc_sh = 0.0;
+    if (CUT && !a.S)
+        for (int k = threadIdx.x; k < rp; k += NTHR) rdph[k] = fast_rcp(a.dphv[k]);
     if (a.xr) {
         for (int k = threadIdx.x; k < rp; k += NTHR) wxs[k] = a.wx[k];
         // the 7 unused cells of the extra 8-deep k-block stay zero for the whole kernel
@@ -1556,7 +1597,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             lds[bsel * bufsz + Tt * ldh + (ii >> 3) * ldr + a.Fm + (ii & 7)] = 0.f;
         }
     }
-    if (threadIdx.x < 25) cnt[threadIdx.x] = 0u;
+    if (threadIdx.x < (CUT ? 36 : 25)) cnt[threadIdx.x] = 0u;
     __syncthreads();
     // A wave WITHOUT work -- an A wave past the last row tile, a B wave without a column tile -- used to walk the tile list
     // anyway, waiting for and posting every signal: a wave that polls LDS takes issue slots from the MFMA wave of its SIMD
@@ -1567,7 +1608,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
     if (a.part_S == 0) {
         const bool bs = a.nf <= 2 && a.nk >= 2;  // (b_shift: see the B team)
         const bool idle_a = w < NA && w >= a.nf && !a.xr;
-        const bool idle_b = w >= NA && w < NA + NB && (bs ? w - NA < 2 : w - NA >= a.nk);
+        const bool idle_b = !CUT && w >= NA && w < NA + NB && (bs ? w - NA < 2 : w - NA >= a.nk);
         if (lane == 0) {
             if (idle_a) p1a[w] = p1b[w] = xdone[w] = 0xffffffffu;
             if (idle_b) p2done[w - NA] = 0xffffffffu;
@@ -1578,9 +1619,10 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
     // Tiles [0, n_full) go through the pipeline, dealt out round-robin.  The tiles of the last PARTIAL round,
     // [n_full, n_tiles), are split over part_S workgroups each: workgroup u < (n_tiles - n_full) * part_S
     // takes part u % part_S of tile n_full + u / part_S as one more staged tile AFTER its pipelined ones.
-    const int n_full = a.part_S > 0 ? a.n_full : a.n_tiles;
+    const int n_full = (!CUT && a.part_S > 0) ? a.n_full : a.n_tiles;
     const int nmy = (int)blockIdx.x < n_full ? (n_full - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-    const bool has_part = a.part_S > 0 && (int)blockIdx.x < (a.n_tiles - n_full) * a.part_S;
+    // (CUT launches keep every tile whole: host rp_S = 0 -- the split's code is not in that instantiation)
+    const bool has_part = !CUT && a.part_S > 0 && (int)blockIdx.x < (a.n_tiles - n_full) * a.part_S;
     const int ptile = has_part ? n_full + (int)blockIdx.x / a.part_S : 0;
     // A workgroup's list of nst items: its nmy pipelined tiles with, when it has one, its part of a split tile in the
     // SECOND TO LAST place -- so that the part's tail (partial stores acknowledged, the arrival counter) runs under the
@@ -1795,11 +1837,77 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             rp_p2_consts(a, kb, lane, dp0);
             if (kb + kpair < a.nk) rp_p2_consts(a, kb + kpair, lane, dp1);
         }
+        unsigned lx_seq = 0;  // CUT: tiles this wave has put through the partial buffers
         auto b_item = [&](const int j) {  // P2 of the whole tile in place j of the list
             const int t0 = tile_of(j) * Tt;
             float* Hs = lds + (j & 1) * bufsz;
             const float* Rs = Hs + Tt * ldh;
             SNMF_STAMP(11);
+            if constexpr (CUT) {
+                const int fl = lane & 31, h = lane >> 5;
+                const float* sp = Rs + fl * ldr + 4 * h;
+                const int nq = a.Fq / 8, nqm = a.xr ? nq - 1 : nq, nq1 = 4 * (a.nf < NA ? a.nf : NA);
+                const int qlo = nqm * wb / NB, qhi = nqm * (wb + 1) / NB;  // this wave's k-blocks of every column tile (+ the extra row's: wave 3)
+                auto gate = [&]() {
+                    if (qhi <= nq1) rp_await(p1a, (unsigned)(j + 1), a.stop);
+                    else rp_await(p1b, (unsigned)(j + 1), a.stop);
+                };
+                auto gate_x = [&]() { rp_await(xdone, (unsigned)(j + 1), a.stop); };
+                const __amdgpu_buffer_rsrc_t rsk = wimage_rsrc(a.Wk4, (size_t)a.nk * a.Fq * 32);
+                const bool two = a.nk > 1;
+                f32x16 acc[2] = {zero16(), zero16()};
+                if (two) {
+                    const int so[2] = {qlo * 1024, a.Fq * 128 + qlo * 1024};
+                    contract_shared_buf<2>(acc, rsk, lane * 16, so, sp + 8 * qlo, qhi - qlo, gate);
+                    if (wb == NB - 1 && a.xr) {
+                        const int so3[2] = {nqm * 1024, a.Fq * 128 + nqm * 1024};
+                        contract_shared_buf<2>(acc, rsk, lane * 16, so3, sp + 8 * nqm, 1, gate_x);
+                    }
+                } else {
+                    f32x16 a1[1] = {zero16()};
+                    const int so[1] = {qlo * 1024};
+                    contract_shared_buf<1>(a1, rsk, lane * 16, so, sp + 8 * qlo, qhi - qlo, gate);
+                    if (wb == NB - 1 && a.xr) {
+                        const int so3[1] = {nqm * 1024};
+                        contract_shared_buf<1>(a1, rsk, lane * 16, so3, sp + 8 * nqm, 1, gate_x);
+                    }
+                    acc[0] = a1[0];
+                }
+                // partial tiles -> LDS, once every wave has read the previous tile's
+                rp_await(rdone, lx_seq, a.stop);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (i == 1 && !two) break;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 o = {acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
+                        *reinterpret_cast<f32x4*>(Ps + ((wb * a.nk + i) * 4 + g) * 256 + lane * 4) = o;
+                    }
+                }
+                ++lx_seq;
+                rp_post(wdone, wb, lx_seq, lane);
+                rp_await(wdone, lx_seq, a.stop);
+                // register group wb of every column tile, the four waves' partials in wave order
+                f32x4 tot[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (i == 1 && !two) break;
+#pragma unroll
+                    for (int ww = 0; ww < NB; ++ww) {
+                        const f32x4 x = *reinterpret_cast<const f32x4*>(Ps + ((ww * a.nk + i) * 4 + wb) * 256 + lane * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) tot[i][e] += x[e];
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                rp_post(rdone, wb, lx_seq, lane);
+                float shsum = 0.f;
+                rp_cut_group_epilogue<OBJ>(a, tot[0], Hs, 0, wb, t0, lane, rdph, shsum);
+                if (two) rp_cut_group_epilogue<OBJ>(a, tot[1], Hs, 1, wb, t0, lane, rdph, shsum);
+                if (OBJ) acc_sh += (double)shsum;
+                rp_post(p2done, wb, (unsigned)(j + 1), lane);
+                return;
+            }
             auto gate_p1a = [&]() { rp_await(p1a, (unsigned)(j + 1), a.stop); };
             const int fl = lane & 31, h = lane >> 5;
             const float* sp = Rs + fl * ldr + 4 * h;
