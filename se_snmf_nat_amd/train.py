@@ -152,13 +152,23 @@ def _run_basis_dnmf_audio(x, d, B, p, *, ctx, mel, h0, want_a=False):
     return (B_hat, A_hat) if want_a else B_hat
 
 
-def run_basis_DNMF(x, d, B, p, *, ctx=None, h0="host"):
+def _check_dtype(dtype):
+    """`dtype` of the callers below: accepted for callers written against the round-3 signature.  The entry they go through takes
+    the waveforms as fp32 (the device front-end's sample type: y = x + d of run_basis_DNMF.m:10 is formed in fp32 on the device,
+    INTEGRATION.md) and returns fp64; any other request is an error rather than silently something else."""
+    if dtype is not None and np.dtype(dtype) not in (np.dtype(np.float64), np.dtype(np.float32)):
+        raise SnmfError(1, "dtype must be float64 or float32")
+
+
+def run_basis_DNMF(x, d, B, p, *, ctx=None, h0="host", dtype=None):
     """B_hat = run_basis_DNMF(x, d, B, p) -- run_basis_DNMF.m:1: clean and noise waveforms, exemplar basis
     B = [B_x, B_d] (F x (R_x+R_d)); p carries the front-end fields, R_x, R_d and the solver fields."""
+    _check_dtype(dtype)
     return _run_basis_dnmf_audio(x, d, B, p, ctx=ctx, mel=False, h0=h0)  # :1-55
 
 
-def run_basis_DNMF_Mel(x, d, B, p, *, ctx=None, h0="host"):
+def run_basis_DNMF_Mel(x, d, B, p, *, ctx=None, h0="host", dtype=None):
     """B_hat = run_basis_DNMF_Mel(x, d, B, p) -- run_basis_DNMF_Mel.m:1: the same loop on the Mel projections of
     the three feature sets (:21-69); B is the Mel exemplar basis (F_order*(2*Splice+1) rows)."""
+    _check_dtype(dtype)
     return _run_basis_dnmf_audio(x, d, B, p, ctx=ctx, mel=True, h0=h0)  # :1-95
