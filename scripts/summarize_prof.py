@@ -47,7 +47,7 @@ with open(f"profiles/{tag}_pmc.csv", "w") as f:
     cols = sorted({c for d in avg.values() for c in d})
     f.write("kernel," + ",".join(cols) + ",hbm_read_bytes(2*FETCH*1024),hbm_write_bytes(WRITE*1024)\n")
     for k, d in sorted(avg.items()):
-        if not any(x in k for x in ("k_hstep", "k_wstats", "k_reduce", "k_wapply", "k_wfin", "k_hsolve", "k_wadapt", "k_o")):
+        if not any(x in k for x in ("k_hstep", "k_wstats", "k_iter_sf", "k_reduce", "k_wapply", "k_wfin", "k_hsolve", "k_wadapt", "k_o")):
             continue
         rd = 2 * d.get("FETCH_SIZE", 0) * 1024
         wr = d.get("WRITE_SIZE", 0) * 1024
@@ -70,11 +70,11 @@ print(open(f"profiles/{tag}_kernel_stats.csv").read())
 print(json.dumps(traffic, indent=1))
 with open(f"profiles/{tag}_mfma_util.txt", "w") as fu:
     for k, d in avg.items():
-        if ("k_hstep" in k or "k_wstats" in k) and "SQ_VALU_MFMA_BUSY_CYCLES" in d and "GRBM_GUI_ACTIVE" in d:
+        if ("k_hstep" in k or "k_wstats" in k or "k_iter_sf" in k) and "SQ_VALU_MFMA_BUSY_CYCLES" in d and "GRBM_GUI_ACTIVE" in d:
             fu.write("%s MFMA pipe utilisation %.1f%% (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs)\n"
                      % (k, 100 * d["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (d["GRBM_GUI_ACTIVE"] / 8)))
 for k, d in avg.items():
-    if "k_hstep" in k or "k_wstats" in k:
+    if "k_hstep" in k or "k_wstats" in k or "k_iter_sf" in k:
         if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "GRBM_GUI_ACTIVE" in d:
             # MFMA busy cycles are summed over all 1024 SIMDs; GUI_ACTIVE is summed over 8 XCDs
             util = d["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (d["GRBM_GUI_ACTIVE"] / 8)
