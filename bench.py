@@ -293,7 +293,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--oneshot-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--c5-T", dest="c5_T", type=int, default=500_000, help=argparse.SUPPRESS)  # frames of the extra C5 leg (tests shrink it)
-    ap.add_argument("--c4-T", dest="c4_T", type=int, default=100_000, help=argparse.SUPPRESS)  # frames PER RANK of the extra C4 leg
+    ap.add_argument("--c4-T", dest="c4_T", type=int, default=800_000, help=argparse.SUPPRESS)  # frames IN ALL of the extra C4 leg
     # --dim-*: the spellings self_launch() passes on (torch.distributed.run's own parser prefix-matches a bare --r)
     ap.add_argument("--F", "--dim-F", dest="F", type=int, default=F_)
     ap.add_argument("--T", "--dim-T", dest="T", type=int, default=T_)
@@ -495,8 +495,9 @@ def main():
         if rank == 0:
             out["c5_strong"] = c5
         # BASELINE configs[3], the config north_star's ">= 6x at 8 GPUs" names: the sharded basis-training path run_basis_DNMF.m:36-55
-        # (3 solves x 50 iterations, 513 x 100000 frames PER RANK, R_x = R_d = 100), A_hat resident between the solves
-        c4 = c4_dnmf_leg(world, rank, local_rank, torch, dist, T_per=args.c4_T)
+        # (3 solves x 50 iterations, 513 x 800000 frames in all, R_x = R_d = 100), A_hat resident between the solves; strong scaling,
+        # with the one-GPU time of the same problem measured by rank 0 in the same process
+        c4 = c4_dnmf_leg(world, rank, local_rank, torch, dist, T_total=args.c4_T)
         if rank == 0:
             out["c4_dnmf"] = c4
         dist.barrier()
@@ -567,31 +568,43 @@ def c5_strong_leg(world, rank, local_rank, torch, dist, F=513, T=500_000, r=512,
         return {"error": f"{type(e).__name__}: {e}"}
 
 
-def c4_dnmf_leg(world, rank, local_rank, torch, dist, F=513, T_per=100_000, R_x=100, R_d=100, iters=50):
+def c4_dnmf_leg(world, rank, local_rank, torch, dist, F=513, T_total=800_000, R_x=100, R_d=100, iters=50):
     """BASELINE configs[3] on the process-per-GPU path: run_basis_DNMF.m:36-55 -- H-only on Y (r = R_x + R_d), W-only on X and on D
-    with the activations of solve 1 -- with the frames sharded over the ranks (T_per frames EACH: weak scaling, more utterances per
-    GPU), one all-reduce of the W statistics per iteration of solves 2 / 3, A_hat handed from solve 1 to solves 2 / 3 on the
-    device.  The three feature blocks are resident (torch CUDA tensors) when the timed region starts; plan creation is inside it.
-    Timed like the headline leg: barrier + synchronize on both sides, MAX over ranks."""
+    with the activations of solve 1 -- with the T_total frames of the corpus sharded over the ranks (STRONG scaling: the problem is
+    the same at every N), one all-reduce of the W statistics per iteration of solves 2 / 3, A_hat handed from solve 1 to solves
+    2 / 3 on the device.  The three feature blocks are resident (torch CUDA tensors) when the timed region starts; plan creation
+    is inside it.  Timed like the headline leg: barrier + synchronize on both sides, MAX over ranks.  Then rank 0 ALONE runs the
+    whole T_total problem through the same code (a one-rank process group) while the others wait: `seconds_one_gpu`, so that the
+    line carries its own strong-scaling ratio, measured in one process on one box."""
     from se_snmf_nat_amd.dist import ShardedTrainer
     err, dev = None, torch.device("cuda", local_rank)
+    r, BLK = R_x + R_d, 50_000
+    Wx = np.random.default_rng(41).gamma(0.5, 1.0, size=(F, 24)).astype(np.float32)
+    Wd = np.random.default_rng(42).gamma(0.5, 1.0, size=(F, 16)).astype(np.float32)
+    B = np.random.default_rng(43).random((F, r)) + 0.05
+
+    def frames(t0, t1):
+        """columns [t0, t1) of the synthetic corpus as device tensors (T, F) / (T, r): generated in global blocks of BLK columns, so
+        that every world size sees the same matrices"""
+        Xd = torch.empty((t1 - t0, F), dtype=torch.float32, device=dev)
+        Dd = torch.empty((t1 - t0, F), dtype=torch.float32, device=dev)
+        H0 = torch.empty((t1 - t0, r), dtype=torch.float32, device=dev)
+        for blk in range(t0 // BLK, (t1 + BLK - 1) // BLK):
+            g = np.random.default_rng([4, blk])
+            n = min(T_total, (blk + 1) * BLK) - blk * BLK
+            xb = (Wx @ g.gamma(0.3, 1.0, size=(24, n)).astype(np.float32) + 1e-9).T
+            db = (Wd @ g.gamma(0.3, 1.0, size=(16, n)).astype(np.float32) + 1e-9).T
+            hb = g.random((n, r), dtype=np.float32)
+            lo, hi = max(t0, blk * BLK), min(t1, blk * BLK + n)
+            sl = slice(lo - blk * BLK, hi - blk * BLK)
+            Xd[lo - t0:hi - t0] = torch.from_numpy(np.ascontiguousarray(xb[sl])).to(dev)
+            Dd[lo - t0:hi - t0] = torch.from_numpy(np.ascontiguousarray(db[sl])).to(dev)
+            H0[lo - t0:hi - t0] = torch.from_numpy(np.ascontiguousarray(hb[sl])).to(dev)
+        return Xd + Dd, Xd, Dd, H0
+
     try:
-        g = np.random.default_rng([4, rank])
-        Wx = np.random.default_rng(41).gamma(0.5, 1.0, size=(F, 24)).astype(np.float32)
-        Wd = np.random.default_rng(42).gamma(0.5, 1.0, size=(F, 16)).astype(np.float32)
-        Xh = np.empty((F, T_per), np.float32, order="F")
-        Dh = np.empty((F, T_per), np.float32, order="F")
-        for a in range(0, T_per, 50000):
-            b = min(T_per, a + 50000)
-            Xh[:, a:b] = Wx @ g.gamma(0.3, 1.0, size=(24, b - a)).astype(np.float32) + 1e-9
-            Dh[:, a:b] = Wd @ g.gamma(0.3, 1.0, size=(16, b - a)).astype(np.float32) + 1e-9
-        # column-major F x T_per = torch (T_per, F) contiguous
-        Xd = torch.from_numpy(np.ascontiguousarray(Xh.T)).to(dev)
-        Dd = torch.from_numpy(np.ascontiguousarray(Dh.T)).to(dev)
-        Yd = Xd + Dd
-        H0 = torch.from_numpy(np.ascontiguousarray(g.random((T_per, R_x + R_d), dtype=np.float32))).to(dev)
-        B = np.random.default_rng(43).random((F, R_x + R_d)) + 0.05
-        del Xh, Dh
+        t0, t1 = T_total * rank // world, T_total * (rank + 1) // world
+        Yd, Xd, Dd, H0 = frames(t0, t1)
         torch.cuda.synchronize()
     except Exception as e:  # noqa: BLE001
         err = f"{type(e).__name__}: {e}"
@@ -599,27 +612,29 @@ def c4_dnmf_leg(world, rank, local_rank, torch, dist, F=513, T_per=100_000, R_x=
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if float(ok.item()) < 1.0:
         return {"error": err or "another rank could not set the C4 shard up"}
+    solo = dist.new_group([0]) if world > 1 else None  # (every rank has to make this call)
     try:
-        r = R_x + R_d
         common = dict(beta=1.0, sparsity=5.0, max_iter=iters, conv_eps=0.0, cost_check=True, device=local_rank)
 
-        def three_solves():
-            t1 = ShardedTrainer(Yd, B, H0, w_update_ind=np.zeros(r, bool), h_update_ind=np.ones(r, bool), **common)
+        def three_solves(Yd, Xd, Dd, H0, group=None):
+            t1 = ShardedTrainer(Yd, B, H0, w_update_ind=np.zeros(r, bool), h_update_ind=np.ones(r, bool), group=group, **common)
             t1.run()
             A = t1.plan.get_h_device()
-            t2 = ShardedTrainer(Xd, B[:, :R_x], A[:, :R_x].contiguous(), w_update_ind=np.ones(R_x, bool), h_update_ind=np.zeros(R_x, bool), **common)
+            t2 = ShardedTrainer(Xd, B[:, :R_x], A[:, :R_x].contiguous(), w_update_ind=np.ones(R_x, bool), h_update_ind=np.zeros(R_x, bool),
+                                group=group, **common)
             t2.run()
-            t3 = ShardedTrainer(Dd, B[:, R_x:], A[:, R_x:].contiguous(), w_update_ind=np.ones(R_d, bool), h_update_ind=np.zeros(R_d, bool), **common)
+            t3 = ShardedTrainer(Dd, B[:, R_x:], A[:, R_x:].contiguous(), w_update_ind=np.ones(R_d, bool), h_update_ind=np.zeros(R_d, bool),
+                                group=group, **common)
             t3.run()
             t3.sync()
             c3 = [c for c in t3.plan.get_objective()[1] if c != 0.0]
             return float(c3[-1]) if c3 else None, t1.plan.describe(), t2.plan.describe()
 
-        three_solves()  # warm-up: code objects, cached device blocks, the clock
+        three_solves(Yd, Xd, Dd, H0)  # warm-up: code objects, cached device blocks, the clock
         dist.barrier()
         torch.cuda.synchronize()
         t = time.perf_counter()
-        cost3, d1, d2 = three_solves()
+        cost3, d1, d2 = three_solves(Yd, Xd, Dd, H0)
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
@@ -630,15 +645,34 @@ def c4_dnmf_leg(world, rank, local_rank, torch, dist, F=513, T_per=100_000, R_x=
         dist.all_reduce(fin, op=dist.ReduceOp.MIN)
         if float(fin.item()) < 1.0:
             return {"error": "a rank did not finish the C4 loop"}
-        T = T_per * world
-        fl = iters * (4.0 * F * T * r + 2 * 4.0 * F * T * R_x)  # H-only: Lam + contraction at r; W-only (x2): the same at R_x (= R_d)
-        return {"workload": f"{world}xMI355X run_basis_DNMF (BASELINE configs[3]): 513 x {T} frames ({T_per} per rank), R_x = R_d = {R_x}, "
-                            f"3 solves x {iters} iterations, A_hat resident between the solves", "seconds": dt,
-                "value": 3 * iters / dt, "unit": "solver iterations/s", "scaling": "weak", "frames_per_rank": T_per,
-                "algorithmic_TFLOPs": fl / dt / 1e12, "frac_of_peak": fl / dt / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
-                "final_cost_solve3": cost3, "geometry_solve1": d1, "geometry_solve2": d2}
+        fl = iters * (4.0 * F * T_total * r + 2 * 4.0 * F * T_total * R_x)  # H-only: Lam + contraction at r; W-only (x2): the same at R_x (= R_d)
+        out = {"workload": f"{world}xMI355X run_basis_DNMF (BASELINE configs[3]): 513 x {T_total} frames sharded over the ranks, "
+                           f"R_x = R_d = {R_x}, 3 solves x {iters} iterations, A_hat resident between the solves", "seconds": dt,
+               "value": 3 * iters / dt, "unit": "solver iterations/s", "scaling": "strong", "frames_total": T_total,
+               "algorithmic_TFLOPs": fl / dt / 1e12, "frac_of_peak": fl / dt / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
+               "final_cost_solve3": cost3, "geometry_solve1": d1, "geometry_solve2": d2}
     except Exception as e:  # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"}
+    if world > 1:
+        # the whole problem on rank 0's GPU alone, same code, a one-rank group; a failure here (memory) leaves the sharded numbers alone
+        one = None
+        try:
+            del Yd, Xd, Dd, H0
+            torch.cuda.empty_cache()
+            if rank == 0:
+                Yd, Xd, Dd, H0 = frames(0, T_total)
+                three_solves(Yd, Xd, Dd, H0, group=solo)
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                c1, _, _ = three_solves(Yd, Xd, Dd, H0, group=solo)
+                torch.cuda.synchronize()
+                one = (time.perf_counter() - t, c1)
+        except Exception as e:  # noqa: BLE001
+            out["one_gpu_error"] = f"{type(e).__name__}: {e}"
+        dist.barrier()
+        if one:
+            out.update({"seconds_one_gpu": one[0], "strong_scaling_vs_one_gpu": one[0] / dt, "final_cost_solve3_one_gpu": one[1]})
+    return out
 
 
 if __name__ == "__main__":

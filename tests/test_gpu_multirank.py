@@ -174,7 +174,11 @@ def test_bench_launches_its_own_ranks():
     # ... and the sharded basis-training path of BASELINE configs[3] (run_basis_DNMF.m:36-55: three solves, A_hat resident)
     c4 = d["c4_dnmf"]
     assert "error" not in c4, c4
-    assert c4["seconds"] > 0 and c4["value"] > 0 and c4["scaling"] == "weak" and c4["frames_per_rank"] == 9600 and c4["final_cost_solve3"] > 0
+    assert c4["seconds"] > 0 and c4["value"] > 0 and c4["scaling"] == "strong" and c4["frames_total"] == 9600 and c4["final_cost_solve3"] > 0
+    # ... whose line carries the same problem on rank 0's GPU alone: same matrices, same initial values -> the same final cost
+    assert "one_gpu_error" not in c4, c4
+    assert c4["seconds_one_gpu"] > 0 and c4["strong_scaling_vs_one_gpu"] > 0
+    assert abs(c4["final_cost_solve3_one_gpu"] - c4["final_cost_solve3"]) <= 1e-6 * c4["final_cost_solve3"]
 
 
 def test_bench_single_gpu_line_keeps_the_contract():
