@@ -82,6 +82,8 @@ for name in which:
         # beta = 2, r > 256, full update: P = W * (H*H') -- the Gram launch is 2 r^2 T flop (+ 2 F r^2 for W * Gram), Q stays 2 F T r
         work["wstats"] = 2.0 * F * T * r + 2.0 * r * r * T + 2.0 * F * r * r
     per_it = (work["hstep"] if c["mode"] != "w" else 0.0) + (work["wstats"] if c["mode"] != "h" else 0.0)
+    if "k_iter_sf" in plan.describe():
+        work["hstep"] = 2 * half  # the fused small-F iteration: H step and W statistics in the one launch timed as "hstep"
     if c["mode"] == "w" and kl:
         per_it = half
     out = {"shape": name, "F": F, "T": T, "r": r, "beta": c["beta"], "mode": c["mode"], "iterations_per_s": iters / dt,
