@@ -20,7 +20,7 @@ from se_snmf_nat_amd import Context, Plan  # noqa: E402
 
 PEAK = 157.3
 K = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 0
-which = [a for a in sys.argv[1:] if a in ("a11", "c4h", "c4w", "c5", "mel", "melh", "smallr", "tw20", "tw30h", "im50")] or ["a11", "c4h", "c4w", "c5"]
+which = [a for a in sys.argv[1:] if a in ("a11", "c4h", "c4w", "c5", "mel", "melh", "melw", "smallr", "tw20", "tw30h", "im50")] or ["a11", "c4h", "c4w", "c5"]
 ctx = Context(0)
 
 SHAPES = {
@@ -31,6 +31,7 @@ SHAPES = {
     # the HBM-side regime: the Mel solve of run_basis_train.m:90-91 (64 x 72000, r = 100) and a small-rank shape
     "mel": dict(F=64, T=72000, r=100, beta=1.0, sparsity=5.0, mode="full", iters=200, settle=300),
     "melh": dict(F=64, T=100000, r=200, beta=1.0, sparsity=5.0, mode="h", iters=200, settle=300),  # run_basis_DNMF_Mel.m:75
+    "melw": dict(F=64, T=100000, r=100, beta=1.0, sparsity=5.0, mode="w", iters=200, settle=300),  # run_basis_DNMF_Mel.m:82,88
     "smallr": dict(F=257, T=100000, r=32, beta=1.0, sparsity=5.0, mode="full", iters=200, settle=300),
     # settings/bak_IS16_results/initial_setting_SNMF_Techwin_201603_RT.m:47-48 (R_x = 20, R_d = 10) and initial_setting_IMCRA.m:47-48 (R = 50) at F = 513
     "tw20": dict(F=513, T=72000, r=20, beta=1.0, sparsity=5.0, mode="full", iters=200, settle=300),

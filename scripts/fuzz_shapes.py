@@ -1,5 +1,8 @@
 """Development helper: random shapes / modes through the product path against the fp64 oracle (GPU box).
-   python scripts/fuzz_shapes.py [seed] [n_cases] [time budget s]  -> one line per case, FAIL lines at the end.
+   python scripts/fuzz_shapes.py [seed] [n_cases] [time budget s] [focus]  -> one line per case, FAIL lines at the end.
+focus = "r5": only the envelopes of round 5's kernels -- k_iter_sf (F = 33..64, r = 65..128, KL, both factors updated) and
+k_hstep_rp<., CUT> (>= 4 row tiles, r <= 64, more tiles than CUs) -- with their edge cases (partial last tile, F on both sides of
+32n + 1, every sparsity form, cost on / off).
 Shapes are drawn to land on the plan's geometry switches: tile counts around multiples of the CU count (the split last
 round), F on both sides of 32n+1, r around the 32-column tiles and the LX / NK limits, all divergences and update modes."""
 import os
@@ -15,6 +18,7 @@ from se_snmf_nat_amd import SnmfError, sparse_nmf
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 budget = float(sys.argv[3]) if len(sys.argv) > 3 else 420.0
+focus = sys.argv[4] if len(sys.argv) > 4 else ""
 rs = np.random.default_rng(seed)
 
 
@@ -22,7 +26,25 @@ def rel(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
+def draw_r5():
+    if rs.integers(0, 2) == 0:   # the fused small-F iteration
+        F = int(rs.choice([64, 64, 40, 33, 63, int(rs.integers(33, 65))]))
+        r = int(rs.choice([100, 128, 65, 96, 97, int(rs.integers(65, 129))]))
+        T = int(rs.choice([int(rs.integers(1, 300)), int(rs.integers(300, 9000)), int(8192 + 32 * rs.integers(1, 700) + rs.integers(-31, 1)),
+                           int(32 * 256 * rs.integers(1, 4) + rs.integers(-40, 40))]))
+        mode = str(rs.choice(["full", "full", "full", "semi"]))
+    else:                        # the contraction cut
+        F = int(rs.choice([257, 513, 129, 128, 512, 385, 256, int(rs.integers(128, 514))]))
+        r = int(rs.choice([20, 10, 30, 32, 33, 50, 64, 1, int(rs.integers(1, 65))]))
+        T = int(8192 + 32 * rs.integers(1, 500) + rs.integers(-31, 1))
+        mode = str(rs.choice(["full", "h", "h", "semi"]))
+    sp = str(rs.choice(["scalar", "scalar", "vec", "mat", "zero"]))
+    return F, T, r, 1.0, mode, sp
+
+
 def draw():
+    if focus == "r5":
+        return draw_r5()
     F = int(rs.choice([257, 513, 129, 65, 64, 128, 512, 385, 97, 64, 40, 32, int(rs.integers(8, 65)), int(rs.integers(8, 600)), int(rs.integers(8, 200))]))
     r = int(rs.choice([int(rs.integers(1, 40)), int(rs.integers(90, 132)), int(rs.integers(190, 260)), 100, 200, 256, 40,
                        int(rs.integers(257, 700)), int(rs.integers(1, 300))]))

@@ -13,7 +13,7 @@ echo "== bench.py"
 timeout -k 10 400 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err || { tail -20 gpurun_out/${TAG}_bench.err; exit 1; }
 tail -c 1500 gpurun_out/${TAG}_bench.json
 echo "== bench_f513"
-timeout -k 10 400 python scripts/bench_f513.py a11 c4h c4w c5 mel melh smallr tw20 tw30h im50 > gpurun_out/${TAG}_bench_f513.jsonl 2> gpurun_out/${TAG}_bench_f513.err || { tail -20 gpurun_out/${TAG}_bench_f513.err; exit 1; }
+timeout -k 10 400 python scripts/bench_f513.py a11 c4h c4w c5 mel melh melw smallr tw20 tw30h im50 > gpurun_out/${TAG}_bench_f513.jsonl 2> gpurun_out/${TAG}_bench_f513.err || { tail -20 gpurun_out/${TAG}_bench_f513.err; exit 1; }
 cut -c 1-420 gpurun_out/${TAG}_bench_f513.jsonl
 echo "== bench_dropin"
 timeout -k 10 900 python scripts/bench_dropin.py pcie a11 c2 c4 mel c4m > gpurun_out/${TAG}_dropin.jsonl 2> gpurun_out/${TAG}_dropin.err || { tail -20 gpurun_out/${TAG}_dropin.err; exit 1; }
