@@ -299,8 +299,11 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     {
         const char* e = getenv("SNMF_RP_CUT");
         const size_t more = 32 + (size_t)4 * pl->nk * 1024 * 4 + (size_t)pl->rp * 4;
-        pl->rp_cut = pl->NLH == 4 && pl->NWH == 8 && pl->bm == BM_KL && pl->nk <= 2 && pl->nf >= 4 && pl->lds_h + more <= lds_cap && !(e && atoi(e) == 0);
-        if (pl->rp_cut) pl->lds_h += more;
+        const bool shape_ok = pl->NLH == 4 && pl->NWH == 8 && pl->bm == BM_KL && pl->nk <= 2 && pl->nf >= 4 && !(e && atoi(e) == 0);
+        // (rp_cut = 2: the PAIR form -- two column tiles, 8 KB of partials -- where the four-way form's 32 KB do not fit: 513 rows, r = 33..64)
+        const size_t more2 = 32 + (size_t)2048 * 4 + (size_t)pl->rp * 4;
+        pl->rp_cut = !shape_ok ? 0 : pl->lds_h + more <= lds_cap ? 1 : (pl->nk == 2 && pl->lds_h + more2 <= lds_cap) ? 2 : 0;
+        if (pl->rp_cut) pl->lds_h += pl->rp_cut == 2 ? more2 : more;
     }
     pl->lds_mdi = std::max<size_t>(lds1, 2 * kMaxNW * 64 * sizeof(double));  // MDI pass: (NW=8, NT=1, NL=0)
     pl->grid_mdi = std::max(1, std::min(pl->Tp / 32, ctx->n_cu));
@@ -652,7 +655,7 @@ extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
                  pl->rp_tiles, pl->hm_grid);
     else if (kl_pipe)
         snprintf(hs, sizeof hs, "k_hstep_rp (4 P1 + 4 P2 + 4 loader waves%s; %d of %d tiles pipelined, last round split %d ways, grid %d)",
-                 pl->rp_cut ? ", P2 cut four ways over the contraction" : "", pl->rp_full, pl->rp_tiles, pl->rp_S, pl->rp_grid);
+                 pl->rp_cut == 2 ? ", P2 in wave pairs cut over the contraction" : pl->rp_cut ? ", P2 cut four ways over the contraction" : "", pl->rp_full, pl->rp_tiles, pl->rp_S, pl->rp_grid);
     else
         snprintf(hs, sizeof hs, "k_hstep");
     if (pl->generic) {

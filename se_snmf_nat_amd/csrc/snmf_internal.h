@@ -110,7 +110,7 @@ struct snmf_plan {
     // k_hstep_rp launch geometry: tiles [0, rp_full) through the pipeline on rp_grid workgroups, the tiles of the last
     // partial round [rp_full, rp_tiles) cut into rp_S row parts, one workgroup each (rp_S = 0: no split)
     int rp_tiles = 0, rp_full = 0, rp_S = 0, rp_grid = 1;
-    bool rp_cut = false;           // k_hstep_rp<., CUT>: r <= 64, P2 cut four ways over the contraction (SNMF_RP_CUT=0: the column-tile deal)
+    int rp_cut = 0;                // k_hstep_rp<., CUT>: r <= 64, P2 cut over the contraction -- 1: four ways, every column tile; 2: wave pairs, a tile each (SNMF_RP_CUT=0: the column-tile deal)
     bool hm = false;               // KL update launches run k_hstep_m (merged roles, one wave per SIMD: snmf_hstep_m.h); SNMF_HSTEP_M=0/1
     int hm_grid = 1;
     bool rh = false;               // KL update launches run k_hstep_rh (9..16 row tiles, e.g. F = 513: one ratio image, pipelined by half tiles)

@@ -1585,7 +1585,8 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
     unsigned *ready = cnt, *p1a = cnt + 4, *p1b = cnt + 8, *p2done = cnt + 12, *xdone = cnt + 16, *vready = cnt + 20;
     unsigned *wdone = cnt + 28, *rdone = cnt + 32;               // CUT: partial tiles written / read (B team internal)
     float* const Ps = reinterpret_cast<float*>(cnt + 40);        // CUT: [4 waves][nk <= 2 tiles][4 g][64 lanes][4] partial numerators
-    float* const rdph = Ps + 4 * a.nk * 1024;                    // CUT: [rp] 1 ./ dph (rp_cut_group_epilogue)
+    const bool cut_pair = CUT && a.lxh == 2;                     // CUT, two column tiles, 16 row tiles (no room for 32 KB of partials): the pair form below
+    float* const rdph = Ps + (cut_pair ? 2048 : 4 * a.nk * 1024);  // CUT: [rp] 1 ./ dph (rp_cut_group_epilogue)
     double acc_div = 0.0, acc_sh = 0.0;
     if (CUT && !a.S)
         for (int k = threadIdx.x; k < rp; k += NTHR) rdph[k] = fast_rcp(a.dphv[k]);
@@ -1847,6 +1848,57 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                 const int fl = lane & 31, h = lane >> 5;
                 const float* sp = Rs + fl * ldr + 4 * h;
                 const int nq = a.Fq / 8, nqm = a.xr ? nq - 1 : nq, nq1 = 4 * (a.nf < NA ? a.nf : NA);
+                if (cut_pair) {
+                    // PAIR form (two column tiles where the four-way form's 32 KB of partial tiles do not fit: 513 rows at r = 33..64,
+                    // settings/bak_IS16_results/initial_setting_IMCRA.m:47-48 R = 50): B waves (2 i, 2 i + 1) share column tile i, each
+                    // half of the contraction (the odd wave also the extra row's block); a wave stores the two register groups its
+                    // partner finishes (2 KB a wave, 8 KB in all), reads the partner's two for its own, adds them in wave order and runs
+                    // the epilogue on groups 2 hf, 2 hf + 1.  Same MFMA count per wave as the four-way form.
+                    const int ti = wb >> 1, hf = wb & 1;
+                    const int qlo = nqm * hf / 2, qhi = nqm * (hf + 1) / 2;
+                    auto gate = [&]() {
+                        if (qhi <= nq1) rp_await(p1a, (unsigned)(j + 1), a.stop);
+                        else rp_await(p1b, (unsigned)(j + 1), a.stop);
+                    };
+                    auto gate_x = [&]() { rp_await(xdone, (unsigned)(j + 1), a.stop); };
+                    const __amdgpu_buffer_rsrc_t rsk = wimage_rsrc(a.Wk4, (size_t)a.nk * a.Fq * 32);
+                    f32x16 a1[1] = {zero16()};
+                    const int so[1] = {ti * a.Fq * 128 + qlo * 1024};
+                    contract_shared_buf<1>(a1, rsk, lane * 16, so, sp + 8 * qlo, qhi - qlo, gate);
+                    if (hf == 1 && a.xr) {
+                        const int so3[1] = {ti * a.Fq * 128 + nqm * 1024};
+                        contract_shared_buf<1>(a1, rsk, lane * 16, so3, sp + 8 * nqm, 1, gate_x);
+                    }
+                    rp_await(rdone, lx_seq, a.stop);
+#pragma unroll
+                    for (int gg = 0; gg < 2; ++gg) {  // the partner's groups 2 (1 - hf) + gg, wave-uniform register choice by two selects
+                        f32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = hf ? a1[0][4 * gg + e] : a1[0][8 + 4 * gg + e];
+                        *reinterpret_cast<f32x4*>(Ps + (wb * 2 + gg) * 256 + lane * 4) = o;
+                    }
+                    ++lx_seq;
+                    rp_post(wdone, wb, lx_seq, lane);
+                    rp_await(wdone, lx_seq, a.stop);
+                    f32x4 tot[2];
+#pragma unroll
+                    for (int gg = 0; gg < 2; ++gg) {
+                        const f32x4 x = *reinterpret_cast<const f32x4*>(Ps + ((wb ^ 1) * 2 + gg) * 256 + lane * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float mine = hf ? a1[0][8 + 4 * gg + e] : a1[0][4 * gg + e];
+                            tot[gg][e] = hf ? x[e] + mine : mine + x[e];  // (the even wave's partial first: one order on both sides)
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    rp_post(rdone, wb, lx_seq, lane);
+                    float shsum = 0.f;
+                    rp_cut_group_epilogue<OBJ>(a, tot[0], Hs, ti, 2 * hf, t0, lane, rdph, shsum);
+                    rp_cut_group_epilogue<OBJ>(a, tot[1], Hs, ti, 2 * hf + 1, t0, lane, rdph, shsum);
+                    if (OBJ) acc_sh += (double)shsum;
+                    rp_post(p2done, wb, (unsigned)(j + 1), lane);
+                    return;
+                }
                 const int qlo = nqm * wb / NB, qhi = nqm * (wb + 1) / NB;  // this wave's k-blocks of every column tile (+ the extra row's: wave 3)
                 auto gate = [&]() {
                     if (qhi <= nq1) rp_await(p1a, (unsigned)(j + 1), a.stop);

@@ -10,7 +10,8 @@ int launch_hstep_rp(snmf_plan* pl, StepArgs a, bool obj) {
     a.part_S = pl->rp_S;
     a.part_buf = pl->part_buf;
     a.part_cnt = pl->part_cnt;
-    if (pl->rp_cut)  // r <= 64: P2 cut four ways over the contraction (snmf_kernels.h: k_hstep_rp<OBJ, CUT>)
+    a.lxh = pl->rp_cut;  // (k_hstep_rh's field, free here: 2 = the pair form of the cut)
+    if (pl->rp_cut)  // r <= 64: P2 cut over the contraction (snmf_kernels.h: k_hstep_rp<OBJ, CUT>)
         return obj ? launch_big(k_hstep_rp<true, true>, g, b, pl->lds_h, pl->ctx->stream, a)
                    : launch_big(k_hstep_rp<false, true>, g, b, pl->lds_h, pl->ctx->stream, a);
     return obj ? launch_big(k_hstep_rp<true>, g, b, pl->lds_h, pl->ctx->stream, a)

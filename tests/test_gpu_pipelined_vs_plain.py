@@ -37,7 +37,9 @@ SHAPES = [(65, 70, 12000), (129, 70, 12000), (65, 32, 12000), (64, 70, 12000), (
           (64, 128, 70000), (40, 20, 33000), (64, 100, 3000), (32, 8, 100), (64, 256, 9000), (64, 130, 8300),
           # one or two column tiles on >= 4 row tiles: k_hstep_rp<., CUT> (every B wave a quarter of the contraction) -- the reference's
           # R = 20 / 10 / 30 settings at F = 513 (settings/bak_IS16_results/initial_setting_SNMF_Techwin_201603_RT.m:47-48)
-          (513, 20, 12000), (513, 30, 9000), (513, 10, 9000), (257, 32, 20000), (385, 10, 12000), (257, 64, 9000), (129, 50, 12000)]
+          (513, 20, 12000), (513, 30, 9000), (513, 10, 9000), (257, 32, 20000), (385, 10, 12000), (257, 64, 9000), (129, 50, 12000),
+          # ... and its PAIR form where two column tiles' partials do not fit four ways (16 row tiles; initial_setting_IMCRA.m:47-48 R = 50)
+          (513, 50, 12000), (512, 64, 9000), (513, 33, 9000), (481, 40, 12000)]
 
 
 def _run(ctx, V, W0, H0, r, *, h_only, iters):
