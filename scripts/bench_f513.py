@@ -20,7 +20,7 @@ from se_snmf_nat_amd import Context, Plan  # noqa: E402
 
 PEAK = 157.3
 K = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 0
-which = [a for a in sys.argv[1:] if a in ("a11", "c4h", "c4w", "c5", "mel", "melh", "melw", "smallr", "tw20", "tw30h", "im50")] or ["a11", "c4h", "c4w", "c5"]
+which = [a for a in sys.argv[1:] if a in ("a11", "c4h", "c4w", "c5", "mel", "mel288", "melh", "melw", "smallr", "tw20", "tw30h", "im50")] or ["a11", "c4h", "c4w", "c5"]
 ctx = Context(0)
 
 SHAPES = {
@@ -30,6 +30,7 @@ SHAPES = {
     "c5": dict(F=513, T=500000, r=512, beta=2.0, sparsity=50.0, mode="full", iters=10, settle=4),
     # the HBM-side regime: the Mel solve of run_basis_train.m:90-91 (64 x 72000, r = 100) and a small-rank shape
     "mel": dict(F=64, T=72000, r=100, beta=1.0, sparsity=5.0, mode="full", iters=200, settle=300),
+    "mel288": dict(F=64, T=288000, r=100, beta=1.0, sparsity=5.0, mode="full", iters=200, settle=300),  # four times the frames: what the kernels reach past the launch's fixed costs
     "melh": dict(F=64, T=100000, r=200, beta=1.0, sparsity=5.0, mode="h", iters=200, settle=300),  # run_basis_DNMF_Mel.m:75
     "melw": dict(F=64, T=100000, r=100, beta=1.0, sparsity=5.0, mode="w", iters=200, settle=300),  # run_basis_DNMF_Mel.m:82,88
     "smallr": dict(F=257, T=100000, r=32, beta=1.0, sparsity=5.0, mode="full", iters=200, settle=300),
