@@ -1678,12 +1678,46 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
         auto rsrc_of = [&](const float* base, int n_cells) {
             return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, n_cells * 16, 0x00020000);
         };
-        for (int j = 0; j < 2 && j < nst; ++j) {
-            float* bH = lds + j * bufsz;
-            stage_in2<NLT, PA, PB>(a.Hin + (size_t)tile_of(j) * Tt * rp, bH, Tt, rp, ldh, a.V + (size_t)tile_of(j) * Tt * Fp,
-                                   bH + Tt * ldh, Tt, Fp, ldr, lt);
-            rp_post(ready, lw, (unsigned)(j + 1), lane);
-            rp_post(vready, lw, (unsigned)(j + 1), lane);
+        // CUT launches also run on 16 row tiles (513 rows at r <= 64), where a V tile is 17 cells a loader thread and does not fit the
+        // register path (`fits`; with PB = 17 the loaders spill 66 registers and every CUT shape got slower).  The refill after
+        // p2done was stage_in's batches of 8 cells -- two or three exposed HBM round trips per tile: the A team waited 10 k of
+        // its 19 k cycles per tile for `ready` (phase stamps, 513 x 72000 r = 20).  Under CUT that path is LDS-DMA: every piece of
+        // the tile (a padded row of H, three pieces of a row of V) in flight at once, no registers, one round trip.
+        typedef __attribute__((address_space(3))) void* lds_ptr_t;
+        auto dma_v = [&](int tile, float* bH) {
+            const __amdgpu_buffer_rsrc_t rv =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.V + (size_t)tile * Tt * Fp), 0, Tt * Fp * 4, 0x00020000);
+            for (int t = lw; t < Tt; t += NL)
+                for (int pc = 0; pc * 256 < Fp; ++pc)
+                    if (pc * 256 + lane * 4 < Fp)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(bH + Tt * ldh + t * ldr + pc * 256), 16, lane * 16,
+                                                                 (t * Fp + pc * 256) * 4, 0, 0);
+        };
+        auto dma_h = [&](int tile, float* bH) {
+            const __amdgpu_buffer_rsrc_t rh =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Hin + (size_t)tile * Tt * rp), 0, Tt * rp * 4, 0x00020000);
+            for (int t = lw; t < Tt; t += NL)
+                if (lane * 4 < rp)  // (rp <= 64 under CUT: one piece per row)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, (lds_ptr_t)(bH + t * ldh), 16, lane * 16, t * rp * 4, 0, 0);
+        };
+        if (CUT && !fits) {
+            for (int j = 0; j < 2 && j < nst; ++j) {
+                dma_h(tile_of(j), lds + j * bufsz);
+                dma_v(tile_of(j), lds + j * bufsz);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing else orders a ds_read behind an LDS-DMA
+            for (int j = 0; j < 2 && j < nst; ++j) {
+                rp_post(ready, lw, (unsigned)(j + 1), lane);
+                rp_post(vready, lw, (unsigned)(j + 1), lane);
+            }
+        } else {
+            for (int j = 0; j < 2 && j < nst; ++j) {
+                float* bH = lds + j * bufsz;
+                stage_in2<NLT, PA, PB>(a.Hin + (size_t)tile_of(j) * Tt * rp, bH, Tt, rp, ldh, a.V + (size_t)tile_of(j) * Tt * Fp,
+                                       bH + Tt * ldh, Tt, Fp, ldr, lt);
+                rp_post(ready, lw, (unsigned)(j + 1), lane);
+                rp_post(vready, lw, (unsigned)(j + 1), lane);
+            }
         }
         for (int j = 0; j < nst; ++j) {
             float* bH = lds + (j & 1) * bufsz;
@@ -1718,13 +1752,24 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                 continue;
             }
             float* const dstH = a.Hout + (size_t)tile_of(j) * Tt * rp;
-            if (!fits) {  // shape too big for the register path: plain copy-out, then a plain (latency-exposed) refill
-                stage_out<NLT>(dstH, bH, Tt, rp, ldh, lt);
-                if (more) {
-                    stage_in<NLT>(a.Hin + (size_t)tile_of(j + 2) * Tt * rp, bH, Tt, rp, ldh, lt);
-                    stage_in<NLT>(a.V + (size_t)tile_of(j + 2) * Tt * Fp, bH + Tt * ldh, Tt, Fp, ldr, lt);
-                    rp_post(ready, lw, (unsigned)(j + 3), lane);
-                    rp_post(vready, lw, (unsigned)(j + 3), lane);
+            if (!fits) {  // shape too big for the register path: plain copy-out, then a refill that starts only now
+                if constexpr (CUT) {
+                    if (more) dma_v(tile_of(j + 2), bH);  // (the ratio image is free: P2 of tile j is done)
+                    stage_out<NLT>(dstH, bH, Tt, rp, ldh, lt);
+                    if (more) {
+                        dma_h(tile_of(j + 2), bH);         // (behind the copy-out's LDS reads in program order)
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        rp_post(ready, lw, (unsigned)(j + 3), lane);
+                        rp_post(vready, lw, (unsigned)(j + 3), lane);
+                    }
+                } else {
+                    stage_out<NLT>(dstH, bH, Tt, rp, ldh, lt);
+                    if (more) {
+                        stage_in<NLT>(a.Hin + (size_t)tile_of(j + 2) * Tt * rp, bH, Tt, rp, ldh, lt);
+                        stage_in<NLT>(a.V + (size_t)tile_of(j + 2) * Tt * Fp, bH + Tt * ldh, Tt, Fp, ldr, lt);
+                        rp_post(ready, lw, (unsigned)(j + 3), lane);
+                        rp_post(vready, lw, (unsigned)(j + 3), lane);
+                    }
                 }
                 continue;
             }
@@ -1764,7 +1809,11 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             SNMF_STAMP(11);
             bool waited = false;
             auto gate_ready = [&]() {  // the tile's H image: waited for once, behind the first W fragments of the tile
-                if (!waited) rp_await(ready, (unsigned)(j + 1), a.stop);
+                if (!waited) {
+                    SNMF_STAMP(4);
+                    rp_await(ready, (unsigned)(j + 1), a.stop);
+                    SNMF_STAMP(3);  // (diagnostic builds: the wait for the staged tile by itself)
+                }
                 waited = true;
             };
             bool vwaited = false;
@@ -1775,6 +1824,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             const int fl = lane & 31, h = lane >> 5;
             const float* sp = Hs + fl * ldh + 4 * h;
             float dsum = 0.f;
+            const bool early_pair = CUT && a.nf > 2 * NA;  // (see the B team's k-ranges under CUT)
             for (int phi = w; phi < a.nf; phi += 2 * NA) {
                 if (phi + NA < a.nf) {
                     f32x16 acc[2] = {zero16(), zero16()};
@@ -1783,8 +1833,9 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     SNMF_STAMP(4);
                     gate_v();
                     rp_p1_epilogue<OBJ>(a, acc[0], Rs, phi, t0, lane, dsum);
-                    if (phi == w) rp_post(p1a, w, (unsigned)(j + 1), lane);  // row tile w < NA: this wave's share of the first 32*NA ratio rows
+                    if (phi == w && !early_pair) rp_post(p1a, w, (unsigned)(j + 1), lane);  // row tile w < NA: this wave's share of the first 32*NA ratio rows
                     rp_p1_epilogue<OBJ>(a, acc[1], Rs, phi + NA, t0, lane, dsum);
+                    if (phi == w && early_pair) rp_post(p1a, w, (unsigned)(j + 1), lane);   // CUT, 9..16 row tiles: the first 64*NA rows
                     SNMF_STAMP(5);
                 } else {
                     f32x16 acc[1] = {zero16()};
@@ -1847,7 +1898,8 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             if constexpr (CUT) {
                 const int fl = lane & 31, h = lane >> 5;
                 const float* sp = Rs + fl * ldr + 4 * h;
-                const int nq = a.Fq / 8, nqm = a.xr ? nq - 1 : nq, nq1 = 4 * (a.nf < NA ? a.nf : NA);
+                const int nq = a.Fq / 8, nqm = a.xr ? nq - 1 : nq;
+                const int ne0 = 4 * NA * (a.nf > 2 * NA ? 2 : 1), ne = ne0 < nqm ? ne0 : nqm;  // k-blocks over the ratio rows p1a covers
                 if (cut_pair) {
                     // PAIR form (two column tiles where the four-way form's 32 KB of partial tiles do not fit: 513 rows at r = 33..64,
                     // settings/bak_IS16_results/initial_setting_IMCRA.m:47-48 R = 50): B waves (2 i, 2 i + 1) share column tile i, each
@@ -1855,20 +1907,28 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     // partner finishes (2 KB a wave, 8 KB in all), reads the partner's two for its own, adds them in wave order and runs
                     // the epilogue on groups 2 hf, 2 hf + 1.  Same MFMA count per wave as the four-way form.
                     const int ti = wb >> 1, hf = wb & 1;
-                    const int qlo = nqm * hf / 2, qhi = nqm * (hf + 1) / 2;
-                    auto gate = [&]() {
-                        if (qhi <= nq1) rp_await(p1a, (unsigned)(j + 1), a.stop);
-                        else rp_await(p1b, (unsigned)(j + 1), a.stop);
-                    };
+                    auto gate_e = [&]() { rp_await(p1a, (unsigned)(j + 1), a.stop); };
+                    auto gate_l = [&]() { rp_await(p1b, (unsigned)(j + 1), a.stop); };
                     auto gate_x = [&]() { rp_await(xdone, (unsigned)(j + 1), a.stop); };
                     const __amdgpu_buffer_rsrc_t rsk = wimage_rsrc(a.Wk4, (size_t)a.nk * a.Fq * 32);
                     f32x16 a1[1] = {zero16()};
-                    const int so[1] = {ti * a.Fq * 128 + qlo * 1024};
-                    contract_shared_buf<1>(a1, rsk, lane * 16, so, sp + 8 * qlo, qhi - qlo, gate);
+                    {   // this wave's half of the EARLY rows (those p1a covers), then its half of the late ones
+                        const int qlo = ne * hf / 2, qhi = ne * (hf + 1) / 2;
+                        const int so[1] = {ti * a.Fq * 128 + qlo * 1024};
+                        contract_shared_buf<1>(a1, rsk, lane * 16, so, sp + 8 * qlo, qhi - qlo, gate_e);
+                    }
+                    if (nqm > ne) {
+                        const int qlo = ne + (nqm - ne) * hf / 2, qhi = ne + (nqm - ne) * (hf + 1) / 2;
+                        const int so[1] = {ti * a.Fq * 128 + qlo * 1024};
+                        contract_shared_buf<1>(a1, rsk, lane * 16, so, sp + 8 * qlo, qhi - qlo, gate_l);
+                    } else {
+                        gate_l();
+                    }
                     if (hf == 1 && a.xr) {
                         const int so3[1] = {ti * a.Fq * 128 + nqm * 1024};
                         contract_shared_buf<1>(a1, rsk, lane * 16, so3, sp + 8 * nqm, 1, gate_x);
                     }
+                    SNMF_STAMP(9);
                     rp_await(rdone, lx_seq, a.stop);
 #pragma unroll
                     for (int gg = 0; gg < 2; ++gg) {  // the partner's groups 2 (1 - hf) + gg, wave-uniform register choice by two selects
@@ -1897,28 +1957,48 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     rp_cut_group_epilogue<OBJ>(a, tot[1], Hs, ti, 2 * hf + 1, t0, lane, rdph, shsum);
                     if (OBJ) acc_sh += (double)shsum;
                     rp_post(p2done, wb, (unsigned)(j + 1), lane);
+                    SNMF_STAMP(10);
                     return;
                 }
-                const int qlo = nqm * wb / NB, qhi = nqm * (wb + 1) / NB;  // this wave's k-blocks of every column tile (+ the extra row's: wave 3)
-                auto gate = [&]() {
-                    if (qhi <= nq1) rp_await(p1a, (unsigned)(j + 1), a.stop);
-                    else rp_await(p1b, (unsigned)(j + 1), a.stop);
-                };
+                // this wave's k-blocks of every column tile: a quarter of the EARLY ratio rows (those p1a covers: the first 32 NA, or
+                // 64 NA on more than 2 NA row tiles) and a quarter of the late ones (p1b) -- every B wave starts while the A team is
+                // still at work and has only half of its blocks left when the last ratio row lands (as contiguous quarters two
+                // waves sat idle until p1b); wave 3 also takes the extra row's block
+                auto gate_e = [&]() { rp_await(p1a, (unsigned)(j + 1), a.stop); };
+                auto gate_l = [&]() { rp_await(p1b, (unsigned)(j + 1), a.stop); };
                 auto gate_x = [&]() { rp_await(xdone, (unsigned)(j + 1), a.stop); };
+                const int qe0 = ne * wb / NB, qe1 = ne * (wb + 1) / NB;
+                const int ql0 = ne + (nqm - ne) * wb / NB, ql1 = ne + (nqm - ne) * (wb + 1) / NB;
                 const __amdgpu_buffer_rsrc_t rsk = wimage_rsrc(a.Wk4, (size_t)a.nk * a.Fq * 32);
                 const bool two = a.nk > 1;
                 f32x16 acc[2] = {zero16(), zero16()};
                 if (two) {
-                    const int so[2] = {qlo * 1024, a.Fq * 128 + qlo * 1024};
-                    contract_shared_buf<2>(acc, rsk, lane * 16, so, sp + 8 * qlo, qhi - qlo, gate);
+                    {
+                        const int so[2] = {qe0 * 1024, a.Fq * 128 + qe0 * 1024};
+                        contract_shared_buf<2>(acc, rsk, lane * 16, so, sp + 8 * qe0, qe1 - qe0, gate_e);
+                    }
+                    if (ql1 > ql0) {
+                        const int so[2] = {ql0 * 1024, a.Fq * 128 + ql0 * 1024};
+                        contract_shared_buf<2>(acc, rsk, lane * 16, so, sp + 8 * ql0, ql1 - ql0, gate_l);
+                    } else {
+                        gate_l();
+                    }
                     if (wb == NB - 1 && a.xr) {
                         const int so3[2] = {nqm * 1024, a.Fq * 128 + nqm * 1024};
                         contract_shared_buf<2>(acc, rsk, lane * 16, so3, sp + 8 * nqm, 1, gate_x);
                     }
                 } else {
                     f32x16 a1[1] = {zero16()};
-                    const int so[1] = {qlo * 1024};
-                    contract_shared_buf<1>(a1, rsk, lane * 16, so, sp + 8 * qlo, qhi - qlo, gate);
+                    {
+                        const int so[1] = {qe0 * 1024};
+                        contract_shared_buf<1>(a1, rsk, lane * 16, so, sp + 8 * qe0, qe1 - qe0, gate_e);
+                    }
+                    if (ql1 > ql0) {
+                        const int so[1] = {ql0 * 1024};
+                        contract_shared_buf<1>(a1, rsk, lane * 16, so, sp + 8 * ql0, ql1 - ql0, gate_l);
+                    } else {
+                        gate_l();
+                    }
                     if (wb == NB - 1 && a.xr) {
                         const int so3[1] = {nqm * 1024};
                         contract_shared_buf<1>(a1, rsk, lane * 16, so3, sp + 8 * nqm, 1, gate_x);
@@ -1926,6 +2006,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     acc[0] = a1[0];
                 }
                 // partial tiles -> LDS, once every wave has read the previous tile's
+                SNMF_STAMP(9);
                 rp_await(rdone, lx_seq, a.stop);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -1958,6 +2039,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                 if (two) rp_cut_group_epilogue<OBJ>(a, tot[1], Hs, 1, wb, t0, lane, rdph, shsum);
                 if (OBJ) acc_sh += (double)shsum;
                 rp_post(p2done, wb, (unsigned)(j + 1), lane);
+                SNMF_STAMP(10);
                 return;
             }
             auto gate_p1a = [&]() { rp_await(p1a, (unsigned)(j + 1), a.stop); };

@@ -33,8 +33,8 @@ static void snmf_prof_report(snmf_plan* pl) {
             for (int i = 0; i < nw; ++i)
                 for (int j = 0; j < 12; ++j) ((i & 7) < 4 ? ta : tb)[j] += (double)hp[(size_t)i * 12 + j];
             for (int j = 0; j < 12; ++j) { sa += ta[j]; sb += tb[j]; }
-            fprintf(stderr, " | A team (cycles/wave %.0f): loop+wait %.1f%% epilogues %.1f%% other %.1f%% p1b+xrow %.1f%% | B team (%.0f): gates+loop %.1f%% epilogues %.1f%% post+top %.1f%%",
-                    sa / (nw / 2), 100 * ta[4] / sa, 100 * ta[5] / sa, 100 * ta[6] / sa, 100 * ta[11] / sa, sb / (nw / 2), 100 * tb[9] / sb,
+            fprintf(stderr, " | A team (cycles/wave %.0f): wait for ready %.1f%% loop %.1f%% epilogues %.1f%% other %.1f%% p1b+xrow %.1f%% | B team (%.0f): gates+loop %.1f%% epilogues %.1f%% post+top %.1f%%",
+                    sa / (nw / 2), 100 * ta[3] / sa, 100 * ta[4] / sa, 100 * ta[5] / sa, 100 * ta[6] / sa, 100 * ta[11] / sa, sb / (nw / 2), 100 * tb[9] / sb,
                     100 * tb[10] / sb, 100 * tb[11] / sb);
         }
         std::vector<unsigned long long> hc((size_t)2 * nw);
