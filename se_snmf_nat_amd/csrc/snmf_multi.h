@@ -172,7 +172,12 @@ static bool multi_barrier(snmf_multi* m, int seq, bool i_failed) {
 // ---- teams ---------------------------------------------------------------------------------------------------------
 static std::mutex g_team_mu;
 static std::vector<MultiTeam*> g_teams;   // every team of the process (idle ones have refs == 0)
-constexpr int kMaxIdleTeams = 4;
+// Idle teams kept for the next handle on the same device list (SNMF_TEAM_CACHE overrides; 0 = none).  A rank of a team that has
+// moved host arrays holds its contexts' bounce buffers (2 x 48 MiB pinned + as much device staging), so the cache is kept short.
+static int max_idle_teams() {
+    const char* e = getenv("SNMF_TEAM_CACHE");
+    return e ? std::max(0, atoi(e)) : 2;
+}
 
 static void team_destroy(MultiTeam* t) {
     for (int g = 0; g < (int)t->ctx.size(); ++g) {
@@ -253,6 +258,7 @@ static int team_reserve(MultiTeam* t, size_t xlen) {
         hipStreamSynchronize(t->ctx[g]->aux->stream);
         if (t->slots[g]) hipFree(t->slots[g]);
         t->slots[g] = nullptr;
+        t->slots_cap = 0;  // (a failure below leaves some ranks without a buffer: the next handle starts over)
         if (hipExtMallocWithFlags((void**)&t->slots[g], need * sizeof(double), hipDeviceMallocFinegrained) != hipSuccess) {
             (void)hipGetLastError();
             t->fine_grained = false;  // (coarse-grained memory: only EVENTS ordering is safe, see snmf_multi_set_exchange)
@@ -288,7 +294,7 @@ static void team_release(MultiTeam* t) {
         if (--t->refs > 0) return;
         int idle = 0;
         for (MultiTeam* q : g_teams) idle += q->refs == 0;
-        if (idle > kMaxIdleTeams) {
+        if (idle > max_idle_teams()) {
             g_teams.erase(std::find(g_teams.begin(), g_teams.end(), t));
             kill = t;
         }

@@ -188,3 +188,26 @@ def test_a_refused_device_list_leaves_no_sticky_error_behind(gpu_ctx, lib):
     V, W0, H0 = synth_problem(64, 40, 8)
     w, _, o = sparse_nmf(V, dict(cf="kl", sparsity=1, max_iter=3, init_w=W0, init_h=H0, cost_check=1), ctx=gpu_ctx)
     assert np.isfinite(w).all() and o["n_iter"] == 3
+
+
+def test_device_list_calls_reuse_or_rebuild_their_team(gpu_ctx, monkeypatch):
+    """A device list's set-up (contexts, peer access, gather buffers) is cached per list between calls (csrc/snmf_multi.h: MultiTeam);
+    SNMF_TEAM_CACHE=0 tears it down with the handle.  Either way a call must not see anything of its predecessors: the same
+    problem gives the same bits, a LARGER exchange after a smaller one (the gather buffers are re-allocated under the
+    cached team) and a different rank count in between included."""
+    from se_snmf_nat_amd import sparse_nmf
+    small = dict(F=129, T=700, r=24, cf="kl", sparsity=0.3, max_iter=8, conv_eps=0.0, n=2)
+    big = dict(F=257, T=2100, r=64, cf="kl", sparsity=5.0, max_iter=8, conv_eps=0.0, n=2)
+    out = {}
+    for cache in ("2", "0"):
+        monkeypatch.setenv("SNMF_TEAM_CACHE", cache)
+        res = []
+        for case, n in ((small, 2), (big, 2), (small, 3), (big, 2), (small, 2)):
+            V, W0, H0 = synth_problem(case["F"], case["T"], case["r"])
+            w, h, o = sparse_nmf(V, _p(case, W0, H0), devices=[0] * n)
+            res.append((case["F"], n, w, h, o["cost"]))
+        out[cache] = res
+        assert np.array_equal(res[0][2], res[4][2]) and np.array_equal(res[0][3], res[4][3])   # small, 2 ranks: first and last call
+        assert np.array_equal(res[1][2], res[3][2]) and np.array_equal(res[1][3], res[3][3])   # big, 2 ranks
+    for a, b in zip(out["2"], out["0"]):
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
