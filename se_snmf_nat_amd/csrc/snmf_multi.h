@@ -292,11 +292,15 @@ static void team_release(MultiTeam* t) {
     {
         std::lock_guard<std::mutex> lk(g_team_mu);
         if (--t->refs > 0) return;
+        // most recently used last; past the limit the LEAST recently used idle team goes (with a limit of 0: this one)
+        g_teams.erase(std::find(g_teams.begin(), g_teams.end(), t));
+        g_teams.push_back(t);
         int idle = 0;
         for (MultiTeam* q : g_teams) idle += q->refs == 0;
         if (idle > max_idle_teams()) {
-            g_teams.erase(std::find(g_teams.begin(), g_teams.end(), t));
-            kill = t;
+            auto it = std::find_if(g_teams.begin(), g_teams.end(), [](MultiTeam* q) { return q->refs == 0; });
+            kill = *it;
+            g_teams.erase(it);
         }
     }
     if (kill) team_destroy(kill);
