@@ -487,6 +487,24 @@ def main():
         # the contract times the CPU baseline on rank 0 at N = 1 only
     del tr
     torch.cuda.empty_cache()
+    guard = None
+    if world > 1:
+        # The extra legs below must never cost the headline measurement: if a rank fails INSIDE one of their loops its peers sit in
+        # a collective until the backend's own time-out (ten minutes) kills the job -- and the line with it.  A timer on every rank
+        # ends the process first; rank 0 prints what it has.
+        import threading
+
+        def bail():
+            if rank == 0:
+                out.setdefault("c5_strong", {"error": "the extra legs timed out"})
+                out.setdefault("c4_dnmf", {"error": "the extra legs timed out"})
+                out.setdefault("exchange_oneshot", {"error": "skipped: the extra legs timed out"})
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        guard = threading.Timer(float(os.environ.get("SNMF_BENCH_EXTRA_TIMEOUT", "420")), bail)
+        guard.daemon = True
+        guard.start()
     if world > 1:
         # SURVEY.md section 8d asks strong scaling on "C2 and C5": the SAME loop on BASELINE configs[4] (513 x 500000, r = 512,
         # beta = 2, lambda = 50: 11 ms per iteration on one GPU, the config where the fixed costs of an iteration are small
@@ -507,7 +525,11 @@ def main():
             # the same problem through the one-shot peer-store exchange behind the C ABI, AFTER the timed RCCL leg (the
             # other ranks are gone or idle by now); reported beside `value`, never instead of it
             out["exchange_oneshot"] = finish_oneshot_child(oneshot)
+        if guard:
+            guard.cancel()
         print(json.dumps(out), flush=True)
+    elif guard:
+        guard.cancel()
 
 
 def c5_strong_leg(world, rank, local_rank, torch, dist, F=513, T=500_000, r=512, steps=10, warm=4):

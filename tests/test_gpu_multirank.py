@@ -181,6 +181,27 @@ def test_bench_launches_its_own_ranks():
     assert abs(c4["final_cost_solve3_one_gpu"] - c4["final_cost_solve3"]) <= 1e-6 * c4["final_cost_solve3"]
 
 
+def test_bench_extra_legs_cannot_cost_the_headline_line():
+    """The N > 1 line's extra legs (C5, the sharded DNMF, the one-shot exchange) run behind a timer: when they do not come back --
+    a rank failed inside a loop and its peers sit in a collective -- rank 0 still prints the ONE line with the headline
+    measurement, the legs marked as timed out, and every rank exits cleanly."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SNMF_DIST_BACKEND="gloo", SNMF_FORCE_DEVICE="0", SNMF_BENCH_EXTRA_TIMEOUT="0.001")
+    pr = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                         "--T", "6400", "--r", "64", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE,
+                        stderr=subprocess.PIPE, text=True, timeout=900)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, pr.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["steps"] == 4
+    assert "timed out" in d["c5_strong"]["error"] and "timed out" in d["c4_dnmf"]["error"]
+
+
 def test_bench_single_gpu_line_keeps_the_contract():
     """One GPU, default launcher-less invocation: ONE JSON line with the contract's keys, the roofline object (bound,
     achieved, peak, unit, frac, traffic, measured on the engine's stream with HIP events) and -- with the CPU leg on -- the
