@@ -463,9 +463,18 @@ def main():
     div, cost, n_it = tr.plan.get_objective()
     last_cost = [c for c in cost if c != 0.0]
     fams = [fam]
+    replicas_identical = None
     if world > 1:
         fams = [None] * world
         dist.all_gather_object(fams, fam)
+        # every rank applies the same deterministic W update to the same summed statistics: the replicas of W must agree BIT FOR BIT
+        # (outside the timed region; on a node with a device per rank this is the check that the exchange delivered the same sum to all)
+        import zlib
+        crc = torch.tensor([float(zlib.crc32(np.ascontiguousarray(tr.plan.get_w()).tobytes()))], dtype=torch.float64, device="cuda")
+        lo, hi = crc.clone(), crc.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_identical = bool(lo.item() == hi.item())
     if rank == 0:
         ms = dt / K * 1e3
         tot = 2 * flops_half / (ms * 1e-3) / 1e12
@@ -483,6 +492,8 @@ def main():
                          "kernel_ms_per_rank": fams},
             "final_cost": float(last_cost[-1]) if last_cost else None,
         }
+        if replicas_identical is not None:
+            out["w_replicas_bit_identical"] = replicas_identical
         out["cost_vs_oracle"] = cost_vs_oracle(F, T, r, len(last_cost), out["final_cost"])
         # the contract times the CPU baseline on rank 0 at N = 1 only
     del tr

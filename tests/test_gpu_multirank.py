@@ -158,6 +158,7 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1, pr.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2 and d["value"] > 0
+    assert d["w_replicas_bit_identical"] is True
     assert d["scaling"] == "strong" and "frames/2" in d["config"]["parallelism"]
     assert len(d["roofline"]["kernel_ms_per_rank"]) == 2 and all(k["hstep"] > 0 for k in d["roofline"]["kernel_ms_per_rank"])
     assert d["final_cost"] and d["final_cost"] > 0
