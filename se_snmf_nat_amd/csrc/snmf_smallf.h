@@ -451,7 +451,8 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_wstats_sf(StepArgs a, int 
 //                 (t, h)) comes out of the hand-off buffer with the 16-byte reads that mirror the writes, P4's B operand (H_new
 //                 with the components in lanes) with 4-byte reads of the same buffer -- no second trip to L2 for H, nothing of
 //                 it in the wave's vmcnt queue; V once more with the rows in lanes (4-byte loads of lines its partner fetched
-//                 a tile earlier).  It owns the statistics of BOTH row tiles: NF * NK accumulator tiles, pinned to a[0:127].
+//                 a tile earlier).  It owns the statistics of BOTH row tiles: NF * NK accumulator tiles (pinning them to a[0:127] with an "a" asm constraint
+//                 fixed the kernel-wide register split at 128 / 128 and made the H waves spill: they are ordinary values).
 // Why pairs and not one wave that does everything: the statistics of both row tiles are 128 registers and a tile's other state
 // ~240, so a do-everything wave is alone on its SIMD -- built first, 68.8 us against 73.0 for the two launches (Mel 64 x 72000,
 // r = 100): with one wave per SIMD every latency of the tile (the operand loads' HBM round trip first of all) is exposed.
@@ -465,12 +466,6 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_wstats_sf(StepArgs a, int 
 // Dynamic LDS: Wt4 image (P1 and P3), Wk4 image (P2), 1 ./ dph and lambda_k [rp] each, 4 hand-off buffers, 8 progress words; the
 // end of the kernel reuses it for the pairs' partial statistics as k_wstats_sf does.
 
-// G += a (x) b with the accumulator tile PINNED to the accumulation registers ("a" constraint).  The NF * NK statistics tiles live
-// across the whole kernel; left to the allocator they are ordinary values that move between the two register classes around
-// every phase (hundreds of v_accvgpr moves per tile).  As operands of this statement their home is a[...].
-__device__ __forceinline__ void mfma32_acc_agpr(f32x16& g, float a, float b) {
-    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(g) : "v"(a), "v"(b));
-}
 __device__ __forceinline__ void sf_post(unsigned* word, unsigned val, int lane) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     if (lane == 0) __hip_atomic_store(word, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
