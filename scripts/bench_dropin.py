@@ -8,6 +8,7 @@ MATLAB doubles), split into host->device / solve / device->host, next to the bar
         as three sparse_nmf calls (round 3's path), as ONE resident call on features (fp64 and fp32 host arrays), and from the
         two waveforms (audio in, B_hat out)
   mel   run_basis_train.m:91: the Mel solve (64 x 72000, r = 100) -- the HBM-side shape
+  c4mel the three solves of run_basis_DNMF_Mel.m (64 Mel bands, 100000 frames): one resident call, and the solves alone
   c4m   BASELINE configs[3] behind a DEVICE LIST (snmf_run_basis_dnmf_multi_f64): n = 2, 4, 8 ranks that share device 0 (the box
         has one GPU: EVENTS ordering), the whole 513 x 100000 problem sharded; beside it n x (one shard's three resident solves)
 
@@ -173,6 +174,31 @@ if "c4" in which:
         t = time.perf_counter(); Bh = train.run_basis_DNMF(xs, ds, B, fp, ctx=ctx, h0="device"); best = min(best, time.perf_counter() - t)
     emit(config=f"C4 run_basis_DNMF(x, d, B, p) from the waveforms ({n} samples -> {F}x{T}), B_hat out", call_s=best,
          solver_iterations_per_s=150 / best, audio_MB=2 * n * 4 / 1e6)
+
+if "c4mel" in which:
+    # run_basis_DNMF_Mel.m:75-88 -- the same three solves on 64 Mel bands (H-only at r = 200: k_hstep_sf, W-only x 2 at r = 100: k_wstats_sf)
+    from se_snmf_nat_amd.api import _run_basis_dnmf_resident
+    F, T, Rx, Rd = 64, 100_000, 100, 100
+    X, _, _ = synth(F, T, Rx, 1); D, _, _ = synth(F, T, Rd, 2)
+    Y = np.asfortranarray(X + D + 1e-9)
+    B = np.asfortranarray(np.random.default_rng(3).random((F, Rx + Rd)))
+    p = dict(cf="kl", sparsity=5, max_iter=50, conv_eps=0, cost_check=1, random_seed=1)
+    run_basis_dnmf(Y[:, :4096], X[:, :4096], D[:, :4096], B, Rx, Rd, p, ctx=ctx)
+    for dtype in (np.float64, np.float32):
+        Yd, Xd, Dd = (np.asfortranarray(M, dtype=dtype) for M in (Y, X, D))
+        best = 1e9
+        for _ in range(3):
+            t = time.perf_counter()
+            _run_basis_dnmf_resident(Yd, Xd, Dd, B, Rx, Rd, p, ctx=ctx, dtype=dtype, h0="device", want_a=False)
+            best = min(best, time.perf_counter() - t)
+        emit(config=f"C4-Mel run_basis_DNMF_Mel 3 solves x 50 it, {F}x{T}, R_x=R_d=100: one resident call, B_hat only", host_dtype=np.dtype(dtype).name,
+             call_s=best, solver_iterations_per_s=150 / best)
+    solve = 0.0
+    _, _, H0 = synth(F, T, Rx + Rd, 5, np.float32)
+    solve += resident_solve_s(F, T, Rx + Rd, 50, Y, B, H0, beta=1.0, sparsity=5.0, w_update_ind=np.zeros(Rx + Rd, bool))
+    for M, r0 in ((X, 0), (D, Rx)):
+        solve += resident_solve_s(F, T, Rx, 50, M, B[:, r0:r0 + Rx], H0[r0:r0 + Rx], beta=1.0, sparsity=5.0, h_update_ind=np.zeros(Rx, bool))
+    emit(config="C4-Mel the three solves alone, data resident", resident_solve_s=solve, solver_iterations_per_s=150 / solve)
 
 if "c4m" in which:
     # The device-list entry of run_basis_DNMF (round 5): every rank's shard through its own pinned pipeline, A_hat resident per rank.

@@ -16,7 +16,7 @@ echo "== bench_f513"
 timeout -k 10 400 python scripts/bench_f513.py a11 c4h c4w c5 mel melh melw smallr tw20 tw30h im50 > gpurun_out/${TAG}_bench_f513.jsonl 2> gpurun_out/${TAG}_bench_f513.err || { tail -20 gpurun_out/${TAG}_bench_f513.err; exit 1; }
 cut -c 1-420 gpurun_out/${TAG}_bench_f513.jsonl
 echo "== bench_dropin"
-timeout -k 10 900 python scripts/bench_dropin.py pcie a11 c2 c4 mel c4m > gpurun_out/${TAG}_dropin.jsonl 2> gpurun_out/${TAG}_dropin.err || { tail -20 gpurun_out/${TAG}_dropin.err; exit 1; }
+timeout -k 10 900 python scripts/bench_dropin.py pcie a11 c2 c4 mel c4mel c4m > gpurun_out/${TAG}_dropin.jsonl 2> gpurun_out/${TAG}_dropin.err || { tail -20 gpurun_out/${TAG}_dropin.err; exit 1; }
 cut -c 1-500 gpurun_out/${TAG}_dropin.jsonl
 echo "== bench_online"
 timeout -k 10 300 python scripts/bench_online.py > gpurun_out/${TAG}_bench_online.jsonl 2> gpurun_out/${TAG}_bench_online.err || { tail -20 gpurun_out/${TAG}_bench_online.err; exit 1; }
