@@ -443,8 +443,8 @@ int snmf_sparse_nmf_multi_f32(const int32_t* devices, int32_t n_dev, const snmf_
  * columns of A_hat in HBM for solves 2 / 3, one exchange of the W statistics per iteration, only B_hat (and A_hat when asked
  * for) comes back.  H0 == NULL: rank g draws columns [col_g, col_g+1) of the (R_x + R_d) x T Philox draw, so the result does not
  * depend on the number of ranks beyond the order in which the ranks' statistics are summed (a few fp32 ulp on B_hat; A_hat
- * bit for bit).  The ranks' contexts, gather buffers and peer-access grants are built once per device list and kept for the
- * life of the process (csrc/snmf_multi.h: teams). */
+ * bit for bit).  The ranks' contexts, gather buffers and peer-access grants are built once per device list and kept for later calls
+ * on the same list (csrc/snmf_multi.h: teams; the two most recently used idle lists, SNMF_TEAM_CACHE=n overrides, 0 = none). */
 int snmf_run_basis_dnmf_multi_f64(const int32_t* devices, int32_t n_dev, const snmf_params* p, int32_t R_x, int32_t R_d,
                                   const double* Y, int64_t ldY, const double* X, int64_t ldX, const double* D, int64_t ldD,
                                   const double* B, int64_t ldB, const double* H0, uint64_t seed, double* B_hat, int64_t ldBh,
