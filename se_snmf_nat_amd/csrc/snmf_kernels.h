@@ -1755,9 +1755,23 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             if (!fits) {  // shape too big for the register path: plain copy-out, then a refill that starts only now
                 if constexpr (CUT) {
                     if (more) dma_v(tile_of(j + 2), bH);  // (the ratio image is free: P2 of tile j is done)
-                    stage_out<NLT>(dstH, bH, Tt, rp, ldh, lt);
+                    // H_new leaves BY ROWS, wave lw the rows lw, lw + 4, ... it is about to overwrite: stage_out's linear cell deal
+                    // left another wave's cells of such a row unread when this wave's DMA landed in it (found by the shape fuzzer:
+                    // 6 of 39 solves with three or more tiles per workgroup off by 1e-3 .. 1e-1; two tiles per workgroup -- all
+                    // the unit tests had -- never refill)
+                    {
+                        const char* const bHr = reinterpret_cast<const char*>(bH) + hv;
+#pragma unroll
+                        for (int b0 = 0; b0 < PR; b0 += 4) {
+                            f32x4 ho[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) ho[u] = *reinterpret_cast<const f32x4*>(bHr + (lw + NL * (b0 + u)) * ldh * 4);
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) stA(rsrc_of(dstH, nA), b0 + u, ho[u]);
+                        }
+                    }
                     if (more) {
-                        dma_h(tile_of(j + 2), bH);         // (behind the copy-out's LDS reads in program order)
+                        dma_h(tile_of(j + 2), bH);         // (behind THIS wave's reads of the same rows in program order)
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         rp_post(ready, lw, (unsigned)(j + 3), lane);
                         rp_post(vready, lw, (unsigned)(j + 3), lane);

@@ -39,7 +39,10 @@ SHAPES = [(65, 70, 12000), (129, 70, 12000), (65, 32, 12000), (64, 70, 12000), (
           # R = 20 / 10 / 30 settings at F = 513 (settings/bak_IS16_results/initial_setting_SNMF_Techwin_201603_RT.m:47-48)
           (513, 20, 12000), (513, 30, 9000), (513, 10, 9000), (257, 32, 20000), (385, 10, 12000), (257, 64, 9000), (129, 50, 12000),
           # ... and its PAIR form where two column tiles' partials do not fit four ways (16 row tiles; initial_setting_IMCRA.m:47-48 R = 50)
-          (513, 50, 12000), (512, 64, 9000), (513, 33, 9000), (481, 40, 12000)]
+          (513, 50, 12000), (512, 64, 9000), (513, 33, 9000), (481, 40, 12000),
+          # ... with THREE or more tiles per workgroup: only then does a loader refill a buffer (LDS-DMA on more than 10 row tiles), and
+          # only then did the race between one loader wave's DMA and another's copy-out of the same H rows show (round 5, found by fuzzing)
+          (513, 20, 21000), (385, 33, 21157), (422, 32, 17725), (513, 64, 19530), (385, 50, 19546), (421, 30, 17743), (257, 32, 26000)]
 
 
 def _run(ctx, V, W0, H0, r, *, h_only, iters):
