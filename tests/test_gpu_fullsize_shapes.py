@@ -1,4 +1,4 @@
-"""The full-size shapes of scripts/bench_f513.py that run on round 5's kernels -- eight or more tiles per workgroup, which is where a
+"""The full-size shapes of scripts/bench_f513.py -- eight or more tiles per workgroup, which is where a
 loader refills a tile buffer and a workgroup's hand-off buffers wrap around -- against the fp64 oracle on the same inputs:
 three iterations each, W and H at 1e-4, costs at 1e-5 (the tolerances of tests/test_gpu_parity.py).  The unit-test shapes are
 sized for seconds and have two or three tiles per workgroup; a race in a refill path (profiles/r05_experiments.md section 10) was
@@ -16,6 +16,11 @@ SHAPES = [  # name, F, T, r, mode, kernel the plan must report
     ("R50_513", 513, 72000, 50, "full", "wave pairs cut"),     # settings/bak_IS16_results/initial_setting_IMCRA.m:47-48
     ("R32_257", 257, 100000, 32, "full", "cut four ways"),
     ("mel_R100", 64, 72000, 100, "full", "k_iter_sf"),          # run_basis_train.m:90-91
+    # ... and the reference's shipped geometry on the kernels of rounds 3 / 4 (k_hstep_rh in both cut modes, k_wstats with LX columns)
+    ("a11", 513, 72000, 100, "full", "k_hstep_rh"),             # run_basis_train.m:88
+    ("c4_solve1", 513, 100000, 200, "h", "k_hstep_rh"),         # run_basis_DNMF.m:40
+    ("c4_solve2", 513, 100000, 100, "w", "wstats: NK=4"),       # run_basis_DNMF.m:47
+    ("mel_dnmf_h", 64, 100000, 200, "h", "k_hstep_sf"),         # run_basis_DNMF_Mel.m:75
 ]
 
 
@@ -34,6 +39,9 @@ def test_bench_shapes_at_full_size_against_the_oracle(gpu_ctx, name, F, T, r, mo
     if mode == "h":
         p["w_update_ind"] = np.zeros(r, bool)
         kw["w_update_ind"] = np.zeros(r, bool)
+    if mode == "w":
+        p["h_update_ind"] = np.zeros(r, bool)
+        kw["h_update_ind"] = np.zeros(r, bool)
     pl = Plan(gpu_ctx, F, T, r, beta=1.0, max_iter=3, conv_eps=0.0, cost_check=True, sparsity=5.0, **kw)
     geo = pl.describe()
     pl.close()
