@@ -21,6 +21,8 @@ SHAPES = [  # name, F, T, r, mode, kernel the plan must report
     ("c4_solve1", 513, 100000, 200, "h", "k_hstep_rh"),         # run_basis_DNMF.m:40
     ("c4_solve2", 513, 100000, 100, "w", "wstats: NK=4"),       # run_basis_DNMF.m:47
     ("mel_dnmf_h", 64, 100000, 200, "h", "k_hstep_sf"),         # run_basis_DNMF_Mel.m:75
+    # BASELINE configs[4] (beta = 2, lambda = 50, r = 512) at 60000 frames -- seven tiles per workgroup; the oracle needs ~10 s for these
+    ("c5_60k", 513, 60000, 512, "ed", "Gram matrix"),
 ]
 
 
@@ -36,13 +38,17 @@ def test_bench_shapes_at_full_size_against_the_oracle(gpu_ctx, name, F, T, r, mo
     W0, H0 = rs.random((F, r)), rs.random((r, T))
     p = dict(cf="kl", sparsity=5.0, max_iter=3, conv_eps=0, cost_check=1, init_w=W0, init_h=H0)
     kw = {}
+    beta = 1.0
+    if mode == "ed":
+        p.update(cf="ed", sparsity=50.0)
+        beta = 2.0
     if mode == "h":
         p["w_update_ind"] = np.zeros(r, bool)
         kw["w_update_ind"] = np.zeros(r, bool)
     if mode == "w":
         p["h_update_ind"] = np.zeros(r, bool)
         kw["h_update_ind"] = np.zeros(r, bool)
-    pl = Plan(gpu_ctx, F, T, r, beta=1.0, max_iter=3, conv_eps=0.0, cost_check=True, sparsity=5.0, **kw)
+    pl = Plan(gpu_ctx, F, T, r, beta=beta, max_iter=3, conv_eps=0.0, cost_check=True, sparsity=p["sparsity"], **kw)
     geo = pl.describe()
     pl.close()
     assert kern in geo, geo  # the kernel this test is about is the one the plan takes
