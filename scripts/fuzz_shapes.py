@@ -2,7 +2,7 @@
    python scripts/fuzz_shapes.py [seed] [n_cases] [time budget s] [focus]  -> one line per case, FAIL lines at the end.
 focus = "r5": only the envelopes of round 5's kernels -- k_iter_sf (F = 33..64, r = 65..128, KL, both factors updated) and
 k_hstep_rp<., CUT> (>= 4 row tiles, r <= 64, more tiles than CUs) -- with their edge cases (partial last tile, F on both sides of
-32n + 1, every sparsity form, cost on / off).
+32n + 1, every sparsity form, cost on / off).  focus = "big": 33000..90000 frames (4..11 tiles per workgroup) on the main families.
 Shapes are drawn to land on the plan's geometry switches: tile counts around multiples of the CU count (the split last
 round), F on both sides of 32n+1, r around the 32-column tiles and the LX / NK limits, all divergences and update modes."""
 import os
@@ -42,9 +42,22 @@ def draw_r5():
     return F, T, r, 1.0, mode, sp
 
 
+def draw_big():
+    """long solves: 4..11 tiles of 32 frames per workgroup on 256 CUs -- every buffer of every pipeline wraps around several times"""
+    F = int(rs.choice([257, 513, 129, 64, 64, 385, 512, 40, int(rs.integers(33, 65)), int(rs.integers(100, 514))]))
+    r = int(rs.choice([20, 30, 32, 50, 64, 100, 100, 128, 200, 256, int(rs.integers(1, 257))]))
+    T = int(rs.integers(33000, 90000))
+    beta = float(rs.choice([1.0, 1.0, 1.0, 1.0, 2.0, 0.0, 0.5]))
+    mode = str(rs.choice(["full", "full", "h", "w", "semi"]))
+    sp = str(rs.choice(["scalar", "scalar", "vec", "zero"]))
+    return F, T, r, beta, mode, sp
+
+
 def draw():
     if focus == "r5":
         return draw_r5()
+    if focus == "big":
+        return draw_big()
     F = int(rs.choice([257, 513, 129, 65, 64, 128, 512, 385, 97, 64, 40, 32, int(rs.integers(8, 65)), int(rs.integers(8, 600)), int(rs.integers(8, 200))]))
     r = int(rs.choice([int(rs.integers(1, 40)), int(rs.integers(90, 132)), int(rs.integers(190, 260)), 100, 200, 256, 40,
                        int(rs.integers(257, 700)), int(rs.integers(1, 300))]))
