@@ -25,6 +25,17 @@ namespace snmf {
 
 constexpr int kSfWaves = 8;  // waves per workgroup (two per SIMD), one workgroup per CU
 
+// The W images into LDS by LDS-DMA: they are contiguous on both sides -- 1 KiB per instruction, a few per wave, all in flight at
+// once, no registers (as a load / store loop the fill was two dependent round trips of eight loads a thread: 1.5 us of every launch
+// of this family).  The caller waits (s_waitcnt vmcnt(0)) in front of its barrier: nothing else orders a ds_read behind an LDS-DMA.
+__device__ __forceinline__ void sf_fill_image(const float* src, float* dst, int nbytes, int w, int lane) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, nbytes, 0x00020000);
+    for (int o = w * 1024; o < nbytes; o += kSfWaves * 1024)
+        if (o + lane * 16 < nbytes) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + o / 4), 16, lane * 16, o, 0, 0);
+}
+
+
 // NF row tiles (1..2), NK column tiles of H (1..8; 254 VGPRs at 8, no scratch).  Dynamic LDS: Wt4 image [NF][rp/8][2][32][4], Wk4 image [NK][Fq/8][2][32][4],
 // 1 ./ dph [rp], lambda_k [rp], then [2][kSfWaves] doubles for the objective partials.
 template <int NF, int NK, bool OBJ>
@@ -54,15 +65,13 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_hstep_sf(StepArgs a) {
         for (int q = 0; q < NF * 4; ++q) vq[q] = *reinterpret_cast<const f32x4*>(vp + 8 * q);
     };
     {
-        const int n4 = (NF * rp * 32 + NK * a.Fq * 32) / 4, nt4 = NF * rp * 32 / 4;
-        for (int i = threadIdx.x; i < n4; i += kSfWaves * 64) {
-            const f32x4 x = i < nt4 ? reinterpret_cast<const f32x4*>(a.Wt4)[i] : reinterpret_cast<const f32x4*>(a.Wk4)[i - nt4];
-            reinterpret_cast<f32x4*>(lds)[i] = x;
-        }
+        sf_fill_image(a.Wt4, wt, NF * rp * 32 * 4, w, lane);
+        sf_fill_image(a.Wk4, wk, NK * a.Fq * 32 * 4, w, lane);
         for (int k = threadIdx.x; k < rp; k += kSfWaves * 64) {
             rdp[k] = a.S ? 0.f : fast_rcp(a.dphv[k]);
             lmk[k] = a.S ? 0.f : a.lamk[k];
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
 
@@ -269,10 +278,8 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_wstats_sf(StepArgs a, int 
     const int phi = w / NCL, c = w % NCL;
     const int chunk = blockIdx.x;
     const int tb = (int)(((long long)a.n_tiles * chunk) / n_chunks), te = (int)(((long long)a.n_tiles * (chunk + 1)) / n_chunks);
-    {
-        const int n4 = NF * rp * 32 / 4;
-        for (int i = threadIdx.x; i < n4; i += kSfWaves * 64) reinterpret_cast<f32x4*>(lds)[i] = reinterpret_cast<const f32x4*>(a.Wt4)[i];
-    }
+    sf_fill_image(a.Wt4, lds, NF * rp * 32 * 4, w, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const f32x4* const wtl = reinterpret_cast<const f32x4*>(lds) + lane + (size_t)phi * nq8 * 64;
 
@@ -530,16 +537,14 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_iter_sf(StepArgs a, int n_
     const int chunk = blockIdx.x;
     const int tb = (int)(((long long)a.n_tiles * chunk) / n_chunks), te = (int)(((long long)a.n_tiles * (chunk + 1)) / n_chunks);
     {
-        const int n4 = (NF * rp * 32 + NK * a.Fq * 32) / 4, nt4 = NF * rp * 32 / 4;
-        for (int i = threadIdx.x; i < n4; i += NTHR) {
-            const f32x4 x = i < nt4 ? reinterpret_cast<const f32x4*>(a.Wt4)[i] : reinterpret_cast<const f32x4*>(a.Wk4)[i - nt4];
-            reinterpret_cast<f32x4*>(lds)[i] = x;
-        }
+        sf_fill_image(a.Wt4, wt, NF * rp * 32 * 4, w, lane);
+        sf_fill_image(a.Wk4, wk, NK * a.Fq * 32 * 4, w, lane);
         for (int k = threadIdx.x; k < rp; k += NTHR) {
             rdp[k] = a.S ? 0.f : fast_rcp(a.dphv[k]);
             lmk[k] = a.S ? 0.f : a.lamk[k];
         }
         if (threadIdx.x < 2 * NP + 1) sig[threadIdx.x] = 0u;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing else orders a ds_read behind an LDS-DMA
     }
     __syncthreads();
     const f32x4* const wtl = reinterpret_cast<const f32x4*>(wt) + lane;  // fragment (phi, q): wtl[(phi * nq8 + q) * 64]
