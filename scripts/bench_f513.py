@@ -64,12 +64,16 @@ for name in which:
         kw["w_update_ind"] = np.zeros(r, bool)
     if c["mode"] == "w":
         kw["h_update_ind"] = np.zeros(r, bool)
-    plan = Plan(ctx, F, T, r, beta=c["beta"], max_iter=2 * c["settle"] + 2 * iters + 2, conv_eps=0.0, cost_check="--no-cost" not in sys.argv,
+    plan = Plan(ctx, F, T, r, beta=c["beta"], max_iter=2 * c["settle"] + 4 * iters + 2, conv_eps=0.0, cost_check="--no-cost" not in sys.argv,
                 sparsity=c["sparsity"], **kw)
     plan.set_v(V); plan.set_w(W0); plan.set_h(H0); plan.init()
     del V, H0
     plan.run_async(c["settle"]); ctx.sync()
-    t = time.perf_counter(); plan.run_async(iters); ctx.sync(); dt = time.perf_counter() - t
+    # three timed passes of `iters` iterations, the best one counts: the first shape of a process on a cold GPU measured 7 % more wall
+    # per iteration than its own kernels take (clock ramp / first-use costs on the host side), the later shapes did not
+    dt = 1e9
+    for _ in range(3):
+        t = time.perf_counter(); plan.run_async(iters); ctx.sync(); dt = min(dt, time.perf_counter() - t)
     ctx.timing(True); plan.run_async(iters); ctx.sync()
     fam = {f: ctx.timing_get(f) for f in ("hstep", "wstats", "reduce", "wapply", "wfin")}
     ctx.timing(False)
