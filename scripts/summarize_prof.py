@@ -16,7 +16,7 @@ import os
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-cmd = sys.argv[2] if len(sys.argv) > 2 else "bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+cmd = sys.argv[2] if len(sys.argv) > 2 else "bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-dropin"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 
