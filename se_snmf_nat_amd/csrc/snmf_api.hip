@@ -1506,11 +1506,15 @@ struct Prefault {
         for (int i = 0; i < n_thr; ++i) {
             const uintptr_t a = lo + (n_pg * i / n_thr) * pg, b = lo + (n_pg * (i + 1) / n_thr) * pg;
             if (b <= a) continue;
-            th.emplace_back([a, b, pg] {
-                (void)madvise((void*)a, b - a, MADV_HUGEPAGE);  // (a hint where transparent huge pages are opt-in: 100 faults instead of 50 000)
-                if (madvise((void*)a, b - a, MADV_POPULATE_WRITE) == 0) return;
-                for (uintptr_t q = a; q < b; q += pg) *(volatile char*)q = 0;  // (older kernels: EINVAL)
-            });
+            try {
+                th.emplace_back([a, b, pg] {
+                    (void)madvise((void*)a, b - a, MADV_HUGEPAGE);  // (a hint where transparent huge pages are opt-in: 100 faults instead of 50 000)
+                    if (madvise((void*)a, b - a, MADV_POPULATE_WRITE) == 0) return;
+                    for (uintptr_t q = a; q < b; q += pg) *(volatile char*)q = 0;  // (older kernels: EINVAL)
+                });
+            } catch (...) {  // no thread to be had: the copy-out takes the faults itself (nothing may throw across the C ABI)
+                break;
+            }
         }
     }
     void join() {
