@@ -690,3 +690,29 @@ def test_fused_small_f_iteration_equals_the_two_launches(gpu_ctx, shape, monkeyp
     assert a[3][2] == b[3][2]
     for x, y in zip(a[3][1], b[3][1]):
         assert abs(x - y) <= 1e-9 * abs(y)
+
+
+@pytest.mark.parametrize("mode", ["full", "semi"])
+def test_fused_small_f_iteration_stops_where_the_oracle_stops(gpu_ctx, mode):
+    """Early stop (src/sparse_nmf.m:272-284) on the one-launch iteration k_iter_sf: the H step of iteration j + 1 has already run inside
+    the launch whose k_wfin fires the stop test of iteration j -- the result must be iterate j's, and the stop index the oracle's."""
+    from se_snmf_nat_amd import Plan, sparse_nmf
+    F, r, T = 64, 100, 20000
+    rs = np.random.default_rng(7)
+    V = rs.gamma(0.5, 1.0, (F, 12)) @ rs.gamma(0.3, 1.0, (12, T)) + 1e-3
+    W0, H0 = rs.random((F, r)), rs.random((r, T))
+    p = dict(cf="kl", sparsity=1.0, max_iter=120, conv_eps=3e-3, cost_check=1, init_w=W0, init_h=H0)
+    kw = {}
+    if mode == "semi":
+        p["w_update_ind"] = np.arange(r) >= r // 2
+        kw["w_update_ind"] = p["w_update_ind"]
+    pl = Plan(gpu_ctx, F, T, r, beta=1.0, max_iter=120, conv_eps=3e-3, cost_check=True, sparsity=1.0, **kw)
+    geo = pl.describe()
+    pl.close()
+    assert "k_iter_sf" in geo, geo
+    w, h, o = sparse_nmf(V, p, ctx=gpu_ctx)
+    wr, hr, orf = oracle_nmf(V, p)
+    assert 2 < orf["n_iter"] < 120, orf["n_iter"]  # (the case does stop early)
+    assert o["n_iter"] == orf["n_iter"]
+    assert rel(w, wr) < REL_WH and rel(h, hr) < REL_WH
+    np.testing.assert_allclose(o["cost"], orf["cost"], rtol=REL_COST)
