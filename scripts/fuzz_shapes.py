@@ -104,8 +104,13 @@ for ci in range(n_cases):
     W0 = rs.random((F, r))
     H0 = rs.random((r, T))
     iters = int(rs.integers(2, 6))
-    p = dict(cf={1.0: "kl", 2.0: "ed", 0.0: "is"}.get(beta, "x"), beta=beta, max_iter=iters, conv_eps=0, cost_check=int(rs.integers(0, 4) > 0),
-             init_w=W0, init_h=H0)
+    # early stop (src/sparse_nmf.m:272-284): now and then a solve that may stop by itself -- the stop index must be the oracle's unless the
+    # oracle's own decision was within 2 % of the threshold at some iteration (then the case is counted as borderline, not compared)
+    eps = float(rs.choice([0, 0, 0, 1e-3, 3e-3, 1e-2])) if focus != "big" else 0.0
+    if eps > 0:
+        iters = int(rs.integers(8, 40))
+    p = dict(cf={1.0: "kl", 2.0: "ed", 0.0: "is"}.get(beta, "x"), beta=beta, max_iter=iters, conv_eps=eps,
+             cost_check=1 if eps > 0 else int(rs.integers(0, 4) > 0), init_w=W0, init_h=H0)
     p["sparsity"] = {"scalar": float(rs.choice([0.1, 1.0, 5.0])), "zero": 0.0, "vec": rs.random(r) * 4,
                      "mat": rs.random((r, T)) * 3}[sp]
     if mode == "h":
@@ -114,13 +119,23 @@ for ci in range(n_cases):
         p["h_update_ind"] = np.zeros(r, bool)
     elif mode == "semi":
         p["w_update_ind"] = np.arange(r) >= r // 2
-    tag = f"F={F} T={T} r={r} beta={beta} {mode} sp={sp} it={iters} cc={p['cost_check']} dv={dv}"
+    tag = f"F={F} T={T} r={r} beta={beta} {mode} sp={sp} it={iters} eps={eps:g} cc={p['cost_check']} dv={dv}"
     try:
         w, h, o = sparse_nmf(V, p)
     except SnmfError as e:
         print(f"{ci:3d} {tag}: REFUSED {str(e)[:90]}")
         continue
     wr, hr, orf = onmf(V, p)
+    if eps > 0:
+        c = np.asarray(orf["cost"], float)
+        rc = np.abs(np.diff(c)) / np.abs(c[:-1]) if len(c) > 1 else np.array([])
+        if len(rc) and np.min(np.abs(rc - eps)) < 0.02 * eps:
+            print(f"{ci:3d} {tag}: borderline stop decision in the oracle itself (skipped)")
+            continue
+        if o["n_iter"] != orf["n_iter"]:
+            print(f"{ci:3d} {tag}: n_iter {o['n_iter']} != oracle {orf['n_iter']}  <<< FAIL", flush=True)
+            fails.append(tag + " (stop index)")
+            continue
     n = min(len(o["cost"]), len(orf["cost"]))
     ec = float(np.max(np.abs(o["cost"][:n] - orf["cost"][:n]) / np.abs(orf["cost"][:n]))) if n and p["cost_check"] else 0.0
     ew, eh = rel(w, wr), rel(h, hr)
