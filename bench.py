@@ -383,6 +383,34 @@ def main():
             "final_cost": float(last_cost[-1]) if last_cost else None,
         }
         out["cost_vs_oracle"] = cost_vs_oracle(F, T, r, len(last_cost), out["final_cost"])
+        # The same resident loop FROM A RANDOM START (no settle steps): kernel time depends on the iterate (dense random
+        # activations toggle more operand bits than the sparse ones the L1 penalty leaves; the clock follows the power), so
+        # a short solve pays more per iteration than `value`.  200 iterations = BASELINE configs[1]; 100 = the reference's
+        # default max_iter (settings/initial_setting_SNMF_NAT.m:108).  Outside the timed region; never `value`.
+        try:
+            frs = {}
+            for n_it in (200, 100):
+                best = None
+                for _ in range(2):
+                    pl = Plan(ctx, F, T, r, beta=1.0, max_iter=n_it, conv_eps=0.0, cost_check=True, sparsity=SPARSITY)
+                    pl.set_v(V.astype(np.float32))
+                    pl.set_w(W0)
+                    pl.set_h(H0.astype(np.float32))
+                    pl.init()
+                    ctx.sync()
+                    t = time.perf_counter()
+                    pl.run_async(n_it)
+                    ctx.sync()
+                    dts = time.perf_counter() - t
+                    pl.close()
+                    best = dts if best is None else min(best, dts)
+                frs[f"iters_{n_it}"] = {"iterations_per_s": n_it / best, "ms_per_step": best / n_it * 1e3, "solve_ms": best * 1e3}
+            out["from_random_start"] = frs["iters_200"]["iterations_per_s"]
+            out["from_random_start_detail"] = dict(frs, note="one resident solve from the random start, data in HBM, no settle steps; "
+                                                             "includes the final objective pass; best of two")
+        except Exception as e:  # noqa: BLE001 -- the extra leg must never fail the bench
+            out["from_random_start"] = None
+            out["from_random_start_detail"] = {"error": f"{type(e).__name__}: {e}"}
         # What a caller of the drop-in boundary waits for (outside the timed region; never `value`): the same K iterations
         # through [w, h, objective] = sparse_nmf(v, p) on HOST fp64 arrays -- MATLAB's doubles in, W / H / objective out
         # (snmf_sparse_nmf_f64: chunked pinned upload, solve, download).  scripts/bench_dropin.py has the full breakdown.

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SNMF_ABI_VERSION 4  /* 4: snmf_run_basis_dnmf_multi_*; 3: snmf_run_basis_dnmf_*, snmf_run_basis_train_audio_f64, snmf_sparse_nmf_oop_*, snmf_plan_set_h_random, snmf_ctx_xfer_stats; 2: snmf_multi_* */
+#define SNMF_ABI_VERSION 5  /* 5: snmf_multi_release_cache, snmf_multi_cached_teams (the device RNG of snmf_plan_set_h_random changed with 4: draws seeded under ABI 3 are not reproducible); 4: snmf_run_basis_dnmf_multi_*; 3: snmf_run_basis_dnmf_*, snmf_run_basis_train_audio_f64, snmf_sparse_nmf_oop_*, snmf_plan_set_h_random, snmf_ctx_xfer_stats; 2: snmf_multi_* */
 
 typedef enum snmf_status {
     SNMF_OK = 0,
@@ -402,6 +402,16 @@ typedef struct snmf_multi snmf_multi;
 int snmf_multi_create(const int32_t* devices, int32_t n_dev, const snmf_params* params, const int64_t* col_begin,
                       snmf_multi** out);
 void snmf_multi_destroy(snmf_multi* m);
+/* What a device list keeps for the life of the process (csrc/snmf_multi.h, MultiTeam): per rank two contexts -- each with
+ * up to 3 x 16 MiB of pinned host bounce buffers, as much device staging and the cached device blocks of destroyed plans --
+ * plus the fine-grained gather buffers, arrival words and events; an 8-device list retains about 1.5 GB of pinned host
+ * memory after one run_basis_dnmf(devices = ...) call.  At most SNMF_TEAM_CACHE (default 2) idle device lists are kept; a
+ * team on which a run FAILED is never kept (its exchange numbers and arrival words may disagree between the ranks).
+ * snmf_multi_release_cache destroys every idle team now and returns how many it destroyed (teams in use are not touched):
+ * call it when the host is done with its device lists -- a MEX file from its mexAtExit hook (integration/sparse_nmf_mex.cpp
+ * does).  snmf_multi_cached_teams: idle teams currently held. */
+int32_t snmf_multi_release_cache(void);
+int32_t snmf_multi_cached_teams(void);
 /* How push and sum of the per-iteration exchange are ordered (csrc/snmf_multi.h).  FLAGS: on the devices (arrival words
  * polled by the summing kernel; a rank's host thread only enqueues) -- AUTO picks it when every rank has a device of its
  * own.  EVENTS: hipEvents + a host barrier per iteration -- AUTO picks it when ranks share a device (single-GPU testing),

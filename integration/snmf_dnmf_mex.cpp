@@ -30,6 +30,7 @@
 static snmf_ctx* g_ctx = nullptr;
 
 static void at_exit() {
+    snmf_multi_release_cache();  // the device lists' contexts, pinned buffers and gather buffers (opts.devices)
     if (g_ctx) {
         snmf_ctx_destroy(g_ctx);
         g_ctx = nullptr;

@@ -63,8 +63,9 @@ SYMBOLS = [
     "snmf_plan_set_h_random", "snmf_run_basis_dnmf_f64", "snmf_run_basis_dnmf_f32", "snmf_run_basis_dnmf_audio_f64",
     "snmf_run_basis_train_audio_f64", "snmf_ctx_xfer_stats", "snmf_sparse_nmf_oop_f64", "snmf_sparse_nmf_oop_f32",
     "snmf_run_basis_dnmf_multi_f64", "snmf_run_basis_dnmf_multi_f32",
+    "snmf_multi_release_cache", "snmf_multi_cached_teams",
 ]
-ABI_VERSION = 4  # include/snmf.h: SNMF_ABI_VERSION this binding was written against
+ABI_VERSION = 5  # include/snmf.h: SNMF_ABI_VERSION this binding was written against
 EXCHANGE_AUTO, EXCHANGE_FLAGS, EXCHANGE_EVENTS = 0, 1, 2
 
 SNMF_OK = 0
@@ -260,6 +261,8 @@ def load():
         sig[f"snmf_plan_set_sparsity_{ty}"] = (C.c_int, [vp, vp, C.c_int])
     sig["snmf_multi_create"] = (C.c_int, [vp, i32, PP, vp, C.POINTER(vp)])
     sig["snmf_multi_destroy"] = (None, [vp])
+    sig["snmf_multi_release_cache"] = (i32, [])
+    sig["snmf_multi_cached_teams"] = (i32, [])
     for nm in ("v", "w", "h"):
         for ty in ("f64", "f32"):
             sig[f"snmf_multi_set_{nm}_{ty}"] = (C.c_int, [vp, vp, i64])

@@ -1488,6 +1488,7 @@ extern "C" int snmf_plan_solve_frames_f32(snmf_plan* pl, int32_t tps, const floa
 // an array with huge pages, 10-11 ms behind a solve in the same process).  The out-of-place entries know the destination from the
 // start, so a few host threads make its pages exist WHILE the device solves: madvise(MADV_POPULATE_WRITE) (Linux 5.14: faults the
 // range in without writing to it), else one write per page -- joined before the download, so nothing can be overwritten.
+#include <cerrno>
 #include <sys/mman.h>
 #include <unistd.h>
 #include <thread>
@@ -1510,7 +1511,11 @@ struct Prefault {
                 th.emplace_back([a, b, pg] {
                     (void)madvise((void*)a, b - a, MADV_HUGEPAGE);  // (a hint where transparent huge pages are opt-in: 100 faults instead of 50 000)
                     if (madvise((void*)a, b - a, MADV_POPULATE_WRITE) == 0) return;
-                    for (uintptr_t q = a; q < b; q += pg) *(volatile char*)q = 0;  // (older kernels: EINVAL)
+                    // kernels without MADV_POPULATE_WRITE answer EINVAL: one write per page instead (the range is an OUTPUT
+                    // array nothing has been stored into yet: the caller checked that it overlaps no input).  Any other errno
+                    // (ENOMEM, EFAULT, EPERM on a sealed mapping): leave the pages alone, the copy-out takes the faults
+                    if (errno != EINVAL) return;
+                    for (uintptr_t q = a; q < b; q += pg) *(volatile char*)q = 0;
                 });
             } catch (...) {  // no thread to be had: the copy-out takes the faults itself (nothing may throw across the C ABI)
                 break;
@@ -1525,9 +1530,17 @@ struct Prefault {
 };
 }  // namespace
 
+// [a, a + na) and [b, b + nb) share a byte
+static bool ranges_overlap(const void* a, size_t na, const void* b, size_t nb) {
+    if (!a || !b || !na || !nb) return false;
+    const uintptr_t a0 = (uintptr_t)a, b0 = (uintptr_t)b;
+    return a0 < b0 + nb && b0 < a0 + na;
+}
+
+// oop: called through an out-of-place entry (W / H are result arrays of their own: only then may their pages be touched early)
 template <typename T>
 static int sparse_nmf_impl(snmf_ctx* ctx, const snmf_params* p, const T* V, int64_t ldV, const T* W0, const T* H0, T* W, T* H,
-                           const T* sparsity, double* div_out, double* cost_out, int32_t* n_iter_out) {
+                           const T* sparsity, double* div_out, double* cost_out, int32_t* n_iter_out, bool oop) {
     if (!ctx) return fail(SNMF_ERR_INVALID, "ctx is NULL");
     if (!V || !W || !H || !W0 || !H0) return fail(SNMF_ERR_INVALID, "V, W and H must be non-NULL");
     snmf_plan* pl = nullptr;
@@ -1541,7 +1554,17 @@ static int sparse_nmf_impl(snmf_ctx* ctx, const snmf_params* p, const T* V, int6
         else SN_STEP(s, set_s<T>(pl, sparsity, 0));
     }
     Prefault pf;
-    if (s == SNMF_OK && (const T*)H != H0) pf.start(H, (size_t)p->r * p->T * sizeof(T));  // out-of-place: H holds nothing yet
+    if (s == SNMF_OK && oop) {
+        // out-of-place: H holds nothing yet -- unless the caller handed in a result array that overlaps one of the inputs
+        // (partially aliased buffers are legal for the copy-out, which runs after every input has been consumed, but the
+        // pre-fault's fallback WRITES into the pages while the inputs may still be being read)
+        const size_t hb = (size_t)p->r * p->T * sizeof(T);
+        const size_t sb = p->sparsity_kind == SNMF_SPARSITY_SCALAR ? 0 : (p->sparsity_kind == SNMF_SPARSITY_RVEC ? (size_t)p->r : (size_t)p->r * p->T) * sizeof(T);
+        const bool clash = ranges_overlap(H, hb, H0, hb) || ranges_overlap(H, hb, W0, (size_t)p->F * p->r * sizeof(T)) ||
+                           ranges_overlap(H, hb, V, (size_t)ldV * p->T * sizeof(T)) || ranges_overlap(H, hb, sparsity, sb) ||
+                           ranges_overlap(H, hb, W, (size_t)p->F * p->r * sizeof(T));
+        if (!clash) pf.start(H, hb);
+    }
     SN_STEP(s, snmf_plan_init(pl));
     if (s == SNMF_OK) SN_STEP(s, snmf_plan_run(pl, p->max_iter, nullptr));
     pf.join();
@@ -1562,24 +1585,24 @@ static int sparse_nmf_impl(snmf_ctx* ctx, const snmf_params* p, const T* V, int6
 extern "C" int snmf_sparse_nmf_f64(snmf_ctx* ctx, const snmf_params* p, const double* V, int64_t ldV, double* W,
                                    double* H, const double* sparsity, double* div_out, double* cost_out,
                                    int32_t* n_iter_out) {
-    return sparse_nmf_impl<double>(ctx, p, V, ldV, W, H, W, H, sparsity, div_out, cost_out, n_iter_out);
+    return sparse_nmf_impl<double>(ctx, p, V, ldV, W, H, W, H, sparsity, div_out, cost_out, n_iter_out, false);
 }
 extern "C" int snmf_sparse_nmf_f32(snmf_ctx* ctx, const snmf_params* p, const float* V, int64_t ldV, float* W,
                                    float* H, const float* sparsity, double* div_out, double* cost_out,
                                    int32_t* n_iter_out) {
-    return sparse_nmf_impl<float>(ctx, p, V, ldV, W, H, W, H, sparsity, div_out, cost_out, n_iter_out);
+    return sparse_nmf_impl<float>(ctx, p, V, ldV, W, H, W, H, sparsity, div_out, cost_out, n_iter_out, false);
 }
 // The same with the initial factors read-only and the results in arrays of their own: MATLAB's value semantics (inputs are
 // never modified, outputs freshly allocated: SURVEY.md section 8b) without duplicating init_h first -- 14 ms per 205 MB on the host.
 extern "C" int snmf_sparse_nmf_oop_f64(snmf_ctx* ctx, const snmf_params* p, const double* V, int64_t ldV, const double* W0,
                                        const double* H0, const double* sparsity, double* W, double* H, double* div_out,
                                        double* cost_out, int32_t* n_iter_out) {
-    return sparse_nmf_impl<double>(ctx, p, V, ldV, W0, H0, W, H, sparsity, div_out, cost_out, n_iter_out);
+    return sparse_nmf_impl<double>(ctx, p, V, ldV, W0, H0, W, H, sparsity, div_out, cost_out, n_iter_out, true);
 }
 extern "C" int snmf_sparse_nmf_oop_f32(snmf_ctx* ctx, const snmf_params* p, const float* V, int64_t ldV, const float* W0,
                                        const float* H0, const float* sparsity, float* W, float* H, double* div_out,
                                        double* cost_out, int32_t* n_iter_out) {
-    return sparse_nmf_impl<float>(ctx, p, V, ldV, W0, H0, W, H, sparsity, div_out, cost_out, n_iter_out);
+    return sparse_nmf_impl<float>(ctx, p, V, ldV, W0, H0, W, H, sparsity, div_out, cost_out, n_iter_out, true);
 }
 
 // ---- spectrogram front-end ---------------------------------------------------------------------

@@ -37,6 +37,7 @@
 
 #include <atomic>
 #include <thread>
+#include <system_error>
 
 namespace snmf {
 
@@ -117,6 +118,11 @@ struct MultiTeam {
     unsigned xseq = 0;                // exchanges issued so far (the next one is number xseq + 1)
     int par = 0;                      // parity of the next exchange
     int refs = 0;                     // 0: idle in the cache
+    // A run on this team ended in a failure (a rank's call failed, a rank left its loop early, a bounded device-side wait gave
+    // up): exchange number, parity and the on-device arrival words may no longer agree between the ranks -- a peer may have
+    // posted arrival values AHEAD of the number the failed rank recorded, and the next handle's exchanges would accept them as
+    // their own and sum zeroed or stale slots.  A poisoned team is destroyed when its last user lets go, never cached.
+    bool poisoned = false;
 };
 
 struct snmf_multi {
@@ -294,6 +300,9 @@ static void team_release(MultiTeam* t) {
         if (--t->refs > 0) return;
         // most recently used last; past the limit the LEAST recently used idle team goes (with a limit of 0: this one)
         g_teams.erase(std::find(g_teams.begin(), g_teams.end(), t));
+        if (t->poisoned) {
+            kill = t;  // (see MultiTeam::poisoned: fresh flags, slots and exchange numbers for the next handle on this list)
+        } else {
         g_teams.push_back(t);
         int idle = 0;
         for (MultiTeam* q : g_teams) idle += q->refs == 0;
@@ -302,8 +311,50 @@ static void team_release(MultiTeam* t) {
             kill = *it;
             g_teams.erase(it);
         }
+        }
     }
     if (kill) team_destroy(kill);
+}
+
+// Give back what idle teams hold (per rank: two contexts with their pinned bounce buffers -- up to 2 x 48 MiB of host memory
+// -- device staging, cached plan blocks, gather buffers): a long-lived host (MATLAB, a Python server) calls this when it is
+// done with its device lists; a MEX file from its mexAtExit hook.  Teams in use are not touched.  Returns the number destroyed.
+extern "C" int32_t snmf_multi_release_cache(void) {
+    std::vector<MultiTeam*> kill;
+    {
+        std::lock_guard<std::mutex> lk(g_team_mu);
+        for (auto it = g_teams.begin(); it != g_teams.end();)
+            if ((*it)->refs == 0) {
+                kill.push_back(*it);
+                it = g_teams.erase(it);
+            } else {
+                ++it;
+            }
+    }
+    int dev_before = -1;
+    (void)hipGetDevice(&dev_before);
+    for (MultiTeam* t : kill) team_destroy(t);
+    if (dev_before >= 0) (void)hipSetDevice(dev_before);
+    return (int32_t)kill.size();
+}
+// idle teams in the cache (tests)
+extern "C" int32_t snmf_multi_cached_teams(void) {
+    std::lock_guard<std::mutex> lk(g_team_mu);
+    int n = 0;
+    for (MultiTeam* t : g_teams) n += t->refs == 0;
+    return n;
+}
+
+// Threads of the multi-device entries start through here: std::thread's constructor throws std::system_error when the
+// process is out of threads, and these run inside extern "C" entries -- an exception must not unwind into MATLAB / ctypes
+// (or reach std::terminate with earlier threads still joinable).  On failure the work runs on the calling thread instead.
+template <typename Fn>
+static void spawn_or_run(std::vector<std::thread>& th, Fn fn) {
+    try {
+        th.emplace_back(fn);
+    } catch (const std::system_error&) {
+        fn();
+    }
 }
 
 extern "C" void snmf_multi_destroy(snmf_multi* m) {
@@ -443,7 +494,7 @@ static int multi_for_ranks(snmf_multi* m, Fn fn) {
         if (rc[g] != SNMF_OK) er[g] = g_err;
     };
     std::vector<std::thread> th;
-    for (int g = 1; g < m->n; ++g) th.emplace_back(one, g);
+    for (int g = 1; g < m->n; ++g) spawn_or_run(th, [&one, g] { one(g); });
     one(0);
     for (auto& t : th) t.join();
     if (dev_before >= 0) (void)hipSetDevice(dev_before);
@@ -583,7 +634,12 @@ static void multi_rank_loop(snmf_multi* m, int g, int it0, int target, bool fina
     // keeps the separate k_push_stats / k_sum_ranks launches (tests compare the two: bit-identical)
     const char* uf = getenv("SNMF_MULTI_UNFUSED");
     const bool fused = m->upd_w && m->n > 1 && m->xoff == 0 && !(uf && atoi(uf) != 0);
+    // fault injection (tests only): SNMF_MULTI_TEST_FAIL="rank:iteration" makes that rank's H step of that iteration (0-based,
+    // counted from the solve's start) report a failure, as a refused launch would
+    int inj_rank = -1, inj_it = -1;
+    if (const char* fi = getenv("SNMF_MULTI_TEST_FAIL")) (void)sscanf(fi, "%d:%d", &inj_rank, &inj_it);
     for (int it = it0; it < target && all_ok; ++it) {
+        if (rc == SNMF_OK && g == inj_rank && it == inj_it) step(fail(SNMF_ERR_INTERNAL, "injected failure (SNMF_MULTI_TEST_FAIL)"));
         if (rc == SNMF_OK) step(snmf_plan_hstep(m->plan[g]));
         snmf_plan::Exchange X;
         ++xs;
@@ -651,19 +707,53 @@ extern "C" int snmf_multi_run(snmf_multi* m, int32_t n_iters, int32_t* iters_don
         m->failed_at.store(0x7fffffff);
         m->bar_count.store(0);
         std::vector<std::thread> th;
-        for (int g = 1; g < m->n; ++g) th.emplace_back(multi_rank_loop, m, g, m->it, target, finalize, &stopped);
+        // (the rank loops meet at host barriers, so a rank whose thread cannot be started cannot run inline behind the others:
+        //  every thread is created first and held at a latch; if the process is out of threads nobody has begun, the ones that
+        //  exist leave at once and the run is refused -- std::system_error must not unwind through this extern "C" entry)
+        std::atomic<int> go{0};  // 0: hold, 1: run, -1: leave
+        const int it0 = m->it;
+        bool spawned = true;
+        try {
+            for (int g = 1; g < m->n; ++g)
+                th.emplace_back([&, g] {
+                    while (go.load(std::memory_order_acquire) == 0) std::this_thread::yield();
+                    if (go.load(std::memory_order_acquire) > 0) multi_rank_loop(m, g, it0, target, finalize, &stopped);
+                });
+        } catch (const std::system_error&) {
+            spawned = false;
+        }
+        if (!spawned) {
+            go.store(-1, std::memory_order_release);
+            for (auto& t : th) t.join();
+            return fail(SNMF_ERR_NOMEM, "snmf_multi_run: the process cannot start %d rank threads", m->n - 1);
+        }
+        go.store(1, std::memory_order_release);
         multi_rank_loop(m, 0, m->it, target, finalize, &stopped);
         for (auto& t : th) t.join();
         if (dev_before >= 0) (void)hipSetDevice(dev_before);
+        // Any failure below leaves the team's exchange number / parity / arrival words in a state the ranks may not agree on
+        // (MultiTeam::poisoned): the team is not cached again.
         for (int g = 0; g < m->n; ++g)
-            if (m->rc[g] != SNMF_OK) return fail(m->rc[g], "rank %d (device %d): %s", g, m->dev[g], m->err[g].c_str());
-        if (m->failed_at.load() != 0x7fffffff) return fail(SNMF_ERR_INTERNAL, "a rank failed");
+            if (m->rc[g] != SNMF_OK) {
+                m->team->poisoned = true;
+                return fail(m->rc[g], "rank %d (device %d): %s", g, m->dev[g], m->err[g].c_str());
+            }
+        if (m->failed_at.load() != 0x7fffffff) {
+            m->team->poisoned = true;
+            return fail(SNMF_ERR_INTERNAL, "a rank failed");
+        }
         for (int g = 0; g < m->n; ++g) {  // a device-side wait that gave up (FLAGS mode: a peer never arrived) invalidates the run
             DevState hs{};
-            if (hipSetDevice(m->dev[g]) != hipSuccess) return fail(SNMF_ERR_NO_DEVICE, "hipSetDevice(%d) failed", m->dev[g]);
+            if (hipSetDevice(m->dev[g]) != hipSuccess) {
+                m->team->poisoned = true;
+                return fail(SNMF_ERR_NO_DEVICE, "hipSetDevice(%d) failed", m->dev[g]);
+            }
             const int rs = read_state(m->plan[g], &hs);
             if (dev_before >= 0) (void)hipSetDevice(dev_before);
-            if (rs != SNMF_OK) return fail(rs, "rank %d (device %d): %s", g, m->dev[g], g_err.c_str());
+            if (rs != SNMF_OK) {
+                m->team->poisoned = true;
+                return fail(rs, "rank %d (device %d): %s", g, m->dev[g], g_err.c_str());
+            }
         }
         m->it = m->plan[0]->it_done;
         if (stopped) m->stopped = true;
@@ -808,7 +898,7 @@ static int dnmf_multi_impl(const int32_t* devices, int32_t n_dev, const snmf_par
     // X, D and the two halves of B go up on the second contexts while solve 1 runs
     int rc_up = SNMF_OK;
     std::string err_up;
-    std::thread up([&] {
+    auto up_fn = [&] {
         rc_up = multi_for_ranks(m2, [&](int g) {
             SN_TRY(set_v<T>(m2->plan[g], X + (size_t)m2->col[g] * ldX, ldX, 0));
             SN_TRY(set_v<T>(m3->plan[g], D + (size_t)m3->col[g] * ldD, ldD, 0));
@@ -817,11 +907,17 @@ static int dnmf_multi_impl(const int32_t* devices, int32_t n_dev, const snmf_par
             return (int)SNMF_OK;
         });
         if (rc_up != SNMF_OK) err_up = g_err;
-    });
+    };
+    std::thread up;
+    try {
+        up = std::thread(up_fn);
+    } catch (const std::system_error&) {
+        up_fn();  // out of threads: the uploads run first instead of under solve 1
+    }
     int32_t n1 = 0, n2 = 0, n3 = 0;
     int s = snmf_multi_init(m1);
     SN_STEP(s, snmf_multi_run(m1, p->max_iter, &n1));  // [~, A_hat] = sparse_nmf(Y, p)   (:40)
-    up.join();
+    if (up.joinable()) up.join();
     if (s != SNMF_OK) return s;
     if (rc_up != SNMF_OK) return fail(rc_up, "%s", err_up.c_str());
     // p.init_h = A_hat(1:R_x,:) / A_hat(R_x+1:end,:)   (:46, :52): rows of each rank's resident fp32 H, device to device
@@ -836,10 +932,17 @@ static int dnmf_multi_impl(const int32_t* devices, int32_t n_dev, const snmf_par
     int rc_a = SNMF_OK;
     std::string err_a;
     std::thread dl;
-    if (A_hat) dl = std::thread([&] {  // A_hat -> host under solves 2 / 3 (solve 1's contexts are idle now)
+    auto dl_fn = [&] {  // A_hat -> host under solves 2 / 3 (solve 1's contexts are idle now)
         rc_a = sizeof(T) == 8 ? snmf_multi_get_h_f64(m1, (double*)A_hat, ldA) : snmf_multi_get_h_f32(m1, (float*)A_hat, ldA);
         if (rc_a != SNMF_OK) err_a = g_err;
-    });
+    };
+    if (A_hat) {
+        try {
+            dl = std::thread(dl_fn);
+        } catch (const std::system_error&) {
+            dl_fn();  // out of threads: the download runs ahead of solves 2 / 3
+        }
+    }
     s = snmf_multi_init(m2);
     SN_STEP(s, snmf_multi_run(m2, p->max_iter, &n2));  // [B_hat_x, ~] = sparse_nmf(X, p)  (:47)
     SN_STEP(s, snmf_multi_init(m3));

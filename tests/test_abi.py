@@ -28,7 +28,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol(lib):
     from se_snmf_nat_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "snmf.h")).read()
     ver = int(re.search(r"#define SNMF_ABI_VERSION (\d+)", hdr).group(1))
-    assert lib.snmf_abi_version() == ver == _lib.ABI_VERSION == 4  # header, library and binding agree (the binding refuses another)
+    assert lib.snmf_abi_version() == ver == _lib.ABI_VERSION == 5  # header, library and binding agree (the binding refuses another)
     assert lib.snmf_device_count() >= 0
 
 

@@ -211,3 +211,54 @@ def test_device_list_calls_reuse_or_rebuild_their_team(gpu_ctx, monkeypatch):
         assert np.array_equal(res[1][2], res[3][2]) and np.array_equal(res[1][3], res[3][3])   # big, 2 ranks
     for a, b in zip(out["2"], out["0"]):
         assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+
+
+def test_a_failed_run_poisons_its_team_and_the_next_handle_starts_fresh(gpu_ctx, lib, monkeypatch):
+    """a team went back into the process-wide cache after a FAILED snmf_multi_run, and the next handle on the
+    same device list inherited its exchange number, parity and arrival words (in FLAGS mode a peer may have posted arrival
+    values ahead of the number the failed rank recorded: the next run would skip waits and sum stale slots).  A rank failure
+    is injected (SNMF_MULTI_TEST_FAIL = rank:iteration); the call must fail, the team must NOT be cached, and a second solve
+    on the same device list must equal a solve on a process that never failed -- bit for bit.  Then the cache control:
+    snmf_multi_release_cache() empties the idle teams."""
+    from se_snmf_nat_amd import _lib, release_device_lists
+    from se_snmf_nat_amd.api import _make_params
+    F, T, r, iters = 129, 900, 24, 7
+    V, W0, H0 = synth_problem(F, T, r)
+    Vf, Hf, Wf = np.asfortranarray(V, np.float32), np.asfortranarray(H0, np.float32), np.asfortranarray(W0)
+    devs = np.asarray([0, 0, 0], np.int32)  # a device list no other test of this module uses (3 ranks on device 0)
+
+    def solve(expect_fail):
+        sp = _make_params(F, T, r, 1.0, iters, 0.0, 1, True, 0, 5.0, None, None)
+        h = C.c_void_p()
+        _lib.check(lib.snmf_multi_create(C.c_void_p(devs.ctypes.data), 3, C.byref(sp), None, C.byref(h)))
+        try:
+            _lib.check(lib.snmf_multi_set_v_f32(h, C.c_void_p(Vf.ctypes.data), F))
+            _lib.check(lib.snmf_multi_set_w_f64(h, C.c_void_p(Wf.ctypes.data), F))
+            _lib.check(lib.snmf_multi_set_h_f32(h, C.c_void_p(Hf.ctypes.data), r))
+            _lib.check(lib.snmf_multi_init(h))
+            done = C.c_int32()
+            rc = lib.snmf_multi_run(h, iters, C.byref(done))
+            if expect_fail:
+                assert rc != 0 and b"injected failure" in lib.snmf_last_error()
+                return None
+            _lib.check(rc)
+            W = np.empty((F, r), order="F")
+            Hh = np.empty((r, T), order="F")
+            _lib.check(lib.snmf_multi_get_w_f64(h, C.c_void_p(W.ctypes.data), F))
+            _lib.check(lib.snmf_multi_get_h_f64(h, C.c_void_p(Hh.ctypes.data), r))
+            return W, Hh
+        finally:
+            lib.snmf_multi_destroy(h)
+
+    release_device_lists()
+    assert lib.snmf_multi_cached_teams() == 0
+    w_ref, h_ref = solve(False)
+    assert lib.snmf_multi_cached_teams() == 1      # a healthy team is kept for the next handle
+    monkeypatch.setenv("SNMF_MULTI_TEST_FAIL", "1:3")
+    solve(True)
+    monkeypatch.delenv("SNMF_MULTI_TEST_FAIL")
+    assert lib.snmf_multi_cached_teams() == 0      # ... a poisoned one is destroyed with its last user
+    w2, h2 = solve(False)
+    assert np.array_equal(w2, w_ref) and np.array_equal(h2, h_ref)
+    assert lib.snmf_multi_cached_teams() == 1
+    assert release_device_lists() == 1 and lib.snmf_multi_cached_teams() == 0

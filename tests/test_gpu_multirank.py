@@ -239,6 +239,13 @@ def test_bench_single_gpu_line_keeps_the_contract():
         assert rf["traffic"] >= rf["algorithmic_bytes_per_launch"] and rf["traffic_ratio"] == pytest.approx(rf["traffic"] / rf["algorithmic_bytes_per_launch"])
     cb = d["cpu_baseline"]
     assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] in ("port", "reference") and cb["sample"]
+    # the cold number beside the settled one: a resident 200-iteration (BASELINE configs[1]) and a 100-iteration solve (the
+    # reference's default max_iter) from the random start; never faster than the settled `value` (5 % for the timer's noise
+    # on this test's small shape, where a step is tens of microseconds)
+    assert d["from_random_start"] is not None, d["from_random_start_detail"]
+    assert 0 < d["from_random_start"] <= 1.05 * d["value"]
+    fr = d["from_random_start_detail"]
+    assert fr["iters_200"]["iterations_per_s"] == d["from_random_start"] and fr["iters_100"]["iterations_per_s"] > 0
 
 
 def _dnmf_worker(rank, world, port, prob, q):
