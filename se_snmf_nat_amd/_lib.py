@@ -17,6 +17,9 @@ LIB_PATH = os.path.join(_HERE, "libsnmf_hip.so")
 import glob as _glob
 # The library is several translation units compiled in parallel and linked once (csrc/snmf_internal.h says which is which).
 SRC = sorted(_glob.glob(os.path.join(_HERE, "csrc", "*.hip")))
+# experiment kernels (csrc/experiments/: k_hstep_m, the merged-role H step -- 15 % slower than the shipped kernel, kept for its
+# counters): only in builds that ask for them, SNMF_EXPERIMENTS=1 python scripts/build_variant.py exp -> -DSNMF_EXPERIMENTS
+SRC_EXPERIMENTS = sorted(_glob.glob(os.path.join(_HERE, "csrc", "experiments", "*.hip")))
 OBJ_DIR = os.path.join(_ROOT, "build", "obj")
 # headers each translation unit includes beyond the ones every unit does (an edit to a header rebuilds only its users)
 _COMMON_HDRS = ["snmf_internal.h", "snmf_kernels.h", os.path.join(_ROOT, "include", "snmf.h")]
@@ -33,7 +36,8 @@ _TU_HDRS = {
     "snmf_tu_dnmf.hip": ["snmf_frontend.h"],
     "snmf_tu_smallf.hip": ["snmf_smallf.h"],
     "snmf_tu_itersf.hip": ["snmf_smallf.h"],
-    "snmf_tu_hstep_m.hip": ["snmf_hstep_m.h"],
+    "snmf_tu_smallr.hip": ["snmf_smallf.h", "snmf_smallr.h"],
+    "snmf_tu_hstep_m.hip": ["experiments/snmf_hstep_m.h"],
 }
 HDRS = sorted(_glob.glob(os.path.join(_HERE, "csrc", "*.h"))) + [os.path.join(_ROOT, "include", "snmf.h")]
 
@@ -141,8 +145,11 @@ def build(force=False, verbose=False, jobs=None, extra_flags=(), lib_path=None, 
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value",
              "-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_HERE, "csrc")] + list(extra_flags)
+    experiments = os.environ.get("SNMF_EXPERIMENTS", "0") == "1" or "-DSNMF_EXPERIMENTS" in flags
+    if experiments and "-DSNMF_EXPERIMENTS" not in flags:
+        flags.append("-DSNMF_EXPERIMENTS")
     todo, objs = [], []
-    for src in SRC:
+    for src in SRC + (SRC_EXPERIMENTS if experiments else []):
         obj = os.path.join(obj_dir, os.path.splitext(os.path.basename(src))[0] + ".o")
         objs.append(obj)
         deps = [d for d in _tu_deps(src) if os.path.exists(d)]

@@ -34,7 +34,7 @@
 // Envelope (host: snmf_api.hip): KL, H update, 8 row tiles (+ the extra row), 8 column tiles, no r x T sparsity matrix; every
 // tile whole (no split last round yet).  Bit-identical H to k_hstep / k_hstep_rp: same MFMA order per output tile.
 #pragma once
-#include "snmf_kernels.h"
+#include "../snmf_kernels.h"
 
 namespace snmf {
 

@@ -1,6 +1,7 @@
 // snmf_tu_hstep_m.hip -- launch of k_hstep_m, the KL H half-step with merged roles (one wave per SIMD does P1, both epilogues and
 // P2 of its own rows / columns: snmf_hstep_m.h).  A translation unit of its own (snmf_internal.h).
-#include "snmf_internal.h"
+// EXPERIMENT: compiled and linked only into -DSNMF_EXPERIMENTS builds (se_snmf_nat_amd/_lib.py: SNMF_EXPERIMENTS=1).
+#include "../snmf_internal.h"
 #include "snmf_hstep_m.h"
 
 int launch_hstep_m(snmf_plan* pl, StepArgs a, bool obj) {

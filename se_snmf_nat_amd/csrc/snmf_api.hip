@@ -339,11 +339,16 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     }
     // k_hstep_m (merged roles: one wave per SIMD runs P1, both epilogues and P2 of its own rows / columns, snmf_hstep_m.h): the
     // double-buffered geometry with exactly 8 row tiles and 8 column tiles (C2).  SNMF_HSTEP_M=1 selects it (A/B against k_hstep_rp).
+    // An EXPERIMENT (15 % slower than k_hstep_rp, kept as the vehicle of the counters in profiles/r05_experiments.md section 1): only
+    // in builds with -DSNMF_EXPERIMENTS (SNMF_EXPERIMENTS=1 python scripts/build_variant.py exp), whose sources then include
+    // csrc/experiments/; the product library has neither the kernel nor the switch.
+#ifdef SNMF_EXPERIMENTS
     {
         const char* e = getenv("SNMF_HSTEP_M");
         pl->hm = e && atoi(e) != 0 && pl->hstep_rp && pl->NWH == 8 && pl->NLH == 4 && pl->bm == BM_KL && pl->nf == 8 && pl->nk == 8 && !pl->generic;
         pl->hm_grid = std::max(1, std::min(pl->rp_tiles, ctx->n_cu));
     }
+#endif
     // At most two row tiles and eight column tiles (the Mel solves, r <= 256): a tile per WAVE, nothing handed between waves
     // (snmf_smallf.h).  Follows SNMF_HSTEP_RP (tests compare against the barrier-phased kernels); SNMF_HSTEP_SF=0 keeps the
     // role pipeline.
@@ -431,6 +436,26 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         const size_t tail = ((size_t)ncl * pl->nf * pl->nk * 1024 + (size_t)ncl * pl->rp) * 4 + 2 * ncl * sizeof(double);
         pl->lds_isf = std::max(body, tail) + 64;
         pl->isf = pl->sf && pl->wsf && pl->nf == 2 && pl->nk >= 3 && pl->upd_h && pl->upd_w && pl->lds_isf <= lds_cap && !(e && atoi(e) == 0);
+    }
+    // Small rank on tall spectrograms (r <= 32 on 3..16 row tiles; the reference's R = 20 / 10 / 30 at F = 513): a tile per workgroup
+    // cut by ROW TILES over its eight waves, every operand straight into the MFMA layouts (snmf_smallr.h).  Follow SNMF_HSTEP_RP /
+    // SNMF_WSTATS_NL like the other fast paths (tests compare against the plain kernels); SNMF_HSTEP_SR=0 / SNMF_WSTATS_SR=0 keep the role pipelines.
+    {
+        const char* e = getenv("SNMF_HSTEP_SR");
+        const char* e2 = getenv("SNMF_WSTATS_SR");
+        const char* e3 = getenv("SNMF_WSTATS_NL");
+        const bool shape = pl->bm == BM_KL && pl->nf >= 3 && pl->nf <= 16 && pl->nk == 1 && !pl->generic && pl->TTW == 32 && pl->TTH == 32;
+        pl->lds_sr = sr_hstep_lds_bytes(pl->nk, pl->Fq, pl->rp);
+        pl->sr = shape && pl->upd_h && pl->hstep_rp && pl->lds_sr <= lds_cap && !(e && atoi(e) == 0);
+        pl->sr_grid = std::max(1, std::min((T + 31) / 32, ctx->n_cu));
+        if (const char* e4 = getenv("SNMF_SR_STAG")) pl->sr_stagger = atoi(e4);
+        pl->lds_wsr = sr_wstats_lds_bytes(pl->rp);
+        pl->wsr = shape && pl->upd_w && pl->NLW && !(e2 && atoi(e2) == 0) && !(e3 && atoi(e3) == 0);
+        if (pl->wsr) {  // one workgroup per frame chunk carries every row tile: no row groups
+            pl->n_fg = 1;
+            pl->n_kg = 1;
+            pl->til = 1;
+        }
     }
     const int wg_w = pl->NLW ? 1 : pl->WPS;  // workgroups per CU
     pl->n_chunks = std::max(1, std::min(n_tiles_w, ctx->n_cu * wg_w / std::max(1, pl->n_fg * pl->n_kg)));
@@ -643,7 +668,10 @@ extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
     char hs[256];
     const bool rh_pipe = pl->rh && pl->upd_h && !pl->M;
     const bool sf_pipe = pl->sf && !pl->M;
-    if (sf_pipe && pl->isf && pl->wfin)
+    const bool sr_pipe = pl->sr && !pl->M;
+    if (sr_pipe)
+        snprintf(hs, sizeof hs, "k_hstep_sr (a tile per workgroup cut by row tiles over 8 waves, operands straight into the MFMA layouts, partial numerators meet in LDS; %d tiles, grid %d)", pl->rp_tiles, pl->sr_grid);
+    else if (sf_pipe && pl->isf && pl->wfin)
         snprintf(hs, sizeof hs, "k_iter_sf (H step + W statistics of a full update in ONE launch, 4 SIMD pairs of an H wave and a W wave per workgroup; %d tiles, grid %d; step API: k_hstep_sf)", pl->rp_tiles, pl->n_chunks);
     else if (sf_pipe)
         snprintf(hs, sizeof hs, "k_hstep_sf (a tile per wave from first load to last store, 8 waves per workgroup; %d tiles, grid %d)", pl->rp_tiles, pl->sf_grid);
@@ -667,9 +695,9 @@ extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
              "F=%d T=%d r=%d beta=%g | Fm=%d(+%d VALU row) rp=%d Tp=%d | hstep: %s, tile=%d frames, grid=%d x %d thr, lds=%zu B | "
              "wstats: NK=%d waves=%d+%d grid=(%d chunks,%d fgroups,%d kgroups; group-1 chunks %d) lds=%zu B%s | W finish (run loop): %s | n_cu=%d",
              pl->p.F, pl->p.T, pl->p.r, pl->p.beta, pl->Fm, pl->xr, pl->rp, pl->Tp, hs, pl->TTH * pl->NT,
-             sf_pipe ? pl->sf_grid : ((kl_pipe || rh_pipe) ? pl->rp_grid : pl->grid_h), sf_pipe ? 512 : (rh_pipe ? 768 : (pl->NWH + pl->NLH) * 64),
-             sf_pipe ? pl->lds_sf : (rh_pipe ? pl->lds_rh : pl->lds_h), pl->NKT, pl->NWB, pl->NLW, pl->n_chunks, pl->n_fg, pl->n_kg, pl->n_ch1 ? pl->n_ch1 : pl->n_chunks, pl->lds_w,
-             pl->gram_p ? ", P = W*(H*H') through the Gram matrix" : (pl->wsf ? ", k_wstats_sf: a tile per wave" : (pl->til > 1 ? (pl->til == 2 ? ", 2 consumer teams take the tiles in turn" : ", 4+ consumer teams take the tiles in turn") : "")), pl->wfin ? "k_wfin" : (pl->upd_w ? "k_reduce + k_wapply" : "none"), pl->ctx->n_cu);
+             sr_pipe ? pl->sr_grid : sf_pipe ? pl->sf_grid : ((kl_pipe || rh_pipe) ? pl->rp_grid : pl->grid_h), (sr_pipe || sf_pipe) ? 512 : (rh_pipe ? 768 : (pl->NWH + pl->NLH) * 64),
+             sr_pipe ? pl->lds_sr : sf_pipe ? pl->lds_sf : (rh_pipe ? pl->lds_rh : pl->lds_h), pl->NKT, pl->NWB, pl->NLW, pl->n_chunks, pl->n_fg, pl->n_kg, pl->n_ch1 ? pl->n_ch1 : pl->n_chunks, pl->lds_w,
+             pl->gram_p ? ", P = W*(H*H') through the Gram matrix" : (pl->wsr ? ", k_wstats_sr: statistics rows per wave, operands straight into the MFMA layouts" : pl->wsf ? ", k_wstats_sf: a tile per wave" : (pl->til > 1 ? (pl->til == 2 ? ", 2 consumer teams take the tiles in turn" : ", 4+ consumer teams take the tiles in turn") : "")), pl->wfin ? "k_wfin" : (pl->upd_w ? "k_reduce + k_wapply" : "none"), pl->ctx->n_cu);
     return SNMF_OK;
 }
 
@@ -1115,6 +1143,7 @@ static bool hupd_is_rp(const snmf_plan* pl) {
 static int hupd_parts(const snmf_plan* pl) {
     if (pl->generic) return kGBlocks;
     if (pl->M) return pl->grid_mdi;
+    if (pl->sr) return pl->sr_grid;
     if (pl->sf) return pl->sf_grid;
     if (hupd_is_rp(pl)) return (pl->hm && !pl->rh && !pl->S) ? pl->hm_grid : pl->rp_grid;
     return pl->grid_h;

@@ -128,6 +128,12 @@ struct snmf_plan {
     size_t lds_isf = 0;
     int sf_stagger = 0;   // cycles by which the second wave of each SIMD starts late (k_hstep_sf)
     size_t lds_sf = 0;
+    // small rank on tall spectrograms (r <= 64, 3..16 row tiles: snmf_smallr.h): a tile per WORKGROUP cut by row tiles, operands straight
+    // into the MFMA layouts; KL H-update launches through k_hstep_sr, KL statistics through k_wstats_sr (SNMF_HSTEP_SR / SNMF_WSTATS_SR = 0: the role pipelines)
+    bool sr = false, wsr = false;
+    int sr_grid = 1;
+    int sr_stagger = 1300;  // cycles by which the second wave of each SIMD starts late (k_hstep_sr / k_wstats_sr; SNMF_SR_STAG)
+    size_t lds_sr = 0, lds_wsr = 0;
     int til = 1;  // k_wstats: consumer teams that share a chunk's tiles (StepArgs::til)
     int n_ch1 = 0;  // k_wstats: chunks of row group 1 when the two row groups are split unevenly (else 0)
     // beta = 2, r > 256: the V*H^T launch (needs no Lam') runs the loader-wave geometry <8,4,4,2> once per 256-column
@@ -262,6 +268,8 @@ int launch_hstep_rh(snmf_plan* pl, StepArgs a, bool obj);  // snmf_tu_hstep_rh.h
 int launch_hstep_m(snmf_plan* pl, StepArgs a, bool obj);   // snmf_tu_hstep_m.hip
 int launch_hstep_sf(snmf_plan* pl, StepArgs a, bool obj);  // snmf_tu_smallf.hip
 int launch_wstats_sf(snmf_plan* pl, const StepArgs& a, bool obj);  // snmf_tu_smallf.hip
+int launch_hstep_sr(snmf_plan* pl, StepArgs a, bool obj);            // snmf_tu_smallr.hip
+int launch_wstats_sr(snmf_plan* pl, const StepArgs& a, bool obj);   // snmf_tu_smallr.hip
 int launch_iter_sf(snmf_plan* pl, bool obj);  // snmf_tu_smallf.hip: H step + W statistics of one full KL iteration, H[cur] -> H[cur ^ 1]
 int launch_wstats(snmf_plan* pl, bool obj);
 int launch_wstats_nk4(snmf_plan* pl, const StepArgs& a, bool obj);  // snmf_tu_wstats4.hip

@@ -610,6 +610,25 @@ __device__ __forceinline__ double wg_sum_256(double v, double* scratch /*[4]*/, 
     return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
 }
 
+// two sums at once (each with wg_sum_256's tree, so each comes out bit for bit as a call of its own would): one pair of barriers
+// and one exposed shuffle chain instead of two -- the F x r epilogue is a chain of latencies on a mostly idle chip
+__device__ __forceinline__ void wg_sum2_256(double& v0, double& v1, double* scratch0 /*[4]*/, double* scratch1 /*[4]*/, int tid) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double u0 = __shfl_xor(v0, o, 64), u1 = __shfl_xor(v1, o, 64);
+        v0 += u0;
+        v1 += u1;
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) {
+        scratch0[tid >> 6] = v0;
+        scratch1[tid >> 6] = v1;
+    }
+    __syncthreads();
+    v0 = (scratch0[0] + scratch0[1]) + (scratch0[2] + scratch0[3]);
+    v1 = (scratch1[0] + scratch1[1]) + (scratch1[2] + scratch1[3]);
+}
+
 // extra row (F = 32*nf + 1): lam_x[t] = sum_k W[Fm,k] H[k,t] on the VALU, 4 columns x 16 lanes at a time
 template <int NW, int NT, int BM, bool OBJ, bool VG = false, bool MDI = false, int TT = 32>
 __device__ __forceinline__ void hstep_p1_xrow(const StepArgs& a, float* Hs, float* Rs, const float* wxs, int t0, int w,
@@ -990,7 +1009,27 @@ __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(Step
 // the missing arrival of a slow one whenever a wave may run a tile ahead of its team.  The loaders stage tiles 0 and 1
 // back to back, so with a total `ready` the A team, or the loaders' own extra-row pass, could start on a tile that one
 // loader wave had not finished staging; a probe over awkward shapes found it.)
+// -DSNMF_STRESS (scripts/build_variant.py stress -DSNMF_STRESS; tests/test_gpu_fuzz.py and the pipelined-vs-plain lists run on it:
+// profiles/r06_stress.log): a pseudo-random delay at EVERY hand-off of the role pipelines -- in front of each progress post (the
+// signal arrives late) and behind each satisfied wait (the consumer starts late), at the split tiles' arrival counter, the fused
+// small-F iteration's pair hand-off and the adaptation kernel's grid exchange.  The unit tests run with deterministic timing; a
+// protocol that is only right for the timing the kernels happen to have (round 5's DMA refill under another wave's copy-out) shows
+// when one hand-off in four is late by up to 64 x 64 cycles -- a fifth of a tile period.  The shipped kernels contain none of this.
+#ifdef SNMF_STRESS
+__device__ __forceinline__ void stress_jitter() {
+    unsigned t = (unsigned)__builtin_amdgcn_s_memtime() ^ ((unsigned)threadIdx.x >> 6) * 0x85EBCA6Bu ^ (unsigned)blockIdx.x * 0xC2B2AE35u;
+    t ^= t >> 7;
+    t *= 0x9E3779B1u;
+    t ^= t >> 15;
+    const int n = __builtin_amdgcn_readfirstlane((t & 3u) == 0u ? (int)((t >> 2) & 63u) : 0);
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+}
+#else
+__device__ __forceinline__ void stress_jitter() {}
+#endif
+
 __device__ __forceinline__ void rp_post(unsigned* slots, int wave_in_role, unsigned tiles_done, int lane) {
+    stress_jitter();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     if (lane == 0) __hip_atomic_store(slots + wave_in_role, tiles_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -1010,6 +1049,7 @@ __device__ __forceinline__ void rp_await(const unsigned* slots, unsigned target,
         __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    stress_jitter();
 }
 
 // acc[i] += sum_q Wfrag_i(q) (x) Sfrag(q), i < NA: NA output tiles that share the LDS operand stream (one ds_read_b128
@@ -1745,6 +1785,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                 // the part: nothing to copy out (its H block stays for the finishing pass: no later item takes this buffer).
                 // Every B wave has waited for its partial stores: bump the tile's arrival counter; whoever brings it to a
                 // multiple of S is the last of the tile's S workgroups and will finish it at the end of the kernel
+                if (lw == 0) stress_jitter();
                 if (lw == 0 && lane == 0) {
                     const unsigned old = __hip_atomic_fetch_add(a.part_cnt + (ptile - n_full), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     *plast = (old % (unsigned)a.part_S == (unsigned)a.part_S - 1u) ? 1u : 0u;
@@ -2345,6 +2386,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rh(StepArgs a) {
             }
             rp_await(p2done, (unsigned)(j + 1), a.stop);
             if (j == ppos) {  // the part: no H to copy out (its H block stays for the finishing pass); bump the tile's arrival counter
+                if (lw == 0) stress_jitter();
                 if (lw == 0 && lane == 0) {
                     const unsigned old = __hip_atomic_fetch_add(a.part_cnt + (ptile - n_full), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     *plast = (old % (unsigned)pS == (unsigned)pS - 1u) ? 1u : 0u;
@@ -3738,12 +3780,13 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats_teams(StepArgs 
 // in the reduced statistics.  Every workgroup evaluates it identically (no races: it reads only
 // the statistics and the cost of iteration it-1, written by an earlier launch); one thread
 // records.  Returns true when the loop must stop at `it`.
+// last_pre: costh[it - 2] loaded by the caller ahead of time (k_wfin issues every global load of the launch up front), or nullptr
 __device__ __forceinline__ bool conv_test(const double* sc, double* divh, double* costh, DevState* st, int it,
-                                          double conv_eps, bool recorder) {
+                                          double conv_eps, bool recorder, const double* last_pre = nullptr) {
     const double div = sc[0], cost = sc[0] + sc[1];
     bool stopnow = false;
     if (it > 1 && conv_eps > 0.0) {
-        const double last = costh[it - 2];
+        const double last = last_pre ? *last_pre : costh[it - 2];
         const double e = fabs(cost - last) / last;
         stopnow = e < conv_eps;
     }
@@ -3978,8 +4021,10 @@ struct ApplyArgs {
 // F x r: keeping it in fp64 costs nothing measurable.
 // Q / P: this column of the reduced statistics; P == nullptr: KL, the
 // "P" of every row is the row sum sk of H.
+// wpre: this thread's rows of the column (wc[tid + 256 i], i < 5; F <= 1280) loaded by the caller ahead of time, or nullptr
+// (by reference + a flag, every index a compile-time constant: through a pointer the array went to scratch)
 __device__ __forceinline__ void wapply_column(const ApplyArgs& a, int k, int tid, const double* Q, const double* P,
-                                              double sk, double (&red)[3][256]) {
+                                              double sk, double (&red)[3][256], const double (&wpre)[5], bool use_pre) {
     double* wc = a.Wc + (size_t)k * a.Fp;
     const bool upd = a.init_mode ? false : (a.w_ind[k] != 0);
     // This thread's rows f = tid, tid + 256, ... of the column live in registers for the whole epilogue (F <= 1024 + 1
@@ -3992,7 +4037,7 @@ __device__ __forceinline__ void wapply_column(const ApplyArgs& a, int k, int tid
         for (int i = 0; i < NR; ++i) {
             const int f = tid + 256 * i;
             const bool ok = f < a.F;
-            wv[i] = ok ? wc[f] : 0.0;
+            wv[i] = use_pre ? wpre[i] : (ok ? wc[f] : 0.0);
             qv[i] = (ok && upd) ? Q[f] : 0.0;
             pv[i] = (ok && upd) ? (P ? P[f] : sk) : 0.0;
         }
@@ -4013,8 +4058,7 @@ __device__ __forceinline__ void wapply_column(const ApplyArgs& a, int k, int tid
                 cPW += (P ? P[f] : sk) * w0;
             }
         }
-        cQW = wg_sum_256(cQW, &red[0][0], tid);
-        cPW = wg_sum_256(cPW, &red[1][0], tid);
+        wg_sum2_256(cQW, cPW, &red[0][0], &red[1][0], tid);
     }
     // updated (un-normalised) entry: dpw = max(P + W.*colsum(Q.*W), flr); dmw = Q + W.*colsum(P.*W)
     auto upd_val = [&](double w0, double Qv, double Pv) -> double {
@@ -4115,6 +4159,7 @@ static __global__ __launch_bounds__(256) void k_wapply(ApplyArgs a) {
     }
     if (!a.do_update && !a.init_mode) return;
     if (k >= a.r) return;
+    const double no_pre[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     if (a.gather) {
         double* Qs = wap_cols;
         double* Ps = wap_cols + a.Fp;
@@ -4136,13 +4181,13 @@ static __global__ __launch_bounds__(256) void k_wapply(ApplyArgs a) {
             for (int q = 1; q < a.ngather; ++q) sk += a.gather[(size_t)q * a.gather_len + i];
         }
         __syncthreads();
-        wapply_column(a, k, tid, Qs, a.n_mat == 2 ? Ps : nullptr, sk, red);
+        wapply_column(a, k, tid, Qs, a.n_mat == 2 ? Ps : nullptr, sk, red, no_pre, false);
         return;
     }
     const double* Q = a.stats + (size_t)k * a.Fp;
     const double* P = (a.n_mat == 2) ? a.stats + nel + (size_t)k * a.Fp : nullptr;
     const double sk = (a.n_mat == 2 || a.init_mode) ? 0.0 : a.stats[nel * a.n_mat + k];
-    wapply_column(a, k, tid, Q, P, sk, red);
+    wapply_column(a, k, tid, Q, P, sk, red, no_pre, false);
 }
 #endif  // SNMF_AUX_KERNELS (k_wapply)
 
@@ -4163,39 +4208,62 @@ __global__ __launch_bounds__(768) void k_wfin(ReduceArgs ra, ApplyArgs a) {
     __shared__ double red[3][256];
     __shared__ double red2[2][256];
     __shared__ double skp[8];
-    if (a.st->stop) return;
     const int k = blockIdx.x, tid = threadIdx.x;
     const size_t nel = (size_t)a.rp * a.Fp;
     const int nE = a.Fp / 4, nI = NMAT * nE;  // f32x4 of a column (of both matrices)
     double* part = wfin_lds;                  // [8][nI][4]
     double* QP = wfin_lds + (size_t)8 * nI * 4;  // [NMAT][Fp]
     const size_t cstride = nel * NMAT;
+    // Round 6: the launch was a CHAIN of dependent global round trips on a mostly idle chip (the stop flag, then the slab pieces,
+    // then the objective partials, then the previous cost for the convergence test, then the column of W: ~1.5 us each of the
+    // kernel's 14-16 us, which do not shrink with T).  Every global load whose address does not depend on another load is now
+    // ISSUED before the first one is waited for: vmcnt retires in issue order, so the slab pieces (issued first) are consumed
+    // first while the rest is already on its way.
+    const int stop_now = __hip_atomic_load(&a.st->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // The column's slab pieces: item (g, e) = chunk group g, f32x4 e.  768 threads for this phase only (sixteen loads of
     // a thread in flight: one memory round trip for a column of C2, where 256 threads needed four); the W update behind
     // it is wapply_column's 256 threads, the other waves end at the barrier.
-    for (int i = tid; i < 8 * nI; i += 768) {
+    auto item_geo = [&](int i, int& cb, int& ce, const float*& p) {
         const int g = i / nI, e = i - g * nI, m = e / nE, e4 = e - m * nE;
-        const int cb = (int)(((long long)ra.n_chunks * g) / 8), ce = (int)(((long long)ra.n_chunks * (g + 1)) / 8);
-        const float* p = ra.slabs + (size_t)m * nel + (size_t)k * a.Fp + 4 * e4;
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        int c = cb;
-        for (; c + 16 <= ce; c += 16) {
-            f32x4 x[16];
+        cb = (int)(((long long)ra.n_chunks * g) / 8);
+        ce = (int)(((long long)ra.n_chunks * (g + 1)) / 8);
+        p = ra.slabs + (size_t)m * nel + (size_t)k * a.Fp + 4 * e4;
+    };
+    f32x4 x[16];  // sixteen chunks of the current item in flight
+    int it_i = tid, cb = 0, ce = 0;
+    const float* p = nullptr;
+    auto load_batch = [&](int c) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) x[j] = *reinterpret_cast<const f32x4*>(p + (size_t)(c + j) * cstride);
+        for (int j = 0; j < 16; ++j)
+            if (c + j < ce) x[j] = *reinterpret_cast<const f32x4*>(p + (size_t)(c + j) * cstride);
+    };
+    if (it_i < 8 * nI) {
+        item_geo(it_i, cb, ce, p);
+        load_batch(cb);
+    }
+    // this thread's rows of the column of W (wapply_column's register layout), the first 256 objective partials, the previous cost
+    constexpr int NR = 5;
+    double wpre[NR] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    double pd0 = 0.0, ph0 = 0.0, last_cost = 0.0;
+    const bool pre_w = a.F <= NR * 256 && k < a.r;
+    if (tid < 256) {
+        if (pre_w) {
+            const double* wc = a.Wc + (size_t)k * a.Fp;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                s0 += (double)x[j][0];
-                s1 += (double)x[j][1];
-                s2 += (double)x[j][2];
-                s3 += (double)x[j][3];
-            }
+            for (int i = 0; i < NR; ++i)
+                if (tid + 256 * i < a.F) wpre[i] = wc[tid + 256 * i];
         }
-        if (c < ce) {  // the rest of the group (up to 15 chunks), again all loads first
-            f32x4 x[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (c + j < ce) x[j] = *reinterpret_cast<const f32x4*>(p + (size_t)(c + j) * cstride);
+        if (ra.do_obj && tid < ra.n_part) {
+            pd0 = ra.part[2 * tid];
+            ph0 = ra.part[2 * tid + 1];
+        }
+        if (a.check_it > 1) last_cost = a.costh[a.check_it - 2];
+    }
+    SNMF_PIN();
+    if (stop_now) return;
+    while (it_i < 8 * nI) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        for (int c = cb;;) {  // (chunks in ascending order, as k_reduce adds them)
 #pragma unroll
             for (int j = 0; j < 16; ++j)
                 if (c + j < ce) {
@@ -4204,11 +4272,19 @@ __global__ __launch_bounds__(768) void k_wfin(ReduceArgs ra, ApplyArgs a) {
                     s2 += (double)x[j][2];
                     s3 += (double)x[j][3];
                 }
+            c += 16;
+            if (c >= ce) break;
+            load_batch(c);
         }
-        part[(size_t)i * 4 + 0] = s0;
-        part[(size_t)i * 4 + 1] = s1;
-        part[(size_t)i * 4 + 2] = s2;
-        part[(size_t)i * 4 + 3] = s3;
+        part[(size_t)it_i * 4 + 0] = s0;
+        part[(size_t)it_i * 4 + 1] = s1;
+        part[(size_t)it_i * 4 + 2] = s2;
+        part[(size_t)it_i * 4 + 3] = s3;
+        it_i += 768;
+        if (it_i < 8 * nI) {
+            item_geo(it_i, cb, ce, p);
+            load_batch(cb);
+        }
     }
     // row sum of H (KL): eight chunk groups as well
     if (NMAT == 1 && tid >= 760) {  // (threads of the last wave: it has the fewest items above)
@@ -4228,9 +4304,9 @@ __global__ __launch_bounds__(768) void k_wfin(ReduceArgs ra, ApplyArgs a) {
     }
     // objective partials (k_reduce's last block: strided, then a tree)
     if (tid < 256) {
-        double d = 0.0, h = 0.0;
+        double d = pd0, h = ph0;
         if (ra.do_obj) {
-            for (int c = tid; c < ra.n_part; c += 256) {
+            for (int c = tid + 256; c < ra.n_part; c += 256) {
                 d += ra.part[2 * c];
                 h += ra.part[2 * c + 1];
             }
@@ -4262,7 +4338,7 @@ __global__ __launch_bounds__(768) void k_wfin(ReduceArgs ra, ApplyArgs a) {
         scg[1] = sc[1];
     }
     if (a.check_it > 0) {
-        const bool stopnow = conv_test(sc, a.divh, a.costh, a.st, a.check_it, a.conv_eps, k == 0 && tid == 0);
+        const bool stopnow = conv_test(sc, a.divh, a.costh, a.st, a.check_it, a.conv_eps, k == 0 && tid == 0, &last_cost);
         if (stopnow) return;
     }
     double sk = 0.0;
@@ -4270,7 +4346,7 @@ __global__ __launch_bounds__(768) void k_wfin(ReduceArgs ra, ApplyArgs a) {
 #pragma unroll
         for (int gg = 0; gg < 8; ++gg) sk += skp[gg];
     }
-    wapply_column(a, k, tid, QP, NMAT == 2 ? QP + a.Fp : nullptr, sk, red);
+    wapply_column(a, k, tid, QP, NMAT == 2 ? QP + a.Fp : nullptr, sk, red, wpre, pre_w);
 }
 
 
@@ -4450,5 +4526,15 @@ __global__ __launch_bounds__(256) void k_mdi_final(const float* __restrict__ V, 
         }
     }
 }
+
+// ---- small-rank family (snmf_smallr.h): what the host's geometry selection needs of it -----------------------------------------
+constexpr int kSrWaves = 8;  // waves per workgroup (two per SIMD), one workgroup per CU
+// LDS of k_hstep_sr: Wk4 image [NK][Fq/8][2][32][4] | wx [rp] | 1 ./ dph [rp] | lambda_k [rp] | partial slots [2 buffers][8 waves][NK][16][64]
+// | ratio of the extra row [2][32] | progress words [32] | doubles [2][8]
+inline size_t sr_hstep_lds_bytes(int nk, int Fq, int rp) {
+    return ((size_t)nk * Fq * 32 + 3 * (size_t)rp + (size_t)2 * kSrWaves * nk * 1024 + 64 + 32) * 4 + 2 * kSrWaves * sizeof(double);
+}
+// LDS of k_wstats_sr: wx [rp] | row sums [rp] | extra row of the slab [rp] | pad [16] | doubles [8]
+inline size_t sr_wstats_lds_bytes(int rp) { return ((size_t)3 * rp + 16) * 4 + kSrWaves * sizeof(double); }
 
 }  // namespace snmf

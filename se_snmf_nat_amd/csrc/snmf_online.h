@@ -665,6 +665,7 @@ __device__ __forceinline__ bool grid_bar(unsigned* ctr, unsigned nwg, unsigned& 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's exchange stores are acknowledged ...
     __syncthreads();                                   // ... and so are everybody's in the workgroup
     ++gen;
+    if (threadIdx.x < 64) stress_jitter();  // (-DSNMF_STRESS builds only: snmf_kernels.h)
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = gen * nwg;

@@ -474,6 +474,7 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_wstats_sf(StepArgs a, int 
 // end of the kernel reuses it for the pairs' partial statistics as k_wstats_sf does.
 
 __device__ __forceinline__ void sf_post(unsigned* word, unsigned val, int lane) {
+    stress_jitter();  // (-DSNMF_STRESS builds only: snmf_kernels.h)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     if (lane == 0) __hip_atomic_store(word, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -482,6 +483,7 @@ __device__ __forceinline__ void sf_post(unsigned* word, unsigned val, int lane) 
 // to 256 + 11 spilled (either of the two fences alone did it).  The hardware needs none of that: LDS operations of a wave
 // complete in order, the data written behind the wait and ahead of the post are registers of this wave.
 __device__ __forceinline__ void sf_post_raw(unsigned word_addr, unsigned val) {
+    stress_jitter();
     asm volatile("ds_write_b32 %0, %1" ::"v"(word_addr), "v"(val));
 }
 __device__ __forceinline__ void sf_await_raw(unsigned word_addr, unsigned target, const int* stop) {
@@ -496,6 +498,7 @@ __device__ __forceinline__ void sf_await_raw(unsigned word_addr, unsigned target
         }
         __builtin_amdgcn_s_sleep(1);
     }
+    stress_jitter();
 }
 __device__ __forceinline__ void sf_await(const unsigned* word, unsigned target, const int* stop) {
     int spin = 0;
@@ -507,6 +510,7 @@ __device__ __forceinline__ void sf_await(const unsigned* word, unsigned target, 
         __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    stress_jitter();
 }
 
 // SK: the sparsity kind (0: one lambda for every row, 1: a lambda per row, 2: an r x T matrix in H's layout) -- a parameter of the

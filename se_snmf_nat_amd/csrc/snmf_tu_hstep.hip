@@ -47,10 +47,13 @@ int launch_hstep(snmf_plan* pl, bool obj, bool upd) {
         if (pl->bm == BM_EUC) return launch_hstep_mdi_b<BM_EUC>(pl, a, obj, upd);
         return launch_hstep_mdi_b<BM_GEN>(pl, a, obj, upd);
     }
+    if (pl->sr && upd) return launch_hstep_sr(pl, a, obj);  // KL update launches, r <= 64 on 3..16 row tiles: a tile per workgroup cut by row tiles (snmf_tu_smallr.hip)
     if (pl->sf && upd) return launch_hstep_sf(pl, a, obj);  // KL update launches, F <= 64: a tile per wave (snmf_tu_smallf.hip)
     if (pl->rh && upd) return launch_hstep_rh(pl, a, obj);  // KL update launches of the 9..16-row-tile geometry (snmf_tu_hstep_rh.hip)
     if (pl->NWH == 8 && pl->NLH == 4) {
-        if (pl->hm && pl->bm == BM_KL && upd && !a.S) return launch_hstep_m(pl, a, obj);  // merged roles, one wave per SIMD (snmf_tu_hstep_m.hip)
+#ifdef SNMF_EXPERIMENTS
+        if (pl->hm && pl->bm == BM_KL && upd && !a.S) return launch_hstep_m(pl, a, obj);  // merged roles, one wave per SIMD (experiments/snmf_tu_hstep_m.hip)
+#endif
         if (pl->hstep_rp && pl->bm == BM_KL && upd) return launch_hstep_rp(pl, a, obj);  // KL update launches: the role pipeline (snmf_tu_hstep_rp.hip)
         return launch_hstep_g<8, 1, 4>(pl, a, obj, upd);
     }

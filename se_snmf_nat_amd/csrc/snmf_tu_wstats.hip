@@ -15,6 +15,7 @@ int launch_wstats(snmf_plan* pl, bool obj) {
     a.til = pl->til;
 
     ScopedTimer tm(pl->ctx, FAM_WSTATS);
+    if (pl->wsr) return launch_wstats_sr(pl, a, obj);  // r <= 64 on 3..16 row tiles, KL: statistics rows per wave, operands straight into the MFMA layouts (snmf_tu_smallr.hip)
     if (pl->wsf) return launch_wstats_sf(pl, a, obj);  // F <= 64, r <= 128, KL: a tile per wave (snmf_tu_smallf.hip)
     if (pl->NKT == 4) return launch_wstats_nk4(pl, a, obj);
     if (pl->NKT == 8) return launch_wstats_nk8(pl, a, obj);

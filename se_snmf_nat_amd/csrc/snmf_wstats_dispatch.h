@@ -86,8 +86,12 @@ static int launch_wstats_geo(snmf_plan* pl, const StepArgs& a, bool obj) {
         if constexpr (NL > 0 && TT == 32 && NK == 4) {
             if (lx == 1) return obj ? launch_wstats_one<NK, NWB, NL, WPS, 0, BM_KL, true, TT, 1>(pl, a, 0)
                                     : launch_wstats_one<NK, NWB, NL, WPS, 0, BM_KL, false, TT, 1>(pl, a, 0);
-            if (lx == 2) return obj ? launch_wstats_one<NK, NWB, NL, WPS, 0, BM_KL, true, TT, 2>(pl, a, 0)
-                                    : launch_wstats_one<NK, NWB, NL, WPS, 0, BM_KL, false, TT, 2>(pl, a, 0);
+            // (two leftover groups only on the four-consumer geometry: at its 168-register limit the eight-consumer one answered the
+            //  second group with 55-79 spilled VGPRs -- r = 101..104 at F = 513 take the padded fourth MFMA tile there instead)
+            if constexpr (NWB == 4) {
+                if (lx == 2) return obj ? launch_wstats_one<NK, NWB, NL, WPS, 0, BM_KL, true, TT, 2>(pl, a, 0)
+                                        : launch_wstats_one<NK, NWB, NL, WPS, 0, BM_KL, false, TT, 2>(pl, a, 0);
+            }
         }
         return obj ? launch_wstats_one<NK, NWB, NL, WPS, 0, BM_KL, true, TT>(pl, a, 0)
                    : launch_wstats_one<NK, NWB, NL, WPS, 0, BM_KL, false, TT>(pl, a, 0);

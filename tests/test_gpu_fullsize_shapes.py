@@ -11,10 +11,12 @@ from oracle.sparse_nmf_oracle import sparse_nmf as oracle_nmf
 pytestmark = pytest.mark.gpu
 
 SHAPES = [  # name, F, T, r, mode, kernel the plan must report
-    ("R20_513", 513, 72000, 20, "full", "cut four ways"),      # settings/bak_IS16_results/initial_setting_SNMF_Techwin_201603_RT.m:47-48
-    ("R30_513_h", 513, 72000, 30, "h", "cut four ways"),
+    ("R20_513", 513, 72000, 20, "full", "k_hstep_sr"),         # settings/bak_IS16_results/initial_setting_SNMF_Techwin_201603_RT.m:47-48
+    ("R30_513_h", 513, 72000, 30, "h", "k_hstep_sr"),
+    ("R10_513_w", 513, 72000, 10, "w", "k_wstats_sr"),         # ... R_d = 10, the W-only solve of run_basis_DNMF.m:53 at those settings
     ("R50_513", 513, 72000, 50, "full", "wave pairs cut"),     # settings/bak_IS16_results/initial_setting_IMCRA.m:47-48
-    ("R32_257", 257, 100000, 32, "full", "cut four ways"),
+    ("R32_257", 257, 100000, 32, "full", "k_hstep_sr"),
+    ("R64_257", 257, 100000, 64, "full", "over the contraction"),
     ("mel_R100", 64, 72000, 100, "full", "k_iter_sf"),          # run_basis_train.m:90-91
     # ... and the reference's shipped geometry on the kernels of rounds 3 / 4 (k_hstep_rh in both cut modes, k_wstats with LX columns)
     ("a11", 513, 72000, 100, "full", "k_hstep_rh"),             # run_basis_train.m:88

@@ -68,30 +68,34 @@ def test_pipelined_kernels_equal_plain_kernels(gpu_ctx, shape, monkeypatch):
     h_new, _, geo, obj_new = _run(gpu_ctx, V, W0, H0, r, h_only=True, iters=2)
     _, w_new, geo_full, _ = _run(gpu_ctx, V, W0, H0, r, h_only=False, iters=3)
     n_cu = int(re.search(r"n_cu=(\d+)", geo).group(1))
+    sr = "k_hstep_sr" in geo  # r <= 64 on 3..16 row tiles: a tile per workgroup cut by row tiles (round 6, csrc/snmf_smallr.h)
     if (T + 31) // 32 <= n_cu and "k_hstep_sf" not in geo:
         # one tile per workgroup: nothing to pipeline, the plan takes the barrier-phased kernels by itself (C1's case)
         assert "k_hstep_rp" not in geo and "k_hstep_rh" not in geo  # (k_wstats keeps its loader waves while a workgroup has several tiles)
         n_full, n_tiles, S = (T + 31) // 32, (T + 31) // 32, 0
     else:
-        assert "k_hstep_rp" in geo or "k_hstep_rh" in geo or "k_hstep_sf" in geo  # the pipelined path is what ran
+        assert "k_hstep_rp" in geo or "k_hstep_rh" in geo or "k_hstep_sf" in geo or sr  # the pipelined path is what ran
         m = re.search(r"(\d+) of (\d+) tiles pipelined, last round split (\d+) ways", geo)
         if "k_hstep_sf" in geo:  # (F <= 64, r <= 256: a tile per wave, never split)
             assert F <= 64 and r <= 256
+            n_full, n_tiles, S = (T + 31) // 32, (T + 31) // 32, 0
+        elif sr:  # (never split either; r = 33..64 keep k_hstep_rp<., CUT>: two column tiles do not fit the registers)
+            assert r <= 32 and 65 <= F <= 544 and "k_wstats_sr" in geo_full
             n_full, n_tiles, S = (T + 31) // 32, (T + 31) // 32, 0
         else:
             n_full, n_tiles, S = (int(x) for x in m.groups())
     monkeypatch.setenv("SNMF_HSTEP_SPLIT", "0")
     h_ns, _, geo_ns, _ = _run(gpu_ctx, V, W0, H0, r, h_only=True, iters=2)
     _, w_ns, _, _ = _run(gpu_ctx, V, W0, H0, r, h_only=False, iters=3)
-    assert "split 0 ways" in geo_ns or "k_hstep," in geo_ns or "k_hstep_sf" in geo_ns
+    assert "split 0 ways" in geo_ns or "k_hstep," in geo_ns or "k_hstep_sf" in geo_ns or "k_hstep_sr" in geo_ns
     monkeypatch.setenv("SNMF_HSTEP_RP", "0")
     monkeypatch.setenv("SNMF_WSTATS_NL", "0")
     h_old, _, geo_old, obj_old = _run(gpu_ctx, V, W0, H0, r, h_only=True, iters=2)
     _, w_old, _, _ = _run(gpu_ctx, V, W0, H0, r, h_only=False, iters=3)
-    assert "k_hstep_rp" not in geo_old and "k_hstep_rh" not in geo_old and "k_hstep_sf" not in geo_old
+    assert "k_hstep_rp" not in geo_old and "k_hstep_rh" not in geo_old and "k_hstep_sf" not in geo_old and "k_hstep_sr" not in geo_old and "k_wstats_sr" not in geo_old
     # every tile in the pipeline: the plain kernels bit for bit -- except where k_hstep_rh cuts P2 over the contraction
     # (r = 97..100 on 16 row tiles: four partial sums per numerator instead of one chain), which is a summation order of its own
-    lxh = "over the contraction" in geo  # (r = 97..100 four ways, r = 193..200 in wave pairs)
+    lxh = "over the contraction" in geo or sr  # (r = 97..100 four ways, r = 193..200 in wave pairs; k_hstep_sr: eight partial numerators by row tiles, added in wave order)
     if lxh:
         d = np.abs(h_ns - h_old)
         assert (d <= 2e-5 * np.abs(h_old) + 1e-30).all(), d.max()
@@ -131,8 +135,10 @@ def test_merged_role_h_step_equals_plain(gpu_ctx, shape, monkeypatch):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv("SNMF_HSTEP_M", "1")
     h_m, _, geo, obj_m = _run(gpu_ctx, V, W0, H0, r, h_only=True, iters=2)
-    _, w_m, _, _ = _run(gpu_ctx, V, W0, H0, r, h_only=False, iters=3)
     n_cu = int(re.search(r"n_cu=(\d+)", geo).group(1))
+    if "k_hstep_m" not in geo and (T + 31) // 32 > n_cu:
+        pytest.skip("k_hstep_m is an experiment: only in -DSNMF_EXPERIMENTS builds (SNMF_EXPERIMENTS=1 python scripts/build_variant.py exp)")
+    _, w_m, _, _ = _run(gpu_ctx, V, W0, H0, r, h_only=False, iters=3)
     assert ("k_hstep_m" in geo) == ((T + 31) // 32 > n_cu)
     monkeypatch.setenv("SNMF_HSTEP_M", "0")
     monkeypatch.setenv("SNMF_HSTEP_RP", "0")
