@@ -1800,6 +1800,9 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                     // left another wave's cells of such a row unread when this wave's DMA landed in it (found by the shape fuzzer:
                     // 6 of 39 solves with three or more tiles per workgroup off by 1e-3 .. 1e-1; two tiles per workgroup -- all
                     // the unit tests had -- never refill)
+#ifdef SNMF_REVERT_R5_RACE  // (diagnostic builds only: round 5's race put back, to show that the -m gpu fuzz test fails on it: profiles/r06_experiments.md)
+                    stage_out<NLT>(dstH, bH, Tt, rp, ldh, lt);
+#else
                     {
                         const char* const bHr = reinterpret_cast<const char*>(bH) + hv;
 #pragma unroll
@@ -1811,6 +1814,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
                             for (int u = 0; u < 4; ++u) stA(rsrc_of(dstH, nA), b0 + u, ho[u]);
                         }
                     }
+#endif
                     if (more) {
                         dma_h(tile_of(j + 2), bH);         // (behind THIS wave's reads of the same rows in program order)
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

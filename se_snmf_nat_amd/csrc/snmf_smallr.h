@@ -166,9 +166,12 @@ __global__ __launch_bounds__(kSrWaves * 64, 2) void k_hstep_sr(StepArgs a) {
             n0 += x[0];
             n1 += x[1];
         }
+        // (ratio_x: posted with the partials by the tile's x-wave -- read BEFORE this wave reports the buffer as read: a first build
+        //  read it behind the post, and the x-wave of tile jp + 2 could overwrite it in between; 1 % errors in H on a few frames,
+        //  found by tests/test_gpu_fuzz.py[pipe] and test_pipelined_kernels_equal_plain_kernels[F257_r32_T26000])
+        const float rx_p = a.xr ? rxs[(jp & 1) * 32 + t] : 0.f;
         sf_post(rdone + w, (unsigned)(jp + 1), lane);
-        if (a.xr) {  // the extra row's k-block of W^T * ratio: W[Fm, k] * ratio_x[t]  (ratio_x: posted with the partials by the tile's x-wave)
-            const float rx_p = rxs[(jp & 1) * 32 + t];
+        if (a.xr) {  // the extra row's k-block of W^T * ratio: W[Fm, k] * ratio_x[t]
             n0 += wxs[k0] * rx_p;
             n1 += wxs[k0 + 1] * rx_p;
         }
