@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SNMF_ABI_VERSION 5  /* 5: snmf_multi_release_cache, snmf_multi_cached_teams (the device RNG of snmf_plan_set_h_random changed with 4: draws seeded under ABI 3 are not reproducible); 4: snmf_run_basis_dnmf_multi_*; 3: snmf_run_basis_dnmf_*, snmf_run_basis_train_audio_f64, snmf_sparse_nmf_oop_*, snmf_plan_set_h_random, snmf_ctx_xfer_stats; 2: snmf_multi_* */
+#define SNMF_ABI_VERSION 5  /* 5: snmf_multi_release_cache, snmf_multi_cached_teams, snmf_rccl_*, snmf_plan_run_sharded_rccl (the device RNG of snmf_plan_set_h_random changed with 4: draws seeded under ABI 3 are not reproducible); 4: snmf_run_basis_dnmf_multi_*; 3: snmf_run_basis_dnmf_*, snmf_run_basis_train_audio_f64, snmf_sparse_nmf_oop_*, snmf_plan_set_h_random, snmf_ctx_xfer_stats; 2: snmf_multi_* */
 
 typedef enum snmf_status {
     SNMF_OK = 0,
@@ -177,6 +177,22 @@ int snmf_plan_stopped(snmf_plan* plan, int32_t* stopped);
 typedef int (*snmf_allreduce_fn)(double* stats_dev, int64_t len, void* user);
 int snmf_plan_run_sharded(snmf_plan* plan, int32_t n_iters, double* stats_dev, snmf_allreduce_fn all_reduce, void* user,
                           int32_t poll_every, int32_t finalize, int32_t* iters_done);
+/* The same loop with the collective issued by the library itself: ncclAllReduce (RCCL over xGMI) of the statistics on the
+ * context's stream, once per iteration -- no callback into the host language (a ctypes / MEX trampoline per iteration was 29 us of
+ * host work, a quarter of an iteration on a short shard).  librccl.so is resolved with dlopen when first needed (SNMF_RCCL_LIB, else
+ * the copy the process already holds -- PyTorch's --, else the system's), so this library loads without it; snmf_rccl_available()
+ * says whether it was found.  The communicator is set up by the caller's own out-of-band channel: rank 0 calls
+ * snmf_rccl_get_unique_id (128 bytes), every rank receives them (torch.distributed broadcast, MPI, a file) and calls
+ * snmf_rccl_comm_create(device, id, n_ranks, rank) -- ncclCommInitRank, collective over the ranks -- and later
+ * snmf_rccl_comm_destroy.  One communicator per rank, on the plan's device.  Reference: the one sum per iteration that sharding the
+ * frames of run_basis_train.m:88 / run_basis_DNMF.m:47,53 over ranks needs (the statistics of src/sparse_nmf.m:215-239, :248-261). */
+typedef struct snmf_rccl_comm snmf_rccl_comm;
+int snmf_rccl_available(void);
+int snmf_rccl_get_unique_id(void* id_out, int64_t cap);
+int snmf_rccl_comm_create(int32_t device, const void* id, int32_t n_ranks, int32_t rank, snmf_rccl_comm** out);
+void snmf_rccl_comm_destroy(snmf_rccl_comm* comm);
+int snmf_plan_run_sharded_rccl(snmf_plan* plan, int32_t n_iters, double* stats_dev, snmf_rccl_comm* comm, int32_t poll_every,
+                               int32_t finalize, int32_t* iters_done);
 
 /* Online separation stream (src/NTF_sep_event_RT.m:67-107 -> src/bnmf_sep_event_RT_IS16.m:138-154):
  * the SAME dictionary W and the SAME initial activations H0 (the reference re-seeds its generator

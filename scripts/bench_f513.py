@@ -20,7 +20,7 @@ from se_snmf_nat_amd import Context, Plan  # noqa: E402
 
 PEAK = 157.3
 K = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 0
-which = [a for a in sys.argv[1:] if a in ("a11", "c4h", "c4w", "c5", "mel", "mel288", "melh", "melw", "smallr", "tw20", "tw30h", "im50")] or ["a11", "c4h", "c4w", "c5"]
+which = [a for a in sys.argv[1:] if a in ("a11", "c4h", "c4w", "c5", "mel", "mel288", "melh", "melw", "smallr", "tw20", "tw30h", "im50", "c2", "tw10w")] or ["a11", "c4h", "c4w", "c5"]
 ctx = Context(0)
 
 SHAPES = {
@@ -38,6 +38,8 @@ SHAPES = {
     "tw20": dict(F=513, T=72000, r=20, beta=1.0, sparsity=5.0, mode="full", iters=200, settle=300),
     "tw30h": dict(F=513, T=72000, r=30, beta=1.0, sparsity=5.0, mode="h", iters=200, settle=300),
     "im50": dict(F=513, T=72000, r=50, beta=1.0, sparsity=5.0, mode="full", iters=200, settle=300),
+    "tw10w": dict(F=513, T=72000, r=10, beta=1.0, sparsity=5.0, mode="w", iters=200, settle=300),  # ... R_d = 10, W-only (run_basis_DNMF.m:53 at those settings)
+    "c2": dict(F=257, T=100000, r=256, beta=1.0, sparsity=5.0, mode="full", iters=100, settle=150),  # BASELINE configs[1] (bench.py's headline shape)
 }
 HBM_PEAK, HBM_ACHIEVABLE = 8.0e12, 6.3e12  # /opt/skills/guides/MI355X_MICROARCH.md: peak, and what a streaming kernel reaches
 

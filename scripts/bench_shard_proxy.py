@@ -63,11 +63,17 @@ def proxy(name, c, fixed_us):
         ctx.timing(False)
         plan.close()
         ctx.close()
-        tr = ShardedTrainer(V, W0, H0, beta=c["beta"], sparsity=c["sparsity"], max_iter=W + K + 1, conv_eps=0.0, cost_check=True, device=0,
+        tr = ShardedTrainer(V, W0, H0, beta=c["beta"], sparsity=c["sparsity"], max_iter=W + 2 * K + 41, conv_eps=0.0, cost_check=True, device=0,
                             w_update_ind=kw.get("w_update_ind"), h_update_ind=kw.get("h_update_ind"))
         tr.world = 2  # take the RCCL branch (one-rank group: identity)
         tr.run(W); tr.sync()
         t = time.perf_counter(); tr.run(K); th = time.perf_counter() - t; tr.sync(); b = (time.perf_counter() - t) / K * 1e3
+        # (round 6) ... and with the collective issued by the library itself: ncclAllReduce from C on the engine's stream (snmf_plan_run_sharded_rccl)
+        nat = ""
+        if tr.use_native_rccl(force_single=True):
+            tr.run(20); tr.sync()
+            t = time.perf_counter(); tr.run(K); thn = time.perf_counter() - t; tr.sync(); bn = (time.perf_counter() - t) / K * 1e3
+            nat = f"   step loop + RCCL call FROM C {bn:.4f} ms/it ({(bn - a) * 1e3:+.1f} us against the C loop; host issue {thn / K * 1e3:.4f} ms/it)"
         del tr
         base.setdefault("a", a); base.setdefault("b", b)
         out[n] = a
@@ -76,7 +82,7 @@ def proxy(name, c, fixed_us):
             w_ms = a + fixed_us[n] * 1e-3
             wi = f"  what-if (C loop + the multi entry's fixed part {fixed_us[n]:+.1f} us): {w_ms:.4f} ms/it = {base['a'] / w_ms:.2f}x"
         print(f"{name} N={n}: shard {F}x{Tn} r={r}  C loop {a:.4f} ms/it (bound {base['a'] / a:.2f}x)   step-API loop + RCCL call {b:.4f} ms/it "
-              f"(bound {base['b'] / b:.2f}x; host issue {th / K * 1e3:.4f} ms/it)  kernels us {fam}{wi}", flush=True)
+              f"(bound {base['b'] / b:.2f}x; host issue {th / K * 1e3:.4f} ms/it){nat}  kernels us {fam}{wi}", flush=True)
     return out
 
 

@@ -68,6 +68,7 @@ SYMBOLS = [
     "snmf_run_basis_train_audio_f64", "snmf_ctx_xfer_stats", "snmf_sparse_nmf_oop_f64", "snmf_sparse_nmf_oop_f32",
     "snmf_run_basis_dnmf_multi_f64", "snmf_run_basis_dnmf_multi_f32",
     "snmf_multi_release_cache", "snmf_multi_cached_teams",
+    "snmf_rccl_available", "snmf_rccl_get_unique_id", "snmf_rccl_comm_create", "snmf_rccl_comm_destroy", "snmf_plan_run_sharded_rccl",
 ]
 ABI_VERSION = 5  # include/snmf.h: SNMF_ABI_VERSION this binding was written against
 EXCHANGE_AUTO, EXCHANGE_FLAGS, EXCHANGE_EVENTS = 0, 1, 2
@@ -169,7 +170,7 @@ def build(force=False, verbose=False, jobs=None, extra_flags=(), lib_path=None, 
     if todo:
         with ThreadPoolExecutor(max_workers=jobs) as ex:
             list(ex.map(compile_one, todo))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-z,defs", "-o", lib_path] + objs + ["-lpthread"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-z,defs", "-o", lib_path] + objs + ["-lpthread", "-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
@@ -292,6 +293,11 @@ def load():
     sig["snmf_run_basis_train_audio_f64"] = (C.c_int, [vp, PP, SP, dbl, vp, i32, vp, i64, vp, i32, vp, u64, vp, vp, vp, vp, vp])
     sig["snmf_ctx_xfer_stats"] = (C.c_int, [vp, vp, C.c_int])
     sig["snmf_plan_run_sharded"] = (C.c_int, [vp, i32, vp, ALLREDUCE_FN, vp, i32, i32, C.POINTER(i32)])
+    sig["snmf_rccl_available"] = (C.c_int, [])
+    sig["snmf_rccl_get_unique_id"] = (C.c_int, [vp, i64])
+    sig["snmf_rccl_comm_create"] = (C.c_int, [i32, vp, i32, i32, C.POINTER(vp)])
+    sig["snmf_rccl_comm_destroy"] = (None, [vp])
+    sig["snmf_plan_run_sharded_rccl"] = (C.c_int, [vp, i32, vp, vp, i32, i32, C.POINTER(i32)])
     for ty in ("f64", "f32"):
         sig[f"snmf_sparse_nmf_oop_{ty}"] = (C.c_int, [vp, PP, vp, i64, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i32)])
     lib.snmf_abi_version.restype = C.c_int

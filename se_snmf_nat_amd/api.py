@@ -427,6 +427,40 @@ def dnmf_adapt(Y, D, B, p, *, ctx=None, dtype=np.float64):
     return B_a
 
 
+class RcclComm:
+    """One rank's RCCL communicator behind the C ABI (snmf_rccl_comm_create): the collective of the process-per-GPU loop without a
+    callback into Python.  `unique_id()` on rank 0, ship the 128 bytes to every rank over any channel, then RcclComm(device, id,
+    n_ranks, rank) on every rank (collective: ncclCommInitRank)."""
+
+    @staticmethod
+    def available():
+        return bool(_lib.load().snmf_rccl_available())
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_ubyte * 128)()
+        _lib.check(_lib.load().snmf_rccl_get_unique_id(buf, 128))
+        return bytes(buf)
+
+    def __init__(self, device, unique_id, n_ranks, rank):
+        self._lib = _lib.load()
+        self.handle = C.c_void_p()
+        buf = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
+        _lib.check(self._lib.snmf_rccl_comm_create(int(device), buf, int(n_ranks), int(rank), C.byref(self.handle)))
+        self.n_ranks, self.rank = int(n_ranks), int(rank)
+
+    def close(self):
+        if self.handle:
+            self._lib.snmf_rccl_comm_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
 class Plan:
     """snmf_plan: a problem resident in HBM (V, W, H + workspaces).  Arrays may be numpy (host)
     or anything exposing ``data_ptr()``/``dtype`` on the context's device (torch tensors)."""
@@ -562,6 +596,14 @@ class Plan:
         if err:
             raise err[0]
         _lib.check(rc)
+        return int(done.value)
+
+    def run_sharded_rccl(self, n_iters, stats_ptr, comm, *, poll_every=4, finalize=True):
+        """snmf_plan_run_sharded_rccl: the same loop with the library itself issuing ncclAllReduce on the context's stream
+        (comm: an RcclComm of this rank).  Returns the iterations run."""
+        done = C.c_int32()
+        _lib.check(self._lib.snmf_plan_run_sharded_rccl(self._h, int(n_iters), C.c_void_p(stats_ptr), comm.handle, int(poll_every),
+                                                        1 if finalize else 0, C.byref(done)))
         return int(done.value)
 
     # -- results ------------------------------------------------------------------------------

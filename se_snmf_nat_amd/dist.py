@@ -46,6 +46,7 @@ class ShardedLoop:
         self.poll_every = int(poll_every)
         self.it = 0
         self.finalized = False
+        self.rccl_comm = None  # an api.RcclComm: the product engine's loop then calls RCCL from C (ShardedTrainer sets it)
 
     def _ptr(self):
         s = self.stats
@@ -71,8 +72,14 @@ class ShardedLoop:
                     raise ValueError("collective asked for a range outside the statistics buffer")
                 self.all_reduce(self.stats[off:off + int(n)])
             last = target >= self.max_iter
-            ran = self.e.run_sharded(target - self.it, self._ptr(), ar, poll_every=self.poll_every if self.can_stop else 0,
-                                     finalize=last and self.cost_check and not self.finalized)
+            fin = last and self.cost_check and not self.finalized
+            if self.rccl_comm is not None:
+                # the collective issued by the library itself (ncclAllReduce on the engine's stream, csrc/snmf_tu_rccl.hip): no callback
+                # into Python per iteration (29 us of host work: a quarter of an iteration on a 12 500-frame shard of BASELINE configs[1])
+                ran = self.e.run_sharded_rccl(target - self.it, self._ptr(), self.rccl_comm, poll_every=self.poll_every if self.can_stop else 0,
+                                              finalize=fin)
+            else:
+                ran = self.e.run_sharded(target - self.it, self._ptr(), ar, poll_every=self.poll_every if self.can_stop else 0, finalize=fin)
             self.it += ran
             if last and self.it >= self.max_iter and self.cost_check and self.it > 0:
                 self.finalized = True
@@ -139,6 +146,30 @@ class ShardedTrainer:
         self.loop = ShardedLoop(self.plan, self.stats, self._all_reduce, max_iter=max_iter,
                                 can_stop=bool(cost_check) and conv_eps > 0, cost_check=cost_check,
                                 step_view=self.stats if w_any else self.stats[-2:])
+        self.rccl = None
+        if self.world > 1 and self.stream is not None:
+            self.use_native_rccl()
+
+    def use_native_rccl(self, force_single=False):
+        """Route the per-iteration sum through the library's own ncclAllReduce (api.RcclComm) instead of the torch.distributed
+        callback: RCCL backend only (a gloo dry run keeps the callback), SNMF_RCCL_NATIVE=0 opts out.  The communicator's id travels
+        from rank 0 over the torch.distributed group the trainer was given.  force_single: a one-rank communicator (tests: the
+        call path on a one-GPU box, where RCCL refuses two ranks on one device).  Returns True when the native path is in use."""
+        import os
+        from .api import RcclComm
+        if os.environ.get("SNMF_RCCL_NATIVE", "1") == "0" or not RcclComm.available():
+            return False
+        if force_single:
+            self.rccl = RcclComm(self.device.index, RcclComm.unique_id(), 1, 0)
+        else:
+            if self.dist.get_backend(self.group) != "nccl":
+                return False
+            rank = self.dist.get_rank(self.group)
+            box = [RcclComm.unique_id() if rank == 0 else None]
+            self.dist.broadcast_object_list(box, src=self.dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            self.rccl = RcclComm(self.device.index, box[0], self.world, rank)
+        self.loop.rccl_comm = self.rccl
+        return True
 
     def _all_reduce(self, t):
         """In-place sum over the ranks of `t`, a slice of the statistics buffer."""
