@@ -432,7 +432,8 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     {
         const char* e = getenv("SNMF_ITER_SF");
         const int ncl = 4;  // SIMD pairs (H wave + W wave) per workgroup = chunk lanes of k_wstats_sf at two row tiles
-        const size_t body = ((size_t)pl->nf * pl->rp * 32 + (size_t)pl->nk * pl->Fq * 32 + 2 * (size_t)pl->rp + (size_t)(ncl + 1) * 32 * (32 * pl->nk + 4) + 2 * ncl + 1) * 4;
+        // (images, 1 ./ dph and lambda, ncl + 1 hand-off buffers, 16 progress words, the H waves' fp64 objective sums and the W waves' row sums per lane)
+        const size_t body = ((size_t)pl->nf * pl->rp * 32 + (size_t)pl->nk * pl->Fq * 32 + 2 * (size_t)pl->rp + (size_t)(ncl + 1) * 32 * (32 * pl->nk + 4) + 16) * 4 + (size_t)ncl * 64 * 2 * sizeof(double) + (size_t)ncl * 64 * 4 * 4;
         const size_t tail = ((size_t)ncl * pl->nf * pl->nk * 1024 + (size_t)ncl * pl->rp) * 4 + 2 * ncl * sizeof(double);
         pl->lds_isf = std::max(body, tail) + 64;
         pl->isf = pl->sf && pl->wsf && pl->nf == 2 && pl->nk >= 3 && pl->upd_h && pl->upd_w && pl->lds_isf <= lds_cap && !(e && atoi(e) == 0);

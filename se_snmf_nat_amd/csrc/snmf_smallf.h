@@ -513,6 +513,16 @@ __device__ __forceinline__ void sf_await(const unsigned* word, unsigned target, 
     stress_jitter();
 }
 
+// This lane's index, re-derived where it is needed (two VALU instructions, no input register) and OPAQUE to the optimiser: everything
+// computed from it -- frame / half, operand offsets, image pointers -- is then a value of the tile it is used in, not a loop invariant
+// that lives through the whole kernel.  k_iter_sf kept the thread index and a dozen values derived from it alive under its 128
+// accumulators and SPILLED them (the cheapest values there are); a kernel that touches scratch at all pays 6-7 us per launch.
+__device__ __forceinline__ int fresh_lane() {
+    int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(l));
+    return l;
+}
+
 // SK: the sparsity kind (0: one lambda for every row, 1: a lambda per row, 2: an r x T matrix in H's layout) -- a parameter of the
 // KERNEL here, not of a tile-loop lambda as in k_hstep_sf (three loops in one function: the register allocation of the worst).
 template <int NK, bool OBJ, int SK>
@@ -520,7 +530,7 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_iter_sf(StepArgs a, int n_
     if (a.stop && *a.stop) return;
     constexpr int NF = 2, NP = kSfWaves / 2, NTHR = kSfWaves * 64, LDT = 32 * NK + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63, w = wave_index();
+    const int w = wave_index();
     const bool is_w = w >= NP;          // W wave of pair c
     const int c = is_w ? w - NP : w;
     const int rp = a.rp, Fp = a.Fp;
@@ -532,17 +542,18 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_iter_sf(StepArgs a, int n_
     float* const hb = lmk + rp + (size_t)c * 32 * LDT;        // this pair's hand-off buffer [32][LDT]
     float* const xb = lmk + rp + (size_t)NP * 32 * LDT;       // one more buffer: a chunk's single remainder tile (below)
     unsigned* const sig = reinterpret_cast<unsigned*>(xb + 32 * LDT);  // full[NP], empty[NP], xfull
+    double* const accd = reinterpret_cast<double*>(sig + 16);           // [NP H waves][64 lanes][2] fp64 partial sums of the objective
+    float* const ssl = reinterpret_cast<float*>(accd + (size_t)NP * 64 * 2);  // [NP W waves][64 lanes][4] row sums of H_new per lane (NK <= 4)
     unsigned* const full = sig + c;
     unsigned* const empty = sig + NP + c;
     const unsigned full_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)full;
     const unsigned empty_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)empty;
     const unsigned xfull_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(sig + 2 * NP);
-    const int t = lane & 31, h = lane >> 5;                   // (as a frame index: lane (t, h); as a row / component index: fl = t)
     const int chunk = blockIdx.x;
     const int tb = (int)(((long long)a.n_tiles * chunk) / n_chunks), te = (int)(((long long)a.n_tiles * (chunk + 1)) / n_chunks);
     {
-        sf_fill_image(a.Wt4, wt, NF * rp * 32 * 4, w, lane);
-        sf_fill_image(a.Wk4, wk, NK * a.Fq * 32 * 4, w, lane);
+        sf_fill_image(a.Wt4, wt, NF * rp * 32 * 4, w, (int)(threadIdx.x & 63));
+        sf_fill_image(a.Wk4, wk, NK * a.Fq * 32 * 4, w, (int)(threadIdx.x & 63));
         for (int k = threadIdx.x; k < rp; k += NTHR) {
             rdp[k] = a.S ? 0.f : fast_rcp(a.dphv[k]);
             lmk[k] = a.S ? 0.f : a.lamk[k];
@@ -551,8 +562,7 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_iter_sf(StepArgs a, int n_
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing else orders a ds_read behind an LDS-DMA
     }
     __syncthreads();
-    const f32x4* const wtl = reinterpret_cast<const f32x4*>(wt) + lane;  // fragment (phi, q): wtl[(phi * nq8 + q) * 64]
-    const f32x4* const wkl = reinterpret_cast<const f32x4*>(wk) + lane;  // fragment (kap, q): wkl[(kap * nqf + q) * 64]
+    // (fragment (phi, q) of an image: wtl[(phi * nq8 + q) * 64], wkl[(kap * nqf + q) * 64] with wtl / wkl = image + this lane: formed per tile, see fresh_lane)
 
     // (the end of the kernel -- barrier, partial statistics into LDS, barrier -- is written out in BOTH role branches: the statistics
     //  tiles must not be live in the H waves' code, whose registers they would take: 128 of the 256 a wave has at two per SIMD)
@@ -561,7 +571,15 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_iter_sf(StepArgs a, int n_
     double* const dred = reinterpret_cast<double*>(sred + NP * rp);   // [2][NP]
 
     if (!is_w) {
-        double acc_div = 0.0, acc_sh = 0.0;
+        // The two fp64 partial sums of the objective live in LDS, a slot pair per lane, updated once per tile with inline ds_read_b64 /
+        // ds_write_b64 (no compiler-visible memory effects: see sf_post_raw): as registers they were four of the VGPRs this kernel does
+        // not have -- they were spilled across the tile body, and a kernel that touches scratch at all pays 6-7 us per launch
+        // (scripts/scratch_probe.hip), a tenth of this one's run time.
+        if (OBJ) {
+            const unsigned acc_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(accd + ((size_t)c * 64 + fresh_lane()) * 2);
+            const double z = 0.0;
+            asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %1 offset:8" ::"v"(acc_a), "v"(z));
+        }
         // ================================ H wave: k_hstep_sf's tile body + the hand-off ================================
         // this pair's H tasks: tile c of every whole round of NP tiles and remainder tile c (if there is one).  A SINGLE remainder tile
         // (n = 4 R + 1: Mel 64 x 72000 is 9 tiles a chunk) is pair 0's FIRST task and goes into the extra buffer, which nobody has to
@@ -570,9 +588,13 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_iter_sf(StepArgs a, int n_
         const int n_my = te - tb, n_rnd = n_my / NP, n_rem = n_my - n_rnd * NP;
         const bool x_first = n_rem == 1 && c == 0;
         const unsigned n_h = (unsigned)(n_rnd + (c < n_rem ? 1 : 0));
-        const int hlo = (t * rp + 4 * h) * 4, vlo = (t * Fp + 4 * h) * 4;  // this lane's byte offsets inside a tile of H / V
         SNMF_STAMP_DECL
         for (unsigned ith = 0; ith < n_h; ++ith) {
+            const int ln = fresh_lane(), t = ln & 31, h = ln >> 5;  // (lane (t, h): frame t, component / row half h)
+            const int hlo = (t * rp + 4 * h) * 4, vlo = (t * Fp + 4 * h) * 4;  // this lane's byte offsets inside a tile of H / V
+            const f32x4* const wtl = reinterpret_cast<const f32x4*>(wt) + ln;
+            const f32x4* const wkl = reinterpret_cast<const f32x4*>(wk) + ln;
+            const unsigned acc_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(accd + ((size_t)c * 64 + ln) * 2);
             const bool is_x = x_first && ith == 0;                  // the remainder tile, into the extra buffer
             const unsigned it = x_first ? ith - 1u : ith;           // index among the tiles that go through this pair's own buffer
             const int tile = is_x ? tb + n_rnd * NP : tb + c + (int)it * NP;
@@ -635,7 +657,12 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_iter_sf(StepArgs a, int n_
                     }
                 }
             }
-            if (OBJ) acc_div += (double)dsum;
+            if (OBJ) {
+                double ad;
+                asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(ad) : "v"(acc_a));
+                ad += (double)dsum;
+                asm volatile("ds_write_b64 %0, %1" ::"v"(acc_a), "v"(ad));
+            }
             SNMF_STAMP(1);
             // ---- P2 + the H update ----
             float shsum = 0.f;
@@ -706,7 +733,12 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_iter_sf(StepArgs a, int n_
                     p2_update(acc0, kap);
                 }
             }
-            if (OBJ) acc_sh += (double)shsum;
+            if (OBJ) {
+                double as;
+                asm volatile("ds_read_b64 %0, %1 offset:8\n\ts_waitcnt lgkmcnt(0)" : "=v"(as) : "v"(acc_a));
+                as += (double)shsum;
+                asm volatile("ds_write_b64 %0, %1 offset:8" ::"v"(acc_a), "v"(as));
+            }
             SNMF_STAMP(2);
             // ---- H_new leaves the way it came ... ----
             {
@@ -732,12 +764,15 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_iter_sf(StepArgs a, int n_
         __syncthreads();  // (every wave is through with the W images and the hand-off buffers)
         SNMF_STAMP(10);
         if (OBJ) {
+            double acc_div, acc_sh;  // (the slots are this lane's own, outside xs / sred / dred)
+            const unsigned acc_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(accd + ((size_t)c * 64 + fresh_lane()) * 2);
+            asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)" : "=v"(acc_div), "=v"(acc_sh) : "v"(acc_a));
 #pragma unroll
             for (int s = 32; s > 0; s >>= 1) {
                 acc_div += __shfl_xor(acc_div, s, 64);
                 acc_sh += __shfl_xor(acc_sh, s, 64);
             }
-            if (lane == 0) {
+            if (fresh_lane() == 0) {
                 dred[c] = acc_div;
                 dred[NP + c] = acc_sh;
             }
@@ -749,17 +784,25 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_iter_sf(StepArgs a, int n_
     } else {
         // ================================ W wave: k_wstats_sf's tile body on the partner's tile ================================
         f32x16 G[NF][NK];
-        float ssum[NK];
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
 #pragma unroll
             for (int phi = 0; phi < NF; ++phi) G[phi][k] = zero16();
-            ssum[k] = 0.f;
+        }
+        // (the row sums of H_new: per-lane LDS slots updated with ds_add_f32 -- one lane, one slot, program order: the same sums in the
+        //  same order as a register would hold -- instead of NK more registers under the 128 accumulators)
+        {
+            const unsigned sa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(ssl + ((size_t)c * 64 + fresh_lane()) * 4);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            asm volatile("ds_write_b128 %0, %1" ::"v"(sa), "v"(z));
         }
         SNMF_STAMP_DECL
         // One W task: the statistics of `tile` out of hand-off buffer `hbx`, once its H wave has posted `target` on `fullx`.
         auto w_tile = [&](const int tile, const float* const hbx, const unsigned* const fullx, const unsigned target) {
             const int t0 = tile * 32;
+            const int ln = fresh_lane(), t = ln & 31, h = ln >> 5;
+            const f32x4* const wtl = reinterpret_cast<const f32x4*>(wt) + ln;
+            const unsigned sa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(ssl + ((size_t)c * 64 + ln) * 4);
             // V with the rows in lanes (lane (f, h): frames drow(i, h)): lines the partner fetched a tile ago.  ONE row tile's values
             // at a time: those of the second are loaded into the same registers in front of its P3.
             float vt[16];
@@ -809,27 +852,21 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_iter_sf(StepArgs a, int n_
                 // component 32 kap + fl), one column tile ahead; the row sums ride on the reads of the first row tile ----
                 {
                     const float* bp = hbx + (4 * h) * LDT + t;
-                    float b0[16];
-                    auto ldb = [&](float (&b)[16], int kap) {
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) b[i] = bp[drow(i, 0) * LDT + kap * 32];
-                    };
-                    auto ktile = [&](const float (&b)[16], int kap) {
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) G[phi][kap] = mfma32(R[i], b[i], G[phi][kap]);
-                        if (phi == 0) {
-                            float s4 = 0.f;
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) s4 += b[i];
-                            ssum[kap] += s4;
-                        }
-                    };
                     // (one operand set, read right in front of its MFMAs: the partner wave's MFMAs cover the LDS round trip of the first
                     //  read, and a second set in flight cost this wave 16 of the registers it does not have)
 #pragma unroll
                     for (int kap = 0; kap < NK; ++kap) {
-                        ldb(b0, kap);
-                        ktile(b0, kap);
+                        float b0[16];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) b0[i] = bp[drow(i, 0) * LDT + kap * 32];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) G[phi][kap] = mfma32(R[i], b0[i], G[phi][kap]);
+                        if (phi == 0) {
+                            float s4 = 0.f;
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) s4 += b0[i];
+                            asm volatile("ds_add_f32 %0, %1" ::"v"(sa + 4u * (unsigned)kap), "v"(s4));
+                        }
                     }
                 }
                 SNMF_STAMP(7);
@@ -843,7 +880,7 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_iter_sf(StepArgs a, int n_
         if (n_rem == 1 && jx == 0) w_tile(tb + n_rnd * NP, xb, sig + 2 * NP, 1u);
         for (int it = 0; it < n_rnd; ++it) {
             w_tile(tb + c + it * NP, hb, full, (unsigned)(it + 1));
-            sf_post(empty, (unsigned)(it + 1), lane);  // (the last reads of the buffer have returned: the MFMAs consumed them)
+            sf_post(empty, (unsigned)(it + 1), fresh_lane());  // (the last reads of the buffer have returned: the MFMAs consumed them)
         }
         if (n_rem > 1 && jx < n_rem)  // (the last tile of pair jx's buffer: nobody waits for `empty` behind it)
             w_tile(tb + n_rnd * NP + jx, lmk + rp + (size_t)jx * 32 * LDT, sig + jx, (unsigned)(n_rnd + 1));
@@ -853,6 +890,7 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_iter_sf(StepArgs a, int n_
         // Every W wave writes its NF * NK tiles; tile j = phi * NK + kap is then summed over the pairs IN PAIR ORDER (the order in which
         // k_wstats_sf's lane 0 adds them) by wave j % NP, which writes that tile's rows of the slab: the four waves share the
         // reduction instead of waiting for pair 0's W wave (its 384 dependent LDS reads were ~4 us at the end of the kernel).
+        const int lane = fresh_lane(), t = lane & 31, h = lane >> 5;
 #pragma unroll
         for (int phi = 0; phi < NF; ++phi)
 #pragma unroll
@@ -861,10 +899,15 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_iter_sf(StepArgs a, int n_
 #pragma unroll
                 for (int i = 0; i < 16; ++i) dst[i * 64] = G[phi][k][i];
             }
+        {
+            f32x4 ssum;
+            const unsigned sa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(ssl + ((size_t)c * 64 + lane) * 4);
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(ssum) : "v"(sa));
 #pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            const float other = __shfl_xor(ssum[k], 32, 64);  // the two lane halves hold the two halves of a tile's frames
-            if (h == 0) sred[c * rp + k * 32 + t] = ssum[k] + other;
+            for (int k = 0; k < NK; ++k) {
+                const float other = __shfl_xor(ssum[k], 32, 64);  // the two lane halves hold the two halves of a tile's frames
+                if (h == 0) sred[c * rp + k * 32 + t] = ssum[k] + other;
+            }
         }
         __syncthreads();
         for (int j = c; j < NF * NK; j += NP) {
@@ -891,12 +934,13 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_iter_sf(StepArgs a, int n_
         SNMF_STAMP_OUT(a.prof + ((size_t)blockIdx.x * 8 + w) * 12, 12);
         SNMF_STAMP_CLK(a.prof, (size_t)blockIdx.x * 8 + w);
     }
-    for (int k = threadIdx.x; k < rp; k += NTHR) {
+    const int tid_e = w * 64 + fresh_lane();  // (not threadIdx.x: that register would live -- spilled -- through the whole kernel)
+    for (int k = tid_e; k < rp; k += NTHR) {
         float sk = 0.f;
         for (int p = 0; p < NP; ++p) sk += sred[p * rp + k];
         a.spart[(size_t)chunk * rp + k] = sk;
     }
-    if (OBJ && threadIdx.x == 0) {
+    if (OBJ && tid_e == 0) {
         double d = 0.0, s2 = 0.0;
         for (int i = 0; i < NP; ++i) {
             d += dred[i];
