@@ -520,6 +520,16 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
 
     pl->lds_wfin = (size_t)9 * pl->n_mat * pl->Fp * sizeof(double);
     pl->wfin = pl->upd_w && pl->lds_wfin + 12 * 1024 <= lds_cap;
+    // very few columns (r <= 32: the reference's R = 20 / 10 / 30): cut every column's rows into slices, a workgroup each (k_wfin,
+    // gridDim.y): r * S workgroups of at least eight 16-byte cells each.  Measured (513 x 72000): r = 10 W-only 13 824 -> 14 474 it/s,
+    // r = 20 7 615 -> 7 744; from r = 100 up the gather costs what the wider read saves (a11 17.3 -> 17.4 us, Mel 11.3 -> 12.5), so
+    // those keep one workgroup per column.  SNMF_WFIN_SPLIT=0: never split.
+    {
+        const char* e = getenv("SNMF_WFIN_SPLIT");
+        int S = r <= 32 ? std::max(1, std::min(8, ctx->n_cu / std::max(1, r))) : 1;
+        while (S > 1 && (pl->Fp / 4 + S - 1) / S < 8) --S;
+        pl->wfin_S = (pl->wfin && !(e && atoi(e) == 0)) ? S : 1;
+    }
 
     // persistent single-launch path for the online shape (H-only, at most one 32-frame tile)
     {
@@ -589,6 +599,10 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     if (pl->upd_w) {
         A(palloc(&pl->slabs, (size_t)pl->n_chunks * pl->n_mat * nW));
         A(palloc(&pl->spart, (size_t)pl->n_chunks * pl->rp));
+        if (pl->wfin_S > 1) {
+            A(palloc(&pl->qp_buf, (size_t)r * pl->n_mat * pl->Fp));
+            A(palloc(&pl->fin_cnt, (size_t)r));
+        }
     }
     if (pl->gram_p) {
         A(palloc(&pl->gram_slabs, (size_t)pl->gram_chunks * pl->rp * pl->rp));
@@ -633,6 +647,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     hipMemsetAsync(pl->Wk4, 0, nWk * 4, st);
     hipMemsetAsync(pl->wx, 0, (size_t)pl->rp * 4, st);
     if (pl->part_cnt) hipMemsetAsync(pl->part_cnt, 0, (size_t)(pl->rp_tiles - pl->rp_full) * 4, st);
+    if (pl->fin_cnt) hipMemsetAsync(pl->fin_cnt, 0, (size_t)r * 4, st);
     if (pl->slabs) hipMemsetAsync(pl->slabs, 0, (size_t)pl->n_chunks * pl->n_mat * nW * 4, st);
     hipMemsetAsync(pl->H[0], 0, nH * 4, st);
     hipMemsetAsync(pl->H[1], 0, nH * 4, st);
@@ -968,6 +983,8 @@ static ReduceArgs make_reduce_args(snmf_plan* pl, double* stats, bool do_mats, b
     ra.stats = stats;
     ra.stop = &pl->st->stop;
     ra.n_chunks = pl->n_chunks;
+    ra.qp_buf = pl->qp_buf;
+    ra.fin_cnt = pl->fin_cnt;
     ra.n_mat = pl->n_mat;
     ra.n_part = n_part;
     ra.rp = pl->rp;
@@ -1060,7 +1077,7 @@ static int launch_wfin(snmf_plan* pl, double* stats, bool do_obj, int n_part, bo
     ScopedTimer tm(pl->ctx, FAM_WFIN);
     auto launch = [&](auto kern) -> int {
         SN_TRY(ensure_dyn_lds(pl->ctx->device, (const void*)kern, pl->lds_wfin));
-        hipLaunchKernelGGL(kern, dim3(pl->p.r), dim3(768), pl->lds_wfin, pl->ctx->stream, ra, aa);
+        hipLaunchKernelGGL(kern, dim3(pl->p.r, pl->wfin_S), dim3(768), pl->lds_wfin, pl->ctx->stream, ra, aa);
         HIP_TRY(hipGetLastError());
         return SNMF_OK;
     };
@@ -1086,6 +1103,7 @@ extern "C" int snmf_plan_init(snmf_plan* pl) {
     // arrival counters of the split tiles: "last to arrive" is old % S == S - 1, so a launch that ended in the fault path
     // (or was otherwise left partial) must not leave them misaligned for the next solve
     if (pl->part_cnt) HIP_TRY(hipMemsetAsync(pl->part_cnt, 0, (size_t)(pl->rp_tiles - pl->rp_full) * 4, st));
+    if (pl->fin_cnt) HIP_TRY(hipMemsetAsync(pl->fin_cnt, 0, (size_t)pl->p.r * 4, st));  // (k_wfin's split form: the same alignment argument)
     HIP_TRY(hipMemsetAsync(pl->divh, 0, sizeof(double) * std::max(1, pl->p.max_iter), st));
     HIP_TRY(hipMemsetAsync(pl->costh, 0, sizeof(double) * std::max(1, pl->p.max_iter), st));
     // wn = sqrt(sum(w.^2)); w = w./wn  (+ operand images, colsum, dphv).  When only V / H changed since

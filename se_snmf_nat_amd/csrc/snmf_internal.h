@@ -142,6 +142,9 @@ struct snmf_plan {
     // snmf_plan_run: k_reduce + k_wapply as one launch (k_wfin) when a column's chunk-group sums fit the LDS
     int rh_lxh = 0;  // k_hstep_rh: P2 cut over the contraction (1: r = 97..100 four ways; 2: r = 193..200 in pairs), leftover columns as 4x4x1 MFMAs
     bool wfin = false;
+    int wfin_S = 1;             // k_wfin: row slices per column (few columns: r <= 128), gathered by the column's last arriver
+    double* qp_buf = nullptr;   // [r][n_mat * Fp]
+    unsigned* fin_cnt = nullptr;  // [r] arrivals per column (monotonic)
     size_t lds_wfin = 0;
     // shapes beyond the fused kernels' LDS / register envelope: the same iteration with its intermediates in HBM
     // (csrc/snmf_generic.h); Lam / ratio / denominator images [Tp][Fp], numerator / denominator of the H update [Tp][rp]

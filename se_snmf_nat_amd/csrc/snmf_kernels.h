@@ -3815,6 +3815,8 @@ struct ReduceArgs {
     double* stats;
     const int* stop;
     int n_chunks, n_mat, n_part, rp, Fp;
+    double* qp_buf;       // k_wfin with gridDim.y = S > 1 (few columns: r <= 128): [r][n_mat * Fp] summed statistics of a column, a row slice per workgroup
+    unsigned* fin_cnt;    // ... [r] arrivals per column (monotonic; a launch adds S to each)
     int r;                // real columns of W: rows k >= r of every slab are zero and stay zero in the statistics
     int do_mats;          // reduce slabs + s
     int do_obj;           // reduce objective partials
@@ -4211,12 +4213,18 @@ __global__ __launch_bounds__(768) void k_wfin(ReduceArgs ra, ApplyArgs a) {
     extern __shared__ __attribute__((aligned(16))) double wfin_lds[];
     __shared__ double red[3][256];
     __shared__ double red2[2][256];
-    __shared__ double skp[8];
+    __shared__ double skp[10];  // [8] row-sum groups, [8]: the split form's last-arriver flag (a static of its own would shift the dynamic LDS off 16 bytes)
     const int k = blockIdx.x, tid = threadIdx.x;
     const size_t nel = (size_t)a.rp * a.Fp;
-    const int nE = a.Fp / 4, nI = NMAT * nE;  // f32x4 of a column (of both matrices)
+    // Few columns (r <= 128: the reference's R = 100, 20, 10): r workgroups are a fraction of the chip, and each read its column of
+    // EVERY chunk's slab -- 6.8 of the launch's 19 us at 513 x 72000, r = 20.  With gridDim.y = S > 1 the column's rows are cut into S
+    // slices, a workgroup each (the sums per element are the same sums: bit-identical statistics); the slices meet in qp_buf and the
+    // LAST of a column's S workgroups to arrive (nobody waits for anybody) runs the epilogue on the whole column.
+    const int S = (int)gridDim.y, nEa = a.Fp / 4, nEs = (nEa + S - 1) / S;
+    const int e_lo = (int)blockIdx.y * nEs, e_hi = e_lo + nEs < nEa ? e_lo + nEs : nEa;
+    const int nE = e_hi > e_lo ? e_hi - e_lo : 0, nI = NMAT * nE;  // f32x4 of this workgroup's slice of the column (of both matrices)
     double* part = wfin_lds;                  // [8][nI][4]
-    double* QP = wfin_lds + (size_t)8 * nI * 4;  // [NMAT][Fp]
+    double* QP = wfin_lds + (size_t)8 * NMAT * nEs * 4;  // [NMAT][Fp]
     const size_t cstride = nel * NMAT;
     // Round 6: the launch was a CHAIN of dependent global round trips on a mostly idle chip (the stop flag, then the slab pieces,
     // then the objective partials, then the previous cost for the convergence test, then the column of W: ~1.5 us each of the
@@ -4231,7 +4239,7 @@ __global__ __launch_bounds__(768) void k_wfin(ReduceArgs ra, ApplyArgs a) {
         const int g = i / nI, e = i - g * nI, m = e / nE, e4 = e - m * nE;
         cb = (int)(((long long)ra.n_chunks * g) / 8);
         ce = (int)(((long long)ra.n_chunks * (g + 1)) / 8);
-        p = ra.slabs + (size_t)m * nel + (size_t)k * a.Fp + 4 * e4;
+        p = ra.slabs + (size_t)m * nel + (size_t)k * a.Fp + 4 * (e_lo + e4);
     };
     f32x4 x[16];  // sixteen chunks of the current item in flight
     int it_i = tid, cb = 0, ce = 0;
@@ -4320,11 +4328,33 @@ __global__ __launch_bounds__(768) void k_wfin(ReduceArgs ra, ApplyArgs a) {
     }
     __syncthreads();
     if (tid >= 256) return;  // (ended waves do not count at later barriers)
-    for (int idx = tid; idx < nI * 4; idx += 256) {  // (nE * 4 = Fp: element idx of [NMAT][Fp])
+    for (int idx = tid; idx < nI * 4; idx += 256) {  // element idx of this slice: (matrix m, row 4 e_lo + ...)
         double t = 0.0;
 #pragma unroll
         for (int gg = 0; gg < 8; ++gg) t += part[((size_t)gg * nI) * 4 + idx];
-        QP[idx] = t;
+        const int m = idx / (4 * nE), fo = idx - m * 4 * nE;
+        QP[m * a.Fp + 4 * e_lo + fo] = t;
+    }
+    if (S > 1) {
+        // this slice -> qp_buf; the last arriver of the column gathers the S slices and goes on alone.  The slices come from other
+        // XCDs' L2s: agent-scope (sc1, write-through) stores acknowledged before the arrival is counted, sc1 loads on the other side --
+        // NOT fences: a __threadfence() here writes back everything dirty in the XCD's L2 (the H step's output) and made the launch
+        // 34-46 us where it had been 11-17
+        double* qg = ra.qp_buf + (size_t)k * NMAT * a.Fp;
+        for (int idx = tid; idx < nI * 4; idx += 256) {
+            const int m = idx / (4 * nE), fo = idx - m * 4 * nE;
+            __hip_atomic_store(qg + m * a.Fp + 4 * e_lo + fo, QP[m * a.Fp + 4 * e_lo + fo], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(ra.fin_cnt + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            skp[8] = (old % (unsigned)S == (unsigned)S - 1u) ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        if (skp[8] == 0.0) return;
+        for (int idx = tid; idx < NMAT * a.Fp; idx += 256) QP[idx] = __hip_atomic_load(qg + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
     }
     for (int st = 128; st > 0; st >>= 1) {
         if (tid < st) {
