@@ -1,6 +1,6 @@
 #!/bin/bash
 # Which kernel instantiations do the reference's settings launch?  One rocprofv3 --kernel-trace --stats invocation per shape of
-# scripts/reach_one.py (run on the GPU box) -> gpurun_out/reach/<shape>_kernels.txt -> profiles/r05_reachable.json (scripts/gen_resources.py reads it).
+# scripts/reach_one.py (run on the GPU box) -> gpurun_out/reach/<shape>_kernels.txt -> profiles/r06_reachable.json (scripts/gen_resources.py reads it).
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/reach
 rm -rf $OUT; mkdir -p $OUT

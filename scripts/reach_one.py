@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One reference shape for a few iterations (scripts/reach.sh runs it under rocprofv3 --kernel-trace --stats, one invocation per
-shape): which kernel instantiations does a setting of the reference actually launch?  -> profiles/r05_reachable.json"""
+shape): which kernel instantiations does a setting of the reference actually launch?  -> profiles/r06_reachable.json"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -4347,6 +4347,7 @@ __global__ __launch_bounds__(768) void k_wfin(ReduceArgs ra, ApplyArgs a) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (tid < 64) stress_jitter();  // (-DSNMF_STRESS builds only)
         if (tid == 0) {
             const unsigned old = __hip_atomic_fetch_add(ra.fin_cnt + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             skp[8] = (old % (unsigned)S == (unsigned)S - 1u) ? 1.0 : 0.0;
