@@ -292,8 +292,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true",
-                    help="skip the host-array leg behind the timed region (profiling passes: its launches -- fresh plans, first iterations -- "
-                         "would be averaged into the timed loop's kernel statistics)")
+                    help="skip the legs behind the timed region -- the host-array drop-in call and the solves from a random start -- (profiling "
+                         "passes: their launches -- fresh plans, first iterations -- would be averaged into the timed loop's kernel statistics)")
     ap.add_argument("--oneshot-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--c5-T", dest="c5_T", type=int, default=500_000, help=argparse.SUPPRESS)  # frames of the extra C5 leg (tests shrink it)
     ap.add_argument("--c4-T", dest="c4_T", type=int, default=800_000, help=argparse.SUPPRESS)  # frames IN ALL of the extra C4 leg
@@ -388,6 +388,8 @@ def main():
         # a short solve pays more per iteration than `value`.  200 iterations = BASELINE configs[1]; 100 = the reference's
         # default max_iter (settings/initial_setting_SNMF_NAT.m:108).  Outside the timed region; never `value`.
         try:
+            if args.no_dropin:
+                raise RuntimeError("skipped (--no-dropin: profiling pass)")
             frs = {}
             for n_it in (200, 100):
                 best = None
