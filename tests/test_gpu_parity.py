@@ -716,3 +716,58 @@ def test_fused_small_f_iteration_stops_where_the_oracle_stops(gpu_ctx, mode):
     assert o["n_iter"] == orf["n_iter"]
     assert rel(w, wr) < REL_WH and rel(h, hr) < REL_WH
     np.testing.assert_allclose(o["cost"], orf["cost"], rtol=REL_COST)
+
+
+@pytest.mark.parametrize("F,r,T,mode,spk", [(513, 20, 12000, "full", "scalar"), (513, 30, 21000, "h", "rvec"), (513, 10, 9000, "w", "scalar"),
+                                            (257, 32, 26000, "full", "matrix"), (97, 24, 20011, "full", "scalar"), (100, 20, 30000, "semi", "rvec"),
+                                            (513, 1, 9000, "full", "scalar"), (385, 17, 8231, "h", "matrix"), (544, 32, 16500, "full", "scalar"),
+                                            (129, 5, 40000, "w", "rvec")],
+                         ids=lambda v: str(v))
+def test_small_rank_family_against_oracle(gpu_ctx, F, r, T, mode, spk):
+    """csrc/snmf_smallr.h (round 6): r <= 32 on 3..16 row tiles -- the reference's R = 20 / 10 / 30 settings at F = 513
+    (settings/bak_IS16_results/initial_setting_SNMF_Techwin_201603_RT.m:47-48) and r = 32 at F = 257.  k_hstep_sr (a tile per workgroup
+    cut by row tiles, the partial numerators meet in LDS one tile late) and k_wstats_sr (a wave owns its rows' statistics for the whole
+    chunk) against the fp64 oracle: full, H-only, W-only and partial W updates, every sparsity form (src/sparse_nmf.m:150-155), with and
+    without the extra row (F = 32 n + 1), idle waves (3 row tiles), a partial last tile, three to five tiles per workgroup, the maximum
+    of sixteen + one row tiles (F = 544 has seventeen -> NOT this family), and the k_wfin row split of such shapes."""
+    from se_snmf_nat_amd import Plan, sparse_nmf
+    rs = np.random.default_rng(F * 7 + r)
+    V = rs.gamma(0.5, 1.0, (F, 12)) @ rs.gamma(0.3, 1.0, (12, T)) + 1e-3
+    W0, H0 = rs.random((F, r)), rs.random((r, T))
+    sp = {"scalar": 5.0, "rvec": rs.random(r) * 4, "matrix": rs.random((r, T)) * 3}[spk]
+    p = dict(cf="kl", sparsity=sp, max_iter=4, conv_eps=0, cost_check=1, init_w=W0, init_h=H0)
+    kw = {}
+    if mode == "h":
+        p["w_update_ind"] = kw["w_update_ind"] = np.zeros(r, bool)
+    elif mode == "w":
+        p["h_update_ind"] = kw["h_update_ind"] = np.zeros(r, bool)
+    elif mode == "semi":
+        p["w_update_ind"] = kw["w_update_ind"] = np.arange(r) >= r // 2
+    pl = Plan(gpu_ctx, F, T, r, beta=1.0, max_iter=4, conv_eps=0.0, cost_check=True, sparsity=5.0, **kw)
+    geo = pl.describe()
+    pl.close()
+    in_family = (F + 31) // 32 <= 16 or F == 513  # 3..16 row tiles (513 = 16 tiles + the extra row)
+    assert ("k_hstep_sr" in geo) == (in_family and mode != "w"), geo
+    assert ("k_wstats_sr" in geo) == (in_family and mode != "h"), geo
+    w, h, o = sparse_nmf(V, p, ctx=gpu_ctx)
+    wr, hr, orf = oracle_nmf(V, p)
+    assert o["n_iter"] == orf["n_iter"]
+    assert rel(w, wr) < REL_WH and rel(h, hr) < REL_WH
+    np.testing.assert_allclose(o["cost"], orf["cost"], rtol=REL_COST)
+    # elementwise too: a slice of a tile finished with the wrong tile's data is a handful of frames, invisible in a norm
+    assert np.abs(h - hr).max() <= 2e-4 * np.abs(hr).max()
+
+
+def test_small_rank_family_stops_where_the_oracle_stops(gpu_ctx):
+    """Early stop (src/sparse_nmf.m:272-284) on the small-rank kernels: the device-side flag turns later launches into no-ops, the result
+    is the iterate the oracle stops at."""
+    from se_snmf_nat_amd import sparse_nmf
+    F, r, T = 513, 20, 12000
+    rs = np.random.default_rng(11)
+    V = rs.gamma(0.5, 1.0, (F, 12)) @ rs.gamma(0.3, 1.0, (12, T)) + 1e-3
+    p = dict(cf="kl", sparsity=5.0, max_iter=60, conv_eps=5e-3, cost_check=1, init_w=rs.random((F, r)), init_h=rs.random((r, T)))
+    w, h, o = sparse_nmf(V, p, ctx=gpu_ctx)
+    wr, hr, orf = oracle_nmf(V, p)  # (stops at iteration 7; its closest approach to the threshold is 5 % away: not a borderline decision)
+    assert 2 < orf["n_iter"] < 60 and o["n_iter"] == orf["n_iter"]
+    assert rel(w, wr) < REL_WH and rel(h, hr) < REL_WH
+    np.testing.assert_allclose(o["cost"], orf["cost"], rtol=REL_COST)
