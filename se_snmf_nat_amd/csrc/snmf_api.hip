@@ -206,6 +206,8 @@ extern "C" void snmf_plan_destroy(snmf_plan* pl) {
     delete pl;
 }
 
+static int hupd_parts(const snmf_plan* pl);  // (objective partials of an H-update launch; defined with the step API below)
+
 extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan** out) {
     if (!ctx || !out) return fail(SNMF_ERR_INVALID, "NULL argument");
     *out = nullptr;
@@ -596,6 +598,10 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     A(palloc(&pl->colsum, (size_t)pl->rp));
     A(palloc(&pl->lamk, (size_t)pl->rp));
     if (p->sparsity_kind == SNMF_SPARSITY_FULL) A(palloc(&pl->S, nH));
+    {
+        const char* e = getenv("SNMF_HFOLD");
+        pl->fold_obj = pl->upd_h && !pl->upd_w && !pl->generic && !(e && atoi(e) == 0);
+    }
     if (pl->upd_w) {
         A(palloc(&pl->slabs, (size_t)pl->n_chunks * pl->n_mat * nW));
         A(palloc(&pl->spart, (size_t)pl->n_chunks * pl->rp));
@@ -630,7 +636,7 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     A(palloc(&pl->divh, (size_t)std::max(1, p->max_iter)));
     A(palloc(&pl->costh, (size_t)std::max(1, p->max_iter)));
     A(palloc(&pl->wn, (size_t)pl->rp));
-    A(palloc(&pl->st, (size_t)1));
+    A(palloc(&pl->st, (size_t)1 + (sizeof(FoldBlock) + sizeof(DevState) - 1) / sizeof(DevState)));  // DevState, then the FoldBlock
     A(palloc(&pl->w_ind, (size_t)pl->rp));
 #ifdef SNMF_PROF
     A(palloc(&pl->prof, (size_t)1024 * 8 * 12 + 3 * 8192 + 16384));  // phase slots, then (cycles, 100 MHz ticks) and start tick per wave
@@ -656,6 +662,8 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
     hipMemsetAsync(pl->w_ind, 0, pl->rp, st);
     hipMemcpyAsync(pl->w_ind, pl->h_w_ind.data(), r, hipMemcpyHostToDevice, st);
     hipMemsetAsync(pl->st, 0, sizeof(DevState), st);  // solve_frames never goes through snmf_plan_init
+    pl->fold_host = FoldBlock{0u, hupd_parts(pl), p->conv_eps, pl->stats + (size_t)pl->n_mat * pl->rp * pl->Fp + pl->rp, pl->divh, pl->costh};
+    hipMemcpyAsync(pl->st + 1, &pl->fold_host, sizeof(FoldBlock), hipMemcpyHostToDevice, st);
     hipMemsetAsync(pl->divh, 0, sizeof(double) * std::max(1, p->max_iter), st);
     hipMemsetAsync(pl->costh, 0, sizeof(double) * std::max(1, p->max_iter), st);
     {
@@ -713,7 +721,7 @@ extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
              pl->p.F, pl->p.T, pl->p.r, pl->p.beta, pl->Fm, pl->xr, pl->rp, pl->Tp, hs, pl->TTH * pl->NT,
              sr_pipe ? pl->sr_grid : sf_pipe ? pl->sf_grid : ((kl_pipe || rh_pipe) ? pl->rp_grid : pl->grid_h), (sr_pipe || sf_pipe) ? 512 : (rh_pipe ? 768 : (pl->NWH + pl->NLH) * 64),
              sr_pipe ? pl->lds_sr : sf_pipe ? pl->lds_sf : (rh_pipe ? pl->lds_rh : pl->lds_h), pl->NKT, pl->NWB, pl->NLW, pl->n_chunks, pl->n_fg, pl->n_kg, pl->n_ch1 ? pl->n_ch1 : pl->n_chunks, pl->lds_w,
-             pl->gram_p ? ", P = W*(H*H') through the Gram matrix" : (pl->wsr ? ", k_wstats_sr: statistics rows per wave, operands straight into the MFMA layouts" : pl->wsf ? ", k_wstats_sf: a tile per wave" : (pl->til > 1 ? (pl->til == 2 ? ", 2 consumer teams take the tiles in turn" : ", 4+ consumer teams take the tiles in turn") : "")), pl->wfin ? "k_wfin" : (pl->upd_w ? "k_reduce + k_wapply" : "none"), pl->ctx->n_cu);
+             pl->gram_p ? ", P = W*(H*H') through the Gram matrix" : (pl->wsr ? ", k_wstats_sr: statistics rows per wave, operands straight into the MFMA layouts" : pl->wsf ? ", k_wstats_sf: a tile per wave" : (pl->til > 1 ? (pl->til == 2 ? ", 2 consumer teams take the tiles in turn" : ", 4+ consumer teams take the tiles in turn") : "")), pl->wfin ? "k_wfin" : (pl->upd_w ? "k_reduce + k_wapply" : (pl->fold_obj && !pl->M ? "none (objective fold + convergence test on the H step's last workgroup)" : "none (objective fold + convergence test: k_reduce)")), pl->ctx->n_cu);
     return SNMF_OK;
 }
 
@@ -884,6 +892,7 @@ StepArgs make_args(snmf_plan* pl) {
     a.beta = (float)pl->p.beta;
     const double bb1 = pl->p.beta * (pl->p.beta - 1.0);
     a.inv_bb1 = bb1 != 0.0 ? (float)(1.0 / bb1) : 0.f;
+    a.fold_it = pl->fold_now;  // (> 0 only while snmf_plan_run issues the H step of an H-only iteration)
     return a;
 }
 
@@ -1104,6 +1113,7 @@ extern "C" int snmf_plan_init(snmf_plan* pl) {
     // (or was otherwise left partial) must not leave them misaligned for the next solve
     if (pl->part_cnt) HIP_TRY(hipMemsetAsync(pl->part_cnt, 0, (size_t)(pl->rp_tiles - pl->rp_full) * 4, st));
     if (pl->fin_cnt) HIP_TRY(hipMemsetAsync(pl->fin_cnt, 0, (size_t)pl->p.r * 4, st));  // (k_wfin's split form: the same alignment argument)
+    HIP_TRY(hipMemsetAsync(&reinterpret_cast<FoldBlock*>(pl->st + 1)->cnt, 0, 4, st));  // (the H-only loop's folding H step: likewise)
     HIP_TRY(hipMemsetAsync(pl->divh, 0, sizeof(double) * std::max(1, pl->p.max_iter), st));
     HIP_TRY(hipMemsetAsync(pl->costh, 0, sizeof(double) * std::max(1, pl->p.max_iter), st));
     // wn = sqrt(sum(w.^2)); w = w./wn  (+ operand images, colsum, dphv).  When only V / H changed since
@@ -1343,7 +1353,14 @@ extern "C" int snmf_plan_run(snmf_plan* pl, int32_t n_iters, int32_t* iters_done
             SN_TRY(launch_wfin(pl, pl->stats, obj, pl->n_chunks, false, obj ? j - 1 : 0));
             pl->it_done = j;
         } else {
-        SN_TRY(snmf_plan_hstep(pl));
+        // H-only: the objective fold and the convergence test of iteration j - 1 ride on the H step of iteration j (its last
+        // workgroup to arrive folds, obj_partial_out); without that, k_reduce with the test behind it (the step API's k_reduce + k_check)
+        const bool h_only = pl->upd_h && !pl->upd_w && !pl->M;
+        pl->fold_now = (h_only && pl->fold_obj && want_obj(pl, pl->it_done + 1)) ? pl->it_done : 0;
+        const int rc_h = snmf_plan_hstep(pl);
+        const bool folded = pl->fold_now > 0;
+        pl->fold_now = 0;
+        SN_TRY(rc_h);
         if (pl->wfin) {
             // (what snmf_plan_wstats + snmf_plan_wapply do for a W update, the reduction and the update in one launch)
             const int j = pl->it_done + 1;
@@ -1353,9 +1370,8 @@ extern "C" int snmf_plan_run(snmf_plan* pl, int32_t n_iters, int32_t* iters_done
             SN_TRY(launch_wfin(pl, pl->stats, obj, n_part, !pl->upd_h, obj ? j - 1 : 0));
             pl->it_done = j;
         } else if (pl->upd_h && !pl->upd_w && !pl->M) {
-            // H-only: the objective fold and the convergence test in one launch (the step API's k_reduce + k_check)
             const int j = pl->it_done + 1;
-            if (want_obj(pl, j)) SN_TRY(launch_reduce(pl, pl->stats, false, true, hupd_parts(pl), false, j - 1));
+            if (want_obj(pl, j) && !folded) SN_TRY(launch_reduce(pl, pl->stats, false, true, hupd_parts(pl), false, j - 1));
             pl->it_done = j;
         } else {
             SN_TRY(snmf_plan_wstats(pl, pl->stats));

@@ -146,6 +146,11 @@ struct snmf_plan {
     double* qp_buf = nullptr;   // [r][n_mat * Fp]
     unsigned* fin_cnt = nullptr;  // [r] arrivals per column (monotonic)
     size_t lds_wfin = 0;
+    // H-only loop of snmf_plan_run: the objective fold + convergence test ride on the H step (obj_partial_out in snmf_kernels.h:
+    // the last workgroup to arrive folds) instead of a k_reduce launch per iteration.  SNMF_HFOLD=0 keeps the launch.
+    bool fold_obj = false;
+    FoldBlock fold_host{};         // what the FoldBlock behind *st holds (the source of the copy at plan creation)
+    int fold_now = 0;              // > 0 while snmf_plan_run issues the H step that carries the test of that iteration
     // shapes beyond the fused kernels' LDS / register envelope: the same iteration with its intermediates in HBM
     // (csrc/snmf_generic.h); Lam / ratio / denominator images [Tp][Fp], numerator / denominator of the H update [Tp][rp]
     // Euclidean W step, r > 256, full updates: P = max(W*H, flr) * H' is formed as W * (H*H') -- the r x r Gram matrix

@@ -174,6 +174,21 @@ struct StepArgs {
                           // k_wstats with loader waves, FEWER row tiles than consumer waves (nf <= NWB / 2, no extra row): the consumers
                           // are til teams of NWB / til waves; team p takes the tiles it % til == p of the chunk and the teams' partial
                           // statistics are added through LDS at the end (fixed order).  0 / 1: every consumer wave on every tile
+    // (APPENDED behind til, for the reason given there; ONE scalar: k_hstep_rp<true, false> holds 63 spilled SGPRs in one VGPR's
+    // 64 lanes, and the seven words of a first version -- pointers, eps, counts as kernel arguments -- gave it a scratch slot.)
+    // The H-only loop of snmf_plan_run, fold_it > 0: the objective fold and the convergence test of iteration fold_it ride on
+    // this H step -- the workgroup that arrives LAST adds the partials in k_reduce's order and records (obj_partial_out below;
+    // everything else it needs sits in the FoldBlock behind the plan's DevState); no k_reduce launch follows.
+    int fold_it;
+};
+// behind the plan's DevState in the same allocation (stop -> DevState -> + 1), written once at plan creation
+struct FoldBlock {
+    unsigned cnt;     // arrivals (monotonic; a folding launch adds gridDim.x)
+    int n;            // objective partials of an H-update launch (= its grid)
+    double eps;       // conv_eps
+    double* sc;       // (div, sum S.*H) of the statistics buffer
+    double* divh;
+    double* costh;
 };
 
 
@@ -202,6 +217,103 @@ struct StepArgs {
 #define SNMF_STAMP_CLK(prof, idx)
 #define SNMF_STAMP_TILE(prof, wg, it)
 #endif
+
+// (-DSNMF_STRESS: the note in front of rp_post below)
+#ifdef SNMF_STRESS
+__device__ __forceinline__ void stress_jitter() {
+    unsigned t = (unsigned)__builtin_amdgcn_s_memtime() ^ ((unsigned)threadIdx.x >> 6) * 0x85EBCA6Bu ^ (unsigned)blockIdx.x * 0xC2B2AE35u;
+    t ^= t >> 7;
+    t *= 0x9E3779B1u;
+    t ^= t >> 15;
+    const int n = __builtin_amdgcn_readfirstlane((t & 3u) == 0u ? (int)((t >> 2) & 63u) : 0);
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+}
+#else
+__device__ __forceinline__ void stress_jitter() {}
+#endif
+
+// Convergence test of src/sparse_nmf.m:260-285 for iteration `it` (1-based) whose (div, sh) sit
+// in the reduced statistics.  Every workgroup evaluates it identically (no races: it reads only
+// the statistics and the cost of iteration it-1, written by an earlier launch); one thread
+// records.  Returns true when the loop must stop at `it`.
+// last_pre: costh[it - 2] loaded by the caller ahead of time (k_wfin issues every global load of the launch up front), or nullptr
+__device__ __forceinline__ bool conv_test(const double* sc, double* divh, double* costh, DevState* st, int it,
+                                          double conv_eps, bool recorder, const double* last_pre = nullptr) {
+    const double div = sc[0], cost = sc[0] + sc[1];
+    bool stopnow = false;
+    if (it > 1 && conv_eps > 0.0) {
+        const double last = last_pre ? *last_pre : costh[it - 2];
+        const double e = fabs(cost - last) / last;
+        stopnow = e < conv_eps;
+    }
+    if (recorder) {
+        divh[it - 1] = div;
+        costh[it - 1] = cost;
+        st->n_iter = it;
+        if (stopnow) st->stop = 1;
+    }
+    return stopnow;
+}
+
+// The end of every H-step kernel with the objective: wave 0 hands in the workgroup's partial sums (d, s valid in lane 0; all 64
+// lanes call).  Ordinarily that is two stores and k_reduce / k_wfin fold the partials of the launch.  In the H-only loop of
+// snmf_plan_run (a.fold_it > 0) the fold rides on this launch: partials go out as agent-scope (sc1, write-through) stores, are
+// acknowledged, then the arrival is counted; the wave that arrives last reads all of them with sc1 loads and adds them in
+// k_reduce's order exactly -- thread t of its 256 adds partials t, t + 256, ... and a tree 128, 64, ..., 1 follows: lane l of
+// this wave plays threads l, l + 64, l + 128, l + 192 -- so cost histories and stopping iterations are those of the separate launch
+// to the bit.  (No fences: a __threadfence() would write back the H tiles this XCD's L2 still holds, see k_wfin.)
+__device__ __forceinline__ void obj_partial_out(const StepArgs& a, int slot, double d, double s) {
+    const int lane = threadIdx.x & 63;
+    if (a.fold_it <= 0) {
+        if (lane == 0) {
+            a.part[2 * slot] = d;
+            a.part[2 * slot + 1] = s;
+        }
+        return;
+    }
+    DevState* st = reinterpret_cast<DevState*>(const_cast<int*>(a.stop));
+    FoldBlock* fb = reinterpret_cast<FoldBlock*>(st + 1);
+    int last = 0;
+    if (lane == 0) {
+        __hip_atomic_store(a.part + 2 * slot, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.part + 2 * slot + 1, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    stress_jitter();  // (-DSNMF_STRESS builds only)
+    if (lane == 0) {
+        const unsigned old = __hip_atomic_fetch_add(&fb->cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = (old % gridDim.x) == gridDim.x - 1u;
+    }
+    if (!__builtin_amdgcn_readfirstlane(last)) return;
+    const int n = fb->n;
+    double xd[4], xs[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        xd[q] = 0.0;
+        xs[q] = 0.0;
+        for (int c = lane + 64 * q; c < n; c += 256) {
+            xd[q] += __hip_atomic_load(a.part + 2 * c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            xs[q] += __hip_atomic_load(a.part + 2 * c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    xd[0] += xd[2];
+    xs[0] += xs[2];
+    xd[1] += xd[3];
+    xs[1] += xs[3];
+    xd[0] += xd[1];
+    xs[0] += xs[1];
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) {
+        xd[0] += __shfl_down(xd[0], sh, 64);
+        xs[0] += __shfl_down(xs[0], sh, 64);
+    }
+    if (lane == 0) {
+        double sc[2] = {xd[0], xs[0]};
+        fb->sc[0] = sc[0];
+        fb->sc[1] = sc[1];
+        conv_test(sc, fb->divh, fb->costh, st, a.fold_it, fb->eps, true);
+    }
+}
 
 #define SNMF_PIN()                          \
     do {                                    \
@@ -961,10 +1073,7 @@ __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(Step
             }
             __syncthreads();
         }
-        if (threadIdx.x == 0) {
-            a.part[2 * blockIdx.x] = red[0];
-            a.part[2 * blockIdx.x + 1] = red[NTHR];
-        }
+        if (threadIdx.x < 64) obj_partial_out(a, blockIdx.x, red[0], red[NTHR]);
     }
 }
 
@@ -1015,18 +1124,7 @@ __global__ __launch_bounds__((NW + NL) * 64, (NL > 0 ? 3 : 2)) void k_hstep(Step
 // small-F iteration's pair hand-off and the adaptation kernel's grid exchange.  The unit tests run with deterministic timing; a
 // protocol that is only right for the timing the kernels happen to have (round 5's DMA refill under another wave's copy-out) shows
 // when one hand-off in four is late by up to 64 x 64 cycles -- a fifth of a tile period.  The shipped kernels contain none of this.
-#ifdef SNMF_STRESS
-__device__ __forceinline__ void stress_jitter() {
-    unsigned t = (unsigned)__builtin_amdgcn_s_memtime() ^ ((unsigned)threadIdx.x >> 6) * 0x85EBCA6Bu ^ (unsigned)blockIdx.x * 0xC2B2AE35u;
-    t ^= t >> 7;
-    t *= 0x9E3779B1u;
-    t ^= t >> 15;
-    const int n = __builtin_amdgcn_readfirstlane((t & 3u) == 0u ? (int)((t >> 2) & 63u) : 0);
-    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
-}
-#else
-__device__ __forceinline__ void stress_jitter() {}
-#endif
+// (stress_jitter itself: near the top of this file, with the objective fold that also uses it)
 
 __device__ __forceinline__ void rp_post(unsigned* slots, int wave_in_role, unsigned tiles_done, int lane) {
     stress_jitter();
@@ -2195,10 +2293,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             }
             __syncthreads();
         }
-        if (threadIdx.x == 0) {
-            a.part[2 * blockIdx.x] = red[0];
-            a.part[2 * blockIdx.x + 1] = red[NTHR];
-        }
+        if (threadIdx.x < 64) obj_partial_out(a, blockIdx.x, red[0], red[NTHR]);
     }
 }
 
@@ -2743,10 +2838,7 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rh(StepArgs a) {
             }
             __syncthreads();
         }
-        if (threadIdx.x == 0) {
-            a.part[2 * blockIdx.x] = red[0];
-            a.part[2 * blockIdx.x + 1] = red[NTHR];
-        }
+        if (threadIdx.x < 64) obj_partial_out(a, blockIdx.x, red[0], red[NTHR]);
     }
 }
 
@@ -3780,28 +3872,7 @@ __global__ __launch_bounds__((NWB + NL) * 64, WPS) void k_wstats_teams(StepArgs 
     wstats_body<NK, NWB, NL, WPS, WM, BM, OBJ, TT, LX, true>(a, n_chunks, mat_index, n_mat);
 }
 
-// Convergence test of src/sparse_nmf.m:260-285 for iteration `it` (1-based) whose (div, sh) sit
-// in the reduced statistics.  Every workgroup evaluates it identically (no races: it reads only
-// the statistics and the cost of iteration it-1, written by an earlier launch); one thread
-// records.  Returns true when the loop must stop at `it`.
-// last_pre: costh[it - 2] loaded by the caller ahead of time (k_wfin issues every global load of the launch up front), or nullptr
-__device__ __forceinline__ bool conv_test(const double* sc, double* divh, double* costh, DevState* st, int it,
-                                          double conv_eps, bool recorder, const double* last_pre = nullptr) {
-    const double div = sc[0], cost = sc[0] + sc[1];
-    bool stopnow = false;
-    if (it > 1 && conv_eps > 0.0) {
-        const double last = last_pre ? *last_pre : costh[it - 2];
-        const double e = fabs(cost - last) / last;
-        stopnow = e < conv_eps;
-    }
-    if (recorder) {
-        divh[it - 1] = div;
-        costh[it - 1] = cost;
-        st->n_iter = it;
-        if (stopnow) st->stop = 1;
-    }
-    return stopnow;
-}
+// (conv_test: near the top of this file, in front of obj_partial_out)
 
 // ============================================================================================
 // Statistics buffer (fp64, device), the unit that is all-reduced across ranks:

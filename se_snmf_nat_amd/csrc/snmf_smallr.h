@@ -331,14 +331,13 @@ __global__ __launch_bounds__(kSrWaves * 64, 2) void k_hstep_sr(StepArgs a) {
             red[kSrWaves + w] = acc_sh;
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (threadIdx.x < 64) {
             double d = 0.0, s = 0.0;
             for (int i = 0; i < kSrWaves; ++i) {
                 d += red[i];
                 s += red[kSrWaves + i];
             }
-            a.part[2 * blockIdx.x] = d;
-            a.part[2 * blockIdx.x + 1] = s;
+            obj_partial_out(a, blockIdx.x, d, s);
         }
     }
 }
