@@ -361,6 +361,24 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         pl->sf = pl->bm == BM_KL && pl->upd_h && !pl->xr && pl->nf <= 2 && pl->nk <= 8 && pl->lds_sf <= lds_cap && !pl->generic &&
                  !(e && atoi(e) == 0) && !(e2 && atoi(e2) == 0);
         pl->sf_grid = std::max(1, std::min((T + 31) / 32, ctx->n_cu));
+        // the shared last tile: when the partial wave level behind the whole ones is the FIRST on its SIMDs (level 0 or 4 of 8: any other
+        // level runs beside whole tiles of the same round on other SIMDs and sharing it would not end the launch earlier).  SNMF_HSTEP_SPLIT=0
+        // keeps every tile whole, like the split last round of k_hstep_rp.
+        {
+            const int nw = 8 * pl->sf_grid, R = pl->rp_tiles % nw, wfull = R / pl->sf_grid, xb = R % pl->sf_grid;
+            const char* e4 = getenv("SNMF_HSTEP_SPLIT");
+            const size_t more = (size_t)pl->nf * 16384 + 16;
+            pl->sf_share = 0;
+            pl->sf_nfull = pl->rp_tiles;
+            // (not for the full updates that snmf_plan_run fuses into k_iter_sf: the step API's two launches -- the sharded loop -- stay
+            //  bit for bit what the fused launch computes, tests/test_gpu_parity.py::test_fused_small_f_iteration_equals_the_two_launches)
+            const bool isf_shape = pl->upd_h && pl->upd_w && pl->nf == 2 && pl->nk >= 3 && pl->nk <= 4;
+            if (pl->sf && !isf_shape && xb > 0 && (wfull == 0 || wfull == 4) && pl->nk >= 2 && pl->lds_sf + more <= lds_cap && !(e4 && atoi(e4) == 0)) {
+                pl->sf_share = xb;
+                pl->sf_nfull = pl->rp_tiles - xb;
+                pl->lds_sf += more;
+            }
+        }
         pl->sf_stagger = 8000;
         if (const char* e3 = getenv("SNMF_SF_STAG")) pl->sf_stagger = atoi(e3);
     }
@@ -428,6 +446,8 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         pl->wsf = pl->bm == BM_KL && pl->upd_w && !pl->xr && pl->nf <= 2 && pl->nk <= 4 && pl->TTW == 32 && pl->n_kg == 1 && pl->n_fg == 1 &&
                   pl->NLW && !pl->generic && pl->lds_wsf <= lds_cap && !(e && atoi(e) == 0) && !(e2 && atoi(e2) == 0);
         if (pl->wsf) pl->til = 1;
+        const char* e4 = getenv("SNMF_HSTEP_SPLIT");
+        pl->wsf_share = pl->wsf && pl->nf == 2 && pl->nk >= 2 && !(pl->upd_h && pl->nk >= 3) && !(e4 && atoi(e4) == 0);  // (not the shapes of k_iter_sf: see sf_share)
     }
     // ... and, for FULL updates of those shapes, both half-steps in one launch (k_iter_sf; the run loop only: the step API keeps
     // the two launches, between which a multi-rank caller sums nothing but could).  SNMF_ITER_SF=0 keeps two launches.
@@ -698,7 +718,7 @@ extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
     else if (sf_pipe && pl->isf && pl->wfin)
         snprintf(hs, sizeof hs, "k_iter_sf (H step + W statistics of a full update in ONE launch, 4 SIMD pairs of an H wave and a W wave per workgroup; %d tiles, grid %d; step API: k_hstep_sf)", pl->rp_tiles, pl->n_chunks);
     else if (sf_pipe)
-        snprintf(hs, sizeof hs, "k_hstep_sf (a tile per wave from first load to last store, 8 waves per workgroup; %d tiles, grid %d)", pl->rp_tiles, pl->sf_grid);
+        snprintf(hs, sizeof hs, "k_hstep_sf (a tile per wave from first load to last store, 8 waves per workgroup; %d tiles, the last %d shared by four waves each, grid %d)", pl->rp_tiles, pl->sf_share, pl->sf_grid);
     else if (rh_pipe)
         snprintf(hs, sizeof hs, "k_hstep_rh (4 P1 + 4 P2 + 4 loader waves on half tiles%s; %d of %d tiles pipelined, last round split %d ways, grid %d)",
                  pl->rh_lxh == 1 ? ", P2 cut four ways over the contraction + leftover columns as 4x4x1 MFMAs" : (pl->rh_lxh == 2 ? ", P2 in wave pairs cut over the contraction + leftover columns as 4x4x1 MFMAs" : ""), pl->rp_full, pl->rp_tiles, pl->rp_S, pl->rp_grid);
@@ -721,7 +741,7 @@ extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
              pl->p.F, pl->p.T, pl->p.r, pl->p.beta, pl->Fm, pl->xr, pl->rp, pl->Tp, hs, pl->TTH * pl->NT,
              sr_pipe ? pl->sr_grid : sf_pipe ? pl->sf_grid : ((kl_pipe || rh_pipe) ? pl->rp_grid : pl->grid_h), (sr_pipe || sf_pipe) ? 512 : (rh_pipe ? 768 : (pl->NWH + pl->NLH) * 64),
              sr_pipe ? pl->lds_sr : sf_pipe ? pl->lds_sf : (rh_pipe ? pl->lds_rh : pl->lds_h), pl->NKT, pl->NWB, pl->NLW, pl->n_chunks, pl->n_fg, pl->n_kg, pl->n_ch1 ? pl->n_ch1 : pl->n_chunks, pl->lds_w,
-             pl->gram_p ? ", P = W*(H*H') through the Gram matrix" : (pl->wsr ? ", k_wstats_sr: statistics rows per wave, operands straight into the MFMA layouts" : pl->wsf ? ", k_wstats_sf: a tile per wave" : (pl->til > 1 ? (pl->til == 2 ? ", 2 consumer teams take the tiles in turn" : ", 4+ consumer teams take the tiles in turn") : "")), pl->wfin ? "k_wfin" : (pl->upd_w ? "k_reduce + k_wapply" : (pl->fold_obj && !pl->M ? "none (objective fold + convergence test on the H step's last workgroup)" : "none (objective fold + convergence test: k_reduce)")), pl->ctx->n_cu);
+             pl->gram_p ? ", P = W*(H*H') through the Gram matrix" : (pl->wsr ? ", k_wstats_sr: statistics rows per wave, operands straight into the MFMA layouts" : pl->wsf ? (pl->wsf_share ? ", k_wstats_sf: a tile per wave, a single remainder tile shared by the eight waves" : ", k_wstats_sf: a tile per wave") : (pl->til > 1 ? (pl->til == 2 ? ", 2 consumer teams take the tiles in turn" : ", 4+ consumer teams take the tiles in turn") : "")), pl->wfin ? "k_wfin" : (pl->upd_w ? "k_reduce + k_wapply" : (pl->fold_obj && !pl->M ? "none (objective fold + convergence test on the H step's last workgroup)" : "none (objective fold + convergence test: k_reduce)")), pl->ctx->n_cu);
     return SNMF_OK;
 }
 

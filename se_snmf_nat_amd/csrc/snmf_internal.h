@@ -124,10 +124,14 @@ struct snmf_plan {
     int sf_grid = 1;
     bool wsf = false;     // KL statistics through k_wstats_sf (F <= 64, r <= 128)
     size_t lds_wsf = 0;
+    bool wsf_share = false;  // k_wstats_sf / k_iter_sf: a workgroup's single remainder tile is shared by its waves (SNMF_HSTEP_SPLIT=0: whole)
     bool isf = false;     // full KL updates of those shapes: H step + W statistics in ONE launch (k_iter_sf); SNMF_ITER_SF=0 keeps two
     size_t lds_isf = 0;
     int sf_stagger = 0;   // cycles by which the second wave of each SIMD starts late (k_hstep_sf)
     size_t lds_sf = 0;
+    // k_hstep_sf: the tiles [sf_nfull, rp_tiles) -- one per workgroup, the partial wave level behind the whole ones -- are shared by the
+    // four waves of that level (snmf_smallf.h, "the shared last tile"); 0 = every tile whole
+    int sf_share = 0, sf_nfull = 0;
     // small rank on tall spectrograms (r <= 64, 3..16 row tiles: snmf_smallr.h): a tile per WORKGROUP cut by row tiles, operands straight
     // into the MFMA layouts; KL H-update launches through k_hstep_sr, KL statistics through k_wstats_sr (SNMF_HSTEP_SR / SNMF_WSTATS_SR = 0: the role pipelines)
     bool sr = false, wsr = false;

@@ -36,6 +36,46 @@ __device__ __forceinline__ void sf_fill_image(const float* src, float* dst, int 
 }
 
 
+// This lane's index, re-derived where it is needed (two VALU instructions, no input register) and OPAQUE to the optimiser: everything
+// computed from it -- frame / half, operand offsets, image pointers -- is then a value of the tile it is used in, not a loop invariant
+// that lives through the whole kernel.  k_iter_sf kept the thread index and a dozen values derived from it alive under its 128
+// accumulators and SPILLED them (the cheapest values there are); a kernel that touches scratch at all pays 6-7 us per launch.
+__device__ __forceinline__ int fresh_lane() {
+    int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(l));
+    return l;
+}
+
+// LDS progress words between waves of a workgroup (the shared last tile of k_hstep_sf, the pair hand-off of k_iter_sf)
+__device__ __forceinline__ void sf_post(unsigned* word, unsigned val, int lane) {
+    stress_jitter();  // (-DSNMF_STRESS builds only: snmf_kernels.h)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    if (lane == 0) __hip_atomic_store(word, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void sf_await(const unsigned* word, unsigned target, const int* stop) {
+    int spin = 0;
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+        if (++spin > kSpinLimit) {
+            raise_fault(stop);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    stress_jitter();
+}
+
+
+// THE SHARED LAST TILE (a.part_S == 4; plan: sf_share).  Tiles go to waves wave-major over the grid, so 3125 tiles on 2048 waves are
+// one tile for everybody, a second one for waves 0..3 of every workgroup -- one per SIMD -- and 53 more for wave 4 of 53 workgroups:
+// those SIMDs run two tiles side by side while every other SIMD of the chip runs one, and the launch ends a tile period later than
+// its work asks for (64 x 100000, r = 200: 77.5 us against 68.3 us at 98304 frames, scripts/gpu_r6_k.sh).  Those tiles [n_full,
+// n_tiles) are therefore SHARED by the four waves of their level (w0 .. w0 + 3, one per SIMD): wave v takes the column tiles
+// kap = CPW v .. of H -- its k range of Lam = W*H, whose four partial sums meet in LDS and are added in wave order by every wave
+// (so all four hold the same Lam and ratio), then W^T*ratio, the update and the store of its own rows of H.  No other data is exchanged.
+// The four waves take the shared tile FIRST, then their own tiles (the SIMDs' loads are the same either way; see the call).
+// Another order of additions for Lam than the whole tile's one chain: SNMF_HSTEP_SPLIT=0 keeps every tile whole (tests compare).
+
 // NF row tiles (1..2), NK column tiles of H (1..8; 254 VGPRs at 8, no scratch).  Dynamic LDS: Wt4 image [NF][rp/8][2][32][4], Wk4 image [NK][Fq/8][2][32][4],
 // 1 ./ dph [rp], lambda_k [rp], then [2][kSfWaves] doubles for the objective partials.
 template <int NF, int NK, bool OBJ>
@@ -50,6 +90,9 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_hstep_sf(StepArgs a) {
     float* const rdp = wk + (size_t)NK * a.Fq * 32;         // 1 ./ dph   [rp]   (scalar / per-row sparsity)
     float* const lmk = rdp + rp;                            // lambda_k   [rp]
     double* const red = reinterpret_cast<double*>(lmk + rp);  // [2][kSfWaves]
+    f32x4* const xch = reinterpret_cast<f32x4*>(red + 2 * kSfWaves);  // shared last tile: partial Lam [4 waves][NF][4][64] f32x4 ...
+    unsigned* const xfl = reinterpret_cast<unsigned*>(xch + 4 * NF * 4 * 64);  // ... and their four "written" words
+    const int n_main = a.part_S ? a.n_full : a.n_tiles;  // tiles of the wave-major loop
 
     // this wave's tiles: wave-major over the grid, so that the waves with one tile more are spread over all CUs first
     const int gw = w * (int)gridDim.x + (int)blockIdx.x, nw = kSfWaves * (int)gridDim.x;
@@ -71,6 +114,7 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_hstep_sf(StepArgs a) {
             rdp[k] = a.S ? 0.f : fast_rcp(a.dphv[k]);
             lmk[k] = a.S ? 0.f : a.lamk[k];
         }
+        if (a.part_S && threadIdx.x < 4) xfl[threadIdx.x] = 0u;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
@@ -86,12 +130,160 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_hstep_sf(StepArgs a) {
     const f32x4* const wkl = reinterpret_cast<const f32x4*>(wk) + lane;  // fragment (kap, q): wkl[(kap * nqf + q) * 64]
     double acc_div = 0.0, acc_sh = 0.0;
 
+    // ---- the shared last tile (see the note above the kernel): waves w0 .. w0 + NP - 1 of the workgroups that have one ----
+    auto shared_tile = [&](auto sk_tag) {
+        constexpr int SK = decltype(sk_tag)::value;
+        constexpr int CPW = (NK + 3) / 4, NP = (NK + CPW - 1) / CPW;  // column tiles per wave, participating waves
+        const int wv = w - ((a.n_full / (int)gridDim.x) & 7);         // (the level behind the whole ones: 0 or 4, the plan's condition)
+        const int tile = a.n_full + (int)blockIdx.x;
+        if (NP < 2 || wv < 0 || wv >= NP || tile >= a.n_tiles) return;
+        const int kap0 = wv * CPW;
+        const bool two = CPW == 2 && kap0 + 1 < NK;  // (an odd NK leaves the last wave one column tile)
+        // (lane-derived values of THIS block of code: taken from the kernel's own they stay alive across the tile loop above, which
+        //  has no register to spare -- 29 / 63 spilled VGPRs at NK = 7 / 8)
+        const int lane = fresh_lane(), t = lane & 31, h = lane >> 5;
+        int tile_o = tile, rp_o = rp, Fp_o = Fp;
+        asm volatile("" : "+s"(tile_o), "+s"(rp_o), "+s"(Fp_o));  // (nothing of this block is computed ahead of the tile loop)
+        const int t0 = tile_o * 32;
+        const f32x4* const wtl = reinterpret_cast<const f32x4*>(wt) + lane;
+        const f32x4* const wkl = reinterpret_cast<const f32x4*>(wk) + lane;
+        f32x4 hs[CPW * 4], vs[NF * 4];
+        {
+            const float* hp = a.Hin + ((size_t)t0 + t) * rp_o + 32 * kap0 + 4 * h;
+            const float* vp = a.V + ((size_t)t0 + t) * Fp_o + 4 * h;
+#pragma unroll
+            for (int q = 0; q < CPW * 4; ++q) hs[q] = (q < 4 || two) ? *reinterpret_cast<const f32x4*>(hp + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < NF * 4; ++q) vs[q] = *reinterpret_cast<const f32x4*>(vp + 8 * q);
+        }
+        // P1 over this wave's k blocks, partial Lam -> LDS, the four partials added in wave order
+        float dsum = 0.f;
+        {
+            f32x16 acc[NF];
+#pragma unroll
+            for (int phi = 0; phi < NF; ++phi) acc[phi] = zero16();
+#pragma unroll
+            for (int ql = 0; ql < CPW * 4; ++ql) {
+                const int q = kap0 * 4 + ql;
+                if (q >= a.nqk || (ql >= 4 && !two)) break;
+                f32x4 wa[NF];
+#pragma unroll
+                for (int phi = 0; phi < NF; ++phi) wa[phi] = wtl[(phi * nq8 + q) * 64];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int phi = 0; phi < NF; ++phi) acc[phi] = mfma32(wa[phi][e], hs[ql][e], acc[phi]);
+            }
+#pragma unroll
+            for (int phi = 0; phi < NF; ++phi)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    xch[((wv * NF + phi) * 4 + g) * 64 + lane] = f32x4{acc[phi][4 * g], acc[phi][4 * g + 1], acc[phi][4 * g + 2], acc[phi][4 * g + 3]};
+            sf_post(xfl + wv, 1u, lane);
+#pragma unroll
+            for (int v = 0; v < NP; ++v) sf_await(xfl + v, 1u, a.stop);
+#pragma unroll
+            for (int phi = 0; phi < NF; ++phi) {
+                const bool edge = OBJ && !(phi * 32 + 32 <= a.F && t0 + 32 <= a.T);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 lam4 = xch[((0 * NF + phi) * 4 + g) * 64 + lane];
+#pragma unroll
+                    for (int v = 1; v < NP; ++v) {
+                        const f32x4 x = xch[((v * NF + phi) * 4 + g) * 64 + lane];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) lam4[j] += x[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = vs[phi * 4 + g][j];
+                        const float lam = fmaxf(lam4[j], kFlr);
+                        if (OBJ && wv == 0) {  // (the tile's divergence terms count once)
+                            const float d = div_term<BM_KL>(v, lam, a.beta, a.inv_bb1);
+                            if (edge) dsum += (phi * 32 + 8 * g + 4 * h + j < a.F && t0 + t < a.T) ? d : 0.f;
+                            else dsum += d;
+                        }
+                        vs[phi * 4 + g][j] = v * fast_rcp(lam);
+                    }
+                    if (OBJ) __builtin_amdgcn_sched_barrier(0);  // (as in the tile loop: the logarithms one group at a time)
+                }
+            }
+        }
+        if (OBJ) acc_div += (double)dsum;
+        // P2 + update of this wave's column tiles
+        float shsum = 0.f;
+        auto upd = [&](const f32x16& acc, const int c) {  // (p2_update of the tile loop on the local pieces hs[4 c ..])
+            const int kap = kap0 + c;
+            float hsm = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int k0 = kap * 32 + 8 * g + 4 * h;
+                const f32x4 ho = hs[c * 4 + g];
+                f32x4 sp, dp;
+                if constexpr (SK == 2) {
+                    sp = *reinterpret_cast<const f32x4*>(a.S + ((size_t)t0 + t) * rp_o + k0);
+                    const f32x4 cs = *reinterpret_cast<const f32x4*>(a.colsum + k0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dp[j] = fast_rcp(fmaxf(cs[j] + sp[j], kFlr));
+                } else {
+                    dp = *reinterpret_cast<const f32x4*>(rdp + k0);
+                    if constexpr (OBJ && SK == 1) sp = *reinterpret_cast<const f32x4*>(lmk + k0);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hs[c * 4 + g][j] = ho[j] * acc[4 * g + j] * dp[j];
+                if constexpr (OBJ) {
+                    if constexpr (SK == 0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) hsm += ho[j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) shsum += sp[j] * ho[j];
+                    }
+                }
+            }
+            if constexpr (OBJ && SK == 0) shsum += a.lam_u * hsm;
+        };
+        constexpr int NQ = NF * 4;
+        if (two) {
+            if constexpr (CPW == 2) {
+                f32x16 acc0 = zero16(), acc1 = zero16();
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const f32x4 wa0 = wkl[(kap0 * nqf + q) * 64], wa1 = wkl[((kap0 + 1) * nqf + q) * 64];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc0 = mfma32(wa0[e], vs[q][e], acc0);
+                        acc1 = mfma32(wa1[e], vs[q][e], acc1);
+                    }
+                }
+                upd(acc0, 0);
+                upd(acc1, 1);
+            }
+        } else {
+            f32x16 acc0 = zero16();
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const f32x4 wa0 = wkl[(kap0 * nqf + q) * 64];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc0 = mfma32(wa0[e], vs[q][e], acc0);
+            }
+            upd(acc0, 0);
+        }
+        if (OBJ) acc_sh += (double)shsum;
+        {
+            float* op = a.Hout + ((size_t)t0 + t) * rp_o + 32 * kap0 + 4 * h;
+#pragma unroll
+            for (int q = 0; q < CPW * 4; ++q)
+                if (q < 4 || two) *reinterpret_cast<f32x4*>(op + 8 * q) = hs[q];
+        }
+    };
     // The sparsity kind is a compile-time constant of the tile loop (SK 0: one lambda for every row, 1: a lambda per row, 2: an
     // r x T matrix in H's layout): as run-time branches inside the update they cut it into dozens of basic blocks, each ending
     // in register copies.
     auto tiles = [&](auto sk_tag) {
     constexpr int SK = decltype(sk_tag)::value;
-    for (int tile = gw; tile < a.n_tiles; tile += nw) {
+    if (a.part_S) shared_tile(sk_tag);  // (FIRST: behind the tile loop its values stayed alive across the loop -- 29 / 55 spilled VGPRs at NK = 7 / 8)
+    for (int tile = gw; tile < n_main; tile += nw) {
         const int t0 = tile * 32;
         // (the loads sit at the TOP of the loop: issued behind the previous tile's stores they would take 96 registers of their own)
         load_tile(tile);
@@ -278,6 +470,11 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_wstats_sf(StepArgs a, int 
     const int chunk = blockIdx.x;
     const int tb = (int)(((long long)a.n_tiles * chunk) / n_chunks), te = (int)(((long long)a.n_tiles * (chunk + 1)) / n_chunks);
     sf_fill_image(a.Wt4, lds, NF * rp * 32 * 4, w, lane);
+    // (the shared remainder tile, below: partial Lam' [8 waves][4][64] f32x4 and the waves' "written" words, behind the W image in what
+    //  becomes the partial-statistics area at the end of the kernel -- NF = 2, NK >= 2: three times the image)
+    f32x4* const xch = reinterpret_cast<f32x4*>(lds + (size_t)NF * rp * 32);
+    unsigned* const xfl = reinterpret_cast<unsigned*>(xch + kSfWaves * 4 * 64);
+    if (a.part_S && threadIdx.x < kSfWaves) xfl[threadIdx.x] = 0u;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const f32x4* const wtl = reinterpret_cast<const f32x4*>(lds) + lane + (size_t)phi * nq8 * 64;
@@ -295,7 +492,92 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_wstats_sf(StepArgs a, int 
     // Whole rounds of NCL tiles, then the remainder of m = n % NCL tiles: remainder tile j goes to chunk lane (j + m) % NCL -- the
     // deal of k_iter_sf's W tasks (whose H task of that tile sits on pair j, so that no SIMD gets an extra tile of both kinds);
     // the two kernels accumulate the same tiles in the same order, which keeps their slabs bit for bit the same.
-    const int n_my = te - tb, n_rnd = n_my / NCL, n_rem = n_my - n_rnd * NCL;
+    const int n_my = te - tb, n_rnd = n_my / NCL, n_rem0 = n_my - n_rnd * NCL;
+    // THE SHARED REMAINDER TILE (a.part_S == 4; the plan's wsf_share).  12 or 13 tiles for the four chunk lanes of a workgroup are three
+    // rounds -- or three rounds and ONE more tile on one SIMD while the other three idle (64 x 100000, r = 100: 48.2 us against 41.1 us
+    // at 98304 frames, scripts/gpu_r6_k.sh).  A single remainder tile is therefore shared by all eight waves, FIRST (as k_hstep_sf's
+    // shared tile; the accumulators are still zero): wave (phi, c) takes column tile kap = c -- its k range of Lam', whose NK partial
+    // sums meet in LDS and are added in lane order by every wave of the row tile, then its own column tile of G and of the row sums.
+    // Another order of additions than the whole tile's; SNMF_HSTEP_SPLIT=0 keeps the tile whole (tests compare).
+    const bool share = NF == 2 && NK >= 2 && a.part_S == 4 && n_rem0 == 1;
+    const int n_rem = share ? 0 : n_rem0;
+    if (share && c < NK) {
+        const int t0 = (tb + n_rnd * NCL) * 32;
+        f32x4 hq[4];
+        float v[16], b0[16];
+        {
+            const float* hp = a.Hin + ((size_t)t0 + fl) * rp + 32 * c + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hq[q] = *reinterpret_cast<const f32x4*>(hp + 8 * q);
+            const __amdgpu_buffer_rsrc_t rv =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.V + (size_t)t0 * Fp), 0, 32 * Fp * 4, 0x00020000);
+            const int vo = ((4 * h) * Fp + phi * 32 + fl) * 4;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, vo, drow(i, 0) * Fp * 4, 0));
+            const __amdgpu_buffer_rsrc_t rh =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Hin + (size_t)t0 * rp), 0, 32 * rp * 4, 0x00020000);
+            const int ho = ((4 * h) * rp + fl) * 4;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                b0[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rh, ho, (drow(i, 0) * rp + c * 32) * 4, 0));
+        }
+        f32x16 acc = zero16();
+#pragma unroll
+        for (int ql = 0; ql < 4; ++ql) {
+            const int q = 4 * c + ql;
+            if (q >= a.nqk) break;
+            const f32x4 wa = wtl[q * 64];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = mfma32(hq[ql][e], wa[e], acc);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xch[(w * 4 + g) * 64 + lane] = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        sf_post(xfl + w, 1u, lane);
+#pragma unroll
+        for (int p = 0; p < NK; ++p) sf_await(xfl + phi * NCL + p, 1u, a.stop);
+        float R[16];
+        {
+            const int f = phi * 32 + fl;
+            const bool edge = OBJ && !(phi * 32 + 32 <= a.F && t0 + 32 <= a.T);
+            float dsum = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 lam4 = xch[((phi * NCL + 0) * 4 + g) * 64 + lane];
+#pragma unroll
+                for (int p = 1; p < NK; ++p) {
+                    const f32x4 x = xch[((phi * NCL + p) * 4 + g) * 64 + lane];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) lam4[j] += x[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = 4 * g + j;
+                    const float lam = fmaxf(lam4[j], kFlr);
+                    if (OBJ && c == 0) {  // (the tile's divergence terms count once per row tile)
+                        const float d = div_term<BM_KL>(v[i], lam, a.beta, a.inv_bb1);
+                        if (edge) dsum += (f < a.F && t0 + drow(i, h) < a.T) ? d : 0.f;
+                        else dsum += d;
+                    }
+                    R[i] = v[i] * fast_rcp(lam);
+                }
+            }
+            if (OBJ) acc_div += (double)dsum;
+        }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            if (c == k) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) G[k] = mfma32(R[i], b0[i], G[k]);
+                if (do_s) {
+                    float s4 = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) s4 += b0[i];
+                    ssum[k] += s4;
+                }
+            }
+        }
+    }
     const int jx = (c - n_rem + NCL) % NCL;  // the remainder tile of this lane, if jx < n_rem
     const int n_it = n_rnd + (jx < n_rem ? 1 : 0);
     const bool x_first = n_rem == 1 && jx == 0;  // (a single remainder tile is its lane's FIRST tile: see k_iter_sf)
@@ -472,11 +754,6 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_wstats_sf(StepArgs a, int 
 // Dynamic LDS: Wt4 image (P1 and P3), Wk4 image (P2), 1 ./ dph and lambda_k [rp] each, 4 hand-off buffers, 8 progress words; the
 // end of the kernel reuses it for the pairs' partial statistics as k_wstats_sf does.
 
-__device__ __forceinline__ void sf_post(unsigned* word, unsigned val, int lane) {
-    stress_jitter();  // (-DSNMF_STRESS builds only: snmf_kernels.h)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    if (lane == 0) __hip_atomic_store(word, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
 // The H wave's side of the hand-off WITHOUT compiler-visible memory effects: a fence (or a "memory" clobber) inside the tile loop
 // orders every LDS access of the tile around it as far as the compiler knows, and the H waves' code went from 206 registers
 // to 256 + 11 spilled (either of the two fences alone did it).  The hardware needs none of that: LDS operations of a wave
@@ -498,28 +775,6 @@ __device__ __forceinline__ void sf_await_raw(unsigned word_addr, unsigned target
         __builtin_amdgcn_s_sleep(1);
     }
     stress_jitter();
-}
-__device__ __forceinline__ void sf_await(const unsigned* word, unsigned target, const int* stop) {
-    int spin = 0;
-    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
-        if (++spin > kSpinLimit) {
-            raise_fault(stop);
-            break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-    stress_jitter();
-}
-
-// This lane's index, re-derived where it is needed (two VALU instructions, no input register) and OPAQUE to the optimiser: everything
-// computed from it -- frame / half, operand offsets, image pointers -- is then a value of the tile it is used in, not a loop invariant
-// that lives through the whole kernel.  k_iter_sf kept the thread index and a dozen values derived from it alive under its 128
-// accumulators and SPILLED them (the cheapest values there are); a kernel that touches scratch at all pays 6-7 us per launch.
-__device__ __forceinline__ int fresh_lane() {
-    int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    asm volatile("" : "+v"(l));
-    return l;
 }
 
 // SK: the sparsity kind (0: one lambda for every row, 1: a lambda per row, 2: an r x T matrix in H's layout) -- a parameter of the

@@ -24,6 +24,8 @@ static int launch_hstep_sf_f(snmf_plan* pl, const StepArgs& a, bool obj) {
 int launch_hstep_sf(snmf_plan* pl, StepArgs a, bool obj) {
     a.stagger = pl->sf_stagger;
     a.n_tiles = pl->rp_tiles;  // only tiles that hold a frame (the pad tiles of both H buffers are zero and stay zero)
+    a.n_full = pl->sf_nfull;   // ... of which [sf_nfull, rp_tiles) are shared by four waves each
+    a.part_S = pl->sf_share ? 4 : 0;
     return pl->nf == 1 ? launch_hstep_sf_f<1>(pl, a, obj) : launch_hstep_sf_f<2>(pl, a, obj);
 }
 
@@ -52,7 +54,9 @@ static int launch_wstats_sf_f(snmf_plan* pl, const StepArgs& a, bool obj) {
         default: return launch_wstats_sf_n<NF, 4>(pl, a, obj);
     }
 }
-int launch_wstats_sf(snmf_plan* pl, const StepArgs& a, bool obj) {
+int launch_wstats_sf(snmf_plan* pl, const StepArgs& a0, bool obj) {
+    StepArgs a = a0;
+    a.part_S = pl->wsf_share ? 4 : 0;  // a workgroup's single remainder tile is shared by its eight waves (snmf_smallf.h)
     return pl->nf == 1 ? launch_wstats_sf_f<1>(pl, a, obj) : launch_wstats_sf_f<2>(pl, a, obj);
 }
 

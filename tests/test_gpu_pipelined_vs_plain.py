@@ -35,6 +35,8 @@ SHAPES = [(65, 70, 12000), (129, 70, 12000), (65, 32, 12000), (64, 70, 12000), (
           # the SIMDs the A team leaves free, k_wstats with consumer TEAMS that take the tiles of a chunk in turn
           (64, 100, 20000), (64, 40, 12000), (32, 100, 12000), (64, 200, 12000), (128, 100, 12000), (64, 100, 9000),
           (64, 128, 70000), (40, 20, 33000), (64, 100, 3000), (32, 8, 100), (64, 256, 9000), (64, 130, 8300),
+          # ... whose last tiles are shared by four waves (NK = 7 in pairs, NK = 8 on one row tile, NK = 3 / 5: fewer than four participants / an odd count)
+          (64, 200, 37000), (32, 256, 35000), (64, 70, 66000), (64, 160, 68000),
           # one or two column tiles on >= 4 row tiles: k_hstep_rp<., CUT> (every B wave a quarter of the contraction) -- the reference's
           # R = 20 / 10 / 30 settings at F = 513 (settings/bak_IS16_results/initial_setting_SNMF_Techwin_201603_RT.m:47-48)
           (513, 20, 12000), (513, 30, 9000), (513, 10, 9000), (257, 32, 20000), (385, 10, 12000), (257, 64, 9000), (129, 50, 12000),
@@ -43,6 +45,9 @@ SHAPES = [(65, 70, 12000), (129, 70, 12000), (65, 32, 12000), (64, 70, 12000), (
           # ... with THREE or more tiles per workgroup: only then does a loader refill a buffer (LDS-DMA on more than 10 row tiles), and
           # only then did the race between one loader wave's DMA and another's copy-out of the same H rows show (round 5, found by fuzzing)
           (513, 20, 21000), (385, 33, 21157), (422, 32, 17725), (513, 64, 19530), (385, 50, 19546), (421, 30, 17743), (257, 32, 26000)]
+
+
+SF_SHARED = {(64, 128, 70000), (64, 200, 37000), (32, 256, 35000), (64, 70, 66000), (64, 160, 68000)}  # (on 256 compute units)
 
 
 def _run(ctx, V, W0, H0, r, *, h_only, iters):
@@ -76,9 +81,12 @@ def test_pipelined_kernels_equal_plain_kernels(gpu_ctx, shape, monkeypatch):
     else:
         assert "k_hstep_rp" in geo or "k_hstep_rh" in geo or "k_hstep_sf" in geo or sr  # the pipelined path is what ran
         m = re.search(r"(\d+) of (\d+) tiles pipelined, last round split (\d+) ways", geo)
-        if "k_hstep_sf" in geo:  # (F <= 64, r <= 256: a tile per wave, never split)
+        if "k_hstep_sf" in geo:  # (F <= 64, r <= 256: a tile per wave; round 6: the tiles of a partial wave level that is the first on its SIMDs are SHARED by four waves)
             assert F <= 64 and r <= 256
-            n_full, n_tiles, S = (T + 31) // 32, (T + 31) // 32, 0
+            x = int(re.search(r"the last (\d+) shared by four waves each", geo).group(1))
+            n_tiles = (T + 31) // 32
+            n_full, S = n_tiles - x, (4 if x else 0)
+            assert (x > 0) == (shape in SF_SHARED), (shape, x)
         elif sr:  # (never split either; r = 33..64 keep k_hstep_rp<., CUT>: two column tiles do not fit the registers)
             assert r <= 32 and 65 <= F <= 544 and "k_wstats_sr" in geo_full
             n_full, n_tiles, S = (T + 31) // 32, (T + 31) // 32, 0
@@ -87,7 +95,7 @@ def test_pipelined_kernels_equal_plain_kernels(gpu_ctx, shape, monkeypatch):
     monkeypatch.setenv("SNMF_HSTEP_SPLIT", "0")
     h_ns, _, geo_ns, _ = _run(gpu_ctx, V, W0, H0, r, h_only=True, iters=2)
     _, w_ns, _, _ = _run(gpu_ctx, V, W0, H0, r, h_only=False, iters=3)
-    assert "split 0 ways" in geo_ns or "k_hstep," in geo_ns or "k_hstep_sf" in geo_ns or "k_hstep_sr" in geo_ns
+    assert "split 0 ways" in geo_ns or "k_hstep," in geo_ns or "the last 0 shared" in geo_ns or "k_hstep_sr" in geo_ns
     monkeypatch.setenv("SNMF_HSTEP_RP", "0")
     monkeypatch.setenv("SNMF_WSTATS_NL", "0")
     h_old, _, geo_old, obj_old = _run(gpu_ctx, V, W0, H0, r, h_only=True, iters=2)
