@@ -7,7 +7,7 @@ k_hstep_rp<., CUT> (>= 4 row tiles, r <= 64, more tiles than CUs) -- with their 
 every buffer of every pipeline wraps around several times (the race of profiles/r05_experiments.md section 10 only showed with three or
 more tiles per workgroup).  focus = "pipe": every PIPELINED family (k_hstep_rp, its CUT / pair forms, k_hstep_rh modes 0 / 1 / 2,
 k_hstep_sf, k_iter_sf, k_wstats with loader waves / teams, k_wstats_sf) at 3..6 tiles per workgroup with few iterations (cheap for the
-oracle).  focus = "stop": early-stop cases on those families.  No focus: shapes drawn to land on the plan's geometry switches: tile counts
+oracle).  focus = "stop": early-stop cases on those families.  focus = "share": the shared tiles of the small-F family (round 6).  No focus: shapes drawn to land on the plan's geometry switches: tile counts
 around multiples of the CU count (the split last round), F on both sides of 32n+1, r around the 32-column tiles and the LX / NK limits, all
 divergences and update modes, shapes beyond the fused kernels' envelope now and then."""
 import time
@@ -81,10 +81,28 @@ class Fuzz:
         sp = str(rs.choice(["scalar", "scalar", "vec", "zero"]))
         return F, T, r, 1.0, mode, sp
 
+    def draw_share(self):
+        """Round 6's shared tiles of the small-F family (csrc/snmf_smallf.h): k_hstep_sf shares the tiles of a partial wave level that is
+        the first on its SIMDs (tile counts 1025..1279 and 2049..2303 on 256 compute units) among four waves, k_wstats_sf a workgroup's
+        single remainder tile (4 n + 1 tiles in a chunk) among its eight waves; H-only, W-only and (r > 128) full updates."""
+        rs = self.rs
+        F = int(rs.choice([64, 64, 40, 33, 63, 48, 32, 20]))
+        mode = str(rs.choice(["h", "h", "w", "w", "full", "semi"]))
+        if mode == "w":
+            r = int(rs.choice([100, 128, 40, 64, 65, 96, int(rs.integers(33, 129))]))
+        else:
+            r = int(rs.choice([200, 240, 100, 140, 256, 70, 160, int(rs.integers(33, 257))]))
+        tiles = int(rs.choice([1024, 2048])) + int(rs.integers(1, 256)) if mode != "w" else int(rs.choice([1024, 2048, 1280, 2304])) + int(rs.integers(1, 256))
+        T = 32 * tiles - int(rs.integers(0, 32))
+        sp = str(rs.choice(["scalar", "scalar", "vec", "zero", "mat"]))
+        return F, T, r, 1.0, mode, sp
+
     def draw(self):
         rs = self.rs
         if self.focus == "r5":
             return self.draw_r5()
+        if self.focus == "share":
+            return self.draw_share()
         if self.focus == "big":
             return self.draw_big()
         if self.focus in ("pipe", "stop"):
@@ -132,10 +150,10 @@ class Fuzz:
             V[:, rs.random(T) < 0.05] = 0.0
         W0 = rs.random((F, r))
         H0 = rs.random((r, T))
-        iters = int(rs.integers(2, 6)) if focus != "pipe" else int(rs.integers(2, 4))
+        iters = int(rs.integers(2, 6)) if focus not in ("pipe", "share") else int(rs.integers(2, 4))
         # early stop (src/sparse_nmf.m:272-284): now and then a solve that may stop by itself -- the stop index must be the oracle's unless the
         # oracle's own decision was within 2 % of the threshold at some iteration (then the case is counted as borderline, not compared)
-        eps = float(rs.choice([0, 0, 0, 1e-3, 3e-3, 1e-2])) if focus not in ("big", "pipe") else 0.0
+        eps = float(rs.choice([0, 0, 0, 1e-3, 3e-3, 1e-2])) if focus not in ("big", "pipe", "share") else 0.0
         if focus == "stop":
             eps = float(rs.choice([1e-3, 3e-3, 1e-2, 3e-2]))
         if eps > 0:

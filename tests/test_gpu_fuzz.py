@@ -11,7 +11,8 @@ from fuzz_cases import Fuzz
 pytestmark = pytest.mark.gpu
 
 # (focus, seed, cases, time cap in s, fewest cases that must have been compared)
-ENVELOPES = [("pipe", 601, 40, 55.0, 8), ("r5", 602, 40, 30.0, 8), ("big", 603, 12, 35.0, 2), ("stop", 604, 20, 25.0, 3), ("", 605, 40, 25.0, 8)]
+ENVELOPES = [("pipe", 601, 40, 55.0, 8), ("r5", 602, 40, 30.0, 8), ("big", 603, 12, 35.0, 2), ("stop", 604, 20, 25.0, 3), ("", 605, 40, 25.0, 8),
+             ("share", 606, 14, 30.0, 4)]
 
 
 @pytest.mark.parametrize("focus,seed,n_cases,cap,least", ENVELOPES, ids=[e[0] or "general" for e in ENVELOPES])
