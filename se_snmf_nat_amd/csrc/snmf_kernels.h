@@ -4100,10 +4100,14 @@ struct ApplyArgs {
 // "P" of every row is the row sum sk of H.
 // wpre: this thread's rows of the column (wc[tid + 256 i], i < 5; F <= 1280) loaded by the caller ahead of time, or nullptr
 // (by reference + a flag, every index a compile-time constant: through a pointer the array went to scratch)
+// w_ind_k / lamk_k: w_ind[k] and lambda_k[k], LOADED BY THE CALLER at the top of its kernel: read here they were two more dependent
+// global round trips on the launch's critical path (the first decides everything that follows, the second sits between the last
+// column sum and the last store) -- 1.5-2 us each on a cold, mostly idle chip (profiles/r06_experiments.md section 10: phase stamps)
 __device__ __forceinline__ void wapply_column(const ApplyArgs& a, int k, int tid, const double* Q, const double* P,
-                                              double sk, double (&red)[3][256], const double (&wpre)[5], bool use_pre) {
+                                              double sk, double (&red)[3][256], const double (&wpre)[5], bool use_pre,
+                                              int w_ind_k, float lamk_k) {
     double* wc = a.Wc + (size_t)k * a.Fp;
-    const bool upd = a.init_mode ? false : (a.w_ind[k] != 0);
+    const bool upd = a.init_mode ? false : (w_ind_k != 0);
     // This thread's rows f = tid, tid + 256, ... of the column live in registers for the whole epilogue (F <= 1024 + 1
     // rows: up to NR = 5 per thread; larger F loops again through memory like before).
     constexpr int NR = 5;
@@ -4192,7 +4196,7 @@ __device__ __forceinline__ void wapply_column(const ApplyArgs& a, int k, int tid
     if (tid == 0) {
         const float cs = (float)cW;
         a.colsum[k] = cs;
-        a.dphv[k] = fmaxf(cs + a.lamk[k], kFlr);
+        a.dphv[k] = fmaxf(cs + lamk_k, kFlr);
         if (a.init_mode) a.wn[k] = nrm;
     }
 }
@@ -4206,6 +4210,8 @@ static __global__ __launch_bounds__(256) void k_wapply(ApplyArgs a) {
     const int k = blockIdx.x;
     const int tid = threadIdx.x;
     const size_t nel = (size_t)a.rp * a.Fp;
+    const int w_ind_k = a.w_ind[k];   // (issued here, used by wapply_column: see there)
+    const float lamk_k = a.lamk[k];
     if (a.gather) {
         if (a.gflags) {  // FLAGS ordering: every rank's push of this exchange must have arrived (k_sum_ranks' bounded wait)
             if (tid < a.ngather && !__hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
@@ -4258,13 +4264,13 @@ static __global__ __launch_bounds__(256) void k_wapply(ApplyArgs a) {
             for (int q = 1; q < a.ngather; ++q) sk += a.gather[(size_t)q * a.gather_len + i];
         }
         __syncthreads();
-        wapply_column(a, k, tid, Qs, a.n_mat == 2 ? Ps : nullptr, sk, red, no_pre, false);
+        wapply_column(a, k, tid, Qs, a.n_mat == 2 ? Ps : nullptr, sk, red, no_pre, false, w_ind_k, lamk_k);
         return;
     }
     const double* Q = a.stats + (size_t)k * a.Fp;
     const double* P = (a.n_mat == 2) ? a.stats + nel + (size_t)k * a.Fp : nullptr;
     const double sk = (a.n_mat == 2 || a.init_mode) ? 0.0 : a.stats[nel * a.n_mat + k];
-    wapply_column(a, k, tid, Q, P, sk, red, no_pre, false);
+    wapply_column(a, k, tid, Q, P, sk, red, no_pre, false, w_ind_k, lamk_k);
 }
 #endif  // SNMF_AUX_KERNELS (k_wapply)
 
@@ -4342,6 +4348,8 @@ __global__ __launch_bounds__(768) void k_wfin(ReduceArgs ra, ApplyArgs a) {
         }
         if (a.check_it > 1) last_cost = a.costh[a.check_it - 2];
     }
+    const int w_ind_k = a.w_ind[k];  // (wapply_column's two scalars: see there)
+    const float lamk_k = a.lamk[k];
     SNMF_PIN();
     if (stop_now) return;
     while (it_i < 8 * nI) {
@@ -4452,7 +4460,7 @@ __global__ __launch_bounds__(768) void k_wfin(ReduceArgs ra, ApplyArgs a) {
 #pragma unroll
         for (int gg = 0; gg < 8; ++gg) sk += skp[gg];
     }
-    wapply_column(a, k, tid, QP, NMAT == 2 ? QP + a.Fp : nullptr, sk, red, wpre, pre_w);
+    wapply_column(a, k, tid, QP, NMAT == 2 ? QP + a.Fp : nullptr, sk, red, wpre, pre_w, w_ind_k, lamk_k);
 }
 
 
