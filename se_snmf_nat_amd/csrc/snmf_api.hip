@@ -371,7 +371,8 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
             pl->sf_share = 0;
             pl->sf_nfull = pl->rp_tiles;
             // (not for the full updates that snmf_plan_run fuses into k_iter_sf: the step API's two launches -- the sharded loop -- stay
-            //  bit for bit what the fused launch computes, tests/test_gpu_parity.py::test_fused_small_f_iteration_equals_the_two_launches)
+            //  bit for bit what the fused launch computes with every tile whole, tests/test_gpu_parity.py::test_fused_small_f_iteration_equals_the_two_launches;
+            //  k_iter_sf shares a chunk's remainder tile in its own way, isf_share)
             const bool isf_shape = pl->upd_h && pl->upd_w && pl->nf == 2 && pl->nk >= 3 && pl->nk <= 4;
             if (pl->sf && !isf_shape && xb > 0 && (wfull == 0 || wfull == 4) && pl->nk >= 2 && pl->lds_sf + more <= lds_cap && !(e4 && atoi(e4) == 0)) {
                 pl->sf_share = xb;
@@ -459,6 +460,8 @@ extern "C" int snmf_plan_create(snmf_ctx* ctx, const snmf_params* p, snmf_plan**
         const size_t tail = ((size_t)ncl * pl->nf * pl->nk * 1024 + (size_t)ncl * pl->rp) * 4 + 2 * ncl * sizeof(double);
         pl->lds_isf = std::max(body, tail) + 64;
         pl->isf = pl->sf && pl->wsf && pl->nf == 2 && pl->nk >= 3 && pl->upd_h && pl->upd_w && pl->lds_isf <= lds_cap && !(e && atoi(e) == 0);
+        const char* e4 = getenv("SNMF_HSTEP_SPLIT");
+        pl->isf_share = pl->isf && !(e4 && atoi(e4) == 0);
     }
     // Small rank on tall spectrograms (r <= 32 on 3..16 row tiles; the reference's R = 20 / 10 / 30 at F = 513): a tile per workgroup
     // cut by ROW TILES over its eight waves, every operand straight into the MFMA layouts (snmf_smallr.h).  Follow SNMF_HSTEP_RP /
@@ -716,7 +719,7 @@ extern "C" int snmf_plan_describe(const snmf_plan* pl, char* buf, size_t n) {
     if (sr_pipe)
         snprintf(hs, sizeof hs, "k_hstep_sr (a tile per workgroup cut by row tiles over 8 waves, operands straight into the MFMA layouts, partial numerators meet in LDS; %d tiles, grid %d)", pl->rp_tiles, pl->sr_grid);
     else if (sf_pipe && pl->isf && pl->wfin)
-        snprintf(hs, sizeof hs, "k_iter_sf (H step + W statistics of a full update in ONE launch, 4 SIMD pairs of an H wave and a W wave per workgroup; %d tiles, grid %d; step API: k_hstep_sf)", pl->rp_tiles, pl->n_chunks);
+        snprintf(hs, sizeof hs, "k_iter_sf (H step + W statistics of a full update in ONE launch, 4 SIMD pairs of an H wave and a W wave per workgroup%s; %d tiles, grid %d; step API: k_hstep_sf)", pl->isf_share ? ", a chunk's single remainder tile shared by the four pairs" : "", pl->rp_tiles, pl->n_chunks);
     else if (sf_pipe)
         snprintf(hs, sizeof hs, "k_hstep_sf (a tile per wave from first load to last store, 8 waves per workgroup; %d tiles, the last %d shared by four waves each, grid %d)", pl->rp_tiles, pl->sf_share, pl->sf_grid);
     else if (rh_pipe)

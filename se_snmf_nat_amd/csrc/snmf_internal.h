@@ -124,6 +124,7 @@ struct snmf_plan {
     int sf_grid = 1;
     bool wsf = false;     // KL statistics through k_wstats_sf (F <= 64, r <= 128)
     size_t lds_wsf = 0;
+    bool isf_share = false;  // k_iter_sf: a chunk's single remainder tile is shared by the four pairs (SNMF_HSTEP_SPLIT=0: whole)
     bool wsf_share = false;  // k_wstats_sf / k_iter_sf: a workgroup's single remainder tile is shared by its waves (SNMF_HSTEP_SPLIT=0: whole)
     bool isf = false;     // full KL updates of those shapes: H step + W statistics in ONE launch (k_iter_sf); SNMF_ITER_SF=0 keeps two
     size_t lds_isf = 0;

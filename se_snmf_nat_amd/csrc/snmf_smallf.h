@@ -795,7 +795,7 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_iter_sf(StepArgs a, int n_
     float* const lmk = rdp + rp;                              // lambda_k [rp]
     float* const hb = lmk + rp + (size_t)c * 32 * LDT;        // this pair's hand-off buffer [32][LDT]
     float* const xb = lmk + rp + (size_t)NP * 32 * LDT;       // one more buffer: a chunk's single remainder tile (below)
-    unsigned* const sig = reinterpret_cast<unsigned*>(xb + 32 * LDT);  // full[NP], empty[NP], xfull
+    unsigned* const sig = reinterpret_cast<unsigned*>(xb + 32 * LDT);  // full[NP], empty[NP], xfull; the shared remainder tile: hxc, xfc, wxc, wdc (arrival counts)
     double* const accd = reinterpret_cast<double*>(sig + 16);           // [NP H waves][64 lanes][2] fp64 partial sums of the objective
     float* const ssl = reinterpret_cast<float*>(accd + (size_t)NP * 64 * 2);  // [NP W waves][64 lanes][4] row sums of H_new per lane (NK <= 4)
     unsigned* const full = sig + c;
@@ -803,8 +803,27 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_iter_sf(StepArgs a, int n_
     const unsigned full_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)full;
     const unsigned empty_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)empty;
     const unsigned xfull_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(sig + 2 * NP);
+    const unsigned wdc_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(sig + 2 * NP + 4);
     const int chunk = blockIdx.x;
     const int tb = (int)(((long long)a.n_tiles * chunk) / n_chunks), te = (int)(((long long)a.n_tiles * (chunk + 1)) / n_chunks);
+    // THE SHARED REMAINDER TILE (a.part_S == 4; the plan's isf_share).  A chunk of 4 R + 1 tiles is R rounds and one more tile: as an H
+    // task on pair 0 and a W task on pair 1 it made those two SIMDs carry 2 R + 1 tasks against 2 R on the others (64 x 72000: 5 against
+    // 4, 55.7 us where 65536 frames take 46.5).  Now the four H waves share its H task FIRST (each its column tile: a k range of Lam, the
+    // partial sums through LDS in wave order, then its rows of W^T*ratio, update, store and its columns of the extra hand-off buffer), and
+    // the four W waves share its W task first (each: its k range of Lam' for both row tiles, partial sums through LDS, then column tile c
+    // of G and of the row sums).  The exchanges live in the pairs' own hand-off buffers, which are idle until the H waves' first
+    // whole tile is done; four arrival counts order it all (hxc: H partials written; xfc: H_new pieces in the extra buffer; wxc: W
+    // partials written; wdc: W partials read -- only then may an H wave write its pair's buffer).
+    const bool xshare = a.part_S == 4 && (te - tb) % NP == 1;
+    unsigned* const hxc = sig + 2 * NP + 1;
+    unsigned* const xfc = sig + 2 * NP + 2;
+    unsigned* const wxc = sig + 2 * NP + 3;
+    unsigned* const wdc = sig + 2 * NP + 4;
+    auto count_up = [&](unsigned* word, int lane_) {  // (release: this wave's LDS writes are complete before the arrival is counted)
+        stress_jitter();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        if (lane_ == 0) __hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
     {
         sf_fill_image(a.Wt4, wt, NF * rp * 32 * 4, w, (int)(threadIdx.x & 63));
         sf_fill_image(a.Wk4, wk, NK * a.Fq * 32 * 4, w, (int)(threadIdx.x & 63));
@@ -812,7 +831,7 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_iter_sf(StepArgs a, int n_
             rdp[k] = a.S ? 0.f : fast_rcp(a.dphv[k]);
             lmk[k] = a.S ? 0.f : a.lamk[k];
         }
-        if (threadIdx.x < 2 * NP + 1) sig[threadIdx.x] = 0u;
+        if (threadIdx.x < 16) sig[threadIdx.x] = 0u;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing else orders a ds_read behind an LDS-DMA
     }
     __syncthreads();
@@ -839,10 +858,137 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_iter_sf(StepArgs a, int n_
         // (n = 4 R + 1: Mel 64 x 72000 is 9 tiles a chunk) is pair 0's FIRST task and goes into the extra buffer, which nobody has to
         // release: pair 1's W wave takes it while it would otherwise wait for its own partner's second tile, and no SIMD carries an
         // extra task of both kinds behind a chain of hand-offs (5 tasks on the two busiest SIMDs instead of 6 on one).
-        const int n_my = te - tb, n_rnd = n_my / NP, n_rem = n_my - n_rnd * NP;
+        const int n_my = te - tb, n_rnd = n_my / NP, n_rem = xshare ? 0 : n_my - n_rnd * NP;
         const bool x_first = n_rem == 1 && c == 0;
         const unsigned n_h = (unsigned)(n_rnd + (c < n_rem ? 1 : 0));
         SNMF_STAMP_DECL
+        if (xshare && c < NK) {
+            // ---- this wave's quarter of the shared remainder tile's H task ----
+            const int ln = fresh_lane(), t = ln & 31, h = ln >> 5;
+            const int hlo = (t * rp + 4 * h) * 4, vlo = (t * Fp + 4 * h) * 4;
+            const f32x4* const wtl = reinterpret_cast<const f32x4*>(wt) + ln;
+            const f32x4* const wkl = reinterpret_cast<const f32x4*>(wk) + ln;
+            const int t0 = (tb + n_rnd * NP) * 32;
+            f32x4 hs[4], vs[NF * 4];
+            {
+                const __amdgpu_buffer_rsrc_t rhi =
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Hin + (size_t)t0 * rp), 0, 32 * rp * 4, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rvi =
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.V + (size_t)t0 * Fp), 0, 32 * Fp * 4, 0x00020000);
+#pragma unroll
+                for (int ql = 0; ql < 4; ++ql) hs[ql] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rhi, hlo, 32 * (4 * c + ql), 0));
+#pragma unroll
+                for (int q = 0; q < NF * 4; ++q) vs[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rvi, vlo, 32 * q, 0));
+            }
+            float dsum = 0.f;
+            {
+                f32x16 acc[NF];
+#pragma unroll
+                for (int phi = 0; phi < NF; ++phi) acc[phi] = zero16();
+#pragma unroll
+                for (int ql = 0; ql < 4; ++ql) {
+                    const int q = 4 * c + ql;
+                    if (q >= a.nqk) break;
+                    f32x4 wa[NF];
+#pragma unroll
+                    for (int phi = 0; phi < NF; ++phi) wa[phi] = wtl[(phi * nq8 + q) * 64];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int phi = 0; phi < NF; ++phi) acc[phi] = mfma32(wa[phi][e], hs[ql][e], acc[phi]);
+                }
+                f32x4* const xw = reinterpret_cast<f32x4*>(hb) + ln;  // this pair's hand-off buffer: [phi][g][lane] f32x4 (8 of its 16.5 KB)
+#pragma unroll
+                for (int phi = 0; phi < NF; ++phi)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) xw[(phi * 4 + g) * 64] = f32x4{acc[phi][4 * g], acc[phi][4 * g + 1], acc[phi][4 * g + 2], acc[phi][4 * g + 3]};
+                count_up(hxc, ln);
+                sf_await(hxc, (unsigned)NK, a.stop);
+#pragma unroll
+                for (int phi = 0; phi < NF; ++phi) {
+                    const bool edge = OBJ && !(phi * 32 + 32 <= a.F && t0 + 32 <= a.T);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 lam4 = reinterpret_cast<const f32x4*>(lmk + rp)[(phi * 4 + g) * 64 + ln];
+#pragma unroll
+                        for (int p = 1; p < NK; ++p) {
+                            const f32x4 x = reinterpret_cast<const f32x4*>(lmk + rp + (size_t)p * 32 * LDT)[(phi * 4 + g) * 64 + ln];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) lam4[j] += x[j];
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float v = vs[phi * 4 + g][j];
+                            const float lam = fmaxf(lam4[j], kFlr);
+                            if (OBJ && c == 0) {  // (the tile's divergence terms count once)
+                                const float d = div_term<BM_KL>(v, lam, a.beta, a.inv_bb1);
+                                if (edge) dsum += (phi * 32 + 8 * g + 4 * h + j < a.F && t0 + t < a.T) ? d : 0.f;
+                                else dsum += d;
+                            }
+                            vs[phi * 4 + g][j] = v * fast_rcp(lam);
+                        }
+                        if (OBJ) __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            float shsum = 0.f;
+            {
+                constexpr int NQ = NF * 4;
+                f32x16 acc0 = zero16();
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const f32x4 wa0 = wkl[(c * nqf + q) * 64];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc0 = mfma32(wa0[e], vs[q][e], acc0);
+                }
+                float hsm = 0.f;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {  // (p2_update of the tile loop on the local pieces)
+                    const int k0 = c * 32 + 8 * g + 4 * h;
+                    const f32x4 ho = hs[g];
+                    f32x4 sp, dp;
+                    if constexpr (SK == 2) {
+                        sp = *reinterpret_cast<const f32x4*>(a.S + ((size_t)t0 + t) * rp + k0);
+                        const f32x4 cs = *reinterpret_cast<const f32x4*>(a.colsum + k0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) dp[j] = fast_rcp(fmaxf(cs[j] + sp[j], kFlr));
+                    } else {
+                        dp = *reinterpret_cast<const f32x4*>(rdp + k0);
+                        if constexpr (OBJ && SK == 1) sp = *reinterpret_cast<const f32x4*>(lmk + k0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hs[g][j] = ho[j] * acc0[4 * g + j] * dp[j];
+                    if constexpr (OBJ) {
+                        if constexpr (SK == 0) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) hsm += ho[j];
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) shsum += sp[j] * ho[j];
+                        }
+                    }
+                }
+                if constexpr (OBJ && SK == 0) shsum += a.lam_u * hsm;
+            }
+            if (OBJ) {
+                const unsigned acc_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(accd + ((size_t)c * 64 + ln) * 2);
+                double ad, as;
+                asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)" : "=v"(ad), "=v"(as) : "v"(acc_a));
+                ad += (double)dsum;
+                as += (double)shsum;
+                asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:8" ::"v"(acc_a), "v"(ad), "v"(as));
+            }
+            {
+                const __amdgpu_buffer_rsrc_t rho = __builtin_amdgcn_make_buffer_rsrc(a.Hout + (size_t)t0 * rp, 0, 32 * rp * 4, 0x00020000);
+                f32x4* const xp = reinterpret_cast<f32x4*>(xb + t * LDT + 4 * h + 32 * c);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    buf_store_b128(rho, hlo, 32 * (4 * c + g), hs[g]);
+                    xp[2 * g] = hs[g];
+                }
+            }
+            count_up(xfc, ln);
+        }
         for (unsigned ith = 0; ith < n_h; ++ith) {
             const int ln = fresh_lane(), t = ln & 31, h = ln >> 5;  // (lane (t, h): frame t, component / row half h)
             const int hlo = (t * rp + 4 * h) * 4, vlo = (t * Fp + 4 * h) * 4;  // this lane's byte offsets inside a tile of H / V
@@ -1006,6 +1152,7 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_iter_sf(StepArgs a, int n_
             //  of a wave complete in order, so the progress word posted behind them cannot overtake them)
             SNMF_STAMP(3);
             if (!is_x && it > 0) sf_await_raw(empty_a, it, a.stop);
+            if (xshare && it == 0) sf_await_raw(wdc_a, (unsigned)NK, a.stop);  // (the W waves are through with the exchange that lived in this buffer)
             SNMF_STAMP(4);
             {
                 const unsigned tpa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)((is_x ? xb : hb) + t * LDT + 4 * h);
@@ -1129,8 +1276,81 @@ __global__ __launch_bounds__(kSfWaves * 64, 2) void k_iter_sf(StepArgs a, int n_
         // this pair's W tasks: the tiles its own H wave hands over (whole rounds) and -- so that no SIMD carries an extra tile of BOTH kinds --
         // the remainder tile whose H task sits on pair jx = (c - m) mod NP.  A single remainder tile comes FIRST, out of the extra
         // buffer (see the H waves); two or three come last, out of their pairs' own buffers.  k_wstats_sf deals its tiles the same way.
-        const int n_my = te - tb, n_rnd = n_my / NP, n_rem = n_my - n_rnd * NP;
+        const int n_my = te - tb, n_rnd = n_my / NP, n_rem = xshare ? 0 : n_my - n_rnd * NP;
         const int jx = (c - n_rem + NP) % NP;
+        if (xshare && c < NK) {
+            // ---- this wave's quarter of the shared remainder tile's W task (H_new of the tile: the extra buffer, once all NK pieces are in) ----
+            const int t0 = (tb + n_rnd * NP) * 32;
+            const int ln = fresh_lane(), t = ln & 31, h = ln >> 5;
+            const f32x4* const wtl = reinterpret_cast<const f32x4*>(wt) + ln;
+            const unsigned sa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(ssl + ((size_t)c * 64 + ln) * 4);
+            float vt[NF][16];
+            {
+                const __amdgpu_buffer_rsrc_t rv =
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.V + (size_t)t0 * Fp), 0, 32 * Fp * 4, 0x00020000);
+#pragma unroll
+                for (int phi = 0; phi < NF; ++phi)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        vt[phi][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, ((4 * h) * Fp + phi * 32 + t) * 4, drow(i, 0) * Fp * 4, 0));
+            }
+            sf_await(xfc, (unsigned)NK, a.stop);
+            f32x4* const xw = reinterpret_cast<f32x4*>(hb) + ln;  // [phi][g][lane] f32x4 in this pair's hand-off buffer
+            {
+                const float* ap = xb + t * LDT + 4 * h + 32 * c;
+#pragma unroll
+                for (int phi = 0; phi < NF; ++phi) {
+                    f32x16 acc = zero16();
+#pragma unroll
+                    for (int ql = 0; ql < 4; ++ql) {
+                        const int q = 4 * c + ql;
+                        if (q >= a.nqk) break;
+                        const f32x4 ha = *reinterpret_cast<const f32x4*>(ap + 8 * ql), wa = wtl[(phi * nq8 + q) * 64];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc = mfma32(ha[e], wa[e], acc);
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) xw[(phi * 4 + g) * 64] = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                }
+            }
+            count_up(wxc, ln);
+            sf_await(wxc, (unsigned)NK, a.stop);
+            float R[NF][16];
+#pragma unroll
+            for (int phi = 0; phi < NF; ++phi)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 lam4 = reinterpret_cast<const f32x4*>(lmk + rp)[(phi * 4 + g) * 64 + ln];
+#pragma unroll
+                    for (int p = 1; p < NK; ++p) {
+                        const f32x4 x = reinterpret_cast<const f32x4*>(lmk + rp + (size_t)p * 32 * LDT)[(phi * 4 + g) * 64 + ln];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) lam4[j] += x[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) R[phi][4 * g + j] = vt[phi][4 * g + j] * fast_rcp(fmaxf(lam4[j], kFlr));
+                }
+            count_up(wdc, ln);  // (the partials are read: the H waves may use the buffers)
+            {
+                const float* bp = xb + (4 * h) * LDT + t + c * 32;
+                float b0[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) b0[i] = bp[drow(i, 0) * LDT];
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    if (c == k) {
+#pragma unroll
+                        for (int phi = 0; phi < NF; ++phi)
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) G[phi][k] = mfma32(R[phi][i], b0[i], G[phi][k]);
+                    }
+                }
+                float s4 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s4 += b0[i];
+                asm volatile("ds_add_f32 %0, %1" ::"v"(sa + 4u * (unsigned)c), "v"(s4));
+            }
+        }
         if (n_rem == 1 && jx == 0) w_tile(tb + n_rnd * NP, xb, sig + 2 * NP, 1u);
         for (int it = 0; it < n_rnd; ++it) {
             w_tile(tb + c + it * NP, hb, full, (unsigned)(it + 1));

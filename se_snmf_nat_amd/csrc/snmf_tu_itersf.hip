@@ -22,6 +22,7 @@ static int launch_iter_sf_s(snmf_plan* pl, const StepArgs& a) {
 int launch_iter_sf(snmf_plan* pl, bool obj) {
     StepArgs a = make_args(pl);
     a.n_tiles = pl->rp_tiles;
+    a.part_S = pl->isf_share ? 4 : 0;  // a chunk's single remainder tile is shared by the four pairs (snmf_smallf.h)
     ScopedTimer tm(pl->ctx, FAM_HSTEP);
     if (pl->nk == 3) return obj ? launch_iter_sf_s<3, true>(pl, a) : launch_iter_sf_s<3, false>(pl, a);
     return obj ? launch_iter_sf_s<4, true>(pl, a) : launch_iter_sf_s<4, false>(pl, a);

@@ -663,9 +663,12 @@ def test_shapes_beyond_the_fused_kernels_take_the_out_of_envelope_path(gpu_ctx):
 def test_fused_small_f_iteration_equals_the_two_launches(gpu_ctx, shape, monkeypatch):
     """k_iter_sf (csrc/snmf_smallf.h: the H half-step and the W statistics of a full KL update in one launch, SIMD pairs of an H
     wave and a W wave; run_basis_train.m:90-91 on 64 Mel bands at R = 100) against k_hstep_sf + k_wstats_sf: the same arithmetic
-    per tile and the same tiles in the same order on every chunk lane, so W and H agree in EVERY BIT after several iterations
-    (chunks of 4 R, 4 R + 1 -- the remainder tile through the extra hand-off buffer -- and 4 R + 2 / 3 tiles), and the objective
-    to the grouping of its fp64 partials."""
+    per tile and the same tiles in the same order on every chunk lane, so with every tile whole (SNMF_HSTEP_SPLIT=0) W and H agree in
+    EVERY BIT after several iterations (chunks of 4 R, 4 R + 1 -- the remainder tile through the extra hand-off buffer -- and
+    4 R + 2 / 3 tiles), and the objective to the grouping of its fp64 partials.  By default (round 6) a chunk's single remainder tile
+    is SHARED by the four pairs -- Lam and Lam' of that tile are then four partial sums added in wave order, another order of
+    additions: the default launch agrees with the whole-tile one to the summation-order tolerance on those frames and bit for bit
+    on every other frame after ONE iteration (later iterations see the last-bit differences of W everywhere)."""
     from se_snmf_nat_amd import Plan
     F, r, T, sp = shape
     rs = np.random.default_rng(F * 1000 + r)
@@ -674,15 +677,34 @@ def test_fused_small_f_iteration_equals_the_two_launches(gpu_ctx, shape, monkeyp
     H0 = rs.random((r, T)).astype(np.float32)
     sparsity = np.linspace(0.5, 2.0, r) if sp == "rvec" else sp
 
-    def run(fused):
+    def run(fused, iters=4):
         monkeypatch.setenv("SNMF_ITER_SF", "1" if fused else "0")
-        pl = Plan(gpu_ctx, F, T, r, beta=1.0, max_iter=4, conv_eps=0.0, cost_check=True, sparsity=sparsity)
+        pl = Plan(gpu_ctx, F, T, r, beta=1.0, max_iter=iters, conv_eps=0.0, cost_check=True, sparsity=sparsity)
         pl.set_v(V); pl.set_w(W0); pl.set_h(H0); pl.init(); pl.run()
         out = (pl.get_h(np.float32), pl.get_w(), pl.describe(), pl.get_objective())
         pl.close()
         return out
 
-    a, b = run(True), run(False)
+    monkeypatch.delenv("SNMF_HSTEP_SPLIT", raising=False)
+    d4, d1 = run(True), run(True, 1)      # the default launch: shared remainder tiles
+    monkeypatch.setenv("SNMF_HSTEP_SPLIT", "0")
+    a, b, a1 = run(True), run(False), run(True, 1)
+    # shared against whole: which frames sit in a shared tile (chunks of 4 R + 1 tiles: the last tile of the chunk)
+    n_tiles, nch = (T + 31) // 32, min((T + 31) // 32, 256)
+    shared = np.zeros(T, bool)
+    if "k_iter_sf" in d4[2]:
+        for ch in range(nch):
+            tb, te = n_tiles * ch // nch, n_tiles * (ch + 1) // nch
+            if (te - tb) % 4 == 1:
+                shared[32 * (te - 1):32 * te] = True
+    if (T, r) in ((72000, 100), (33000, 70)):
+        assert shared.any()  # (these two shapes do have chunks of 4 R + 1 tiles on 256 compute units)
+    assert np.array_equal(d1[0][:, ~shared], a1[0][:, ~shared])
+    dd = np.abs(d1[0][:, shared] - a1[0][:, shared])
+    assert (dd <= 2e-5 * np.abs(a1[0][:, shared]) + 1e-30).all(), dd.max()
+    assert np.abs(d4[0] - a[0]).max() <= 1e-4 * np.abs(a[0]).max() and np.abs(d4[1] - a[1]).max() <= 2e-6 * np.abs(a[1]).max()
+    for x, y in zip(d4[3][1], a[3][1]):
+        assert abs(x - y) <= 1e-6 * abs(y)
     n_cu = int(re.search(r"n_cu=(\d+)", a[2]).group(1)) if "n_cu=" in a[2] else 256
     assert ("k_iter_sf" in a[2]) == ((T + 31) // 32 > n_cu), a[2]
     assert "k_iter_sf" not in b[2]
