@@ -711,11 +711,40 @@ __device__ __forceinline__ float wave_sum_f(float v) {
            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
 }
 
-// fixed-order sum over the 256 threads of a workgroup: xor butterfly inside each wave (the same tree on every rank), then
-// the four wave sums in wave order.  One workgroup barrier per call instead of the eight of an LDS tree.
+// The sum over each row of 16 lanes as the steps xor 8, 4, 2, 1 of a butterfly on the DPP path (two v_mov_dpp + the add per step;
+// __shfl_xor is two ds_bpermute round trips per step, and these sums sit on the latency chain of k_wfin / k_wapply: phase stamps in
+// profiles/r06_experiments.md section 10).  row_ror:8 pairs lane i with i xor 8; row_ror:4 reads lane (i - 4) mod 16 of the row,
+// whose value -- every lane pair (i, i xor 8) holds the same sum by then -- is lane (i xor 4)'s; the quad permutations are xor 2 and
+// xor 1 themselves.  A fixed order on every rank and in both callers (k_wfin = k_reduce + k_wapply bit for bit).
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
+}
+__device__ __forceinline__ double butterfly_8421(double v) {
+    v += dpp_d<0x128>(v);  // row_ror:8
+    v += dpp_d<0x124>(v);  // row_ror:4
+    v += dpp_d<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_d<0xB1>(v);   // quad_perm [1,0,3,2]
+    return v;
+}
+
+// fixed-order sum over the 256 threads of a workgroup: each wave's sum (the same tree on every rank), then the four wave sums in wave
+// order.  One workgroup barrier per call instead of the eight of an LDS tree.
+// a wave's sum, wave-uniform: the four row sums (DPP), read off lanes 0 / 16 / 32 / 48 and added in row order
+__device__ __forceinline__ double rdlane_d(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_total_d(double v) {
+    v = butterfly_8421(v);
+    return (rdlane_d(v, 0) + rdlane_d(v, 16)) + (rdlane_d(v, 32) + rdlane_d(v, 48));
+}
 __device__ __forceinline__ double wg_sum_256(double v, double* scratch /*[4]*/, int tid) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = wave_total_d(v);
     __syncthreads();  // scratch of the previous call has been read
     if ((tid & 63) == 0) scratch[tid >> 6] = v;
     __syncthreads();
@@ -725,12 +754,8 @@ __device__ __forceinline__ double wg_sum_256(double v, double* scratch /*[4]*/, 
 // two sums at once (each with wg_sum_256's tree, so each comes out bit for bit as a call of its own would): one pair of barriers
 // and one exposed shuffle chain instead of two -- the F x r epilogue is a chain of latencies on a mostly idle chip
 __device__ __forceinline__ void wg_sum2_256(double& v0, double& v1, double* scratch0 /*[4]*/, double* scratch1 /*[4]*/, int tid) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double u0 = __shfl_xor(v0, o, 64), u1 = __shfl_xor(v1, o, 64);
-        v0 += u0;
-        v1 += u1;
-    }
+    v0 = wave_total_d(v0);
+    v1 = wave_total_d(v1);
     __syncthreads();
     if ((tid & 63) == 0) {
         scratch0[tid >> 6] = v0;
@@ -4436,13 +4461,24 @@ __global__ __launch_bounds__(768) void k_wfin(ReduceArgs ra, ApplyArgs a) {
         for (int idx = tid; idx < NMAT * a.Fp; idx += 256) QP[idx] = __hip_atomic_load(qg + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
     }
-    for (int st = 128; st > 0; st >>= 1) {
-        if (tid < st) {
-            red2[0][tid] += red2[0][tid + st];
-            red2[1][tid] += red2[1][tid + st];
+    // (k_reduce's tree 128, 64, ..., 1 -- red[t] += red[t + st] for t < st -- with the same pairs: wave 0 holds elements t, t + 64, t + 128,
+    //  t + 192 of the array, adds 128 and 64 apart in registers and the rest by shuffles: two barriers instead of eight)
+    if (tid < 64) {
+        double d0 = red2[0][tid] + red2[0][tid + 128], d1 = red2[0][tid + 64] + red2[0][tid + 192];
+        double h0 = red2[1][tid] + red2[1][tid + 128], h1 = red2[1][tid + 64] + red2[1][tid + 192];
+        d0 += d1;
+        h0 += h1;
+#pragma unroll
+        for (int st = 32; st > 0; st >>= 1) {
+            d0 += __shfl_down(d0, st, 64);
+            h0 += __shfl_down(h0, st, 64);
         }
-        __syncthreads();
+        if (tid == 0) {
+            red2[0][0] = d0;
+            red2[1][0] = h0;
+        }
     }
+    __syncthreads();
     double sc[2];
     sc[0] = ra.do_obj ? red2[0][0] : 0.0;
     sc[1] = ra.do_obj ? (ra.use_sh_const ? ra.sh_const : red2[1][0]) : 0.0;
