@@ -1477,6 +1477,7 @@ __device__ __forceinline__ void rp_p2_consts(const StepArgs& a, int kap, int lan
 // the one-workgroup order of the pipelined tiles (tests/test_gpu_pipelined_vs_plain.py states the tolerance).
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 constexpr int kAuxSC1 = 16;  // cache-policy bit of the raw buffer builtins: sc1 = agent scope (coherent across the XCDs' L2s)
+constexpr int kAuxNT = 2;    // ... nt = non-temporal (streaming): the line is not kept in the L2 for re-use
 // 16-byte buffer store.  A buffer_store_dwordx4 with a REGISTER scalar offset still reads its data registers after it
 // has issued (found by scripts/rp_shape_probe.py in round 2: the compiler reused one for an LDS address in the very next
 // instruction and the address reached memory; LLVM's hazard recogniser pads only immediate offsets): the s_nop carries
@@ -1837,7 +1838,12 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rp(StepArgs a) {
             if (b == PB - 1) return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gbB, 0, 0));
             return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gv, b < nfB ? b * NLT * 16 : 0, 0));
         };
-        auto stA = [&](__amdgpu_buffer_rsrc_t rs, int i, const f32x4& x) { buf_store_b128(rs, hv, (lw + NL * i) * rp * 4, x); };
+        // (H_new leaves as NON-TEMPORAL stores: nobody reads it before the next launch, and as ordinary stores its 100 MB a launch pushed the
+        //  W images -- which every workgroup re-reads from the L2 for every tile where they do not fit the LDS -- out of the L2s: C2 2 159-2 165 ->
+        //  2 179-2 191 it/s, k_hstep_rp 228.6 -> 225.0 us, the k_wstats behind it 223.5 -> 222.2.  nt on the loaders' V / H LOADS, on
+        //  k_wstats' loads or slab stores, sc1 instead of nt: all slower, profiles/r06_experiments.md section 11; k_hstep_rh, whose
+        //  images fit the LDS: no difference.)
+        auto stA = [&](__amdgpu_buffer_rsrc_t rs, int i, const f32x4& x) { buf_store_b128<kAuxNT>(rs, hv, (lw + NL * i) * rp * 4, x); };
         auto rsrc_of = [&](const float* base, int n_cells) {
             return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, n_cells * 16, 0x00020000);
         };
