@@ -249,7 +249,7 @@ def test_bench_single_gpu_line_keeps_the_contract():
     # (2 105 against 2 163 it/s: dense random activations draw more power, the clock follows); on THIS test's shape a step is 45 us of
     # launch latency, `value` is timed over 5 steps with one sync and the cold solve over 200, so only the order of magnitude binds
     assert d["from_random_start"] is not None, d["from_random_start_detail"]
-    assert 0 < d["from_random_start"] <= 1.3 * d["value"]
+    assert 0 < d["from_random_start"] <= 3.0 * d["value"]  # (observed on this shape: 0.9 .. 1.4 x `value`, whose five steps are mostly launch jitter)
     fr = d["from_random_start_detail"]
     assert fr["iters_200"]["iterations_per_s"] == d["from_random_start"] and fr["iters_100"]["iterations_per_s"] > 0
 
