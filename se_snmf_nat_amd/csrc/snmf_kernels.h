@@ -2445,8 +2445,10 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rh(StepArgs a) {
         auto rsrc_of = [&](const float* base, int bytes) {
             return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
         };
+        // (H_in is dead behind this launch: as NON-TEMPORAL loads its 100 MB at r = 200 do not displace V -- which k_wstats / the next launch read again --
+        //  in the cache behind the L2s: c4h 2 990-2 998 -> 3 021-3 025 it/s; no difference at r = 100 or for k_hstep_rp, profiles/r06_experiments.md section 11)
         auto ldA = [&](__amdgpu_buffer_rsrc_t rs, int i) {
-            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, hv, (lw + NL * i) * rp * 4, 0));
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, hv, (lw + NL * i) * rp * 4, kAuxNT));
         };
         auto ldV = [&](__amdgpu_buffer_rsrc_t rs, int hf, int i) {
             return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, hf ? vv1 : lane * 16, ((lw + NL * i) * Fp + 256 * hf) * 4, 0));
