@@ -2534,7 +2534,9 @@ __global__ __launch_bounds__(768, 3) void k_hstep_rh(StepArgs a) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) ho[u] = *reinterpret_cast<const f32x4*>(bHl + (lw + NL * (b0 + u)) * ldh * 4);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) buf_store_b128(ro, hv, (lw + NL * (b0 + u)) * rp * 4, ho[u]);
+                // (non-temporal, like k_hstep_rp's: with H_in's loads and H_new's stores both streaming, the 205 MB of V at 513 x 100000 stay in the
+                //  cache behind the L2s from one H-only iteration to the next: c4h 3 034 -> 3 051 it/s on top of the loads' 2 994 -> 3 034)
+                for (int u = 0; u < 4; ++u) buf_store_b128<kAuxNT>(ro, hv, (lw + NL * (b0 + u)) * rp * 4, ho[u]);
             }
             // ... and the H block of tile j+2 takes its place
             if (more_h) {
